@@ -1,0 +1,186 @@
+/*
+ * ringsnark_amd.h -- C ABI of librs_hip.so: the MI355X (gfx950) implementation of the ringSNARK
+ * prover hot path.  Plain pointers and sizes only; every bulk argument
+ * named d_* is a DEVICE pointer (hipMalloc / torch tensor storage), every h_* is a HOST pointer.
+ *
+ * The reference has no FFI: its boundary is the C++ concept <RingT, EncT> the provers are
+ * templated on (ringsnark/zk_proof_systems/r1cs_ppzksnark.hpp:173-188).
+ * Each entry point below names the reference member/function it replaces; the header-only
+ * adapters in include/ringsnark_amd/ring.hpp give these the reference's names and signatures,
+ * INTEGRATION.md shows the binding.
+ *
+ * Layouts (uint64_t canonical residues, little endian; identical to the reference's):
+ *   ring element      [L][N]            NTT-slot order, limb-major     (seal/seal_ring.tcc:270)
+ *   ciphertext        [2][K][N_enc]     SEAL NTT order
+ *   encoding element  [L][2][K][N_enc]  one BGV ciphertext per ring limb (seal/seal_ring.hpp:225)
+ *   vectors           [count][...]      element-major ("term-major")
+ *
+ * All functions return RS_OK (0) or an error code; rs_last_error() gives the message
+ * (thread-local).  Entry points are re-entrant with respect to a shared rs_ctx as long as
+ * concurrent calls use distinct streams (the reference calls inner_product from 10 OpenMP
+ * sections, rinocchio.tcc:106-163).  stream is a hipStream_t passed as void* (NULL = default).
+ */
+#ifndef RINGSNARK_AMD_H
+#define RINGSNARK_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_OK 0
+#define RS_ERR_INVALID 1        /* bad argument / unsupported parameter combination */
+#define RS_ERR_HIP 2            /* a HIP runtime call failed */
+#define RS_ERR_UNSUPPORTED 3    /* valid in the reference, not built here (message says what) */
+#define RS_ERR_NOT_INVERTIBLE 4 /* "element is not invertible in ring" (seal_ring.tcc:93,98) */
+
+#define RS_MAX_L 8
+#define RS_MAX_K 12
+
+typedef struct rs_ctx rs_ctx;
+typedef void *rs_stream;
+
+const char *rs_last_error(void);
+int rs_version(void);
+
+/* RingElem::set_context + EncodingElem::set_context(s) (seal/seal_ring.hpp:52-58, 266-320):
+ * ring Z_q[X]/(X^N+1), q = prod q[i]; L encoding contexts of degree N_enc with data primes Q[j]
+ * and plain modulus q[i].  Requires q[i], Q[j] prime, = 1 mod 2*N_enc, < 2^50, pairwise
+ * distinct. */
+int rs_ctx_create(int device, int N, int L, const uint64_t *q, int N_enc, int K, const uint64_t *Q,
+                  rs_ctx **out);
+void rs_ctx_destroy(rs_ctx *ctx);
+
+/* device memory helpers for hosts that do not bring their own allocator */
+int rs_malloc(rs_ctx *ctx, size_t bytes, void **d_ptr);
+int rs_free(rs_ctx *ctx, void *d_ptr);
+int rs_upload(rs_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, rs_stream stream);
+int rs_download(rs_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, rs_stream stream);
+int rs_sync(rs_ctx *ctx, rs_stream stream);
+
+/* ---- a4: negacyclic NTT / inverse NTT over Z_p[X]/(X^N_enc + 1), in place, batched ----------
+ * Replaces SealPoly::ntt_inplace / intt_inplace (microbench.cpp:150,155; examples/example_SEAL
+ * .cpp:71) and the transforms inside BatchEncoder::encode / Evaluator::multiply_plain_inplace
+ * (seal_ring.tcc:534,536).  Forward: natural order in, SEAL (bit-reversed) order out. */
+#define RS_MOD_PLAIN 0 /* p = q[index]: plain modulus of encoding context `index` */
+#define RS_MOD_COEFF 1 /* p = Q[index] */
+int rs_ntt_forward(rs_ctx *ctx, int modset, int index, uint64_t *d_data, size_t batch, rs_stream stream);
+int rs_ntt_inverse(rs_ctx *ctx, int modset, int index, uint64_t *d_data, size_t batch, rs_stream stream);
+
+/* ---- a1-a3: RingElem arithmetic, dyadic on [count][L][N] (seal_ring.tcc:62-247) ---------- */
+int rs_ring_add(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, const uint64_t *d_b, size_t count, rs_stream stream);
+int rs_ring_sub(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, const uint64_t *d_b, size_t count, rs_stream stream);
+int rs_ring_mul(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, const uint64_t *d_b, size_t count, rs_stream stream);
+int rs_ring_neg(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, size_t count, rs_stream stream);
+/* SealPoly::{add,subtract,multiply}_scalar_inplace: scalar reduced per limb */
+int rs_ring_add_scalar(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, uint64_t scalar, size_t count, rs_stream stream);
+int rs_ring_mul_scalar(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, uint64_t scalar, size_t count, rs_stream stream);
+/* SealPoly::invert_inplace: slot-wise inverse; returns RS_ERR_NOT_INVERTIBLE (dst undefined) if
+ * any slot of any element is zero.  Synchronises the stream. */
+int rs_ring_inv(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, size_t count, rs_stream stream);
+/* RingElem::is_zero per element -> h_flags[count] (1 = zero).  Synchronises the stream. */
+int rs_ring_is_zero(rs_ctx *ctx, const uint64_t *d_a, size_t count, uint8_t *h_flags, rs_stream stream);
+
+/* ---- a5-a8: EncodingElem pieces --------------------------------------------------------- */
+/* BatchEncoder::encode as used at seal_ring.tcc:352,534: slot scatter + inverse NTT mod q_i.
+ * d_plain [count][L][N_enc] coefficient form, canonical. */
+int rs_batch_encode(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, size_t count, rs_stream stream);
+/* EncodingElem::operator*=(RingElem), polynomial operand (seal_ring.tcc:530-544): d_enc[k] *= d_ring[k]. */
+int rs_enc_mul_ring(rs_ctx *ctx, uint64_t *d_enc, const uint64_t *d_ring, size_t count, rs_stream stream);
+/* EncodingElem::operator+= on non-empty operands (seal_ring.tcc:489-506). */
+int rs_enc_add(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, const uint64_t *d_b, size_t count, rs_stream stream);
+
+/* ---- a9: EncodingElem::inner_product (seal_ring.tcc:361-433), the "ring-MSM" ------------- */
+#define RS_KIND_POLY 0 /* polynomial operand; an all-zero value contributes nothing (is_zero skip) */
+#define RS_KIND_ONE 2  /* RingElem holding Scalar 1: ciphertext passes through (seal_ring.tcc:525-527) */
+/* out = sum_t d_encs[t] * d_rings[t].  *h_used = number of non-skipped terms; 0 means the
+ * reference returns an EMPTY EncodingElem (d_out is then all zero).  Synchronises only if
+ * h_used != NULL. */
+int rs_inner_product(rs_ctx *ctx, const uint64_t *d_encs, const uint64_t *d_rings, const uint8_t *h_kinds,
+                     size_t T, uint64_t *d_out, size_t *h_used, rs_stream stream);
+
+/* Grouped form used by the provers: several coefficient vectors against several CRS vectors in
+ * one pass.  Vectors of one group are summed AFTER the centred lift, which is bit-identical to
+ * adding their separate inner products (the ciphertext ring is distributive; DESIGN.md "MSM").
+ *   d_out[c][g] = sum_{v in group g} sum_{t < vec[v].T} d_crs[c][t] * vec[v].d_coeff[t]      */
+typedef struct rs_msm_vec {
+  const uint64_t *d_coeff; /* [T][L][N] */
+  const uint8_t *h_kinds;  /* host [T] or NULL */
+  size_t T;                /* terms (<= crs_len) */
+  int group;               /* output group index */
+} rs_msm_vec;
+int rs_msm(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs,
+           int n_vecs, int n_groups, uint64_t *d_out /* [n_crs][n_groups] enc elems */,
+           size_t *h_used /* [n_vecs] or NULL */, rs_stream stream);
+
+/* ---- a14: R1CS in CSR form + linear_combination::evaluate (relations/variable.tcc:246-254) -- */
+typedef struct rs_r1cs rs_r1cs;
+/* For M in {a,b,c}: h_row_ptr[M][m+1], h_col[M][nnz] (0 = constant one, k>=1 = variable k-1),
+ * h_coeff[M][L][nnz] slot-constant residues. */
+int rs_r1cs_create(rs_ctx *ctx, size_t m, size_t n_vars, size_t n_inputs, const uint32_t *const h_row_ptr[3],
+                   const uint32_t *const h_col[3], const uint64_t *const h_coeff[3], const size_t nnz[3],
+                   rs_r1cs **out);
+void rs_r1cs_destroy(rs_r1cs *cs);
+#define RS_EVAL_FULL 0 /* full assignment                      (r1cs_to_qrp.tcc:216-220) */
+#define RS_EVAL_IO 1   /* primary || zeros                      (r1cs_to_qrp.tcc:189-201) */
+#define RS_EVAL_MID 2  /* zeros || auxiliary                    (r1cs_to_qrp.tcc:166-179) */
+int rs_r1cs_evaluate(rs_ctx *ctx, const rs_r1cs *cs, int which /*0=a,1=b,2=c*/, int mode,
+                     const uint64_t *d_assignment /* [n_vars][L][N] */, uint64_t *d_out /* [m][L][N] */,
+                     rs_stream stream);
+
+/* ---- a10-a13: r1cs_to_qrp_witness_map (reductions/r1cs_to_qrp/r1cs_to_qrp.tcc:149-259) ----
+ * Outputs in ring layout: A_io..C_mid [m][L][N], H [m+1][L][N]; h_Z [L][m+1] slot-constant
+ * scalars (coefficients_for_Z).  d1,d2,d3: ring elements [L][N] or all NULL (zero).  Any output
+ * pointer may be NULL to skip it.  Uses an exact quasi-linear algorithm when every q_i has the
+ * 2-adicity for it (q_i = 1 mod 4*next_pow2(m)) and otherwise returns RS_ERR_UNSUPPORTED. */
+int rs_witness_map(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_assignment, const uint64_t *d_d1,
+                   const uint64_t *d_d2, const uint64_t *d_d3, uint64_t *d_A_io, uint64_t *d_B_io,
+                   uint64_t *d_C_io, uint64_t *d_A_mid, uint64_t *d_B_mid, uint64_t *d_C_mid, uint64_t *d_H,
+                   uint64_t *h_Z, rs_stream stream);
+/* util/polynomials.tcc:10-43 on the domain {0..n-1}: d_y, d_out [n][L][N] (may alias). */
+int rs_interpolate(rs_ctx *ctx, const uint64_t *d_y, uint64_t *d_out, size_t n, rs_stream stream);
+
+/* ---- a15 / a16: provers -------------------------------------------------------------------
+ * groth16::prover (zk_proof_systems/groth16/groth16.tcc:70-115).  pk vectors are device
+ * resident; proof = {A,B,C} [3] encoding elements; h_empty[k] = 1 if the reference would leave
+ * element k EMPTY. */
+typedef struct rs_groth16_pk {
+  const uint64_t *d_s_pows;    /* [m+1] */
+  const uint64_t *d_delta_ts;  /* [m+1] */
+  const uint64_t *d_delta_mid; /* [n_aux] */
+  const uint64_t *d_alpha, *d_beta;
+} rs_groth16_pk;
+int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, const uint64_t *d_assignment,
+                     uint64_t *d_proof, int *h_empty /* [3] or NULL */, rs_stream stream);
+
+/* rinocchio::prover (zk_proof_systems/rinocchio/rinocchio.tcc:75-190); d1,d2,d3 are the ZK
+ * blinding elements the reference samples at :88-90 (all NULL = non-ZK branch).  proof =
+ * {A,A',B,B',C,C',D,D',F} [9]. */
+typedef struct rs_rinocchio_pk {
+  const uint64_t *d_s_pows, *d_alpha_s_pows; /* [m+1] */
+  const uint64_t *d_beta_prods;              /* [n_aux] */
+  const uint64_t *d_beta_rv_ts, *d_beta_rw_ts, *d_beta_ry_ts;
+} rs_rinocchio_pk;
+int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk, const uint64_t *d_assignment,
+                       const uint64_t *d_d1, const uint64_t *d_d2, const uint64_t *d_d3, uint64_t *d_proof,
+                       int *h_empty /* [9] or NULL */, rs_stream stream);
+
+/* ---- measurement hooks (bench.py): per-phase device time of the last prover call, in ms ---- */
+typedef struct rs_timings {
+  float evaluate_ms, witness_ms, msm_ms, total_ms;
+  float msm_mac_ms;      /* time inside the dominant MAC kernel */
+  int msm_mac_launches;  /* number of launches of that kernel */
+} rs_timings;
+int rs_last_timings(rs_ctx *ctx, rs_timings *out);
+int rs_set_profiling(rs_ctx *ctx, int enabled);
+
+/* synthetic-workload helpers for the benchmark harness (device-side generators) */
+int rs_fill_uniform(rs_ctx *ctx, uint64_t *d_dst, size_t count, int layout /*0 ring,1 enc*/, uint64_t seed, rs_stream stream);
+/* chain circuit x_{i+2} = x_i * x_{i+1}: fills d_assignment[2..m+2) from [0..2) */
+int rs_chain_assignment(rs_ctx *ctx, uint64_t *d_assignment, size_t m, rs_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,111 @@
+"""ctypes binding of librs_hip.so (include/ringsnark_amd.h).
+
+The library is the product: there is no CPU fallback.  Importing this module without the built
+shared object raises, and every entry point raises RsError on a non-zero status.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librs_hip.so")
+
+RS_OK, RS_ERR_INVALID, RS_ERR_HIP, RS_ERR_UNSUPPORTED, RS_ERR_NOT_INVERTIBLE = 0, 1, 2, 3, 4
+RS_MOD_PLAIN, RS_MOD_COEFF = 0, 1
+RS_KIND_POLY, RS_KIND_ONE = 0, 2
+RS_EVAL_FULL, RS_EVAL_IO, RS_EVAL_MID = 0, 1, 2
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+
+
+class RsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("librs_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class MsmVec(C.Structure):
+    _fields_ = [("d_coeff", vp), ("h_kinds", u8p), ("T", C.c_size_t), ("group", C.c_int)]
+
+
+class Groth16PK(C.Structure):
+    _fields_ = [("d_s_pows", vp), ("d_delta_ts", vp), ("d_delta_mid", vp), ("d_alpha", vp), ("d_beta", vp)]
+
+
+class RinocchioPK(C.Structure):
+    _fields_ = [("d_s_pows", vp), ("d_alpha_s_pows", vp), ("d_beta_prods", vp), ("d_beta_rv_ts", vp),
+                ("d_beta_rw_ts", vp), ("d_beta_ry_ts", vp)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("evaluate_ms", C.c_float), ("witness_ms", C.c_float), ("msm_ms", C.c_float), ("total_ms", C.c_float),
+                ("msm_mac_ms", C.c_float), ("msm_mac_launches", C.c_int)]
+
+
+# name -> (restype, argtypes); every function of include/ringsnark_amd.h
+SIGNATURES = {
+    "rs_last_error": (C.c_char_p, []),
+    "rs_version": (C.c_int, []),
+    "rs_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, u64p, C.c_int, C.c_int, u64p, C.POINTER(vp)]),
+    "rs_ctx_destroy": (None, [vp]),
+    "rs_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "rs_free": (C.c_int, [vp, vp]),
+    "rs_upload": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "rs_download": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "rs_sync": (C.c_int, [vp, vp]),
+    "rs_ntt_forward": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "rs_ntt_inverse": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "rs_ring_add": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp]),
+    "rs_ring_sub": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp]),
+    "rs_ring_mul": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp]),
+    "rs_ring_neg": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "rs_ring_add_scalar": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_size_t, vp]),
+    "rs_ring_mul_scalar": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_size_t, vp]),
+    "rs_ring_inv": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "rs_ring_is_zero": (C.c_int, [vp, vp, C.c_size_t, u8p, vp]),
+    "rs_batch_encode": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "rs_enc_mul_ring": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "rs_enc_add": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp]),
+    "rs_inner_product": (C.c_int, [vp, vp, vp, u8p, C.c_size_t, vp, C.POINTER(C.c_size_t), vp]),
+    "rs_msm": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_size_t, C.POINTER(MsmVec), C.c_int, C.c_int, vp,
+                         C.POINTER(C.c_size_t), vp]),
+    "rs_r1cs_create": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(u32p), C.POINTER(u32p),
+                                 C.POINTER(u64p), C.POINTER(C.c_size_t), C.POINTER(vp)]),
+    "rs_r1cs_destroy": (None, [vp]),
+    "rs_r1cs_evaluate": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "rs_witness_map": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64p, vp]),
+    "rs_interpolate": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "rs_groth16_prove": (C.c_int, [vp, vp, C.POINTER(Groth16PK), vp, vp, C.POINTER(C.c_int), vp]),
+    "rs_rinocchio_prove": (C.c_int, [vp, vp, C.POINTER(RinocchioPK), vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]),
+    "rs_last_timings": (C.c_int, [vp, C.POINTER(Timings)]),
+    "rs_set_profiling": (C.c_int, [vp, C.c_int]),
+    "rs_fill_uniform": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_uint64, vp]),
+    "rs_chain_assignment": (C.c_int, [vp, vp, C.c_size_t, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen librs_hip.so and bind every declared symbol.  Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "ringsnark_amd/librs_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+            "the HIP library is the only implementation, there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != RS_OK:
+        raise RsError(status, load().rs_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,582 @@
+// msm.hip -- EncodingElem pieces (rows a5-a8) and the encoding inner product / ring-MSM (row a9)
+// of SURVEY.md section 8, restructured for the GPU:
+//
+//   reference (seal_ring.tcc:415-431, per term and ring limb i):
+//       plain = iNTT_{q_i}(scatter(b_t[i]))                 BatchEncoder::encode      (:534)
+//       for j < K:  P_j = NTT_{Q_j}(centred_lift(plain))    multiply_plain_inplace    (:536)
+//                   tmp[c][j] = ct_t[i][c][j] * P_j
+//       res += tmp                                           add_inplace              (:494)
+//
+//   here, three kernels over a tile of terms:
+//     plain_center_kernel  one workgroup per (group, term, limb): scatter + inverse NTT mod q_i in
+//                          LDS, centred lift, SUM over the coefficient vectors of the group ->
+//                          C[g][t][i][N_enc] (signed doubles).  Summing after the lift is exact:
+//                          ct*(P1) + ct*(P2) = ct*NTT(lift(p1)+lift(p2)) in Z_{Q_j}.
+//     mac_kernel           one workgroup per (limb, prime j, term chunk): C mod Q_j -> forward NTT
+//                          in LDS -> multiply with both ciphertext polynomials streamed from HBM,
+//                          accumulate in registers across the chunk's terms (lazy reduction).
+//                          Every ciphertext word is read exactly once per pass.
+//     reduce_kernel        sums the per-chunk partial accumulators (+ optional addends).
+//
+// Skipped (is_zero) terms contribute a zero plaintext, which is the identity for the sum, so the
+// value-level result equals the reference's; the EMPTY result (all terms skipped) is reported
+// through the used-term counts.
+#include <algorithm>
+#include <cstring>
+
+#include "ntt_core.cuh"
+#include "rs_internal.hpp"
+
+namespace rs {
+
+constexpr int MAX_GROUP_VECS = 4;
+constexpr int MAX_GROUPS = 6;
+
+struct PlainGroup {
+  const uint64_t *coeff[MAX_GROUP_VECS];
+  const uint8_t *kinds[MAX_GROUP_VECS];
+  unsigned *nz[MAX_GROUP_VECS];
+  unsigned long long T[MAX_GROUP_VECS];
+  int n;
+};
+struct PlainArgs {
+  PlainGroup g[MAX_GROUPS];
+};
+
+// grid (terms in tile, L, groups); EPT = max elements per thread (16 only for N_enc = 16384)
+template <int EPT>
+__global__ void __launch_bounds__(1024)
+plain_center_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t0, unsigned long long tile_terms,
+                    int N, int L, int logn, const uint32_t *__restrict__ index_map, const NttTable *__restrict__ plain_tabs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int n = 1 << logn;
+  const unsigned long long tt = blockIdx.x, t = t0 + tt;
+  const int limb = blockIdx.y, g = blockIdx.z;
+  const PlainGroup &G = args.g[g];
+  const NttTable tab = plain_tabs[limb];
+  const Mod mod = tab.mod;
+  double acc[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; k++) acc[k] = 0.0;
+  for (int v = 0; v < G.n; v++) {
+    if (t >= G.T[v]) continue;
+    const int kind = G.kinds[v] ? (int)G.kinds[v][t] : RS_KIND_POLY;
+    if (kind == RS_KIND_ONE) {  // Scalar 1: plaintext is the constant polynomial 1
+      if (threadIdx.x == 0) {
+        acc[0] += 1.0;
+        if (G.nz[v]) atomicOr(&G.nz[v][t], 1u);
+      }
+      continue;
+    }
+    for (int p = threadIdx.x; p < n; p += blockDim.x) s[pidx(p)] = 0.0;
+    __syncthreads();
+    const uint64_t *src = G.coeff[v] + ((size_t)t * L + limb) * (size_t)N;
+    bool nz = false;
+    for (int x = threadIdx.x; x < N; x += blockDim.x) {
+      const uint64_t val = src[x];
+      nz |= (val != 0);
+      s[pidx((int)index_map[x])] = from_u64(val);
+    }
+    if (!__syncthreads_or(nz)) continue;  // is_zero term (this limb): contributes nothing
+    if (threadIdx.x == 0 && G.nz[v]) atomicOr(&G.nz[v][t], 1u);
+    lds_ntt_inv(s, logn, tab.d_itw, 1, mod, tab.inv_red_mask);
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+      const int p = threadIdx.x + k * blockDim.x;
+      if (p < n) {
+        const double c = canon(mulmod(reduce(s[pidx(p)], mod), tab.ninv, mod), mod);
+        acc[k] += center(c, mod);
+      }
+    }
+    __syncthreads();
+  }
+  double *dst = C + (((size_t)g * tile_terms + tt) * L + limb) * (size_t)n;
+#pragma unroll
+  for (int k = 0; k < EPT; k++) {
+    const int p = threadIdx.x + k * blockDim.x;
+    if (p < n) dst[p] = acc[k];
+  }
+}
+
+// a5: BatchEncoder::encode -> canonical coefficient-form plaintext.  grid (count, L)
+__global__ void __launch_bounds__(1024)
+batch_encode_kernel(const uint64_t *__restrict__ rings, uint64_t *__restrict__ plain, int N, int L, int logn,
+                    const uint32_t *__restrict__ index_map, const NttTable *__restrict__ plain_tabs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int n = 1 << logn;
+  const size_t k = blockIdx.x;
+  const int limb = blockIdx.y;
+  const NttTable tab = plain_tabs[limb];
+  const Mod mod = tab.mod;
+  for (int p = threadIdx.x; p < n; p += blockDim.x) s[pidx(p)] = 0.0;
+  __syncthreads();
+  const uint64_t *src = rings + (k * L + limb) * (size_t)N;
+  for (int x = threadIdx.x; x < N; x += blockDim.x) s[pidx((int)index_map[x])] = from_u64(src[x]);
+  __syncthreads();
+  lds_ntt_inv(s, logn, tab.d_itw, 1, mod, tab.inv_red_mask);
+  uint64_t *dst = plain + (k * L + limb) * (size_t)n;
+  for (int p = threadIdx.x; p < n; p += blockDim.x)
+    dst[p] = to_u64(canon(mulmod(reduce(s[pidx(p)], mod), tab.ninv, mod), mod));
+}
+
+struct MacArgs {
+  const double *C[2];     // per group: [tile_terms][L][n]
+  const uint64_t *crs[2]; // per CRS vector: element 0 of the tile, [terms][L][2][K][n]
+  uint64_t *partial;      // [n_chunks][n_sets_total][L][2][K][n]
+  int set_index[4];       // which set slot (c * n_groups + g) each accumulator set writes
+  int n_sets_total;
+  unsigned long long terms[2];  // per group: number of valid terms in this tile
+  unsigned long long tile_terms;
+  int terms_per_chunk, n_chunks;
+  int accumulate;       // 1: add onto the existing partial slot
+  int acc_period;       // terms between lazy reductions of the accumulators
+  int reduce_u;         // 1: bring NTT outputs back to |u| <= p/2 before the MAC (large primes)
+};
+
+// The dominant kernel.  Accumulator set (c, g): sum_t crs[c][t] * NTT(C[g][t]).
+template <int NG, int NC, int PAIRS>
+__global__ void __launch_bounds__(1024)
+mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff_tabs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int n = 1 << logn;
+  // XCD-aware mapping: blocks b, b+8, b+16, ... (same XCD, dispatched back to back) take the K
+  // primes of one (limb, chunk), so the K readers of a C row share it through that XCD's L2.
+  const unsigned b = blockIdx.x;
+  const int j = (int)((b >> 3) % (unsigned)K);
+  const unsigned r = (b & 7u) + 8u * (b / (8u * (unsigned)K));
+  if (r >= (unsigned)(a.n_chunks * L)) return;
+  const int limb = (int)(r % (unsigned)L), chunk = (int)(r / (unsigned)L);
+  const NttTable tab = coeff_tabs[j];
+  const Mod mod = tab.mod;
+  constexpr int NS = NG * NC;
+  // PAIRS = n / (2 * blockDim): 4, or 8 for N_enc = 16384
+  double acc[NS][2][2 * PAIRS];
+  const size_t enc_words = (size_t)L * 2 * K * n;
+#pragma unroll
+  for (int st = 0; st < NS; st++)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int k = 0; k < PAIRS; k++) {
+        acc[st][c][2 * k] = acc[st][c][2 * k + 1] = 0.0;
+        const int pp = threadIdx.x + k * blockDim.x;
+        if (a.accumulate && pp < (n >> 1)) {
+          const uint64_t *pv = a.partial + ((size_t)chunk * a.n_sets_total + a.set_index[st]) * enc_words +
+                               (((size_t)limb * 2 + c) * K + j) * (size_t)n;
+          const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(pv)[pp];
+          acc[st][c][2 * k] = from_u64(v.x);
+          acc[st][c][2 * k + 1] = from_u64(v.y);
+        }
+      }
+  const unsigned long long tbeg = (unsigned long long)chunk * a.terms_per_chunk;
+  const unsigned long long tend = min(tbeg + (unsigned long long)a.terms_per_chunk, a.tile_terms);
+  int since = 0;
+  for (unsigned long long t = tbeg; t < tend; t++) {
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      if (t >= a.terms[g]) continue;
+      // centred plaintext (|c| < members * q_i / 2) -> residues mod Q_j
+      const double2 *src = reinterpret_cast<const double2 *>(a.C[g] + ((size_t)t * L + limb) * (size_t)n);
+      for (int pp = threadIdx.x; pp < (n >> 1); pp += blockDim.x) {
+        const double2 v = src[pp];
+        const int pi = pidx(2 * pp);
+        s[pi] = reduce(v.x, mod);
+        s[pi + 1] = reduce(v.y, mod);
+      }
+      __syncthreads();
+      lds_ntt_fwd(s, logn, tab.d_tw, 1, mod, tab.fwd_red_mask);
+#pragma unroll
+      for (int k = 0; k < PAIRS; k++) {
+        const int pp = threadIdx.x + k * blockDim.x;
+        if (pp < (n >> 1)) {
+          const int pi = pidx(2 * pp);
+          double u0 = s[pi], u1 = s[pi + 1];
+          if (a.reduce_u) {
+            u0 = reduce(u0, mod);
+            u1 = reduce(u1, mod);
+          }
+#pragma unroll
+          for (int cc = 0; cc < NC; cc++) {
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+              const uint64_t *ct = a.crs[cc] + (size_t)t * enc_words + (((size_t)limb * 2 + c) * K + j) * (size_t)n;
+              const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(ct)[pp];
+              const int st = cc * NG + g;
+              acc[st][c][2 * k] += mulmod(from_u64(v.x), u0, mod);
+              acc[st][c][2 * k + 1] += mulmod(from_u64(v.y), u1, mod);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (++since >= a.acc_period) {
+      since = 0;
+#pragma unroll
+      for (int st = 0; st < NS; st++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+          for (int k = 0; k < 2 * PAIRS; k++) acc[st][c][k] = reduce(acc[st][c][k], mod);
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < NS; st++)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int k = 0; k < PAIRS; k++) {
+        const int pp = threadIdx.x + k * blockDim.x;
+        if (pp < (n >> 1)) {
+          uint64_t *pv = a.partial + ((size_t)chunk * a.n_sets_total + a.set_index[st]) * enc_words +
+                         (((size_t)limb * 2 + c) * K + j) * (size_t)n;
+          ulonglong2 o;
+          o.x = to_u64(canon(acc[st][c][2 * k], mod));
+          o.y = to_u64(canon(acc[st][c][2 * k + 1], mod));
+          reinterpret_cast<ulonglong2 *>(pv)[pp] = o;
+        }
+      }
+}
+
+// out[set] = sum_chunk partial[chunk][set] (+ addend[set]) mod Q_j
+struct ReduceArgs {
+  const uint64_t *addend[12];
+};
+__global__ void __launch_bounds__(256)
+reduce_kernel(const uint64_t *__restrict__ partial, uint64_t *__restrict__ out, ReduceArgs add, int n_chunks,
+              int n_sets, size_t enc_words, int n, int K, const uint64_t *__restrict__ Qint) {
+  const size_t total = (size_t)n_sets * enc_words;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t set = i / enc_words, w = i % enc_words;
+    const int j = (int)((w / (size_t)n) % (size_t)K);
+    uint64_t sum = 0;
+    for (int c = 0; c < n_chunks; c++) sum += partial[((size_t)c * n_sets + set) * enc_words + w];
+    if (add.addend[set]) sum += add.addend[set][w];
+    out[i] = sum % Qint[j];
+  }
+}
+
+// a8: EncodingElem::operator+= (dyadic add mod Q_j)
+__global__ void __launch_bounds__(256)
+enc_add_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ x, const uint64_t *__restrict__ y,
+               size_t words, int n, int K, const uint64_t *__restrict__ Qint) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) {
+    const uint64_t Q = Qint[(i / (size_t)n) % (size_t)K];
+    uint64_t sm = x[i] + y[i];
+    dst[i] = sm >= Q ? sm - Q : sm;
+  }
+}
+
+static int tile_threads(int logn) { return std::max(64, std::min(1024, (1 << logn) >> 3)); }
+
+struct MsmScratch {
+  NttTable *d_plain_tabs = nullptr, *d_coeff_tabs = nullptr;
+  uint64_t *d_Qint = nullptr;
+};
+
+static std::map<rs_ctx *, MsmScratch> g_scratch;
+static std::mutex g_scratch_mu;
+
+static MsmScratch &scratch_for(rs_ctx *ctx) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  auto it = g_scratch.find(ctx);
+  if (it != g_scratch.end()) return it->second;
+  MsmScratch sc;
+  RS_HIP(hipMalloc(&sc.d_plain_tabs, sizeof(NttTable) * ctx->L));
+  RS_HIP(hipMemcpy(sc.d_plain_tabs, ctx->plain, sizeof(NttTable) * ctx->L, hipMemcpyHostToDevice));
+  RS_HIP(hipMalloc(&sc.d_coeff_tabs, sizeof(NttTable) * ctx->K));
+  RS_HIP(hipMemcpy(sc.d_coeff_tabs, ctx->coeff, sizeof(NttTable) * ctx->K, hipMemcpyHostToDevice));
+  RS_HIP(hipMalloc(&sc.d_Qint, sizeof(uint64_t) * ctx->K));
+  RS_HIP(hipMemcpy(sc.d_Qint, ctx->Q, sizeof(uint64_t) * ctx->K, hipMemcpyHostToDevice));
+  return g_scratch[ctx] = sc;
+}
+void msm_scratch_release(rs_ctx *ctx) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  auto it = g_scratch.find(ctx);
+  if (it == g_scratch.end()) return;
+  (void)hipFree(it->second.d_plain_tabs);
+  (void)hipFree(it->second.d_coeff_tabs);
+  (void)hipFree(it->second.d_Qint);
+  g_scratch.erase(it);
+}
+
+template <int NG, int NC, int PAIRS>
+static void launch_mac(rs_ctx *ctx, const MacArgs &a, const MsmScratch &sc, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(double);
+  const int rows = a.n_chunks * ctx->L;
+  const unsigned blocks = (unsigned)(((rows + 7) / 8) * 8 * ctx->K);
+  RS_HIP(hipFuncSetAttribute((const void *)mac_kernel<NG, NC, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (e0) RS_HIP(hipEventRecord(e0, st));
+  hipLaunchKernelGGL((mac_kernel<NG, NC, PAIRS>), dim3(blocks), dim3(tile_threads(ctx->logN_enc)), lds, st, a, ctx->L,
+                     ctx->K, ctx->logN_enc, sc.d_coeff_tabs);
+  if (e1) RS_HIP(hipEventRecord(e1, st));
+  RS_HIP(hipGetLastError());
+}
+
+// Core grouped MSM.  addends: optional per-output (n_crs * n_groups) device pointers to encoding
+// elements added to the result (pk.alpha / pk.beta of groth16.tcc:95,103).
+void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
+             int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st) {
+  RS_REQUIRE(n_crs >= 1 && n_crs <= 2, "n_crs must be 1 or 2");
+  RS_REQUIRE(n_groups >= 1 && n_groups <= MAX_GROUPS, "too many groups");
+  RS_REQUIRE(n_crs * n_groups <= 12, "too many outputs");
+  const int L = ctx->L, K = ctx->K, n = ctx->N_enc;
+  const size_t enc_words = ctx->enc_words();
+  MsmScratch &sc = scratch_for(ctx);
+
+  // group bookkeeping
+  PlainArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  size_t Tmax = 0;
+  std::vector<size_t> group_T(n_groups, 0);
+  std::vector<unsigned *> nz_ptr(n_vecs, nullptr);
+  size_t nz_total = 0, kinds_total = 0;
+  for (int v = 0; v < n_vecs; v++) {
+    RS_REQUIRE(vecs[v].group >= 0 && vecs[v].group < n_groups, "group index out of range");
+    RS_REQUIRE(vecs[v].T <= crs_len, "coefficient vector longer than the CRS vector");
+    RS_REQUIRE(vecs[v].d_coeff || vecs[v].T == 0, "null coefficient vector");
+    Tmax = std::max(Tmax, vecs[v].T);
+    group_T[vecs[v].group] = std::max(group_T[vecs[v].group], vecs[v].T);
+    if (h_used) nz_total += vecs[v].T;
+    if (vecs[v].h_kinds) kinds_total += vecs[v].T;
+  }
+  unsigned *d_nz = nullptr;
+  uint8_t *d_kinds = nullptr;
+  if (nz_total) {
+    d_nz = (unsigned *)ws_get(ctx, 2, nz_total * sizeof(unsigned));
+    RS_HIP(hipMemsetAsync(d_nz, 0, nz_total * sizeof(unsigned), st));
+  }
+  if (kinds_total) d_kinds = (uint8_t *)ws_get(ctx, 3, kinds_total);
+  {
+    size_t nzo = 0, ko = 0;
+    for (int v = 0; v < n_vecs; v++) {
+      PlainGroup &G = pa.g[vecs[v].group];
+      RS_REQUIRE(G.n < MAX_GROUP_VECS, "too many vectors in one group");
+      G.coeff[G.n] = vecs[v].d_coeff;
+      G.T[G.n] = vecs[v].T;
+      if (h_used) {
+        nz_ptr[v] = d_nz + nzo;
+        G.nz[G.n] = nz_ptr[v];
+        nzo += vecs[v].T;
+      }
+      if (vecs[v].h_kinds) {
+        RS_HIP(hipMemcpyAsync(d_kinds + ko, vecs[v].h_kinds, vecs[v].T, hipMemcpyHostToDevice, st));
+        G.kinds[G.n] = d_kinds + ko;
+        ko += vecs[v].T;
+      }
+      G.n++;
+    }
+  }
+
+  const int n_sets = n_crs * n_groups;
+  // tiling: C workspace <= ~2 GiB
+  const size_t c_bytes_per_term = (size_t)n_groups * L * n * sizeof(double);
+  size_t tile_terms = std::max<size_t>(1, std::min<size_t>(Tmax, ((size_t)2 << 30) / c_bytes_per_term));
+  int n_chunks = (int)std::min<size_t>(tile_terms, (size_t)std::max(1, (768 + L * K - 1) / (L * K)));
+  if (Tmax == 0) n_chunks = 1;
+  double *d_C = (double *)ws_get(ctx, 0, std::max<size_t>(256, tile_terms * c_bytes_per_term));
+  uint64_t *d_partial = (uint64_t *)ws_get(ctx, 1, (size_t)n_chunks * n_sets * enc_words * sizeof(uint64_t));
+  const size_t lds = padded_len((size_t)n) * sizeof(double);
+  const int thr = tile_threads(ctx->logN_enc);
+  const bool big = n > 8192;  // 16 elements per thread; one accumulator set per MAC launch
+  if (big)
+    RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  else
+    RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float mac_ms = 0;
+  int mac_launches = 0;
+  if (ctx->profiling) {
+    RS_HIP(hipEventCreate(&e0));
+    RS_HIP(hipEventCreate(&e1));
+  }
+  if (Tmax == 0) RS_HIP(hipMemsetAsync(d_partial, 0, (size_t)n_chunks * n_sets * enc_words * sizeof(uint64_t), st));
+
+  int tile_idx = 0;
+  for (size_t t0 = 0; t0 < Tmax; t0 += tile_terms, tile_idx++) {
+    const size_t tt = std::min(tile_terms, Tmax - t0);
+    if (big)
+      hipLaunchKernelGGL(plain_center_kernel<16>, dim3((unsigned)tt, L, n_groups), dim3(thr), lds, st, pa, d_C,
+                         (unsigned long long)t0, (unsigned long long)tile_terms, ctx->N, L, ctx->logN_enc,
+                         ctx->d_index_map, sc.d_plain_tabs);
+    else
+      hipLaunchKernelGGL(plain_center_kernel<8>, dim3((unsigned)tt, L, n_groups), dim3(thr), lds, st, pa, d_C,
+                         (unsigned long long)t0, (unsigned long long)tile_terms, ctx->N, L, ctx->logN_enc,
+                         ctx->d_index_map, sc.d_plain_tabs);
+    RS_HIP(hipGetLastError());
+    MacArgs base;
+    memset(&base, 0, sizeof(base));
+    base.partial = d_partial;
+    base.n_sets_total = n_sets;
+    base.tile_terms = tt;
+    base.n_chunks = n_chunks;
+    base.terms_per_chunk = (int)((tt + n_chunks - 1) / n_chunks);
+    base.accumulate = tile_idx > 0;
+    uint64_t maxQ = 0;
+    for (int j = 0; j < K; j++) maxQ = std::max(maxQ, ctx->Q[j]);
+    base.acc_period = (int)std::max(1.0, std::floor(4503599627370496.0 / (0.8 * (double)maxQ)) - 1.0);
+    base.acc_period = std::min(base.acc_period, 1 << 20);
+    base.reduce_u = maxQ >= (1ull << 45);
+    auto group_terms = [&](int g) -> unsigned long long {
+      return group_T[g] > t0 ? (unsigned long long)std::min(tt, group_T[g] - t0) : 0ull;
+    };
+    auto Cptr = [&](int g) { return d_C + (size_t)g * tile_terms * L * n; };
+    auto run = [&](int NG, int NC, const int *gs, const int *cs) {
+      MacArgs a = base;
+      for (int g = 0; g < NG; g++) {
+        a.C[g] = Cptr(gs[g]);
+        a.terms[g] = group_terms(gs[g]);
+      }
+      for (int c = 0; c < NC; c++) a.crs[c] = d_crs[cs[c]] + t0 * enc_words;
+      for (int c = 0; c < NC; c++)
+        for (int g = 0; g < NG; g++) a.set_index[c * NG + g] = cs[c] * n_groups + gs[g];
+      if (big)
+        launch_mac<1, 1, 8>(ctx, a, sc, st, e0, e1);
+      else if (NG == 2 && NC == 1)
+        launch_mac<2, 1, 4>(ctx, a, sc, st, e0, e1);
+      else if (NG == 1 && NC == 2)
+        launch_mac<1, 2, 4>(ctx, a, sc, st, e0, e1);
+      else
+        launch_mac<1, 1, 4>(ctx, a, sc, st, e0, e1);
+      if (e0) {
+        RS_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        RS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        mac_ms += ms;
+        mac_launches++;
+      }
+    };
+    if (big) {  // one (crs, group) pair per launch
+      for (int c = 0; c < n_crs; c++)
+        for (int g = 0; g < n_groups; g++) {
+          const int gs[1] = {g}, cs1[1] = {c};
+          run(1, 1, gs, cs1);
+        }
+    } else if (n_crs == 1) {  // share each ciphertext read between two groups
+      int g = 0;
+      const int c0[1] = {0};
+      for (; g + 1 < n_groups; g += 2) {
+        const int gs[2] = {g, g + 1};
+        run(2, 1, gs, c0);
+      }
+      if (g < n_groups) {
+        const int gs[1] = {g};
+        run(1, 1, gs, c0);
+      }
+    } else {  // two CRS vectors: share each plaintext NTT between them
+      const int cs[2] = {0, 1};
+      for (int g = 0; g < n_groups; g++) {
+        const int gs[1] = {g};
+        run(1, 2, gs, cs);
+      }
+    }
+  }
+  ReduceArgs ra;
+  memset(&ra, 0, sizeof(ra));
+  if (addends)
+    for (int s_ = 0; s_ < n_sets; s_++) ra.addend[s_] = addends[s_];
+  {
+    const size_t total = (size_t)n_sets * enc_words;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(256), 0, st, d_partial, d_out, ra, n_chunks, n_sets, enc_words, n,
+                       K, sc.d_Qint);
+    RS_HIP(hipGetLastError());
+  }
+  if (h_used) {
+    std::vector<unsigned> h(nz_total);
+    if (nz_total) RS_HIP(hipMemcpyAsync(h.data(), d_nz, nz_total * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    RS_HIP(hipStreamSynchronize(st));
+    size_t off = 0;
+    for (int v = 0; v < n_vecs; v++) {
+      size_t cnt = 0;
+      for (size_t t = 0; t < vecs[v].T; t++) cnt += h[off + t] != 0;
+      h_used[v] = cnt;
+      off += vecs[v].T;
+    }
+  }
+  if (ctx->profiling) {
+    RS_HIP(hipEventDestroy(e0));
+    RS_HIP(hipEventDestroy(e1));
+    ctx->timings.msm_mac_ms += mac_ms;
+    ctx->timings.msm_mac_launches += mac_launches;
+  }
+}
+
+void enc_add_run(rs_ctx *ctx, uint64_t *dst, const uint64_t *x, const uint64_t *y, size_t count, hipStream_t st) {
+  const size_t words = count * ctx->enc_words();
+  if (!words) return;
+  MsmScratch &sc = scratch_for(ctx);
+  const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(enc_add_kernel, dim3(blocks), dim3(256), 0, st, dst, x, y, words, ctx->N_enc, ctx->K, sc.d_Qint);
+  RS_HIP(hipGetLastError());
+}
+
+}  // namespace rs
+
+using namespace rs;
+
+extern "C" {
+
+int rs_batch_encode(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, size_t count, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_rings && d_plain, "null argument");
+  if (count) {
+    MsmScratch &sc = scratch_for(ctx);
+    const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(double);
+    RS_HIP(hipFuncSetAttribute((const void *)batch_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(batch_encode_kernel, dim3((unsigned)count, ctx->L), dim3(tile_threads(ctx->logN_enc)), lds,
+                       S(stream), d_rings, d_plain, ctx->N, ctx->L, ctx->logN_enc, ctx->d_index_map, sc.d_plain_tabs);
+    RS_HIP(hipGetLastError());
+  }
+  RS_API_END
+}
+
+int rs_msm(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
+           int n_groups, uint64_t *d_out, size_t *h_used, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_crs && vecs && d_out && n_vecs >= 1, "null argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  msm_run(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, nullptr, h_used, S(stream));
+  RS_API_END
+}
+
+int rs_inner_product(rs_ctx *ctx, const uint64_t *d_encs, const uint64_t *d_rings, const uint8_t *h_kinds, size_t T,
+                     uint64_t *d_out, size_t *h_used, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_out && (T == 0 || (d_encs && d_rings)), "null argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  rs_msm_vec v{d_rings, h_kinds, T, 0};
+  const uint64_t *crs[1] = {d_encs};
+  msm_run(ctx, crs, 1, T, &v, 1, 1, d_out, nullptr, h_used, S(stream));
+  RS_API_END
+}
+
+int rs_enc_mul_ring(rs_ctx *ctx, uint64_t *d_enc, const uint64_t *d_ring, size_t count, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_enc && d_ring, "null argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  uint64_t *tmp = (uint64_t *)ws_get(ctx, 4, ctx->enc_words() * sizeof(uint64_t));
+  for (size_t k = 0; k < count; k++) {
+    rs_msm_vec v{d_ring + k * ctx->ring_words(), nullptr, 1, 0};
+    const uint64_t *crs[1] = {d_enc + k * ctx->enc_words()};
+    msm_run(ctx, crs, 1, 1, &v, 1, 1, tmp, nullptr, nullptr, S(stream));
+    RS_HIP(hipMemcpyAsync(d_enc + k * ctx->enc_words(), tmp, ctx->enc_words() * sizeof(uint64_t),
+                          hipMemcpyDeviceToDevice, S(stream)));
+  }
+  RS_API_END
+}
+
+int rs_enc_add(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, const uint64_t *d_b, size_t count, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_dst && d_a && d_b, "null argument");
+  enc_add_run(ctx, d_dst, d_a, d_b, count, S(stream));
+  RS_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,470 @@
+// rs_core.hip -- context, twiddle tables, batched negacyclic NTT (row a4) and the dyadic RingElem
+// kernels (rows a1-a3) of SURVEY.md section 8.
+#include <algorithm>
+#include <cstring>
+
+#include "ntt_core.cuh"
+#include "rs_internal.hpp"
+
+namespace rs {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &m) { g_last_error = m; }
+
+void *ws_get(rs_ctx *ctx, int slot, size_t bytes) {
+  DeviceBuf &b = ctx->ws[slot];
+  if (b.bytes < bytes) {
+    if (b.p) RS_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    RS_HIP(hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+  }
+  return b.p;
+}
+
+// Stages before which every value must be brought back to |v| <= p/2 so that mulmod operands
+// stay below 2^50 (f64mod.hpp).  B tracks the worst-case magnitude in units of p.
+uint32_t fwd_reduce_mask(uint64_t p, int logn) {
+  const double lim = 1125899906842624.0 / (double)p;  // 2^50 / p
+  double B = 1.0;
+  uint32_t mask = 0;
+  for (int s = 0; s < logn; s++) {
+    if (B > lim) {
+      mask |= 1u << s;
+      B = 0.51;
+    }
+    B += 0.75;
+  }
+  return mask;
+}
+uint32_t inv_reduce_mask(uint64_t p, int logn) {
+  const double lim = 1125899906842624.0 / (double)p;
+  double B = 1.0;
+  uint32_t mask = 0;
+  for (int u = 0; u < logn; u++) {
+    if (2.0 * B > lim) {
+      mask |= 1u << u;
+      B = 0.51;
+    }
+    B = std::max(2.0 * B, 0.75);
+  }
+  return mask;
+}
+
+static double *upload_doubles(const std::vector<double> &h) {
+  double *d = nullptr;
+  RS_HIP(hipMalloc(&d, h.size() * sizeof(double)));
+  RS_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+  return d;
+}
+
+// SEAL NTTTables layout: root = minimal primitive 2n-th root psi, tw[bitrev(i)] = psi^i.
+NttTable make_negacyclic_table(uint64_t p, int logn) {
+  using namespace host;
+  NttTable t;
+  t.p = p;
+  t.mod = Mod{(double)p, 1.0 / (double)p};
+  t.logn = logn;
+  const size_t n = (size_t)1 << logn;
+  const uint64_t psi = minimal_primitive_root((uint64_t)2 << logn, p);
+  std::vector<double> tw(n), itw(n);
+  uint64_t pw = 1;
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t k = bitrev((uint32_t)i, logn);
+    tw[k] = balanced(pw, p);
+    itw[k] = balanced(invmod(pw, p), p);
+    pw = mulmod(pw, psi, p);
+  }
+  t.d_tw = upload_doubles(tw);
+  t.d_itw = upload_doubles(itw);
+  t.ninv = balanced(invmod((uint64_t)n % p, p), p);
+  t.fwd_red_mask = fwd_reduce_mask(p, logn);
+  t.inv_red_mask = inv_reduce_mask(p, logn);
+  return t;
+}
+void free_table(NttTable &t) {
+  if (t.d_tw) (void)hipFree(t.d_tw);
+  if (t.d_itw) (void)hipFree(t.d_itw);
+  t.d_tw = t.d_itw = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a4: batched negacyclic NTT.  One workgroup per polynomial; global <-> LDS traffic is one
+// coalesced 16-byte-per-lane read and one write of the polynomial (16*n algorithmic bytes).
+// ---------------------------------------------------------------------------------------------
+template <bool INV>
+__global__ void __launch_bounds__(1024) ntt_kernel(uint64_t *__restrict__ data, int logn,
+                                                   const double *__restrict__ tw, Mod mod, double ninv,
+                                                   uint32_t red_mask) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int n = 1 << logn;
+  uint64_t *poly = data + (size_t)blockIdx.x * n;
+  const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(poly);
+  for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
+    const ulonglong2 v = src[i];
+    const int pi = pidx(2 * i);
+    s[pi] = from_u64(v.x);
+    s[pi + 1] = from_u64(v.y);
+  }
+  __syncthreads();
+  if (INV)
+    lds_ntt_inv(s, logn, tw, 1, mod, red_mask);
+  else
+    lds_ntt_fwd(s, logn, tw, 1, mod, red_mask);
+  ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(poly);
+  for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
+    const int pi = pidx(2 * i);
+    double a = s[pi], b = s[pi + 1];
+    if (INV) {
+      a = mulmod(reduce(a, mod), ninv, mod);
+      b = mulmod(reduce(b, mod), ninv, mod);
+    }
+    ulonglong2 o;
+    o.x = to_u64(canon(a, mod));
+    o.y = to_u64(canon(b, mod));
+    dst[i] = o;
+  }
+}
+
+static int ntt_threads(int logn) {
+  const int n = 1 << logn;
+  return std::max(64, std::min(1024, n >> 3));
+}
+
+void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st) {
+  (void)ctx;
+  if (batch == 0) return;
+  const size_t lds = padded_len((size_t)1 << t.logn) * sizeof(double);
+  const int thr = ntt_threads(t.logn);
+  if (inverse) {
+    RS_HIP(hipFuncSetAttribute((const void *)ntt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ntt_kernel<true>, dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, t.d_itw, t.mod,
+                       t.ninv, t.inv_red_mask);
+  } else {
+    RS_HIP(hipFuncSetAttribute((const void *)ntt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ntt_kernel<false>, dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, t.d_tw, t.mod,
+                       t.ninv, t.fwd_red_mask);
+  }
+  RS_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// a1-a3: dyadic RingElem kernels on [count][L][N]; 16 bytes per lane, grid-stride.
+// ---------------------------------------------------------------------------------------------
+enum RingOp { OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_ADD_SCALAR, OP_MUL_SCALAR };
+
+struct ScalarPerLimb {
+  double v[RS_MAX_L];
+};
+
+template <int OP>
+__device__ __forceinline__ uint64_t ring_apply(uint64_t a, uint64_t b, double sc, const Mod m) {
+  const double x = from_u64(a);
+  double r;
+  if (OP == OP_ADD)
+    r = x + from_u64(b);
+  else if (OP == OP_SUB)
+    r = x - from_u64(b);
+  else if (OP == OP_MUL)
+    r = mulmod(x, center(from_u64(b), m), m);
+  else if (OP == OP_NEG)
+    r = -x;
+  else if (OP == OP_ADD_SCALAR)
+    r = x + sc;
+  else
+    r = mulmod(x, sc, m);
+  return to_u64(canon(r, m));
+}
+
+template <int OP>
+__global__ void __launch_bounds__(256) ring_pointwise_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ a,
+                                                             const uint64_t *__restrict__ b, size_t pairs, int N, int L,
+                                                             const Mod *__restrict__ qmod, ScalarPerLimb sc) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+    const int limb = (int)(((2 * i) / (size_t)N) % (size_t)L);
+    const Mod m = qmod[limb];
+    const ulonglong2 va = reinterpret_cast<const ulonglong2 *>(a)[i];
+    ulonglong2 vb = va;
+    if (OP == OP_ADD || OP == OP_SUB || OP == OP_MUL) vb = reinterpret_cast<const ulonglong2 *>(b)[i];
+    ulonglong2 o;
+    o.x = ring_apply<OP>(va.x, vb.x, sc.v[limb], m);
+    o.y = ring_apply<OP>(va.y, vb.y, sc.v[limb], m);
+    reinterpret_cast<ulonglong2 *>(dst)[i] = o;
+  }
+}
+
+template <int OP>
+static void launch_pointwise(rs_ctx *ctx, uint64_t *dst, const uint64_t *a, const uint64_t *b, size_t count,
+                             uint64_t scalar, hipStream_t st) {
+  const size_t pairs = count * ctx->ring_words() / 2;
+  if (!pairs) return;
+  ScalarPerLimb sc{};
+  for (int i = 0; i < ctx->L; i++) sc.v[i] = host::balanced(scalar % ctx->q[i], ctx->q[i]);
+  const unsigned blocks = (unsigned)std::min<size_t>((pairs + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(ring_pointwise_kernel<OP>, dim3(blocks), dim3(256), 0, st, dst, a, b, pairs, ctx->N, ctx->L,
+                     ctx->d_qmod, sc);
+  RS_HIP(hipGetLastError());
+}
+
+// slot-wise inverse by Fermat (a^(p-2)); flags[0] |= 1 if any slot is zero.
+__global__ void __launch_bounds__(256) ring_inv_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ a,
+                                                       size_t words, int N, int L, const Mod *__restrict__ qmod,
+                                                       const uint64_t *__restrict__ qint, unsigned *flags) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  bool any_zero = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) {
+    const int limb = (int)((i / (size_t)N) % (size_t)L);
+    const Mod m = qmod[limb];
+    const uint64_t e = qint[limb] - 2;
+    const uint64_t av = a[i];
+    any_zero |= (av == 0);
+    double base = center(from_u64(av), m), acc = 1.0;
+    for (int bit = 0; bit < 52; bit++) {
+      if ((e >> bit) & 1ull) acc = mulmod(acc, base, m);
+      base = mulmod(base, base, m);
+    }
+    dst[i] = to_u64(canon(acc, m));
+  }
+  if (any_zero) atomicOr(flags, 1u);
+}
+
+// per-element all-zero test: flags[k] = 1 if element k has a nonzero word
+__global__ void __launch_bounds__(256) ring_nonzero_kernel(const uint64_t *__restrict__ a, size_t words_per_elem,
+                                                           unsigned *__restrict__ flags) {
+  const uint64_t *e = a + (size_t)blockIdx.x * words_per_elem;
+  bool nz = false;
+  for (size_t i = threadIdx.x; i < words_per_elem; i += blockDim.x) nz |= (e[i] != 0);
+  if (__syncthreads_or(nz) && threadIdx.x == 0) flags[blockIdx.x] = 1u;
+}
+
+}  // namespace rs
+
+using namespace rs;
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char *rs_last_error(void) { return g_last_error.c_str(); }
+int rs_version(void) { return 100; }
+
+int rs_ctx_create(int device, int N, int L, const uint64_t *q, int N_enc, int K, const uint64_t *Q, rs_ctx **out) {
+  RS_API_BEGIN
+  RS_REQUIRE(out && q && Q, "null argument");
+  RS_REQUIRE(L >= 1 && L <= RS_MAX_L && K >= 1 && K <= RS_MAX_K, "L or K out of range");
+  RS_REQUIRE(N >= 2 && (N & (N - 1)) == 0 && N_enc >= N && (N_enc & (N_enc - 1)) == 0, "N, N_enc must be powers of two, N <= N_enc");
+  RS_REQUIRE(N_enc >= 16, "N_enc must be >= 16");
+  if (N_enc > 16384)
+    throw Error(RS_ERR_UNSUPPORTED, "N_enc > 16384 does not fit one workgroup's LDS tile (160 KiB); not built in this round");
+  int ndev = 0;
+  RS_HIP(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) throw Error(RS_ERR_HIP, "no HIP device: librs_hip has no CPU fallback");
+  RS_HIP(hipSetDevice(device));
+  for (int i = 0; i < L + K; i++) {
+    const uint64_t p = i < L ? q[i] : Q[i - L];
+    RS_REQUIRE(host::is_prime(p), "modulus is not prime");
+    RS_REQUIRE((p - 1) % (2 * (uint64_t)N_enc) == 0, "modulus must be 1 mod 2*N_enc (batching, seal_ring.hpp:297)");
+    if (p >= (1ull << 50))
+      throw Error(RS_ERR_UNSUPPORTED, "primes >= 2^50 need the integer Montgomery path, which is not built in this round");
+    for (int k = 0; k < i; k++) RS_REQUIRE(p != (k < L ? q[k] : Q[k - L]), "moduli must be pairwise distinct");
+  }
+  rs_ctx *c = new rs_ctx();
+  c->device = device;
+  c->N = N;
+  c->L = L;
+  c->N_enc = N_enc;
+  c->K = K;
+  c->logN_enc = 0;
+  while ((1 << c->logN_enc) < N_enc) c->logN_enc++;
+  std::vector<Mod> qm(L), Qm(K);
+  for (int i = 0; i < L; i++) {
+    c->q[i] = q[i];
+    c->plain[i] = make_negacyclic_table(q[i], c->logN_enc);
+    qm[i] = c->plain[i].mod;
+  }
+  for (int j = 0; j < K; j++) {
+    c->Q[j] = Q[j];
+    c->coeff[j] = make_negacyclic_table(Q[j], c->logN_enc);
+    Qm[j] = c->coeff[j].mod;
+  }
+  RS_HIP(hipMalloc(&c->d_qmod, sizeof(Mod) * L));
+  RS_HIP(hipMemcpy(c->d_qmod, qm.data(), sizeof(Mod) * L, hipMemcpyHostToDevice));
+  RS_HIP(hipMalloc(&c->d_Qmod, sizeof(Mod) * K));
+  RS_HIP(hipMemcpy(c->d_Qmod, Qm.data(), sizeof(Mod) * K, hipMemcpyHostToDevice));
+  // BatchEncoder slot map (SEAL batchencoder.cpp populate_matrix_reps_index_map): generator 3
+  // of Z_{2n}^*, row 0 = powers 3^i, row 1 = their negatives, bit-reversed positions.
+  {
+    std::vector<uint32_t> map(N_enc);
+    const uint64_t mm = (uint64_t)N_enc << 1;
+    const size_t row = (size_t)N_enc >> 1;
+    uint64_t pos = 1;
+    for (size_t i = 0; i < row; i++) {
+      map[i] = host::bitrev((uint32_t)((pos - 1) >> 1), c->logN_enc);
+      map[row | i] = host::bitrev((uint32_t)((mm - pos - 1) >> 1), c->logN_enc);
+      pos = (pos * 3) & (mm - 1);
+    }
+    RS_HIP(hipMalloc(&c->d_index_map, sizeof(uint32_t) * N_enc));
+    RS_HIP(hipMemcpy(c->d_index_map, map.data(), sizeof(uint32_t) * N_enc, hipMemcpyHostToDevice));
+  }
+  *out = c;
+  RS_API_END
+}
+
+void rs_witness_plans_destroy(rs_ctx *ctx);  // witness.hip
+
+void rs_ctx_destroy(rs_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  rs_witness_plans_destroy(c);
+  rs::msm_scratch_release(c);
+  for (int i = 0; i < c->L; i++) free_table(c->plain[i]);
+  for (int j = 0; j < c->K; j++) free_table(c->coeff[j]);
+  if (c->d_qmod) (void)hipFree(c->d_qmod);
+  if (c->d_Qmod) (void)hipFree(c->d_Qmod);
+  if (c->d_index_map) (void)hipFree(c->d_index_map);
+  for (auto &b : c->ws)
+    if (b.p) (void)hipFree(b.p);
+  delete c;
+}
+
+int rs_malloc(rs_ctx *ctx, size_t bytes, void **d_ptr) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_ptr, "null argument");
+  RS_HIP(hipSetDevice(ctx->device));
+  RS_HIP(hipMalloc(d_ptr, bytes));
+  RS_API_END
+}
+int rs_free(rs_ctx *ctx, void *d_ptr) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx, "null argument");
+  if (d_ptr) RS_HIP(hipFree(d_ptr));
+  RS_API_END
+}
+int rs_upload(rs_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx, "null argument");
+  RS_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, S(stream)));
+  RS_HIP(hipStreamSynchronize(S(stream)));
+  RS_API_END
+}
+int rs_download(rs_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx, "null argument");
+  RS_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, S(stream)));
+  RS_HIP(hipStreamSynchronize(S(stream)));
+  RS_API_END
+}
+int rs_sync(rs_ctx *ctx, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx, "null argument");
+  RS_HIP(hipStreamSynchronize(S(stream)));
+  RS_API_END
+}
+
+static const NttTable &pick_table(rs_ctx *ctx, int modset, int index) {
+  RS_REQUIRE(ctx, "null context");
+  if (modset == RS_MOD_PLAIN) {
+    RS_REQUIRE(index >= 0 && index < ctx->L, "limb index out of range");
+    return ctx->plain[index];
+  }
+  RS_REQUIRE(modset == RS_MOD_COEFF && index >= 0 && index < ctx->K, "prime index out of range");
+  return ctx->coeff[index];
+}
+
+int rs_ntt_forward(rs_ctx *ctx, int modset, int index, uint64_t *d_data, size_t batch, rs_stream stream) {
+  RS_API_BEGIN
+  launch_ntt(ctx, pick_table(ctx, modset, index), d_data, batch, false, S(stream));
+  RS_API_END
+}
+int rs_ntt_inverse(rs_ctx *ctx, int modset, int index, uint64_t *d_data, size_t batch, rs_stream stream) {
+  RS_API_BEGIN
+  launch_ntt(ctx, pick_table(ctx, modset, index), d_data, batch, true, S(stream));
+  RS_API_END
+}
+
+#define RS_POINTWISE(NAME, OP, HAS_B)                                                                        \
+  int NAME(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, const uint64_t *d_b, size_t count, rs_stream s) { \
+    RS_API_BEGIN                                                                                             \
+    RS_REQUIRE(ctx && d_dst && d_a && (d_b || !HAS_B), "null argument");                                     \
+    launch_pointwise<OP>(ctx, d_dst, d_a, d_b, count, 0, S(s));                                              \
+    RS_API_END                                                                                               \
+  }
+RS_POINTWISE(rs_ring_add, OP_ADD, true)
+RS_POINTWISE(rs_ring_sub, OP_SUB, true)
+RS_POINTWISE(rs_ring_mul, OP_MUL, true)
+
+int rs_ring_neg(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, size_t count, rs_stream s) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_dst && d_a, "null argument");
+  launch_pointwise<OP_NEG>(ctx, d_dst, d_a, nullptr, count, 0, S(s));
+  RS_API_END
+}
+int rs_ring_add_scalar(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, uint64_t scalar, size_t count, rs_stream s) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_dst && d_a, "null argument");
+  launch_pointwise<OP_ADD_SCALAR>(ctx, d_dst, d_a, nullptr, count, scalar, S(s));
+  RS_API_END
+}
+int rs_ring_mul_scalar(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, uint64_t scalar, size_t count, rs_stream s) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_dst && d_a, "null argument");
+  launch_pointwise<OP_MUL_SCALAR>(ctx, d_dst, d_a, nullptr, count, scalar, S(s));
+  RS_API_END
+}
+
+int rs_ring_inv(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, size_t count, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_dst && d_a, "null argument");
+  const size_t words = count * ctx->ring_words();
+  if (words) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    char *ws = (char *)ws_get(ctx, 7, 256);
+    unsigned *flags = (unsigned *)ws;
+    uint64_t *qint = (uint64_t *)(ws + 64);
+    RS_HIP(hipMemsetAsync(flags, 0, 4, S(stream)));
+    RS_HIP(hipMemcpyAsync(qint, ctx->q, sizeof(uint64_t) * ctx->L, hipMemcpyHostToDevice, S(stream)));
+    const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(ring_inv_kernel, dim3(blocks), dim3(256), 0, S(stream), d_dst, d_a, words, ctx->N, ctx->L,
+                       ctx->d_qmod, qint, flags);
+    unsigned h = 0;
+    RS_HIP(hipMemcpyAsync(&h, flags, 4, hipMemcpyDeviceToHost, S(stream)));
+    RS_HIP(hipStreamSynchronize(S(stream)));
+    if (h) throw Error(RS_ERR_NOT_INVERTIBLE, "element is not invertible in ring");
+  }
+  RS_API_END
+}
+
+int rs_ring_is_zero(rs_ctx *ctx, const uint64_t *d_a, size_t count, uint8_t *h_flags, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_a && h_flags, "null argument");
+  if (count) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    unsigned *flags = (unsigned *)ws_get(ctx, 7, std::max<size_t>(256, count * 4));
+    RS_HIP(hipMemsetAsync(flags, 0, count * 4, S(stream)));
+    hipLaunchKernelGGL(ring_nonzero_kernel, dim3((unsigned)count), dim3(256), 0, S(stream), d_a, ctx->ring_words(), flags);
+    std::vector<unsigned> h(count);
+    RS_HIP(hipMemcpyAsync(h.data(), flags, count * 4, hipMemcpyDeviceToHost, S(stream)));
+    RS_HIP(hipStreamSynchronize(S(stream)));
+    for (size_t k = 0; k < count; k++) h_flags[k] = h[k] ? 0 : 1;
+  }
+  RS_API_END
+}
+
+int rs_set_profiling(rs_ctx *ctx, int enabled) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx, "null argument");
+  ctx->profiling = enabled != 0;
+  RS_API_END
+}
+int rs_last_timings(rs_ctx *ctx, rs_timings *out) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && out, "null argument");
+  *out = ctx->timings;
+  RS_API_END
+}
+
+}  // extern "C"

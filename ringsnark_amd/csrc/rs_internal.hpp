@@ -1,0 +1,117 @@
+// rs_internal.hpp -- shared internals of librs_hip.so (context, tables, error handling).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ringsnark_amd.h"
+#include "f64mod.hpp"
+#include "host_math.hpp"
+
+namespace rs {
+
+// ---- errors ---------------------------------------------------------------------------------
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+void set_last_error(const std::string &m);
+#define RS_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      throw rs::Error(RS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+  } while (0)
+#define RS_REQUIRE(cond, msg)                                 \
+  do {                                                        \
+    if (!(cond)) throw rs::Error(RS_ERR_INVALID, (msg));      \
+  } while (0)
+// wraps a C-ABI body
+#define RS_API_BEGIN try {
+#define RS_API_END                                   \
+  return RS_OK;                                      \
+  }                                                  \
+  catch (const rs::Error &e) {                       \
+    rs::set_last_error(e.what());                    \
+    return e.code;                                   \
+  }                                                  \
+  catch (const std::exception &e) {                  \
+    rs::set_last_error(e.what());                    \
+    return RS_ERR_INVALID;                           \
+  }
+
+// ---- twiddle tables -------------------------------------------------------------------------
+// One table per (prime, transform length n).  tw[k] for k in [1,n): the butterfly twiddle of
+// node k of the radix-2 decimation tree (stage with M groups, group i -> k = M + i), balanced
+// doubles.  Negacyclic tables: tw[k] = psi^{bitrev(k, log n)}  (SEAL NTTTables order).
+// Cyclic tables (witness map): tw[M+i] = w_{2M}^{bitrev(i, log M)}, independent of n.
+struct NttTable {
+  uint64_t p = 0;
+  Mod mod{0, 0};
+  int logn = 0;
+  double *d_tw = nullptr;   // forward, n entries (entry 0 unused)
+  double *d_itw = nullptr;  // inverse twiddles (element-wise inverses)
+  double ninv = 0;          // n^{-1} mod p, balanced
+  uint32_t fwd_red_mask = 0, inv_red_mask = 0;  // stages before which values are re-reduced
+};
+
+struct DeviceBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+};
+
+struct WitnessPlan;  // witness.hip
+struct R1cs;         // r1cs in CSR on device
+
+}  // namespace rs
+
+struct rs_r1cs {
+  size_t m = 0, n_vars = 0, n_inputs = 0;
+  int L = 0;
+  uint32_t *d_row_ptr[3] = {nullptr, nullptr, nullptr};
+  uint32_t *d_col[3] = {nullptr, nullptr, nullptr};
+  double *d_coeff[3] = {nullptr, nullptr, nullptr};  // [L][nnz] balanced doubles
+  size_t nnz[3] = {0, 0, 0};
+  std::vector<uint64_t> h_const[3];  // [L][m] sum of the index-0 (constant-one) coefficients per row
+  bool has_const[3] = {false, false, false};
+};
+
+struct rs_ctx {
+  int device = 0;
+  int N = 0, L = 0, N_enc = 0, K = 0, logN_enc = 0;
+  uint64_t q[RS_MAX_L] = {0}, Q[RS_MAX_K] = {0};
+  rs::NttTable plain[RS_MAX_L];  // mod q_i, length N_enc
+  rs::NttTable coeff[RS_MAX_K];  // mod Q_j, length N_enc
+  uint32_t *d_index_map = nullptr;  // BatchEncoder slot map, first N entries used
+  // constant device arrays of per-limb / per-prime moduli for pointwise kernels
+  rs::Mod *d_qmod = nullptr;  // [L]
+  rs::Mod *d_Qmod = nullptr;  // [K]
+  std::mutex mu;
+  std::map<size_t, rs::WitnessPlan *> plans;  // keyed by padded domain size M
+  // workspace cache (grown on demand, per context; calls that need workspace serialise on mu)
+  rs::DeviceBuf ws[16];
+  bool profiling = false;
+  rs_timings timings{};
+  size_t ring_words() const { return (size_t)L * N; }
+  size_t ct_words() const { return (size_t)2 * K * N_enc; }
+  size_t enc_words() const { return (size_t)L * 2 * K * N_enc; }
+};
+
+namespace rs {
+void *ws_get(rs_ctx *ctx, int slot, size_t bytes);
+NttTable make_negacyclic_table(uint64_t p, int logn);
+void free_table(NttTable &t);
+uint32_t fwd_reduce_mask(uint64_t p, int logn);
+uint32_t inv_reduce_mask(uint64_t p, int logn);
+inline hipStream_t S(rs_stream s) { return (hipStream_t)s; }
+
+// launch helpers implemented in the .hip files
+void msm_scratch_release(rs_ctx *ctx);  // msm.hip
+void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st);
+}  // namespace rs

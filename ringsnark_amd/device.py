@@ -1,0 +1,276 @@
+"""Device context: the Python host side above the C ABI (include/ringsnark_amd.h).
+
+PyTorch is used for what it is good at here -- device memory, streams, torch.distributed -- and
+nothing else: every arithmetic operation goes through librs_hip.so.  Residues live in int64 CUDA
+tensors (bit-identical to the uint64 boundary layout; all values are < 2^50).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .params import RingParams
+from .r1cs import R1CS
+
+
+def to_device(a: np.ndarray, device) -> torch.Tensor:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to(device)
+
+
+def to_host(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().contiguous().numpy().view(np.uint64)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous() and t.dtype == torch.int64, (t.device, t.dtype, t.is_contiguous())
+    return C.c_void_p(t.data_ptr())
+
+
+class DeviceR1CS:
+    def __init__(self, dev, cs: R1CS):
+        self.dev, self.cs = dev, cs
+        self.m, self.n_vars, self.n_inputs = cs.m, cs.n_vars, cs.n_inputs
+        rp = (_lib.u32p * 3)()
+        col = (_lib.u32p * 3)()
+        cf = (_lib.u64p * 3)()
+        nnz = (C.c_size_t * 3)()
+        keep = []
+        for k, name in enumerate("abc"):
+            r, c, f = cs.mats[name]
+            r = np.ascontiguousarray(r, dtype=np.uint32)
+            c = np.ascontiguousarray(c, dtype=np.uint32)
+            f = np.ascontiguousarray(f, dtype=np.uint64)
+            assert f.shape == (dev.L, c.shape[0])
+            keep += [r, c, f]
+            rp[k] = r.ctypes.data_as(_lib.u32p)
+            col[k] = c.ctypes.data_as(_lib.u32p)
+            cf[k] = f.ctypes.data_as(_lib.u64p)
+            nnz[k] = c.shape[0]
+        h = C.c_void_p()
+        _lib.check(dev.lib.rs_r1cs_create(dev.h, cs.m, cs.n_vars, cs.n_inputs, rp, col, cf, nnz, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.dev.lib is not None:
+            self.dev.lib.rs_r1cs_destroy(self.h)
+            self.h = None
+
+
+class Device:
+    """rs_ctx wrapper.  Mirrors RingElem::set_context + EncodingElem::set_context
+    (seal/seal_ring.hpp:52-58, 266-320): one object per (process, GPU)."""
+
+    def __init__(self, prm: RingParams, device_index: int = 0):
+        self.lib = _lib.load()  # raises if librs_hip.so is missing -- no fallback
+        if not torch.cuda.is_available():
+            raise RuntimeError("ringsnark_amd needs a HIP device (torch.cuda.is_available() is False)")
+        self.prm = prm
+        self.N, self.L, self.N_enc, self.K = prm.N, prm.L, prm.N_enc, prm.K
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        q = (C.c_uint64 * self.L)(*prm.q)
+        Q = (C.c_uint64 * self.K)(*prm.Q)
+        h = C.c_void_p()
+        _lib.check(self.lib.rs_ctx_create(device_index, self.N, self.L, q, self.N_enc, self.K, Q, C.byref(h)))
+        self.h = h
+        self.ring_words, self.enc_words = prm.ring_words, prm.enc_words
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.lib is not None:
+            self.lib.rs_ctx_destroy(self.h)
+            self.h = None
+
+    # ---- helpers
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def ring_empty(self, *lead):
+        return torch.empty(tuple(lead) + (self.L, self.N), dtype=torch.int64, device=self.device)
+
+    def enc_empty(self, *lead):
+        return torch.empty(tuple(lead) + (self.L, 2, self.K, self.N_enc), dtype=torch.int64, device=self.device)
+
+    def put(self, a):
+        return to_device(a, self.device)
+
+    def sync(self):
+        _lib.check(self.lib.rs_sync(self.h, self.stream()))
+
+    @staticmethod
+    def _count(t, words):
+        assert t.numel() % words == 0
+        return t.numel() // words
+
+    # ---- a4
+    def ntt(self, data, modset, index, inverse=False):
+        """In-place batched negacyclic NTT over [batch][N_enc]."""
+        batch = self._count(data, self.N_enc)
+        fn = self.lib.rs_ntt_inverse if inverse else self.lib.rs_ntt_forward
+        _lib.check(fn(self.h, modset, index, _ptr(data), batch, self.stream()))
+        return data
+
+    # ---- a1-a3
+    def _bin(self, fn, a, b):
+        out = torch.empty_like(a)
+        _lib.check(fn(self.h, _ptr(out), _ptr(a), _ptr(b), self._count(a, self.ring_words), self.stream()))
+        return out
+
+    def ring_add(self, a, b):
+        return self._bin(self.lib.rs_ring_add, a, b)
+
+    def ring_sub(self, a, b):
+        return self._bin(self.lib.rs_ring_sub, a, b)
+
+    def ring_mul(self, a, b):
+        return self._bin(self.lib.rs_ring_mul, a, b)
+
+    def ring_neg(self, a):
+        out = torch.empty_like(a)
+        _lib.check(self.lib.rs_ring_neg(self.h, _ptr(out), _ptr(a), self._count(a, self.ring_words), self.stream()))
+        return out
+
+    def ring_add_scalar(self, a, s):
+        out = torch.empty_like(a)
+        _lib.check(self.lib.rs_ring_add_scalar(self.h, _ptr(out), _ptr(a), s, self._count(a, self.ring_words), self.stream()))
+        return out
+
+    def ring_mul_scalar(self, a, s):
+        out = torch.empty_like(a)
+        _lib.check(self.lib.rs_ring_mul_scalar(self.h, _ptr(out), _ptr(a), s, self._count(a, self.ring_words), self.stream()))
+        return out
+
+    def ring_inv(self, a):
+        """Raises RsError(RS_ERR_NOT_INVERTIBLE, "element is not invertible in ring")."""
+        out = torch.empty_like(a)
+        _lib.check(self.lib.rs_ring_inv(self.h, _ptr(out), _ptr(a), self._count(a, self.ring_words), self.stream()))
+        return out
+
+    def ring_is_zero(self, a):
+        count = self._count(a, self.ring_words)
+        flags = (C.c_uint8 * count)()
+        _lib.check(self.lib.rs_ring_is_zero(self.h, _ptr(a), count, flags, self.stream()))
+        return [bool(f) for f in flags]
+
+    # ---- a5-a8
+    def batch_encode(self, rings):
+        count = self._count(rings, self.ring_words)
+        out = torch.empty((count, self.L, self.N_enc), dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.rs_batch_encode(self.h, _ptr(rings), _ptr(out), count, self.stream()))
+        return out
+
+    def enc_mul_ring(self, enc, ring):
+        enc = enc.clone()
+        _lib.check(self.lib.rs_enc_mul_ring(self.h, _ptr(enc), _ptr(ring), self._count(enc, self.enc_words), self.stream()))
+        return enc
+
+    def enc_add(self, a, b):
+        out = torch.empty_like(a)
+        _lib.check(self.lib.rs_enc_add(self.h, _ptr(out), _ptr(a), _ptr(b), self._count(a, self.enc_words), self.stream()))
+        return out
+
+    # ---- a9
+    def inner_product(self, encs, rings, kinds=None, want_used=True):
+        """EncodingElem::inner_product.  Returns (out, used); used == 0 <=> EMPTY element."""
+        T = self._count(rings, self.ring_words)
+        assert self._count(encs, self.enc_words) == T
+        out = self.enc_empty()
+        used = C.c_size_t(0)
+        kp = None
+        if kinds is not None:
+            kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
+            kp = kinds.ctypes.data_as(_lib.u8p)
+        _lib.check(self.lib.rs_inner_product(self.h, _ptr(encs), _ptr(rings), kp, T, _ptr(out),
+                                             C.byref(used) if want_used else None, self.stream()))
+        return out, int(used.value)
+
+    def msm(self, crs_list, vecs, n_groups, want_used=False):
+        """vecs: list of (coeff tensor [T][L][N], kinds or None, group)."""
+        n_crs = len(crs_list)
+        crs_len = self._count(crs_list[0], self.enc_words)
+        crs = (C.c_void_p * n_crs)(*[c.data_ptr() for c in crs_list])
+        mv = (_lib.MsmVec * len(vecs))()
+        keep = []
+        for k, (coeff, kinds, group) in enumerate(vecs):
+            mv[k].d_coeff = coeff.data_ptr()
+            mv[k].T = self._count(coeff, self.ring_words)
+            mv[k].group = group
+            if kinds is not None:
+                kk = np.ascontiguousarray(kinds, dtype=np.uint8)
+                keep.append(kk)
+                mv[k].h_kinds = kk.ctypes.data_as(_lib.u8p)
+        out = self.enc_empty(n_crs, n_groups)
+        used = (C.c_size_t * len(vecs))()
+        _lib.check(self.lib.rs_msm(self.h, crs, n_crs, crs_len, mv, len(vecs), n_groups, _ptr(out),
+                                   used if want_used else None, self.stream()))
+        return out, [int(u) for u in used]
+
+    # ---- a10-a14
+    def r1cs(self, cs: R1CS):
+        return DeviceR1CS(self, cs)
+
+    def r1cs_evaluate(self, dcs, which, mode, assignment):
+        out = self.ring_empty(dcs.m)
+        _lib.check(self.lib.rs_r1cs_evaluate(self.h, dcs.h, which, mode, _ptr(assignment), _ptr(out), self.stream()))
+        return out
+
+    def interpolate(self, y):
+        n = self._count(y, self.ring_words)
+        out = torch.empty_like(y)
+        _lib.check(self.lib.rs_interpolate(self.h, _ptr(y), _ptr(out), n, self.stream()))
+        return out
+
+    def witness_map(self, dcs, assignment, d1=None, d2=None, d3=None, want=("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")):
+        m = dcs.m
+        o = {}
+        for k in ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid"):
+            o[k] = self.ring_empty(m) if k in want else None
+        o["H"] = self.ring_empty(m + 1) if "H" in want else None
+        Z = np.zeros((self.L, m + 1), dtype=np.uint64)
+        _lib.check(self.lib.rs_witness_map(
+            self.h, dcs.h, _ptr(assignment), _ptr(d1), _ptr(d2), _ptr(d3), _ptr(o["A_io"]), _ptr(o["B_io"]), _ptr(o["C_io"]),
+            _ptr(o["A_mid"]), _ptr(o["B_mid"]), _ptr(o["C_mid"]), _ptr(o["H"]), Z.ctypes.data_as(_lib.u64p), self.stream()))
+        o["Z"] = Z
+        return o
+
+    # ---- a15 / a16
+    def groth16_prove(self, dcs, pk, assignment, want_empty=True):
+        """pk: dict s_pows, delta_ts, delta_mid, alpha, beta (CUDA tensors)."""
+        s = _lib.Groth16PK(pk["s_pows"].data_ptr(), pk["delta_ts"].data_ptr(),
+                           pk["delta_mid"].data_ptr() if pk.get("delta_mid") is not None else None,
+                           pk["alpha"].data_ptr(), pk["beta"].data_ptr())
+        proof = self.enc_empty(3)
+        empty = (C.c_int * 3)()
+        _lib.check(self.lib.rs_groth16_prove(self.h, dcs.h, C.byref(s), _ptr(assignment), _ptr(proof),
+                                             empty if want_empty else None, self.stream()))
+        return proof, [int(e) for e in empty]
+
+    def rinocchio_prove(self, dcs, pk, assignment, d1=None, d2=None, d3=None):
+        g = lambda k: pk[k].data_ptr() if pk.get(k) is not None else None
+        s = _lib.RinocchioPK(g("s_pows"), g("alpha_s_pows"), g("beta_prods"), g("beta_rv_ts"), g("beta_rw_ts"), g("beta_ry_ts"))
+        proof = self.enc_empty(9)
+        empty = (C.c_int * 9)()
+        _lib.check(self.lib.rs_rinocchio_prove(self.h, dcs.h, C.byref(s), _ptr(assignment), _ptr(d1), _ptr(d2), _ptr(d3),
+                                               _ptr(proof), empty, self.stream()))
+        return proof, [int(e) for e in empty]
+
+    # ---- measurement / synthetic workloads
+    def set_profiling(self, on):
+        _lib.check(self.lib.rs_set_profiling(self.h, 1 if on else 0))
+
+    def last_timings(self):
+        t = _lib.Timings()
+        _lib.check(self.lib.rs_last_timings(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _lib.Timings._fields_}
+
+    def fill_uniform(self, t, layout, seed):
+        words = self.ring_words if layout == 0 else self.enc_words
+        _lib.check(self.lib.rs_fill_uniform(self.h, _ptr(t), self._count(t, words), layout, seed, self.stream()))
+        return t
+
+    def chain_assignment(self, assignment, m):
+        _lib.check(self.lib.rs_chain_assignment(self.h, _ptr(assignment), m, self.stream()))
+        return assignment

@@ -157,6 +157,9 @@ def preset(name: str) -> RingParams:
                            ring_factor=1 << 20, name="C4")
     if name == "C5":  # logistic regression as in the reference file: N=2048 L=1, N_enc=16384 K=8
         return make_params(2048, BFV_DEFAULT_BITS[2048], 16384, BFV_DEFAULT_BITS[16384][:-1], name="C5")
+    if name == "C5s":  # C5's shape with a 49-bit ring prime (the FP64 arithmetic path needs q < 2^50)
+        return make_params(2048, [49], 16384, BFV_DEFAULT_BITS[16384][:-1], name="C5s",
+                           notes="C5 with the 54-bit BFVDefault(2048) prime replaced by a 49-bit one")
     if name == "toy":  # CPU-test scale
         return make_params(32, [30, 30], 64, [40, 40, 41], name="toy")
     if name == "toy49":  # stresses the 50-bit bound of the FP64 modmul path

@@ -1,0 +1,57 @@
+"""The C-ABI library loads and exports every symbol include/ringsnark_amd.h declares (no compute:
+there is no GPU here), and the host logic around it."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ringsnark_amd import params as P
+from ringsnark_amd import r1cs as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ringsnark_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "ringsnark_amd.h")).read()
+    declared = set(re.findall(r"\b(rs_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"rs_stream"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.rs_version() >= 100
+
+
+def test_ctx_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ringsnark_amd.device import Device
+    with pytest.raises(RuntimeError):
+        Device(P.preset("toy"))
+
+
+def test_presets_are_consistent():
+    for name in ("C1", "C2", "C3", "C4", "C5", "C5s", "toy", "toy49"):
+        prm = P.preset(name).validate()
+        if name != "C5":  # BFVDefault(2048) is one 54-bit prime: needs the (unbuilt) integer path
+            assert all(p < (1 << 50) for p in prm.q + prm.Q)
+    c3 = P.preset("C3")
+    assert (c3.N, c3.L, c3.N_enc, c3.K) == (8192, 4, 8192, 4)
+    assert c3.max_constraints_fast() >= 1 << 18
+    assert P.preset("C2").q == P.coeff_modulus_create(16384, [36, 36])
+
+
+def test_chain_and_wide_r1cs_shapes():
+    q = P.preset("toy").q
+    cs = R.chain_r1cs(5, q)
+    assert (cs.m, cs.n_vars, cs.n_inputs, cs.n_aux) == (5, 7, 2, 5)
+    assert [int(x) for x in cs.mats["a"][1]] == [1, 2, 3, 4, 5]
+    w = R.wide_r1cs(5, q)
+    assert w.mats["a"][2].shape == (len(q), 45)
+    assert (w.mats["a"][1] == 0).sum() == 5  # one constant-one term per row
+    neg = (w.mats["a"][2][0] > q[0] // 2).any()
+    assert neg  # negative literals are stored as q - |c|

@@ -1,0 +1,211 @@
+"""HIP path vs the CPU oracle, through the C ABI (librs_hip.so).  Bit-exact: every comparison is
+an integer array equality.  Needs a real MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from ringsnark_amd import params as P
+from ringsnark_amd import r1cs as R
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+_DEV = {}
+
+
+def dev_for(name):
+    from ringsnark_amd.device import Device
+    if name not in _DEV:
+        _DEV[name] = Device(P.preset(name))
+    return _DEV[name]
+
+
+def host(t):
+    from ringsnark_amd.device import to_host
+    return to_host(t)
+
+
+@pytest.mark.parametrize("name", ["toy", "toy49", "C2", "C3", "C5s"])
+def test_ntt_matches_oracle(name):
+    from ringsnark_amd import _lib
+    dev = dev_for(name)
+    prm = dev.prm
+    logn = prm.N_enc.bit_length() - 1
+    rng = np.random.RandomState(1)
+    for modset, primes in ((_lib.RS_MOD_PLAIN, prm.q), (_lib.RS_MOD_COEFF, prm.Q)):
+        for idx, p in enumerate(primes):
+            t = O.NTT(logn, p)
+            batch = 3
+            a = (rng.randint(0, 2**62, size=(batch, prm.N_enc), dtype=np.int64).astype(np.uint64)) % np.uint64(p)
+            a[0, :4] = [0, 1, p - 1, p // 2]
+            d = dev.put(a)
+            dev.ntt(d, modset, idx)
+            got = host(d)
+            for b in range(batch):
+                assert (got[b] == t.fwd(a[b])).all(), (name, modset, idx, b)
+            dev.ntt(d, modset, idx, inverse=True)
+            assert (host(d) == a).all()
+
+
+@pytest.mark.parametrize("name", ["toy", "toy49", "C2"])
+def test_ring_ops_match_oracle(name):
+    dev = dev_for(name)
+    ctx = H.oracle_ctx(dev.prm)
+    a, b = ctx.random_ring(11, 5), ctx.random_ring(12, 5)
+    a[0, :, :3] = 0
+    b[1] = 0
+    da, db = dev.put(a), dev.put(b)
+    assert (host(dev.ring_add(da, db)) == ctx.ring_add(a, b)).all()
+    assert (host(dev.ring_sub(da, db)) == ctx.ring_sub(a, b)).all()
+    assert (host(dev.ring_mul(da, db)) == ctx.ring_mul(a, b)).all()
+    assert (host(dev.ring_neg(da)) == ctx.ring_neg(a)).all()
+    for s in (0, 1, 3, 2**40 + 12345, 2**63 + 99):
+        assert (host(dev.ring_mul_scalar(da, s)) == ctx.ring_mul_scalar(a, s)).all()
+    assert dev.ring_is_zero(db) == [False, True, False, False, False]
+    inv_in = ctx.random_ring(13, 2)
+    inv_in[inv_in == 0] = 1
+    exp, ok = ctx.ring_inv(inv_in)
+    assert ok and (host(dev.ring_inv(dev.put(inv_in))) == exp).all()
+    from ringsnark_amd._lib import RsError, RS_ERR_NOT_INVERTIBLE
+    with pytest.raises(RsError) as ei:
+        dev.ring_inv(da)  # has zero slots
+    assert ei.value.code == RS_ERR_NOT_INVERTIBLE and "not invertible in ring" in str(ei.value)
+
+
+@pytest.mark.parametrize("name", ["toy", "toy49", "C2"])
+def test_batch_encode_and_enc_ops(name):
+    dev = dev_for(name)
+    ctx = H.oracle_ctx(dev.prm)
+    r = ctx.random_ring(21, 2)
+    got = host(dev.batch_encode(dev.put(r)))
+    for k in range(2):
+        for i in range(ctx.L):
+            assert (got[k, i] == ctx.batch_encode(i, r[k, i])).all()
+    e = ctx.random_enc(22, 2)
+    de = dev.put(e)
+    got = host(dev.enc_mul_ring(de, dev.put(r)))
+    for k in range(2):
+        assert (got[k] == ctx.enc_mul_ring(e[k], r[k])).all()
+    assert (host(dev.enc_add(de[0], de[1])) == ctx.enc_add(e[0], e[1])).all()
+
+
+@pytest.mark.parametrize("name,T", [("toy", 1), ("toy", 37), ("toy49", 50), ("C2", 5)])
+def test_inner_product_matches_oracle(name, T):
+    dev = dev_for(name)
+    ctx = H.oracle_ctx(dev.prm)
+    encs, rings = ctx.random_enc(31, T), ctx.random_ring(32, T)
+    kinds = np.zeros(T, dtype=np.uint8)
+    if T > 4:
+        rings[2] = 0           # is_zero term: skipped
+        rings[3, 0] = 0        # one limb zero only: NOT skipped
+        kinds[4] = O.KIND_ONE  # Scalar-1 fast path
+    exp, used = ctx.inner_product(encs, rings, kinds)
+    got, gused = dev.inner_product(dev.put(encs), dev.put(rings), kinds)
+    assert gused == used
+    assert (host(got) == exp).all()
+    # all-zero -> EMPTY
+    got0, u0 = dev.inner_product(dev.put(encs), dev.put(np.zeros_like(rings)))
+    assert u0 == 0 and not host(got0).any()
+
+
+def test_grouped_msm_equals_sum_of_inner_products():
+    dev = dev_for("toy")
+    ctx = H.oracle_ctx(dev.prm)
+    T = 23
+    crs0, crs1 = ctx.random_enc(41, T), ctx.random_enc(42, T)
+    v = [ctx.random_ring(43 + k, T) for k in range(3)]
+    vshort = ctx.random_ring(47, T - 5)
+    # one CRS, two groups: {v0, v1} and {v2, vshort}
+    out, _ = dev.msm([dev.put(crs0)], [(dev.put(v[0]), None, 0), (dev.put(v[1]), None, 0), (dev.put(v[2]), None, 1),
+                                       (dev.put(vshort), None, 1)], 2)
+    e0 = ctx.enc_add(ctx.inner_product(crs0, v[0])[0], ctx.inner_product(crs0, v[1])[0])
+    e1 = ctx.enc_add(ctx.inner_product(crs0, v[2])[0], ctx.inner_product(crs0[: T - 5], vshort)[0])
+    got = host(out)
+    assert (got[0, 0] == e0).all() and (got[0, 1] == e1).all()
+    # two CRS vectors sharing the plaintext transforms
+    out, used = dev.msm([dev.put(crs0), dev.put(crs1)], [(dev.put(v[0]), None, 0), (dev.put(v[2]), None, 1)], 2, want_used=True)
+    got = host(out)
+    assert used == [T, T]
+    for c, crs in enumerate((crs0, crs1)):
+        assert (got[c, 0] == ctx.inner_product(crs, v[0])[0]).all()
+        assert (got[c, 1] == ctx.inner_product(crs, v[2])[0]).all()
+
+
+@pytest.mark.parametrize("name,m,kind", [("toy", 1, "chain"), ("toy", 2, "chain"), ("toy", 7, "wide"), ("toy", 16, "wide"),
+                                          ("toy", 100, "wide"), ("toy49", 33, "wide"), ("toy49", 64, "chain")])
+def test_witness_map_matches_oracle(name, m, kind):
+    from ringsnark_amd import _lib
+    dev = dev_for(name)
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    cs = R.wide_r1cs(m, prm.q) if kind == "wide" else R.chain_r1cs(m, prm.q)
+    asg = H.make_assignment(ctx, cs)
+    dcs = dev.r1cs(cs)
+    dasg = dev.put(asg)
+    ocs = H.oracle_cs(cs)
+    # a14
+    for which in range(3):
+        got = host(dev.r1cs_evaluate(dcs, which, _lib.RS_EVAL_FULL, dasg))
+        for limb in range(prm.L):
+            exp = O.r1cs_evaluate(prm.q[limb], ocs, which, limb, np.ascontiguousarray(asg[:, limb, :]))
+            assert (got[:, limb, :] == exp).all()
+    for zk in (False, True):
+        ds = [ctx.random_ring(60 + k) for k in range(3)] if zk else [None] * 3
+        dds = [dev.put(d) if d is not None else None for d in ds]
+        w = dev.witness_map(dcs, dasg, *dds)
+        for limb in range(prm.L):
+            a = np.ascontiguousarray(asg[:, limb, :])
+            dl = [np.ascontiguousarray(d[limb]) if d is not None else None for d in ds]
+            exp = O.witness_map(prm.q[limb], ocs, limb, a, *dl)
+            for k in ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H"):
+                assert (host(w[k])[:, limb, :] == exp[k]).all(), (k, limb, zk)
+            assert (w["Z"][limb] == exp["Z"]).all()
+
+
+def test_interpolate_known_answer_on_device():
+    # util/interpolation_test.cpp:29-55 through the device path
+    dev = dev_for("toy")
+    prm = dev.prm
+    n = 8
+    y = np.zeros((n, prm.L, prm.N), dtype=np.uint64)
+    for limb, q in enumerate(prm.q):
+        coeffs = np.arange(n, dtype=np.uint64).reshape(n, 1)
+        for x in range(n):
+            y[x, limb, :] = O.poly_eval(q, coeffs, x)[0]
+    got = host(dev.interpolate(dev.put(y)))
+    for k in range(n):
+        assert (got[k] == k).all()
+
+
+@pytest.mark.parametrize("name,m,kind", [("toy", 6, "wide"), ("toy", 16, "chain"), ("toy49", 21, "wide")])
+def test_groth16_prover_matches_oracle(name, m, kind):
+    dev = dev_for(name)
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    cs = R.wide_r1cs(m, prm.q) if kind == "wide" else R.chain_r1cs(m, prm.q)
+    asg = H.make_assignment(ctx, cs)
+    pk = dict(s_pows=ctx.random_enc(71, m + 1), delta_ts=ctx.random_enc(72, m + 1), delta_mid=ctx.random_enc(73, cs.n_aux),
+              alpha=ctx.random_enc(74), beta=ctx.random_enc(75))
+    exp, exp_empty = O.groth16_prove(ctx, H.oracle_cs(cs), pk, asg)
+    got, empty = dev.groth16_prove(dev.r1cs(cs), {k: dev.put(v) for k, v in pk.items()}, dev.put(asg))
+    assert empty == exp_empty
+    assert (host(got) == exp).all()
+
+
+@pytest.mark.parametrize("name,m,zk", [("toy", 5, False), ("toy", 12, True), ("toy49", 16, True)])
+def test_rinocchio_prover_matches_oracle(name, m, zk):
+    dev = dev_for(name)
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    cs = R.wide_r1cs(m, prm.q)
+    asg = H.make_assignment(ctx, cs)
+    pk = dict(s_pows=ctx.random_enc(81, m + 1), alpha_s_pows=ctx.random_enc(82, m + 1), beta_prods=ctx.random_enc(83, cs.n_aux),
+              beta_rv_ts=ctx.random_enc(84), beta_rw_ts=ctx.random_enc(85), beta_ry_ts=ctx.random_enc(86))
+    ds = [ctx.random_ring(90 + k) for k in range(3)] if zk else [None] * 3
+    exp, exp_empty = O.rinocchio_prove(ctx, H.oracle_cs(cs), pk, asg, *ds)
+    got, empty = dev.rinocchio_prove(dev.r1cs(cs), {k: dev.put(v) for k, v in pk.items()}, dev.put(asg),
+                                     *[dev.put(d) if d is not None else None for d in ds])
+    assert empty == exp_empty
+    g = host(got)
+    for k in range(9):
+        assert (g[k] == exp[k]).all(), k

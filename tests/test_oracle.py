@@ -211,3 +211,41 @@ def test_groth16_prover_decodes_to_ring_inner_products():
             exp[2][limb] = ((exp[2][limb].astype(object) + dmid_r[t, limb].astype(object) * asg[cs.n_inputs + t, limb].astype(object)) % prm.q[limb]).astype(np.uint64)
     for k in range(3):
         assert (ctx.enc_decode(sk, proof[k]) == exp[k]).all(), k
+
+
+def test_r1cs_evaluate_matches_reference_headers():
+    """oracle/_ref/ref_r1cs_probe is built from the reference's own relations/ headers (as they lie
+    under /root/reference); it pins linear_combination::evaluate and is_satisfied."""
+    import os
+    import subprocess
+    probe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_r1cs_probe")
+    if not os.path.exists(probe):
+        pytest.skip("oracle/_ref not built (reference sources absent)")
+    q = 0xFFFFEE001
+    m = 9
+    cs = R.wide_r1cs(m, [q])
+    rng = np.random.RandomState(5)
+    vals = [int(rng.randint(1, 2**31)) for _ in range(2)]
+    # forward-solve over Z_q so the system is satisfied
+    for i in range(m):
+        rp, col, cf = cs.mats["a"]
+        a = sum(int(cf[0, e]) * (1 if col[e] == 0 else vals[col[e] - 1]) for e in range(rp[i], rp[i + 1])) % q
+        vals.append(a * vals[i + 1] % q)
+    for tamper in (False, True):
+        v = list(vals)
+        if tamper:
+            v[-1] = (v[-1] + 1) % q
+        lines = ["%d %d %d %d" % (q, m, cs.n_vars, cs.n_inputs)]
+        for name in "abc":
+            rp, col, cf = cs.mats[name]
+            for i in range(m):
+                terms = ["%d %d" % (col[e], cf[0, e]) for e in range(rp[i], rp[i + 1])]
+                lines.append("%d %s" % (len(terms), " ".join(terms)))
+        lines.append(" ".join(str(x) for x in v))
+        out = subprocess.run([probe], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.split("\n")
+        assert out[0] == "sat %d" % (0 if tamper else 1)
+        asg = np.array(v, dtype=np.uint64).reshape(-1, 1)
+        ocs = H.oracle_cs(cs)
+        ev = [O.r1cs_evaluate(q, ocs, k, 0, asg) for k in range(3)]
+        for i in range(m):
+            assert [int(x) for x in out[1 + i].split()] == [int(ev[k][i, 0]) for k in range(3)]

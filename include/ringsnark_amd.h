@@ -91,6 +91,10 @@ int rs_enc_mul_ring(rs_ctx *ctx, uint64_t *d_enc, const uint64_t *d_ring, size_t
 /* EncodingElem::operator+= on non-empty operands (seal_ring.tcc:489-506). */
 int rs_enc_add(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, const uint64_t *d_b, size_t count, rs_stream stream);
 
+/* Canonicalise integer sums of encoding elements in place (x mod Q_j): the epilogue of the
+ * multi-GPU all-reduce of partial inner products; inputs < 2^63. */
+int rs_enc_reduce(rs_ctx *ctx, uint64_t *d_enc, size_t count, rs_stream stream);
+
 /* ---- a9: EncodingElem::inner_product (seal_ring.tcc:361-433), the "ring-MSM" ------------- */
 #define RS_KIND_POLY 0 /* polynomial operand; an all-zero value contributes nothing (is_zero skip) */
 #define RS_KIND_ONE 2  /* RingElem holding Scalar 1: ciphertext passes through (seal_ring.tcc:525-527) */

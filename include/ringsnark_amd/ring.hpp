@@ -1,0 +1,369 @@
+// ring.hpp -- header-only C++ adapters over the C ABI (ringsnark_amd.h) with the reference's
+// names and signatures, so code written against ringsnark::seal::{RingElem, EncodingElem}
+// (ringsnark/seal/seal_ring.hpp:18-409) can switch namespaces.  See INTEGRATION.md.
+//
+//   RingElem      value type, variant<poly [L][N] residues, uint64 scalar> exactly like the
+//                 reference (seal_ring.hpp:26); polynomial arithmetic runs on the device through
+//                 rs_ring_*; scalar fast paths follow seal_ring.tcc:105-247.
+//   EncodingElem  value type, L ciphertexts [2][K][N_enc] (seal_ring.hpp:225), possibly EMPTY.
+//   groth16::prover / rinocchio::prover keep the proving key resident on the device and run the
+//                 fused entry points rs_groth16_prove / rs_rinocchio_prove.
+//
+// Error behaviour mirrors the reference: std::invalid_argument("context not set"),
+// ("cannot re-set context once set"), ("element is not invertible in ring").
+#ifndef RINGSNARK_AMD_RING_HPP
+#define RINGSNARK_AMD_RING_HPP
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../ringsnark_amd.h"
+
+namespace ringsnark::amd {
+
+struct Params {
+  int N = 0, L = 0, N_enc = 0, K = 0;
+  std::vector<uint64_t> q, Q;
+};
+
+inline void check(int status) {
+  if (status == RS_OK) return;
+  if (status == RS_ERR_NOT_INVERTIBLE) throw std::invalid_argument("element is not invertible in ring");
+  throw std::runtime_error(std::string("librs_hip: ") + rs_last_error());
+}
+
+// Process-global context, set exactly once (seal_ring.hpp:52-66, 308-328).
+class Context {
+ public:
+  static void set_context(const Params &p, int device = 0) {
+    if (ctx()) throw std::invalid_argument("cannot re-set context once set");
+    params() = p;
+    check(rs_ctx_create(device, p.N, p.L, p.q.data(), p.N_enc, p.K, p.Q.data(), &ctx()));
+  }
+  static rs_ctx *get_context() {
+    if (!ctx()) throw std::invalid_argument("context not set");
+    return ctx();
+  }
+  static const Params &get_params() {
+    if (!ctx()) throw std::invalid_argument("context not set");
+    return params();
+  }
+  static size_t ring_words() { return (size_t)get_params().L * get_params().N; }
+  static size_t enc_words() { return (size_t)get_params().L * 2 * get_params().K * get_params().N_enc; }
+
+ private:
+  static rs_ctx *&ctx() {
+    static rs_ctx *c = nullptr;
+    return c;
+  }
+  static Params &params() {
+    static Params p;
+    return p;
+  }
+};
+
+// RAII device buffer of uint64 words
+class DeviceWords {
+ public:
+  DeviceWords() = default;
+  explicit DeviceWords(size_t words) : words_(words) {
+    if (words) check(rs_malloc(Context::get_context(), words * 8, &p_));
+  }
+  DeviceWords(const uint64_t *host, size_t words) : DeviceWords(words) {
+    if (words) check(rs_upload(Context::get_context(), p_, host, words * 8, nullptr));
+  }
+  DeviceWords(const DeviceWords &) = delete;
+  DeviceWords &operator=(const DeviceWords &) = delete;
+  DeviceWords(DeviceWords &&o) noexcept : p_(o.p_), words_(o.words_) { o.p_ = nullptr; }
+  ~DeviceWords() {
+    if (p_) rs_free(Context::get_context(), p_);
+  }
+  uint64_t *get() const { return static_cast<uint64_t *>(p_); }
+  size_t words() const { return words_; }
+  void download(uint64_t *host) const { check(rs_download(Context::get_context(), host, p_, words_ * 8, nullptr)); }
+
+ private:
+  void *p_ = nullptr;
+  size_t words_ = 0;
+};
+
+class RingElem {
+ public:
+  using Scalar = uint64_t;
+  RingElem() = default;
+  RingElem(uint64_t value) : scalar_(value) {}  // NOLINT: implicit like seal_ring.hpp:45
+  explicit RingElem(std::vector<uint64_t> residues) : poly_(std::move(residues)), is_poly_(true) {
+    if (poly_.size() != Context::ring_words()) throw std::invalid_argument("wrong residue count");
+  }
+  static RingElem one() { return RingElem(1); }
+  static RingElem zero() { return RingElem(0); }
+
+  bool is_poly() const { return is_poly_; }
+  bool is_scalar() const { return !is_poly_; }
+  Scalar get_scalar() const { return scalar_; }
+  const std::vector<uint64_t> &get_poly() const { return poly_; }
+
+  // seal_ring.tcc:265-277: scalar s -> polynomial with s mod q_i in every slot
+  RingElem &to_poly_inplace() {
+    if (is_poly_) return *this;
+    const Params &p = Context::get_params();
+    poly_.assign(Context::ring_words(), 0);
+    for (int i = 0; i < p.L; i++)
+      for (int x = 0; x < p.N; x++) poly_[(size_t)i * p.N + x] = scalar_ % p.q[i];
+    is_poly_ = true;
+    return *this;
+  }
+  RingElem to_poly() const {
+    RingElem r(*this);
+    r.to_poly_inplace();
+    return r;
+  }
+  bool is_zero() const {  // seal_ring.tcc:26-34
+    if (!is_poly_) return scalar_ == 0;
+    for (uint64_t v : poly_)
+      if (v) return false;
+    return true;
+  }
+  bool fast_is_zero() const { return !is_poly_ && scalar_ == 0; }
+  size_t size_in_bits() const {
+    if (!is_poly_) return 8 * sizeof(Scalar);
+    const Params &p = Context::get_params();
+    size_t s = 0;
+    for (uint64_t qi : p.q) s += (64 - __builtin_clzll(qi)) * (size_t)p.N;
+    return s;
+  }
+  void negate_inplace() {  // seal_ring.tcc:62-72
+    to_poly_inplace();
+    unary(rs_ring_neg);
+  }
+  RingElem operator-() const {
+    RingElem r(*this);
+    r.negate_inplace();
+    return r;
+  }
+  bool is_invertible() const noexcept {
+    try {
+      RingElem r(*this);
+      r.invert_inplace();
+      return true;
+    } catch (...) {
+      return false;
+    }
+  }
+  void invert_inplace() {  // seal_ring.tcc:87-103; throws "element is not invertible in ring"
+    to_poly_inplace();
+    DeviceWords a(poly_.data(), poly_.size()), d(poly_.size());
+    check(rs_ring_inv(Context::get_context(), d.get(), a.get(), 1, nullptr));
+    d.download(poly_.data());
+  }
+  RingElem inverse() const {
+    RingElem r(*this);
+    r.invert_inplace();
+    return r;
+  }
+  RingElem &operator+=(const RingElem &o) {  // seal_ring.tcc:105-155 (scalar+scalar promoted to poly on overflow risk)
+    if (!is_poly_ && scalar_ == 0) return *this = o;
+    if (!o.is_poly_ && o.scalar_ == 0) return *this;
+    return binary(o, rs_ring_add);
+  }
+  RingElem &operator-=(const RingElem &o) {  // seal_ring.tcc:157-186
+    if (!o.is_poly_ && o.scalar_ == 0 && is_poly_) return *this;
+    return binary(o, rs_ring_sub);
+  }
+  RingElem &operator*=(const RingElem &o) {  // seal_ring.tcc:188-247
+    if (!is_poly_ && scalar_ == 1) return *this = o;
+    if (!is_poly_ && scalar_ == 0) return *this;
+    if (!o.is_poly_ && o.scalar_ == 1) return *this;
+    if (!o.is_poly_ && o.scalar_ == 0) return *this = RingElem(0);
+    return binary(o, rs_ring_mul);
+  }
+  RingElem &operator/=(const RingElem &o) { return *this *= o.inverse(); }
+  friend bool operator==(const RingElem &a, const RingElem &b) {  // seal_ring.tcc:249-263
+    if (!a.is_poly_ && !b.is_poly_) return a.scalar_ == b.scalar_;
+    return a.to_poly().poly_ == b.to_poly().poly_;
+  }
+  friend bool operator!=(const RingElem &a, const RingElem &b) { return !(a == b); }
+
+ private:
+  using BinFn = int (*)(rs_ctx *, uint64_t *, const uint64_t *, const uint64_t *, size_t, rs_stream);
+  using UnFn = int (*)(rs_ctx *, uint64_t *, const uint64_t *, size_t, rs_stream);
+  RingElem &binary(const RingElem &o, BinFn fn) {
+    to_poly_inplace();
+    const RingElem op = o.to_poly();
+    DeviceWords a(poly_.data(), poly_.size()), b(op.poly_.data(), op.poly_.size()), d(poly_.size());
+    check(fn(Context::get_context(), d.get(), a.get(), b.get(), 1, nullptr));
+    d.download(poly_.data());
+    return *this;
+  }
+  void unary(UnFn fn) {
+    DeviceWords a(poly_.data(), poly_.size()), d(poly_.size());
+    check(fn(Context::get_context(), d.get(), a.get(), 1, nullptr));
+    d.download(poly_.data());
+  }
+  std::vector<uint64_t> poly_;
+  Scalar scalar_ = 0;
+  bool is_poly_ = false;
+};
+inline RingElem operator+(RingElem a, const RingElem &b) { return a += b; }
+inline RingElem operator-(RingElem a, const RingElem &b) { return a -= b; }
+inline RingElem operator*(RingElem a, const RingElem &b) { return a *= b; }
+inline RingElem operator/(RingElem a, const RingElem &b) { return a /= b; }
+
+class EncodingElem {
+ public:
+  EncodingElem() = default;  // EMPTY (seal_ring.hpp:243,249)
+  explicit EncodingElem(std::vector<uint64_t> words) : w_(std::move(words)) {
+    if (w_.size() != Context::enc_words()) throw std::invalid_argument("wrong ciphertext size");
+  }
+  bool is_empty() const { return w_.empty(); }
+  const std::vector<uint64_t> &words() const { return w_; }
+  size_t size_in_bits() const {
+    if (w_.empty()) return 0;
+    const Params &p = Context::get_params();
+    size_t s = 0;
+    for (uint64_t Qj : p.Q) s += (size_t)p.L * 2 * p.N_enc * (64 - __builtin_clzll(Qj));
+    return s;
+  }
+  EncodingElem &operator+=(const EncodingElem &o) {  // seal_ring.tcc:479-507
+    if (o.is_empty()) return *this;
+    if (is_empty()) return *this = o;
+    DeviceWords a(w_.data(), w_.size()), b(o.w_.data(), o.w_.size());
+    check(rs_enc_add(Context::get_context(), a.get(), a.get(), b.get(), 1, nullptr));
+    a.download(w_.data());
+    return *this;
+  }
+  EncodingElem &operator*=(const RingElem &r) {  // seal_ring.tcc:509-548
+    if (r.is_zero()) {
+      w_.assign(Context::enc_words(), 0);
+      return *this;
+    }
+    if (r.is_scalar() && r.get_scalar() == 1) return *this;
+    const RingElem rp = r.to_poly();
+    DeviceWords e(w_.data(), w_.size()), d(rp.get_poly().data(), rp.get_poly().size());
+    check(rs_enc_mul_ring(Context::get_context(), e.get(), d.get(), 1, nullptr));
+    e.download(w_.data());
+    return *this;
+  }
+  friend bool operator==(const EncodingElem &a, const EncodingElem &b) { return a.w_ == b.w_; }
+
+  // EncodingElem::inner_product (seal_ring.tcc:361-433) on host-resident vectors.  For resident
+  // keys use ProvingKeyDevice below.
+  template <class EncIt, class RingIt>
+  static EncodingElem inner_product(EncIt a_start, EncIt a_end, RingIt b_start, RingIt b_end) {
+    const size_t T = (size_t)(a_end - a_start), ew = Context::enc_words(), rw = Context::ring_words();
+    if ((size_t)(b_end - b_start) != T) throw std::invalid_argument("mismatched sizes");
+    std::vector<uint64_t> encs(T * ew), rings(T * rw);
+    std::vector<uint8_t> kinds(T, RS_KIND_POLY);
+    for (size_t t = 0; t < T; t++) {
+      const EncodingElem &e = *(a_start + t);
+      const RingElem &r = *(b_start + t);
+      if (e.is_empty()) throw std::invalid_argument("empty encoding in inner_product");
+      std::memcpy(&encs[t * ew], e.w_.data(), ew * 8);
+      if (r.is_scalar() && r.get_scalar() == 1) kinds[t] = RS_KIND_ONE;
+      const RingElem rp = r.to_poly();
+      std::memcpy(&rings[t * rw], rp.get_poly().data(), rw * 8);
+    }
+    DeviceWords de(encs.data(), encs.size()), dr(rings.data(), rings.size()), out(ew);
+    size_t used = 0;
+    check(rs_inner_product(Context::get_context(), de.get(), dr.get(), kinds.data(), T, out.get(), &used, nullptr));
+    if (used == 0) return EncodingElem();  // seal_ring.tcc:412,432
+    std::vector<uint64_t> w(ew);
+    out.download(w.data());
+    return EncodingElem(std::move(w));
+  }
+
+ private:
+  std::vector<uint64_t> w_;
+};
+inline EncodingElem operator+(EncodingElem a, const EncodingElem &b) { return a += b; }
+inline EncodingElem operator*(EncodingElem a, const RingElem &r) { return a *= r; }
+inline EncodingElem operator*(const RingElem &r, EncodingElem a) { return a *= r; }
+
+// R1CS handed to the device once (CSR export of r1cs_constraint_system, r1cs.hpp:118-123).
+struct R1csCsr {
+  size_t m = 0, n_vars = 0, n_inputs = 0;
+  std::vector<uint32_t> row_ptr[3], col[3];
+  std::vector<uint64_t> coeff[3];  // [L][nnz]
+};
+class DeviceR1cs {
+ public:
+  explicit DeviceR1cs(const R1csCsr &c) : m(c.m), n_vars(c.n_vars), n_inputs(c.n_inputs) {
+    const uint32_t *rp[3] = {c.row_ptr[0].data(), c.row_ptr[1].data(), c.row_ptr[2].data()};
+    const uint32_t *cl[3] = {c.col[0].data(), c.col[1].data(), c.col[2].data()};
+    const uint64_t *cf[3] = {c.coeff[0].data(), c.coeff[1].data(), c.coeff[2].data()};
+    const size_t nnz[3] = {c.col[0].size(), c.col[1].size(), c.col[2].size()};
+    check(rs_r1cs_create(Context::get_context(), m, n_vars, n_inputs, rp, cl, cf, nnz, &h_));
+  }
+  ~DeviceR1cs() { rs_r1cs_destroy(h_); }
+  DeviceR1cs(const DeviceR1cs &) = delete;
+  rs_r1cs *get() const { return h_; }
+  size_t m, n_vars, n_inputs;
+
+ private:
+  rs_r1cs *h_ = nullptr;
+};
+
+inline std::vector<uint64_t> flatten(const std::vector<EncodingElem> &v) {
+  std::vector<uint64_t> out;
+  out.reserve(v.size() * Context::enc_words());
+  for (const auto &e : v) out.insert(out.end(), e.words().begin(), e.words().end());
+  return out;
+}
+inline std::vector<uint64_t> flatten(const std::vector<RingElem> &v) {
+  std::vector<uint64_t> out;
+  out.reserve(v.size() * Context::ring_words());
+  for (const auto &r : v) {
+    const RingElem p = r.to_poly();
+    out.insert(out.end(), p.get_poly().begin(), p.get_poly().end());
+  }
+  return out;
+}
+
+namespace groth16 {
+// proving_key (zk_proof_systems/groth16/groth16.hpp:14-48) uploaded once, kept in HBM.
+struct proving_key_device {
+  proving_key_device(const R1csCsr &cs_, const std::vector<EncodingElem> &s_pows, const std::vector<EncodingElem> &delta_ts,
+                     const std::vector<EncodingElem> &delta_mid, const EncodingElem &alpha, const EncodingElem &beta)
+      : cs(cs_),
+        s_pows_(up(flatten(s_pows))),
+        delta_ts_(up(flatten(delta_ts))),
+        delta_mid_(up(flatten(delta_mid))),
+        alpha_(up(alpha.words())),
+        beta_(up(beta.words())) {}
+  DeviceR1cs cs;
+  DeviceWords s_pows_, delta_ts_, delta_mid_, alpha_, beta_;
+
+ private:
+  static DeviceWords up(const std::vector<uint64_t> &w) { return DeviceWords(w.data(), w.size()); }
+};
+struct proof {
+  EncodingElem A, B, C;
+};
+// groth16::prover (groth16.tcc:70-115)
+inline proof prover(const proving_key_device &pk, const std::vector<RingElem> &primary_input,
+                    const std::vector<RingElem> &auxiliary_input) {
+  std::vector<RingElem> full(primary_input);
+  full.insert(full.end(), auxiliary_input.begin(), auxiliary_input.end());
+  const std::vector<uint64_t> asg = flatten(full);
+  DeviceWords dasg(asg.data(), asg.size()), dproof(3 * Context::enc_words());
+  rs_groth16_pk k{pk.s_pows_.get(), pk.delta_ts_.get(), pk.delta_mid_.get(), pk.alpha_.get(), pk.beta_.get()};
+  int empty[3] = {0, 0, 0};
+  check(rs_groth16_prove(Context::get_context(), pk.cs.get(), &k, dasg.get(), dproof.get(), empty, nullptr));
+  std::vector<uint64_t> w(3 * Context::enc_words());
+  dproof.download(w.data());
+  proof p;
+  EncodingElem *dst[3] = {&p.A, &p.B, &p.C};
+  for (int i = 0; i < 3; i++)
+    if (!empty[i])
+      *dst[i] = EncodingElem(std::vector<uint64_t>(w.begin() + i * Context::enc_words(), w.begin() + (i + 1) * Context::enc_words()));
+  return p;
+}
+}  // namespace groth16
+
+}  // namespace ringsnark::amd
+#endif

@@ -272,6 +272,14 @@ enc_add_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ x, const
   }
 }
 
+// canonicalise integer sums of residues (after an all-reduce of partial encoding sums)
+__global__ void __launch_bounds__(256)
+enc_reduce_kernel(uint64_t *__restrict__ x, size_t words, int n, int K, const uint64_t *__restrict__ Qint) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride)
+    x[i] = x[i] % Qint[(i / (size_t)n) % (size_t)K];
+}
+
 static int tile_threads(int logn) { return std::max(64, std::min(1024, (1 << logn) >> 3)); }
 
 struct MsmScratch {
@@ -568,6 +576,19 @@ int rs_enc_mul_ring(rs_ctx *ctx, uint64_t *d_enc, const uint64_t *d_ring, size_t
     msm_run(ctx, crs, 1, 1, &v, 1, 1, tmp, nullptr, nullptr, S(stream));
     RS_HIP(hipMemcpyAsync(d_enc + k * ctx->enc_words(), tmp, ctx->enc_words() * sizeof(uint64_t),
                           hipMemcpyDeviceToDevice, S(stream)));
+  }
+  RS_API_END
+}
+
+int rs_enc_reduce(rs_ctx *ctx, uint64_t *d_enc, size_t count, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_enc, "null argument");
+  const size_t words = count * ctx->enc_words();
+  if (words) {
+    MsmScratch &sc = scratch_for(ctx);
+    const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(enc_reduce_kernel, dim3(blocks), dim3(256), 0, S(stream), d_enc, words, ctx->N_enc, ctx->K, sc.d_Qint);
+    RS_HIP(hipGetLastError());
   }
   RS_API_END
 }

@@ -253,7 +253,8 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
       lp.d_ztab = up(zt);
       // coset generator g with Z(g w^i) != 0 for all i
       bool ok = false;
-      for (uint64_t g = 2; g < 1000 && !ok; g++) {
+      // g must avoid {j * w^-i}: every g <= m-1 is itself a domain point (i = 0), so start above it
+      for (uint64_t g = (uint64_t)m + 1; g < (uint64_t)m + 1000 && !ok; g++) {
         std::vector<uint64_t> zc(M, 0), gp(M);
         uint64_t c = 1;
         for (size_t k = 0; k < M; k++) {

@@ -172,6 +172,11 @@ class Device:
         _lib.check(self.lib.rs_enc_add(self.h, _ptr(out), _ptr(a), _ptr(b), self._count(a, self.enc_words), self.stream()))
         return out
 
+    def enc_reduce(self, enc):
+        """In-place x mod Q_j on integer sums of encoding elements (multi-GPU all-reduce epilogue)."""
+        _lib.check(self.lib.rs_enc_reduce(self.h, _ptr(enc), self._count(enc, self.enc_words), self.stream()))
+        return enc
+
     # ---- a9
     def inner_product(self, encs, rings, kinds=None, want_used=True):
         """EncodingElem::inner_product.  Returns (out, used); used == 0 <=> EMPTY element."""

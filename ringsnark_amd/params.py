@@ -161,7 +161,7 @@ def preset(name: str) -> RingParams:
         return make_params(2048, [49], 16384, BFV_DEFAULT_BITS[16384][:-1], name="C5s",
                            notes="C5 with the 54-bit BFVDefault(2048) prime replaced by a 49-bit one")
     if name == "toy":  # CPU-test scale
-        return make_params(32, [30, 30], 64, [40, 40, 41], name="toy")
+        return make_params(32, [30, 30], 64, [40, 40, 41], ring_factor=1 << 12, name="toy")
     if name == "toy49":  # stresses the 50-bit bound of the FP64 modmul path
         return make_params(64, [49, 49], 128, [49, 49, 49], ring_factor=1 << 12, name="toy49")
     raise KeyError(name)

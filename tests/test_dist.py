@@ -1,0 +1,125 @@
+"""Multi-rank prover (ringsnark_amd/dist.py) over gloo, world_size 2, on CPU.
+
+The arithmetic backend is an oracle-backed stand-in (tests may use the oracle); what is under test
+is the production sharding / collective code: limb split, term split + all-reduce + mod-Q
+epilogue, all-gather assembly.  The result must equal the single-process oracle proof bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as O
+from ringsnark_amd import dist as RD
+from ringsnark_amd import params as P
+from ringsnark_amd import r1cs as R
+from tests import helpers as H
+
+
+class OracleBackend:
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    @staticmethod
+    def _np(t):
+        return t.contiguous().numpy().view(np.uint64)
+
+    @staticmethod
+    def _t(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int64))
+
+    def witness(self, cs, assignment, want):
+        asg = self._np(assignment)
+        out = {k: np.zeros((cs.m + (1 if k == "H" else 0), self.ctx.L, self.ctx.N), dtype=np.uint64) for k in want}
+        ocs = H.oracle_cs(cs)
+        for limb in range(self.ctx.L):
+            w = O.witness_map(self.ctx.q[limb], ocs, limb, np.ascontiguousarray(asg[:, limb, :]))
+            for k in want:
+                out[k][:, limb, :] = w[k]
+        return {k: self._t(v) for k, v in out.items()}
+
+    def msm(self, crs_list, vecs, n_groups, addends=None):
+        crs = self._np(crs_list[0])
+        outs = []
+        for g in range(n_groups):
+            acc = np.zeros(self.ctx.enc_shape(), dtype=np.uint64)
+            for v, gg in vecs:
+                if gg != g or v.shape[0] == 0:
+                    continue
+                ip, used = self.ctx.inner_product(crs, self._np(v))
+                if used:
+                    acc = self.ctx.enc_add(acc, ip)
+            if addends is not None:
+                acc = self.ctx.enc_add(acc, self._np(addends[g]))
+            outs.append(acc)
+        return self._t(np.stack(outs))
+
+    def enc_add(self, a, b):
+        return self._t(np.stack([self.ctx.enc_add(x, y) for x, y in zip(self._np(a).reshape((-1,) + self.ctx.enc_shape()),
+                                                                          self._np(b).reshape((-1,) + self.ctx.enc_shape()))]))
+
+    def enc_reduce(self, piece):
+        a = self._np(piece).copy()
+        for j, Q in enumerate(self.ctx.Q):
+            a[..., j, :] %= np.uint64(Q)
+        return self._t(a)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, preset, m, q_override, tmp):
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        prm = P.preset(preset)
+        if q_override:
+            prm = P.RingParams(prm.N, prm.q[:q_override], prm.N_enc, prm.Q)
+        ctx_full = H.oracle_ctx(prm)
+        cs_full = R.wide_r1cs(m, prm.q)
+        asg = H.make_assignment(ctx_full, cs_full)
+        pk = dict(s_pows=ctx_full.random_enc(71, m + 1), delta_ts=ctx_full.random_enc(72, m + 1),
+                  delta_mid=ctx_full.random_enc(73, cs_full.n_aux), alpha=ctx_full.random_enc(74), beta=ctx_full.random_enc(75))
+        plan = RD.make_plan(world, rank, prm.L)
+        tg = RD.groups_for(plan)
+        prm_local = P.RingParams(prm.N, [prm.q[i] for i in plan.limbs], prm.N_enc, prm.Q)
+        backend = OracleBackend(H.oracle_ctx(prm_local))
+        cs_local = R.wide_r1cs(m, prm_local.q)
+        t = OracleBackend._t
+        pk_local = {k: t(v[:, plan.limbs] if v.ndim == 5 else v[plan.limbs]) for k, v in pk.items()}
+        asg_local = t(asg[:, plan.limbs])
+        got = RD.groth16_prove_sharded(backend, plan, tg, cs_local, pk_local, asg_local, m, cs_full.n_inputs, cs_full.n_aux)
+        if rank == 0:
+            exp, _ = O.groth16_prove(ctx_full, H.oracle_cs(cs_full), pk, asg)
+            ok = bool((OracleBackend._np(got) == exp).all())
+            open(tmp, "w").write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("q_override,desc", [(None, "limb split: 2 limbs over 2 ranks"), (1, "term split: 1 limb, all-reduce of partial sums")])
+def test_sharded_groth16_equals_single_process(tmp_path, q_override, desc):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(2, _free_port(), "toy", 7, q_override, out), nprocs=2, join=True)
+    assert open(out).read() == "ok", desc
+
+
+def test_shard_plans():
+    for world, L, exp in [(1, 4, (1, 1)), (2, 4, (2, 1)), (4, 4, (4, 1)), (8, 4, (4, 2)), (8, 6, (2, 4)), (3, 4, (1, 3))]:
+        plans = [RD.make_plan(world, r, L) for r in range(world)]
+        assert (plans[0].limb_groups, plans[0].term_shards) == exp
+        # every (limb, term) cell is covered exactly once
+        T = 37
+        cover = np.zeros((L, T), dtype=int)
+        for p in plans:
+            lo, hi = p.term_range(T)
+            for i in p.limbs:
+                cover[i, lo:hi] += 1
+        assert (cover == 1).all()

@@ -178,6 +178,9 @@ typedef struct rs_timings {
 } rs_timings;
 int rs_last_timings(rs_ctx *ctx, rs_timings *out);
 int rs_set_profiling(rs_ctx *ctx, int enabled);
+/* process-wide tuning knobs for experiments ("ntt_variant": kernel shape of rs_ntt_*); results
+ * are identical for every value. */
+int rs_set_tuning(const char *key, int value);
 
 /* synthetic-workload helpers for the benchmark harness (device-side generators) */
 int rs_fill_uniform(rs_ctx *ctx, uint64_t *d_dst, size_t count, int layout /*0 ring,1 enc*/, uint64_t seed, rs_stream stream);

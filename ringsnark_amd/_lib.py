@@ -82,6 +82,7 @@ SIGNATURES = {
     "rs_rinocchio_prove": (C.c_int, [vp, vp, C.POINTER(RinocchioPK), vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]),
     "rs_last_timings": (C.c_int, [vp, C.POINTER(Timings)]),
     "rs_set_profiling": (C.c_int, [vp, C.c_int]),
+    "rs_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "rs_fill_uniform": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_uint64, vp]),
     "rs_chain_assignment": (C.c_int, [vp, vp, C.c_size_t, vp]),
 }

@@ -241,6 +241,150 @@ mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff
       }
 }
 
+// mac_kernel_v2: the streaming form of the dominant kernel (one accumulator set, 1024 threads,
+// 2048 <= N_enc <= 8192).  Differences from mac_kernel:
+//   * the twiddle table of Q_j lives in LDS next to the tile (68 + 64 KiB), so inside the term loop
+//     the ONLY vector-memory operations are the streamed operands;
+//   * ciphertext words of term t and the plaintext row of term t+1 are loaded into registers before
+//     the transform of term t starts, so HBM latency and transfer overlap the FP64 work;
+//   * the transform is the wave-private form (ntt_core.cuh): one cross-wave round, then each of the
+//     16 waves finishes its own 512-element block and multiplies exactly that block into its
+//     accumulators -- two workgroup barriers per term instead of seven.
+struct TileBlockFactory {
+  double *s;
+  __device__ __forceinline__ LdsBlockIO operator()(int off) const { return LdsBlockIO{s + pidx(off)}; }
+};
+struct MacArgs2 {
+  const double *C;      // [tile_terms][L][n] plaintext rows of the group
+  const uint64_t *crs;  // first ciphertext of the tile
+  uint64_t *partial;    // accumulator slot 0 of this set: [n_chunks] stride part_stride
+  size_t part_stride;   // words between consecutive chunks
+  unsigned long long terms;  // valid terms in this tile
+  int terms_per_chunk, n_chunks;
+  int accumulate, acc_period, reduce_u;
+  int ablate;  // experiment knob: 1 = skip the transform, 2 = skip the ciphertext loads, 4 = skip the C loads
+};
+// THREADS = 512: 8 waves, 256 VGPRs per lane -> the whole ciphertext of term t AND the plaintext
+// row of term t+1 are prefetched into registers, 8 coefficient pairs per lane, radix-16 private
+// rounds.  (A 1024-thread shape has half the registers per lane and spills.)
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+mac_kernel_v2(MacArgs2 a, int L, int K, int logn, const NttTable *__restrict__ coeff_tabs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  constexpr int LOGW = THREADS == 512 ? 3 : 4;
+  constexpr int PP = 8192 / (2 * THREADS);  // coefficient pairs per lane at n = 8192 (fewer for smaller n)
+  const int n = 1 << logn;
+  double *twl = s + padded_len((size_t)n);
+  const unsigned b = blockIdx.x;
+  const int j = (int)((b >> 3) % (unsigned)K);
+  const unsigned r = (b & 7u) + 8u * (b / (8u * (unsigned)K));
+  if (r >= (unsigned)(a.n_chunks * L)) return;
+  const int limb = (int)(r % (unsigned)L), chunk = (int)(r / (unsigned)L);
+  const Mod mod = coeff_tabs[j].mod;
+  const uint32_t red_mask = coeff_tabs[j].fwd_red_mask;
+  {
+    const double *gtw = coeff_tabs[j].d_tw;
+    for (int i = threadIdx.x; i < n; i += THREADS) twl[i] = gtw[i];
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bpairs = n >> (LOGW + 1);      // pairs per wave block
+  const int pbase = wave * bpairs + lane;  // + 64*k, k < PP
+  const size_t enc_words = (size_t)L * 2 * K * n;
+  const size_t slab = (((size_t)limb * 2) * K + j) * (size_t)n;  // component 0; component 1 is + K*n
+  const size_t comp = (size_t)K * n;
+  uint64_t *part = a.partial + (size_t)chunk * a.part_stride + slab;
+  double acc[2][2 * PP];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int k = 0; k < PP; k++) {
+      acc[c][2 * k] = acc[c][2 * k + 1] = 0.0;
+      if (a.accumulate && 64 * k + lane < bpairs) {
+        const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(part + c * comp)[pbase + 64 * k];
+        acc[c][2 * k] = from_u64(v.x);
+        acc[c][2 * k + 1] = from_u64(v.y);
+      }
+    }
+  const unsigned long long tbeg = (unsigned long long)chunk * a.terms_per_chunk;
+  const unsigned long long tend = min(tbeg + (unsigned long long)a.terms_per_chunk, a.terms);
+  const TileBlockFactory bf{s};
+  const LdsIO lds{s};
+  int since = 0;
+  const double2 *crow = reinterpret_cast<const double2 *>(a.C + ((size_t)tbeg * L + limb) * (size_t)n);
+  const uint64_t *ctp = a.crs + (size_t)tbeg * enc_words + slab;
+  double2 cn[PP];
+  if (tbeg < tend) {
+#pragma unroll
+    for (int k = 0; k < PP; k++)
+      if (64 * k + lane < bpairs) cn[k] = crow[pbase + 64 * k];
+  }
+  for (unsigned long long t = tbeg; t < tend; t++) {
+    // plaintext row (already in registers) -> tile, reduced mod Q_j
+#pragma unroll
+    for (int k = 0; k < PP; k++)
+      if (64 * k + lane < bpairs) {
+        const int pi = pidx(2 * (pbase + 64 * k));
+        s[pi] = reduce(cn[k].x, mod);
+        s[pi + 1] = reduce(cn[k].y, mod);
+      }
+    __syncthreads();
+    // stream: this term's ciphertext words and the next plaintext row, in flight during the transform
+    ulonglong2 ct[2][PP];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int k = 0; k < PP; k++)
+        if (64 * k + lane < bpairs) {
+          if (a.ablate & 2)
+            ct[c][k] = make_ulonglong2(12345ull + k, 6789ull + c);
+          else
+            ct[c][k] = reinterpret_cast<const ulonglong2 *>(ctp + c * comp)[pbase + 64 * k];
+        }
+    crow += (size_t)L * (n >> 1);
+    ctp += enc_words;
+    if (t + 1 < tend && !(a.ablate & 4)) {
+#pragma unroll
+      for (int k = 0; k < PP; k++)
+        if (64 * k + lane < bpairs) cn[k] = crow[pbase + 64 * k];
+    }
+    if (!(a.ablate & 1)) lds_ntt_fwd_wp<4, LdsIO, TileBlockFactory, 3>(s, lds, bf, logn, LOGW, twl, mod, red_mask);
+#pragma unroll
+    for (int k = 0; k < PP; k++)
+      if (64 * k + lane < bpairs) {
+        const int pi = pidx(2 * (pbase + 64 * k));
+        double u0 = s[pi], u1 = s[pi + 1];
+        if (a.reduce_u) {
+          u0 = reduce(u0, mod);
+          u1 = reduce(u1, mod);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          acc[c][2 * k] += mulmod(from_u64(ct[c][k].x), u0, mod);
+          acc[c][2 * k + 1] += mulmod(from_u64(ct[c][k].y), u1, mod);
+        }
+      }
+    if (++since >= a.acc_period) {
+      since = 0;
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int k = 0; k < 2 * PP; k++) acc[c][k] = reduce(acc[c][k], mod);
+    }
+    wave_sync();  // this wave's block may now be overwritten by the next row (wave-private region)
+  }
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int k = 0; k < PP; k++)
+      if (64 * k + lane < bpairs) {
+        ulonglong2 o;
+        o.x = to_u64(canon(acc[c][2 * k], mod));
+        o.y = to_u64(canon(acc[c][2 * k + 1], mod));
+        reinterpret_cast<ulonglong2 *>(part + c * comp)[pbase + 64 * k] = o;
+      }
+}
+
 // out[set] = sum_chunk partial[chunk][set] (+ addend[set]) mod Q_j
 struct ReduceArgs {
   const uint64_t *addend[12];
@@ -325,6 +469,20 @@ static void launch_mac(rs_ctx *ctx, const MacArgs &a, const MsmScratch &sc, hipS
   if (e1) RS_HIP(hipEventRecord(e1, st));
   RS_HIP(hipGetLastError());
 }
+
+static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  const size_t lds = (padded_len((size_t)ctx->N_enc) + (size_t)ctx->N_enc) * sizeof(double);
+  const int rows = a.n_chunks * ctx->L;
+  const unsigned blocks = (unsigned)(((rows + 7) / 8) * 8 * ctx->K);
+  RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (e0) RS_HIP(hipEventRecord(e0, st));
+  hipLaunchKernelGGL(mac_kernel_v2<512>, dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K, ctx->logN_enc, sc.d_coeff_tabs);
+  if (e1) RS_HIP(hipEventRecord(e1, st));
+  RS_HIP(hipGetLastError());
+}
+
+int g_mac_ablate = 0;
+int g_mac_variant = 2;  // 2: streaming kernel where applicable; 1: always the generic kernel
 
 // Core grouped MSM.  addends: optional per-output (n_crs * n_groups) device pointers to encoding
 // elements added to the result (pk.alpha / pk.beta of groth16.tcc:95,103).
@@ -460,7 +618,31 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
         mac_launches++;
       }
     };
-    if (big) {  // one (crs, group) pair per launch
+    const bool v2 = g_mac_variant >= 2 && n_crs == 1 && n >= 2048 && n <= 8192;
+    if (v2) {  // streaming kernel: one accumulator set per launch
+      for (int g = 0; g < n_groups; g++) {
+        MacArgs2 a2;
+        a2.C = Cptr(g);
+        a2.terms = group_terms(g);
+        a2.crs = d_crs[0] + t0 * enc_words;
+        a2.partial = d_partial + (size_t)g * enc_words;
+        a2.part_stride = (size_t)n_sets * enc_words;
+        a2.terms_per_chunk = base.terms_per_chunk;
+        a2.n_chunks = base.n_chunks;
+        a2.accumulate = base.accumulate;
+        a2.acc_period = base.acc_period;
+        a2.reduce_u = base.reduce_u;
+        a2.ablate = g_mac_ablate;
+        launch_mac_v2(ctx, a2, sc, st, e0, e1);
+        if (e0) {
+          RS_HIP(hipEventSynchronize(e1));
+          float ms = 0;
+          RS_HIP(hipEventElapsedTime(&ms, e0, e1));
+          mac_ms += ms;
+          mac_launches++;
+        }
+      }
+    } else if (big) {  // one (crs, group) pair per launch
       for (int c = 0; c < n_crs; c++)
         for (int g = 0; g < n_groups; g++) {
           const int gs[1] = {g}, cs1[1] = {c};

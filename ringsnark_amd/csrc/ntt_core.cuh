@@ -1,11 +1,13 @@
 // ntt_core.cuh -- workgroup-cooperative radix-2^R number-theoretic transform over an LDS tile.
 //
-// One workgroup owns one polynomial of n = 2^logn FP64-held residues in LDS (f64mod.hpp).  Stages
-// are processed in "rounds" of R <= 3 stages: a thread pulls the 2^R elements of one radix-2^R
+// One workgroup owns one polynomial of n = 2^logn FP64-held residues (f64mod.hpp).  Stages are
+// processed in "rounds" of R <= MAXR stages: a thread pulls the 2^R elements of one radix-2^R
 // butterfly into registers, runs R stages there and writes them back, so a length-8192 transform
-// costs 5 LDS round trips instead of 13.  LDS indices are padded by one slot per 16 (pidx) so
-// that every stride pattern of every round is bank-conflict free for ds_read/write_b64
-// (MI355X: 64 banks x 4 B, two 32-lane groups per b64 access).
+// with MAXR = 4 costs 4 exchanges instead of 13.  The first round can read its operands straight
+// from global memory and the last can write straight back (IO functors), which removes two more
+// LDS passes.  LDS indices are padded by one slot per 16 (pidx) so that every stride pattern of
+// every round is bank-conflict free for ds_read/write_b64 (MI355X: 64 banks x 4 B, two 32-lane
+// groups per b64 access).
 //
 // Twiddles: table entry tw[M*root + i] serves group i of the stage that has M groups, inside the
 // sub-transform rooted at decimation-tree node `root` (root = 1 for a whole transform).  The
@@ -22,23 +24,53 @@ constexpr int PAD_SHIFT = 4;
 __host__ __device__ __forceinline__ int pidx(int i) { return i + (i >> PAD_SHIFT); }
 __host__ __device__ inline size_t padded_len(size_t n) { return n + (n >> PAD_SHIFT); }
 
+// element accessors for a round: LDS tile (padded) or caller-supplied functors
+struct LdsIO {
+  double *s;
+  __device__ __forceinline__ double load(int i) const { return s[pidx(i)]; }
+  __device__ __forceinline__ void store(int i, double v) const { s[pidx(i)] = v; }
+};
+
+// number of stages of the next round when `rem` stages remain: spread evenly over the minimum
+// number of rounds
+__host__ __device__ __forceinline__ int pick_radix(int rem, int maxr) {
+  const int rounds = (rem + maxr - 1) / maxr;
+  return (rem + rounds - 1) / rounds;
+}
+
 // ---- forward (Cooley-Tukey, natural in -> bit-reversed out) -----------------------------------
 // stage s (0-based) has 2^s groups and gap n >> (s+1); butterfly (x, y) -> (x + w*y, x - w*y).
-template <int R>
-__device__ __forceinline__ void fwd_round(double *__restrict__ s, int logn, int s0,
+// `logsub`: the tile holds 2^(logtot-logsub) independent length-2^logsub transforms on consecutive
+// blocks (logsub == logtot for a single transform).
+// Who executes a round: the whole workgroup (default) or one wave on its own sub-block.
+struct Lanes {
+  int tid, nthr;
+};
+__device__ __forceinline__ Lanes block_lanes() { return Lanes{(int)threadIdx.x, (int)blockDim.x}; }
+__device__ __forceinline__ Lanes wave_lanes() { return Lanes{(int)(threadIdx.x & 63), 64}; }
+// wave-scope ordering of LDS traffic: DS operations of one wave execute in issue order, so a
+// compiler-level fence is all that is needed between a wave-private exchange's writes and reads.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int R, class In, class Out>
+__device__ __forceinline__ void fwd_round(const In in, const Out out, int logtot, int logsub, int s0,
                                           const double *__restrict__ tw, int root, const Mod mod,
-                                          uint32_t red_mask) {
+                                          uint32_t red_mask, const Lanes ln = block_lanes()) {
   constexpr int E = 1 << R;
-  const int n = 1 << logn;
-  const int lstep = logn - s0 - R;  // log2 of the smallest gap in this round
+  const int lstep = logsub - s0 - R;  // log2 of the smallest gap in this round
   const int sstep = 1 << lstep;
-  const int ngroups = n >> R;
-  for (int grp = threadIdx.x; grp < ngroups; grp += blockDim.x) {
-    const int lo = grp & (sstep - 1), hi = grp >> lstep;
-    const int base = (hi << (logn - s0)) + lo;
+  const int ngroups = (1 << logtot) >> R;
+  for (int grp = ln.tid; grp < ngroups; grp += ln.nthr) {
+    const int lo = grp & (sstep - 1), hi_all = grp >> lstep;
+    const int hi = hi_all & ((1 << s0) - 1);
+    const int base = (hi_all << (logsub - s0)) + lo;
     double v[E];
 #pragma unroll
-    for (int e = 0; e < E; e++) v[e] = s[pidx(base + e * sstep)];
+    for (int e = 0; e < E; e++) v[e] = in.load(base + e * sstep);
 #pragma unroll
     for (int k = 0; k < R; k++) {
       if ((red_mask >> (s0 + k)) & 1u) {
@@ -61,53 +93,87 @@ __device__ __forceinline__ void fwd_round(double *__restrict__ s, int logn, int 
       }
     }
 #pragma unroll
-    for (int e = 0; e < E; e++) s[pidx(base + e * sstep)] = v[e];
+    for (int e = 0; e < E; e++) out.store(base + e * sstep, v[e]);
   }
 }
 
-__device__ __forceinline__ int pick_radix(int rem) { return (rem >= 3 && rem != 4) ? 3 : (rem >= 2 ? 2 : 1); }
+template <int MAXR, class In, class Out>
+__device__ __forceinline__ void fwd_round_dispatch(int R, const In in, const Out out, int logtot, int logsub, int s0,
+                                                   const double *__restrict__ tw, int root, const Mod mod,
+                                                   uint32_t red_mask, const Lanes ln = block_lanes()) {
+  if (MAXR >= 5 && R == 5)
+    fwd_round<(MAXR >= 5 ? 5 : 1)>(in, out, logtot, logsub, s0, tw, root, mod, red_mask, ln);
+  else if (MAXR >= 4 && R == 4)
+    fwd_round<(MAXR >= 4 ? 4 : 1)>(in, out, logtot, logsub, s0, tw, root, mod, red_mask, ln);
+  else if (R == 3)
+    fwd_round<3>(in, out, logtot, logsub, s0, tw, root, mod, red_mask, ln);
+  else if (R == 2)
+    fwd_round<2>(in, out, logtot, logsub, s0, tw, root, mod, red_mask, ln);
+  else
+    fwd_round<1>(in, out, logtot, logsub, s0, tw, root, mod, red_mask, ln);
+}
 
-// Whole forward transform of the LDS tile; ends with a barrier.  Caller must have synchronised
-// after filling the tile.
-__device__ __forceinline__ void lds_ntt_fwd(double *s, int logn, const double *__restrict__ tw, int root,
-                                            const Mod mod, uint32_t red_mask) {
+// Whole forward transform(s) of the LDS tile; ends with a barrier.  Caller must have synchronised
+// after filling the tile.  first_in / last_out replace the LDS tile for the first round's loads
+// and the last round's stores.
+template <int MAXR, class In, class Out>
+__device__ __forceinline__ void lds_ntt_fwd_io(double *s, const In first_in, const Out last_out, int logtot, int logsub,
+                                               const double *__restrict__ tw, int root, const Mod mod,
+                                               uint32_t red_mask) {
+  const LdsIO lds{s};
   int st = 0;
-  while (st < logn) {
-    const int R = pick_radix(logn - st);
-    if (R == 3)
-      fwd_round<3>(s, logn, st, tw, root, mod, red_mask);
-    else if (R == 2)
-      fwd_round<2>(s, logn, st, tw, root, mod, red_mask);
+  while (st < logsub) {
+    const int R = pick_radix(logsub - st, MAXR);
+    const bool first = st == 0, last = st + R >= logsub;
+    if (first && last)
+      fwd_round_dispatch<MAXR>(R, first_in, last_out, logtot, logsub, st, tw, root, mod, red_mask);
+    else if (first)
+      fwd_round_dispatch<MAXR>(R, first_in, lds, logtot, logsub, st, tw, root, mod, red_mask);
+    else if (last)
+      fwd_round_dispatch<MAXR>(R, lds, last_out, logtot, logsub, st, tw, root, mod, red_mask);
     else
-      fwd_round<1>(s, logn, st, tw, root, mod, red_mask);
+      fwd_round_dispatch<MAXR>(R, lds, lds, logtot, logsub, st, tw, root, mod, red_mask);
     __syncthreads();
     st += R;
   }
 }
+template <int MAXR = 3>
+__device__ __forceinline__ void lds_ntt_fwd(double *s, int logn, const double *__restrict__ tw, int root,
+                                            const Mod mod, uint32_t red_mask) {
+  const LdsIO lds{s};
+  lds_ntt_fwd_io<MAXR>(s, lds, lds, logn, logn, tw, root, mod, red_mask);
+}
+template <int MAXR = 3>
+__device__ __forceinline__ void lds_bntt_fwd(double *s, int logtot, int logsub, const double *__restrict__ tw,
+                                             const Mod mod, uint32_t red_mask) {
+  const LdsIO lds{s};
+  lds_ntt_fwd_io<MAXR>(s, lds, lds, logtot, logsub, tw, 1, mod, red_mask);
+}
 
 // ---- inverse (Gentleman-Sande, bit-reversed in -> natural out, NOT scaled by n^-1) -----------
 // inverse stage u (0-based) has gap 2^u and n >> (u+1) groups; (a, b) -> (a + b, (a - b)*w).
-template <int R>
-__device__ __forceinline__ void inv_round(double *__restrict__ s, int logn, int u0,
+template <int R, class In, class Out>
+__device__ __forceinline__ void inv_round(const In in, const Out out, int logtot, int logsub, int u0,
                                           const double *__restrict__ itw, int root, const Mod mod,
-                                          uint32_t red_mask) {
+                                          uint32_t red_mask, const Lanes ln = block_lanes()) {
   constexpr int E = 1 << R;
-  const int n = 1 << logn;
   const int g0 = 1 << u0;
-  const int ngroups = n >> R;
-  for (int grp = threadIdx.x; grp < ngroups; grp += blockDim.x) {
-    const int lo = grp & (g0 - 1), hi = grp >> u0;
-    const int base = (hi << (u0 + R)) + lo;
+  const int ngroups = (1 << logtot) >> R;
+  const int gpb_log = logsub - u0 - R;  // log2 of radix groups per sub-transform (per lo)
+  for (int grp = ln.tid; grp < ngroups; grp += ln.nthr) {
+    const int lo = grp & (g0 - 1), hi_all = grp >> u0;
+    const int hi = hi_all & ((1 << gpb_log) - 1);
+    const int base = (hi_all << (u0 + R)) + lo;
     double v[E];
 #pragma unroll
-    for (int e = 0; e < E; e++) v[e] = s[pidx(base + e * g0)];
+    for (int e = 0; e < E; e++) v[e] = in.load(base + e * g0);
 #pragma unroll
     for (int k = 0; k < R; k++) {
       if ((red_mask >> (u0 + k)) & 1u) {
 #pragma unroll
         for (int e = 0; e < E; e++) v[e] = reduce(v[e], mod);
       }
-      const int M = n >> (u0 + k + 1);
+      const int M = (1 << logsub) >> (u0 + k + 1);
       const int twbase = M * root + (hi << (R - 1 - k));
 #pragma unroll
       for (int e = 0; e < E; e++) {
@@ -119,21 +185,145 @@ __device__ __forceinline__ void inv_round(double *__restrict__ s, int logn, int 
       }
     }
 #pragma unroll
-    for (int e = 0; e < E; e++) s[pidx(base + e * g0)] = v[e];
+    for (int e = 0; e < E; e++) out.store(base + e * g0, v[e]);
   }
 }
 
+template <int MAXR, class In, class Out>
+__device__ __forceinline__ void inv_round_dispatch(int R, const In in, const Out out, int logtot, int logsub, int u0,
+                                                   const double *__restrict__ itw, int root, const Mod mod,
+                                                   uint32_t red_mask, const Lanes ln = block_lanes()) {
+  if (MAXR >= 5 && R == 5)
+    inv_round<(MAXR >= 5 ? 5 : 1)>(in, out, logtot, logsub, u0, itw, root, mod, red_mask, ln);
+  else if (MAXR >= 4 && R == 4)
+    inv_round<(MAXR >= 4 ? 4 : 1)>(in, out, logtot, logsub, u0, itw, root, mod, red_mask, ln);
+  else if (R == 3)
+    inv_round<3>(in, out, logtot, logsub, u0, itw, root, mod, red_mask, ln);
+  else if (R == 2)
+    inv_round<2>(in, out, logtot, logsub, u0, itw, root, mod, red_mask, ln);
+  else
+    inv_round<1>(in, out, logtot, logsub, u0, itw, root, mod, red_mask, ln);
+}
+
+template <int MAXR, class In, class Out>
+__device__ __forceinline__ void lds_ntt_inv_io(double *s, const In first_in, const Out last_out, int logtot, int logsub,
+                                               const double *__restrict__ itw, int root, const Mod mod,
+                                               uint32_t red_mask) {
+  const LdsIO lds{s};
+  int st = 0;
+  while (st < logsub) {
+    const int R = pick_radix(logsub - st, MAXR);
+    const bool first = st == 0, last = st + R >= logsub;
+    if (first && last)
+      inv_round_dispatch<MAXR>(R, first_in, last_out, logtot, logsub, st, itw, root, mod, red_mask);
+    else if (first)
+      inv_round_dispatch<MAXR>(R, first_in, lds, logtot, logsub, st, itw, root, mod, red_mask);
+    else if (last)
+      inv_round_dispatch<MAXR>(R, lds, last_out, logtot, logsub, st, itw, root, mod, red_mask);
+    else
+      inv_round_dispatch<MAXR>(R, lds, lds, logtot, logsub, st, itw, root, mod, red_mask);
+    __syncthreads();
+    st += R;
+  }
+}
+template <int MAXR = 3>
 __device__ __forceinline__ void lds_ntt_inv(double *s, int logn, const double *__restrict__ itw, int root,
                                             const Mod mod, uint32_t red_mask) {
-  int st = 0;
-  while (st < logn) {
-    const int R = pick_radix(logn - st);
-    if (R == 3)
-      inv_round<3>(s, logn, st, itw, root, mod, red_mask);
-    else if (R == 2)
-      inv_round<2>(s, logn, st, itw, root, mod, red_mask);
+  const LdsIO lds{s};
+  lds_ntt_inv_io<MAXR>(s, lds, lds, logn, logn, itw, root, mod, red_mask);
+}
+template <int MAXR = 3>
+__device__ __forceinline__ void lds_bntt_inv(double *s, int logtot, int logsub, const double *__restrict__ itw,
+                                             const Mod mod, uint32_t red_mask) {
+  const LdsIO lds{s};
+  lds_ntt_inv_io<MAXR>(s, lds, lds, logtot, logsub, itw, 1, mod, red_mask);
+}
+
+
+// ---- wave-private tail ("wp") ----------------------------------------------------------------
+// With W = 2^logw waves in the workgroup, the first logw stages of a forward transform are the
+// only ones that mix data of different waves.  After them the tile is W independent
+// sub-transforms on contiguous blocks of n/W elements, rooted at decimation-tree nodes W + wave:
+// each wave finishes its own block with wave-private LDS exchanges and NO workgroup barrier, so
+// waves drift apart and their global-memory, LDS and FP64 phases overlap.  (The inverse runs the
+// private rounds first and the cross-wave round last.)  Requires n / W >= 128.
+//
+// An offset view of the tile: valid because block offsets are multiples of 16 (pidx is additive
+// on multiples of 16).
+struct LdsBlockIO {
+  double *s;  // s + pidx(block_offset)
+  __device__ __forceinline__ double load(int i) const { return s[pidx(i)]; }
+  __device__ __forceinline__ void store(int i, double v) const { s[pidx(i)] = v; }
+};
+
+// Forward.  first_in feeds the cross-wave round (global or LDS); the result of the private rounds
+// goes to last_out, addressed with block-local indices + the wave's block offset added by the
+// functor's owner (see WaveOut below).  Ends WITHOUT a workgroup barrier: each wave's block is
+// complete (for that wave) on return.
+template <int MAXR, class In, class OutFactory, int CROSSR = 4>
+__device__ __forceinline__ void lds_ntt_fwd_wp(double *s, const In first_in, const OutFactory make_out, int logn, int logw,
+                                               const double *__restrict__ tw, const Mod mod, uint32_t red_mask) {
+  const LdsIO lds{s};
+  // cross-wave rounds: logw stages in rounds of at most CROSSR (each ends with a barrier)
+  for (int st = 0; st < logw;) {
+    const int R = pick_radix(logw - st, CROSSR);
+    if (st == 0)
+      fwd_round_dispatch<CROSSR>(R, first_in, lds, logn, logn, st, tw, 1, mod, red_mask);
     else
-      inv_round<1>(s, logn, st, itw, root, mod, red_mask);
+      fwd_round_dispatch<CROSSR>(R, lds, lds, logn, logn, st, tw, 1, mod, red_mask);
+    __syncthreads();
+    st += R;
+  }
+  const int wave = threadIdx.x >> 6;
+  const int logb = logn - logw;
+  const int off = wave << logb;
+  const LdsBlockIO blk{s + pidx(off)};
+  const int root = (1 << logw) + wave;
+  const uint32_t mask = red_mask >> logw;
+  const Lanes ln = wave_lanes();
+  int st = 0;
+  while (st < logb) {
+    const int R = pick_radix(logb - st, MAXR);
+    if (st + R >= logb)
+      fwd_round_dispatch<MAXR>(R, blk, make_out(off), logb, logb, st, tw, root, mod, mask, ln);
+    else
+      fwd_round_dispatch<MAXR>(R, blk, blk, logb, logb, st, tw, root, mod, mask, ln);
+    wave_sync();
+    st += R;
+  }
+}
+
+// Inverse.  make_in(off) feeds the first private round with block-local indices; the cross-wave
+// round writes to last_out.  Ends with a workgroup barrier after the cross-wave round.
+template <int MAXR, class InFactory, class Out, int CROSSR = 4>
+__device__ __forceinline__ void lds_ntt_inv_wp(double *s, const InFactory make_in, const Out last_out, int logn, int logw,
+                                               const double *__restrict__ itw, const Mod mod, uint32_t red_mask) {
+  const LdsIO lds{s};
+  const int wave = threadIdx.x >> 6;
+  const int logb = logn - logw;
+  const int off = wave << logb;
+  const LdsBlockIO blk{s + pidx(off)};
+  // inverse stage u of the block == inverse stage u of the whole transform; group index inside the
+  // block's subtree: node = M_block * (W + wave) + i  with M_block groups per block at that stage
+  const int root = (1 << logw) + wave;
+  const Lanes ln = wave_lanes();
+  int st = 0;
+  while (st < logb) {
+    const int R = pick_radix(logb - st, MAXR);
+    if (st == 0)
+      inv_round_dispatch<MAXR>(R, make_in(off), blk, logb, logb, st, itw, root, mod, red_mask, ln);
+    else
+      inv_round_dispatch<MAXR>(R, blk, blk, logb, logb, st, itw, root, mod, red_mask, ln);
+    wave_sync();
+    st += R;
+  }
+  __syncthreads();
+  for (int st = 0; st < logw;) {
+    const int R = pick_radix(logw - st, CROSSR);
+    if (st + R >= logw)
+      inv_round_dispatch<CROSSR>(R, lds, last_out, logn, logn, logb + st, itw, 1, mod, red_mask);
+    else
+      inv_round_dispatch<CROSSR>(R, lds, lds, logn, logn, logb + st, itw, 1, mod, red_mask);
     __syncthreads();
     st += R;
   }

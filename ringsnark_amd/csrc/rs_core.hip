@@ -93,61 +93,208 @@ void free_table(NttTable &t) {
 // a4: batched negacyclic NTT.  One workgroup per polynomial; global <-> LDS traffic is one
 // coalesced 16-byte-per-lane read and one write of the polynomial (16*n algorithmic bytes).
 // ---------------------------------------------------------------------------------------------
-template <bool INV>
-__global__ void __launch_bounds__(1024) ntt_kernel(uint64_t *__restrict__ data, int logn,
-                                                   const double *__restrict__ tw, Mod mod, double ninv,
-                                                   uint32_t red_mask) {
+struct GlobalU64In {
+  const uint64_t *p;
+  __device__ __forceinline__ double load(int i) const { return from_u64(p[i]); }
+  __device__ __forceinline__ void store(int, double) const {}
+};
+template <bool SCALE>
+struct GlobalCanonOut {
+  uint64_t *p;
+  Mod mod;
+  double ninv;
+  __device__ __forceinline__ double load(int) const { return 0.0; }
+  __device__ __forceinline__ void store(int i, double v) const {
+    if (SCALE) v = mulmod(reduce(v, mod), ninv, mod);
+    p[i] = to_u64(canon(v, mod));
+  }
+};
+
+// DIN: first round reads the polynomial straight from global memory; DOUT: last round writes the
+// canonical result straight back.  THREADS is the launch bound (n / 2^MAXR threads do all the work).
+template <bool INV, int MAXR, bool DIN, bool DOUT, int THREADS>
+__global__ void __launch_bounds__(THREADS) ntt_kernel(uint64_t *__restrict__ data, int logn,
+                                                      const double *__restrict__ tw, Mod mod, double ninv,
+                                                      uint32_t red_mask) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   const int n = 1 << logn;
   uint64_t *poly = data + (size_t)blockIdx.x * n;
-  const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(poly);
-  for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
-    const ulonglong2 v = src[i];
-    const int pi = pidx(2 * i);
-    s[pi] = from_u64(v.x);
-    s[pi + 1] = from_u64(v.y);
-  }
-  __syncthreads();
-  if (INV)
-    lds_ntt_inv(s, logn, tw, 1, mod, red_mask);
-  else
-    lds_ntt_fwd(s, logn, tw, 1, mod, red_mask);
-  ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(poly);
-  for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
-    const int pi = pidx(2 * i);
-    double a = s[pi], b = s[pi + 1];
-    if (INV) {
-      a = mulmod(reduce(a, mod), ninv, mod);
-      b = mulmod(reduce(b, mod), ninv, mod);
+  if (!DIN) {
+    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(poly);
+    for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
+      const ulonglong2 v = src[i];
+      const int pi = pidx(2 * i);
+      s[pi] = from_u64(v.x);
+      s[pi + 1] = from_u64(v.y);
     }
-    ulonglong2 o;
-    o.x = to_u64(canon(a, mod));
-    o.y = to_u64(canon(b, mod));
-    dst[i] = o;
+    __syncthreads();
+  }
+  const LdsIO lds{s};
+  const GlobalU64In gin{poly};
+  const GlobalCanonOut<INV> gout{poly, mod, ninv};
+  if (INV) {
+    if (DIN && DOUT)
+      lds_ntt_inv_io<MAXR>(s, gin, gout, logn, logn, tw, 1, mod, red_mask);
+    else if (DIN)
+      lds_ntt_inv_io<MAXR>(s, gin, lds, logn, logn, tw, 1, mod, red_mask);
+    else if (DOUT)
+      lds_ntt_inv_io<MAXR>(s, lds, gout, logn, logn, tw, 1, mod, red_mask);
+    else
+      lds_ntt_inv_io<MAXR>(s, lds, lds, logn, logn, tw, 1, mod, red_mask);
+  } else {
+    if (DIN && DOUT)
+      lds_ntt_fwd_io<MAXR>(s, gin, gout, logn, logn, tw, 1, mod, red_mask);
+    else if (DIN)
+      lds_ntt_fwd_io<MAXR>(s, gin, lds, logn, logn, tw, 1, mod, red_mask);
+    else if (DOUT)
+      lds_ntt_fwd_io<MAXR>(s, lds, gout, logn, logn, tw, 1, mod, red_mask);
+    else
+      lds_ntt_fwd_io<MAXR>(s, lds, lds, logn, logn, tw, 1, mod, red_mask);
+  }
+  if (!DOUT) {
+    ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(poly);
+    for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
+      const int pi = pidx(2 * i);
+      double a = s[pi], b = s[pi + 1];
+      if (INV) {
+        a = mulmod(reduce(a, mod), ninv, mod);
+        b = mulmod(reduce(b, mod), ninv, mod);
+      }
+      ulonglong2 o;
+      o.x = to_u64(canon(a, mod));
+      o.y = to_u64(canon(b, mod));
+      dst[i] = o;
+    }
   }
 }
 
-static int ntt_threads(int logn) {
+// Wave-private variant (ntt_core.cuh "wp"): one cross-wave round, then every wave finishes its own
+// contiguous block without workgroup barriers, and moves it between LDS and global memory itself
+// with fully coalesced 16-byte accesses.
+int g_ntt_repeat = 1;
+// Break chip-wide lockstep: every workgroup of a launch runs the same load -> compute -> store
+// sequence, so without help all of them hit HBM at the same time and then all leave it idle.
+// The first generation of workgroups starts after a pseudo-random delay of up to `units` x ~1.7 us;
+// later generations inherit the spread.
+__device__ __forceinline__ void stagger_start(int units) {
+  if (units <= 0 || blockIdx.x >= 1024) return;
+  const unsigned h = (blockIdx.x * 2654435761u) >> 28;  // 0..15
+  const int n = (int)(h * (unsigned)units) >> 2;
+  for (int k = 0; k < n; k++) __builtin_amdgcn_s_sleep(16);  // 16 * 64 cycles ~ 0.43 us
+}
+struct BlockFactory {
+  double *s;
+  __device__ __forceinline__ LdsBlockIO operator()(int off) const { return LdsBlockIO{s + pidx(off)}; }
+};
+template <bool INV, int MAXR, int THREADS>
+__global__ void __launch_bounds__(THREADS) ntt_kernel_wp(uint64_t *__restrict__ data, int logn, int logw,
+                                                         const double *__restrict__ tw, Mod mod, double ninv,
+                                                         uint32_t red_mask, int repeat) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
   const int n = 1 << logn;
-  return std::max(64, std::min(1024, n >> 3));
+  uint64_t *poly = data + (size_t)blockIdx.x * n;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int logb = logn - logw, bsz = 1 << logb, off = wave << logb;
+  const BlockFactory bf{s};
+  stagger_start(repeat >> 8);
+  repeat &= 255;
+  if (!INV) {
+    lds_ntt_fwd_wp<MAXR>(s, GlobalU64In{poly}, bf, logn, logw, tw, mod, red_mask);
+    for (int r = 1; r < repeat; r++) {  // experiment only: re-run the transform on the LDS tile
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += blockDim.x) s[pidx(i)] = reduce(s[pidx(i)], mod);
+      __syncthreads();
+      lds_ntt_fwd_wp<MAXR>(s, LdsIO{s}, bf, logn, logw, tw, mod, red_mask);
+    }
+    ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(poly + off);
+    for (int i = lane; i < (bsz >> 1); i += 64) {
+      const int pi = pidx(off + 2 * i);
+      ulonglong2 o;
+      o.x = to_u64(canon(s[pi], mod));
+      o.y = to_u64(canon(s[pi + 1], mod));
+      dst[i] = o;
+    }
+  } else {
+    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(poly + off);
+    for (int i = lane; i < (bsz >> 1); i += 64) {
+      const ulonglong2 v = src[i];
+      const int pi = pidx(off + 2 * i);
+      s[pi] = from_u64(v.x);
+      s[pi + 1] = from_u64(v.y);
+    }
+    wave_sync();
+    lds_ntt_inv_wp<MAXR>(s, bf, GlobalCanonOut<true>{poly, mod, ninv}, logn, logw, tw, mod, red_mask);
+  }
+}
+
+template <bool INV, int MAXR, int THREADS>
+static void launch_ntt_wp(const NttTable &t, uint64_t *d_data, size_t batch, hipStream_t st) {
+  const size_t lds = padded_len((size_t)1 << t.logn) * sizeof(double);
+  int logw = 0;
+  while ((64 << logw) < THREADS) logw++;
+  auto kern = ntt_kernel_wp<INV, MAXR, THREADS>;
+  RS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(THREADS), lds, st, d_data, t.logn, logw, INV ? t.d_itw : t.d_tw,
+                     t.mod, t.ninv, INV ? t.inv_red_mask : t.fwd_red_mask, g_ntt_repeat);
+  RS_HIP(hipGetLastError());
+}
+
+int g_ntt_variant = 8;  // tuning knob (rs_set_tuning("ntt_variant", v)): see launch_ntt
+
+template <bool INV, int MAXR, bool DIN, bool DOUT, int THREADS>
+static void launch_ntt_variant(const NttTable &t, uint64_t *d_data, size_t batch, hipStream_t st) {
+  const size_t lds = padded_len((size_t)1 << t.logn) * sizeof(double);
+  const int n = 1 << t.logn;
+  const int thr = std::max(64, std::min(THREADS, n >> MAXR));
+  auto kern = ntt_kernel<INV, MAXR, DIN, DOUT, THREADS>;
+  RS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, INV ? t.d_itw : t.d_tw, t.mod,
+                     t.ninv, INV ? t.inv_red_mask : t.fwd_red_mask);
+  RS_HIP(hipGetLastError());
 }
 
 void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st) {
   (void)ctx;
   if (batch == 0) return;
-  const size_t lds = padded_len((size_t)1 << t.logn) * sizeof(double);
-  const int thr = ntt_threads(t.logn);
-  if (inverse) {
-    RS_HIP(hipFuncSetAttribute((const void *)ntt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ntt_kernel<true>, dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, t.d_itw, t.mod,
-                       t.ninv, t.inv_red_mask);
-  } else {
-    RS_HIP(hipFuncSetAttribute((const void *)ntt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ntt_kernel<false>, dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, t.d_tw, t.mod,
-                       t.ninv, t.fwd_red_mask);
+#define RS_NTT_CASE(V, MAXR, DIN_F, DOUT_F, DIN_I, DOUT_I, THR)                         \
+  case V:                                                                              \
+    if (inverse)                                                                       \
+      launch_ntt_variant<true, MAXR, DIN_I, DOUT_I, THR>(t, d_data, batch, st);        \
+    else                                                                               \
+      launch_ntt_variant<false, MAXR, DIN_F, DOUT_F, THR>(t, d_data, batch, st);       \
+    break;
+  const bool wp_ok = t.logn >= 11;  // wave-private blocks need n / W >= 128
+  if (wp_ok && g_ntt_variant >= 8 && g_ntt_variant <= 11) {
+    switch (g_ntt_variant) {
+      case 8:
+        inverse ? launch_ntt_wp<true, 4, 512>(t, d_data, batch, st) : launch_ntt_wp<false, 4, 512>(t, d_data, batch, st);
+        break;
+      case 9:
+        inverse ? launch_ntt_wp<true, 3, 1024>(t, d_data, batch, st) : launch_ntt_wp<false, 3, 1024>(t, d_data, batch, st);
+        break;
+      case 10:
+        inverse ? launch_ntt_wp<true, 5, 256>(t, d_data, batch, st) : launch_ntt_wp<false, 5, 256>(t, d_data, batch, st);
+        break;
+      default:
+        inverse ? launch_ntt_wp<true, 3, 512>(t, d_data, batch, st) : launch_ntt_wp<false, 3, 512>(t, d_data, batch, st);
+        break;
+    }
+    return;
   }
-  RS_HIP(hipGetLastError());
+  switch (g_ntt_variant) {
+    RS_NTT_CASE(1, 4, false, false, false, false, 512)
+    RS_NTT_CASE(2, 4, true, false, false, true, 512)
+    RS_NTT_CASE(3, 4, true, true, true, true, 512)
+    RS_NTT_CASE(4, 5, false, false, false, false, 256)
+    RS_NTT_CASE(5, 5, true, false, false, true, 256)
+    RS_NTT_CASE(6, 5, true, true, true, true, 256)
+    RS_NTT_CASE(7, 3, true, false, false, true, 1024)
+    default:  // 0, and any wave-private request on a transform too short for it
+      RS_NTT_CASE(0, 3, false, false, false, false, 1024)
+  }
+#undef RS_NTT_CASE
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -451,6 +598,22 @@ int rs_ring_is_zero(rs_ctx *ctx, const uint64_t *d_a, size_t count, uint8_t *h_f
     RS_HIP(hipStreamSynchronize(S(stream)));
     for (size_t k = 0; k < count; k++) h_flags[k] = h[k] ? 0 : 1;
   }
+  RS_API_END
+}
+
+int rs_set_tuning(const char *key, int value) {
+  RS_API_BEGIN
+  RS_REQUIRE(key, "null argument");
+  if (std::string(key) == "ntt_variant")
+    g_ntt_variant = value;
+  else if (std::string(key) == "ntt_repeat")
+    g_ntt_repeat = value;
+  else if (std::string(key) == "mac_variant")
+    g_mac_variant = value;
+  else if (std::string(key) == "mac_ablate")
+    g_mac_ablate = value;
+  else
+    throw Error(RS_ERR_INVALID, std::string("unknown tuning key ") + key);
   RS_API_END
 }
 

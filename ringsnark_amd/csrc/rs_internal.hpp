@@ -78,8 +78,15 @@ struct rs_r1cs {
   uint32_t *d_col[3] = {nullptr, nullptr, nullptr};
   double *d_coeff[3] = {nullptr, nullptr, nullptr};  // [L][nnz] balanced doubles
   size_t nnz[3] = {0, 0, 0};
+  std::vector<uint32_t> h_row_ptr[3], h_col[3];
+  std::vector<uint64_t> h_coeff[3];
   std::vector<uint64_t> h_const[3];  // [L][m] sum of the index-0 (constant-one) coefficients per row
   bool has_const[3] = {false, false, false};
+  // io shortcut cache (witness.hip): interpolated columns of the constant and primary-input variables
+  bool io_built = false;
+  double *d_io_cols = nullptr;  // [ncols][L][M]
+  int *d_io_k[3] = {nullptr, nullptr, nullptr}, *d_io_c[3] = {nullptr, nullptr, nullptr};
+  int io_count[3] = {0, 0, 0}, io_const_col[3] = {-1, -1, -1};
 };
 
 struct rs_ctx {
@@ -113,5 +120,6 @@ inline hipStream_t S(rs_stream s) { return (hipStream_t)s; }
 
 // launch helpers implemented in the .hip files
 void msm_scratch_release(rs_ctx *ctx);  // msm.hip
+extern int g_mac_variant, g_mac_ablate;  // msm.hip tuning knobs
 void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st);
 }  // namespace rs

@@ -39,9 +39,7 @@ struct LimbPlan {
   double *d_ehat = nullptr;                  // [2M] spectrum of (-1)^k/k!, scaled by 1/(2M)
   double *d_dhat = nullptr;                  // [logM+1][M] spectra of D_left per level, scaled by 1/n
   double *d_dlow = nullptr;                  // [SCHOOL_LEVELS+1][M/2] low coefficients of D_left
-  double *d_gpow = nullptr;                  // [M] g^k
-  double *d_ginv = nullptr;                  // [M] g^-k / M
-  double *d_zinv = nullptr;                  // [M] 1 / Z(g w^i) in transform order
+  double *d_shat = nullptr;                  // [2M] spectrum of rev(Z)^-1 mod x^(m-1), scaled 1/(2M)^2
   double *d_ztab = nullptr;                  // [M] Z_k (0 beyond m)
   uint32_t fwd_mask2 = 0, inv_mask2 = 0;     // reduce masks for length 2M
   std::vector<uint64_t> Z;                   // m+1 coefficients of the vanishing polynomial
@@ -251,38 +249,32 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
       std::vector<double> zt(M, 0.0);
       for (size_t k = 0; k < M && k <= m; k++) zt[k] = bal(Z[k]);
       lp.d_ztab = up(zt);
-      // coset generator g with Z(g w^i) != 0 for all i
-      bool ok = false;
-      // g must avoid {j * w^-i}: every g <= m-1 is itself a domain point (i = 0), so start above it
-      for (uint64_t g = (uint64_t)m + 1; g < (uint64_t)m + 1000 && !ok; g++) {
-        std::vector<uint64_t> zc(M, 0), gp(M);
-        uint64_t c = 1;
-        for (size_t k = 0; k < M; k++) {
-          gp[k] = c;
-          if (k <= m) zc[k] = mulmod(Z[k], c, p);
-          c = mulmod(c, g, p);
+      // S = rev(Z)^-1 mod x^(m-1) (Newton iteration): quo(P, Z) = rev(rev(P) * S mod x^(m-1)) for
+      // deg P = 2m-2.  Spectrum at length 2M, scaled by 1/(2M)^2 (two unscaled inverse transforms).
+      std::vector<uint64_t> shat(2 * M, 0);
+      if (m >= 2) {
+        std::vector<uint64_t> f(m - 1);
+        for (size_t i2 = 0; i2 + 1 < m; i2++) f[i2] = Z[m - i2];  // rev(Z), constant term Z[m] = 1
+        std::vector<uint64_t> g = {1};
+        while (g.size() < m - 1) {
+          const size_t k2 = std::min(2 * g.size(), m - 1);
+          std::vector<uint64_t> fk(f.begin(), f.begin() + k2);
+          std::vector<uint64_t> fg = polymul(fk, g, T);
+          fg.resize(k2);
+          for (auto &x : fg) x = (p - x) % p;  // -f*g
+          fg[0] = addmod(fg[0], 2, p);         // 2 - f*g
+          std::vector<uint64_t> ng = polymul(g, fg, T);
+          ng.resize(k2);
+          g = ng;
         }
-        const uint64_t gM = c;  // g^M
-        ntt_fwd(zc, logM, T);
-        if (m == M)
-          for (auto &x : zc) x = addmod(x, gM, p);
-        ok = true;
-        for (auto x : zc) ok = ok && x != 0;
-        if (!ok) continue;
-        std::vector<double> zi(M), gpow(M), ginv(M);
-        const uint64_t gi = invmod(g, p), Minv = invmod((uint64_t)M % p, p);
-        uint64_t ci = Minv;
-        for (size_t k = 0; k < M; k++) {
-          zi[k] = bal(invmod(zc[k], p));
-          gpow[k] = bal(gp[k]);
-          ginv[k] = bal(ci);
-          ci = mulmod(ci, gi, p);
-        }
-        lp.d_zinv = up(zi);
-        lp.d_gpow = up(gpow);
-        lp.d_ginv = up(ginv);
+        for (size_t i2 = 0; i2 < g.size(); i2++) shat[i2] = g[i2];
+        ntt_fwd(shat, logM + 1, T);
+        const uint64_t s2 = invmod((uint64_t)(2 * M) % p, p), s4 = mulmod(s2, s2, p);
+        for (auto &x : shat) x = mulmod(x, s4, p);
       }
-      RS_REQUIRE(ok, "internal: no coset generator found");
+      std::vector<double> sh(2 * M);
+      for (size_t k = 0; k < 2 * M; k++) sh[k] = bal(shat[k]);
+      lp.d_shat = up(sh);
     }
   }
   return P;
@@ -290,7 +282,7 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
 
 static void free_plan(WitnessPlan *P) {
   for (auto &lp : P->limb) {
-    double *ptrs[] = {lp.d_tw, lp.d_itw, lp.d_invfact, lp.d_ehat, lp.d_dhat, lp.d_dlow, lp.d_gpow, lp.d_ginv, lp.d_zinv, lp.d_ztab};
+    double *ptrs[] = {lp.d_tw, lp.d_itw, lp.d_invfact, lp.d_ehat, lp.d_dhat, lp.d_dlow, lp.d_shat, lp.d_ztab};
     for (double *q : ptrs)
       if (q) (void)hipFree(q);
   }
@@ -309,7 +301,7 @@ WitnessPlan *get_plan(rs_ctx *ctx, size_t m) {
 
 struct ColPlan {  // per-limb device pointers handed to the column kernels
   Mod mod;
-  const double *tw, *itw, *invfact, *ehat, *dhat, *dlow, *gpow, *ginv, *zinv, *ztab;
+  const double *tw, *itw, *invfact, *ehat, *dhat, *dlow, *shat, *ztab;
   uint32_t fwd_mask2, inv_mask2;
   uint32_t fmask[16], imask[16];  // reduce masks for transforms of length 2^l
 };
@@ -350,110 +342,6 @@ __global__ void __launch_bounds__(256) transpose_out_kernel(const double *__rest
   }
 }
 
-// batched forward / inverse sub-transforms: the tile of 2^logtot entries is 2^(logtot-logn)
-// independent length-2^logn cyclic transforms on consecutive blocks (all with root 1).
-template <int R>
-__device__ __forceinline__ void bfwd_round(double *__restrict__ s, int logtot, int logn, int s0,
-                                           const double *__restrict__ tw, const Mod mod, uint32_t red_mask) {
-  constexpr int E = 1 << R;
-  const int lstep = logn - s0 - R, sstep = 1 << lstep;
-  const int ngroups = (1 << logtot) >> R;
-  for (int grp = threadIdx.x; grp < ngroups; grp += blockDim.x) {
-    const int lo = grp & (sstep - 1), hi_all = grp >> lstep;
-    const int hi = hi_all & ((1 << s0) - 1);
-    const int base = (hi_all << (logn - s0)) + lo;
-    double v[E];
-#pragma unroll
-    for (int e = 0; e < E; e++) v[e] = s[pidx(base + e * sstep)];
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-      if ((red_mask >> (s0 + k)) & 1u) {
-#pragma unroll
-        for (int e = 0; e < E; e++) v[e] = reduce(v[e], mod);
-      }
-      const int half = E >> (k + 1);
-      const int twbase = (1 << (s0 + k)) + (hi << k);
-#pragma unroll
-      for (int blk = 0; blk < (1 << k); blk++) {
-        const double w = tw[twbase + blk];
-#pragma unroll
-        for (int e0 = 0; e0 < half; e0++) {
-          const int ia = blk * 2 * half + e0, ib = ia + half;
-          const double t = mulmod(v[ib], w, mod);
-          const double a = v[ia];
-          v[ia] = a + t;
-          v[ib] = a - t;
-        }
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < E; e++) s[pidx(base + e * sstep)] = v[e];
-  }
-}
-template <int R>
-__device__ __forceinline__ void binv_round(double *__restrict__ s, int logtot, int logn, int u0,
-                                           const double *__restrict__ itw, const Mod mod, uint32_t red_mask) {
-  constexpr int E = 1 << R;
-  const int g0 = 1 << u0;
-  const int ngroups = (1 << logtot) >> R;
-  const int groups_per_blk_log = logn - u0 - R;  // log2 of radix groups per sub-transform (per lo)
-  for (int grp = threadIdx.x; grp < ngroups; grp += blockDim.x) {
-    const int lo = grp & (g0 - 1), hi_all = grp >> u0;
-    const int hi = hi_all & ((1 << groups_per_blk_log) - 1);
-    const int base = (hi_all << (u0 + R)) + lo;
-    double v[E];
-#pragma unroll
-    for (int e = 0; e < E; e++) v[e] = s[pidx(base + e * g0)];
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-      if ((red_mask >> (u0 + k)) & 1u) {
-#pragma unroll
-        for (int e = 0; e < E; e++) v[e] = reduce(v[e], mod);
-      }
-      const int Mg = (1 << logn) >> (u0 + k + 1);
-      const int twbase = Mg + (hi << (R - 1 - k));
-#pragma unroll
-      for (int e = 0; e < E; e++) {
-        if (e & (1 << k)) continue;
-        const double w = itw[twbase + (e >> (k + 1))];
-        const double a = v[e], b = v[e + (1 << k)];
-        v[e] = a + b;
-        v[e + (1 << k)] = mulmod(a - b, w, mod);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < E; e++) s[pidx(base + e * g0)] = v[e];
-  }
-}
-__device__ __forceinline__ void lds_bntt_fwd(double *s, int logtot, int logn, const double *tw, const Mod mod, uint32_t mask) {
-  int st = 0;
-  while (st < logn) {
-    const int R = pick_radix(logn - st);
-    if (R == 3)
-      bfwd_round<3>(s, logtot, logn, st, tw, mod, mask);
-    else if (R == 2)
-      bfwd_round<2>(s, logtot, logn, st, tw, mod, mask);
-    else
-      bfwd_round<1>(s, logtot, logn, st, tw, mod, mask);
-    __syncthreads();
-    st += R;
-  }
-}
-__device__ __forceinline__ void lds_bntt_inv(double *s, int logtot, int logn, const double *itw, const Mod mod, uint32_t mask) {
-  int st = 0;
-  while (st < logn) {
-    const int R = pick_radix(logn - st);
-    if (R == 3)
-      binv_round<3>(s, logtot, logn, st, itw, mod, mask);
-    else if (R == 2)
-      binv_round<2>(s, logtot, logn, st, itw, mod, mask);
-    else
-      binv_round<1>(s, logtot, logn, st, itw, mod, mask);
-    __syncthreads();
-    st += R;
-  }
-}
-
 // One workgroup per column: values at 0..m-1 (cols[col][0..M)) -> monomial coefficients in place.
 // LDS: 2M padded doubles (A = [0,M) current polynomials, B = [M,2M) scratch).
 // Column c belongs to limb (c % S) / slots_per_limb (several vectors of S columns are batched).
@@ -472,10 +360,10 @@ interp_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned 
     s[pidx(M + j)] = 0.0;
   }
   __syncthreads();
-  lds_ntt_fwd(s, logM + 1, P.tw, 1, mod, P.fwd_mask2);
+  lds_ntt_fwd<4>(s, logM + 1, P.tw, 1, mod, P.fwd_mask2);
   for (int j = threadIdx.x; j < 2 * M; j += blockDim.x) s[pidx(j)] = mulmod(reduce(s[pidx(j)], mod), P.ehat[j], mod);
   __syncthreads();
-  lds_ntt_inv(s, logM + 1, P.itw, 1, mod, P.inv_mask2);
+  lds_ntt_inv<4>(s, logM + 1, P.itw, 1, mod, P.inv_mask2);
   // Newton coefficients f_k = s[k], k < m; everything at k >= m is discarded (invfact is zero
   // there only for the INPUT; the convolution tail must be cleared explicitly).
   for (int j = threadIdx.x; j < M; j += blockDim.x) {
@@ -555,47 +443,66 @@ interp_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned 
 }
 
 
-// H = (A*B - C)/Z per column + the ZK patch of r1cs_to_qrp.tcc:230-235.  A, B, C, H: [cols][M]
-// canonical doubles.  d1,d2,d3: ring elements [L][N] (u64) or NULL.
+// H = quo(A*B, Z) per column + the ZK patch of r1cs_to_qrp.tcc:230-235.  The reference divides
+// A*B - C by Z and drops the remainder (Boost long division, util/polynomials.tcc:76-81); since
+// deg C < deg Z, quo(A*B - C, Z) = quo(A*B, Z): C is not needed.  With P = A*B (degree 2m-2):
+//     rev(H) = rev(P) * rev(Z)^-1  mod x^(m-1)
+// i.e. five length-2M cyclic transforms per column against the precomputed spectrum `shat`.
+// A, B: [cols][M] canonical doubles; H: [cols][M].  d1,d2,d3: ring elements [L][N] (u64) or NULL.
 __global__ void __launch_bounds__(1024)
-h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, const double *__restrict__ Cc,
-                 double *__restrict__ H, int logM, unsigned slots_per_limb, ColPlans plans,
-                 const uint64_t *__restrict__ d1, const uint64_t *__restrict__ d2, const uint64_t *__restrict__ d3) {
+h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, double *__restrict__ H, int logM, int m,
+                 unsigned slots_per_limb, ColPlans plans, const uint64_t *__restrict__ d1,
+                 const uint64_t *__restrict__ d2, const uint64_t *__restrict__ d3) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
-  const int M = 1 << logM;
+  const int M = 1 << logM, M2 = 2 * M;
   const size_t col = blockIdx.x;
   const ColPlan &P = plans.l[col / slots_per_limb];
   const Mod mod = P.mod;
-  const double *srcs[3] = {A + col * (size_t)M, Bc + col * (size_t)M, Cc + col * (size_t)M};
-  double r[8];
-#pragma unroll
-  for (int pass = 0; pass < 3; pass++) {
-    for (int k = threadIdx.x; k < M; k += blockDim.x) s[pidx(k)] = mulmod(srcs[pass][k], P.gpow[k], mod);
+  const double *srcA = A + col * (size_t)M, *srcB = Bc + col * (size_t)M;
+  double r[16];  // this thread's slice of a spectrum: positions tid + k*blockDim
+  for (int pass = 0; pass < 2; pass++) {
+    const double *src = pass ? srcB : srcA;
+    for (int k = threadIdx.x; k < M; k += blockDim.x) {
+      s[pidx(k)] = center(src[k], mod);
+      s[pidx(M + k)] = 0.0;
+    }
     __syncthreads();
-    lds_ntt_fwd(s, logM, P.tw, 1, mod, P.fmask[logM]);
+    lds_ntt_fwd<4>(s, logM + 1, P.tw, 1, mod, P.fwd_mask2);
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < 16; k++) {
       const int p = threadIdx.x + k * blockDim.x;
-      if (p < M) {
+      if (p < M2) {
         const double v = reduce(s[pidx(p)], mod);
-        if (pass == 0)
-          r[k] = v;
-        else if (pass == 1)
-          r[k] = mulmod(r[k], v, mod);
-        else
-          r[k] = mulmod(reduce(r[k] - v, mod), P.zinv[p], mod);
+        r[k] = pass ? mulmod(r[k], v, mod) : v;
       }
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < 16; k++) {
     const int p = threadIdx.x + k * blockDim.x;
-    if (p < M) s[pidx(p)] = r[k];
+    if (p < M2) s[pidx(p)] = r[k];
   }
   __syncthreads();
-  lds_ntt_inv(s, logM, P.itw, 1, mod, P.imask[logM]);
+  lds_ntt_inv<4>(s, logM + 1, P.itw, 1, mod, P.inv_mask2);  // 2M * (A*B), coefficients 0 .. 2m-2
+  // T_i = P_{2m-2-i}, i < m-1, zero-padded
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int i = threadIdx.x + k * blockDim.x;
+    if (i < M2) r[k] = (i < m - 1) ? reduce(s[pidx(2 * m - 2 - i)], mod) : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int i = threadIdx.x + k * blockDim.x;
+    if (i < M2) s[pidx(i)] = r[k];
+  }
+  __syncthreads();
+  lds_ntt_fwd<4>(s, logM + 1, P.tw, 1, mod, P.fwd_mask2);
+  for (int i = threadIdx.x; i < M2; i += blockDim.x) s[pidx(i)] = mulmod(reduce(s[pidx(i)], mod), P.shat[i], mod);
+  __syncthreads();
+  lds_ntt_inv<4>(s, logM + 1, P.itw, 1, mod, P.inv_mask2);  // U_i = rev(H)_i, i < m-1
   double e1 = 0.0, e2 = 0.0, e3 = 0.0, e12 = 0.0;
   const bool zk = d1 != nullptr;
   if (zk) {
@@ -606,13 +513,70 @@ h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, co
   }
   double *dst = H + col * (size_t)M;
   for (int k = threadIdx.x; k < M; k += blockDim.x) {
-    double h = mulmod(reduce(s[pidx(k)], mod), P.ginv[k], mod);
+    double h = (k <= m - 2) ? reduce(s[pidx(m - 2 - k)], mod) : 0.0;
     if (zk) {
-      h += mulmod(e2, center(srcs[0][k], mod), mod) + mulmod(e1, center(srcs[1][k], mod), mod) +
-           mulmod(e12, P.ztab[k], mod);
+      h += mulmod(e2, center(srcA[k], mod), mod) + mulmod(e1, center(srcB[k], mod), mod) + mulmod(e12, P.ztab[k], mod);
       if (k == 0) h -= e3;
     }
     dst[k] = canon(h, mod);
+  }
+}
+
+// Input/primary coefficient vectors without interpolation (io shortcut): interpolation is linear
+// and the io evaluations depend on the n_inputs primary variables only, so
+//     X_io[t] = Lconst[t] + sum_{k <= n_inputs} x_k (*) L_k[t],   L_k = interp(column k of X)
+// with slot-constant L_k computed once per circuit.  grid (m, slot pairs / 256).
+struct IoDesc {
+  const int *k;       // variable index (0 = constant one)
+  const int *column;  // column index into Lcols
+  int count;
+};
+__global__ void __launch_bounds__(256)
+io_coeff_kernel(IoDesc io, const double *__restrict__ Lcols /* [ncols][L][M] */, const uint64_t *__restrict__ asg,
+                uint64_t *__restrict__ out, int N, int L, size_t M, const Mod *__restrict__ qmod) {
+  const size_t t = blockIdx.x, S = (size_t)L * N;
+  const size_t pair = (size_t)blockIdx.y * blockDim.x + threadIdx.x;
+  if (2 * pair >= S) return;
+  const int limb = (int)((2 * pair) / (size_t)N);
+  const Mod mod = qmod[limb];
+  double a0 = 0.0, a1 = 0.0;
+  for (int c = 0; c < io.count; c++) {
+    const double lv = center(Lcols[((size_t)io.column[c] * L + limb) * M + t], mod);
+    const int k = io.k[c];
+    if (k == 0) {
+      a0 += lv;
+      a1 += lv;
+    } else {
+      const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(k - 1) * S)[pair];
+      a0 += mulmod(from_u64(v.x), lv, mod);
+      a1 += mulmod(from_u64(v.y), lv, mod);
+    }
+    if ((c & 3) == 3) {
+      a0 = reduce(a0, mod);
+      a1 = reduce(a1, mod);
+    }
+  }
+  ulonglong2 o;
+  o.x = to_u64(canon(a0, mod));
+  o.y = to_u64(canon(a1, mod));
+  reinterpret_cast<ulonglong2 *>(out + t * S)[pair] = o;
+}
+
+// term-major: full[t] <- full[t] - io[t] + const[limb][t]
+__global__ void __launch_bounds__(256)
+mid_tm_kernel(uint64_t *__restrict__ full, const uint64_t *__restrict__ io, const double *__restrict__ cst /* [L][M] or null */,
+              size_t m, int N, int L, size_t M, const Mod *__restrict__ qmod) {
+  const size_t S = (size_t)L * N, total = m * S / 2, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t t = (2 * i) / S;
+    const int limb = (int)(((2 * i) % S) / (size_t)N);
+    const Mod mod = qmod[limb];
+    const double c = cst ? cst[(size_t)limb * M + t] : 0.0;
+    const ulonglong2 f = reinterpret_cast<const ulonglong2 *>(full)[i], g = reinterpret_cast<const ulonglong2 *>(io)[i];
+    ulonglong2 o;
+    o.x = to_u64(canon(from_u64(f.x) - from_u64(g.x) + c, mod));
+    o.y = to_u64(canon(from_u64(f.y) - from_u64(g.y) + c, mod));
+    reinterpret_cast<ulonglong2 *>(full)[i] = o;
   }
 }
 
@@ -684,9 +648,7 @@ static ColPlans make_colplans(rs_ctx *ctx, const WitnessPlan *P) {
     c.ehat = lp.d_ehat;
     c.dhat = lp.d_dhat;
     c.dlow = lp.d_dlow;
-    c.gpow = lp.d_gpow;
-    c.ginv = lp.d_ginv;
-    c.zinv = lp.d_zinv;
+    c.shat = lp.d_shat;
     c.ztab = lp.d_ztab;
     c.fwd_mask2 = lp.fwd_mask2;
     c.inv_mask2 = lp.inv_mask2;
@@ -720,6 +682,60 @@ void r1cs_evaluate_run(rs_ctx *ctx, const rs_r1cs *cs, int which, int mode, cons
   RS_HIP(hipGetLastError());
 }
 
+constexpr size_t IO_SHORTCUT_MAX_INPUTS = 64;
+
+// Per-circuit cache for the io shortcut: L_k = interp(column k of X), k = 0 (constant) .. n_inputs.
+static void build_io_cache(rs_ctx *ctx, const rs_r1cs *cs, const WitnessPlan *P, const ColPlans &cp, hipStream_t st) {
+  if (cs->io_built) return;
+  const size_t m = cs->m, M = P->M, L = (size_t)ctx->L;
+  std::vector<double> cols;  // [ncols][L][M]
+  std::vector<int> hk[3], hc[3];
+  int ncols = 0;
+  for (int w = 0; w < 3; w++) {
+    const size_t z = cs->nnz[w];
+    for (size_t k = 0; k <= cs->n_inputs; k++) {
+      std::vector<uint64_t> y(L * m, 0);
+      bool any = false;
+      for (size_t r = 0; r < m; r++)
+        for (uint32_t e = cs->h_row_ptr[w][r]; e < cs->h_row_ptr[w][r + 1]; e++)
+          if (cs->h_col[w][e] == k)
+            for (size_t i = 0; i < L; i++) {
+              const uint64_t c = cs->h_coeff[w][i * z + e] % ctx->q[i];
+              y[i * m + r] = host::addmod(y[i * m + r], c, ctx->q[i]);
+              any = any || c != 0;
+            }
+      if (!any) continue;
+      cols.resize((size_t)(ncols + 1) * L * M, 0.0);
+      for (size_t i = 0; i < L; i++)
+        for (size_t r = 0; r < m; r++) cols[((size_t)ncols * L + i) * M + r] = (double)y[i * m + r];
+      hk[w].push_back((int)k);
+      hc[w].push_back(ncols);
+      ncols++;
+    }
+  }
+  rs_r1cs *mc = const_cast<rs_r1cs *>(cs);
+  RS_HIP(hipMalloc(&mc->d_io_cols, std::max<size_t>(1, cols.size()) * sizeof(double)));
+  if (ncols) {
+    RS_HIP(hipMemcpy(mc->d_io_cols, cols.data(), cols.size() * sizeof(double), hipMemcpyHostToDevice));
+    launch_interp(ctx, P, cp, mc->d_io_cols, (size_t)ncols * L, L, 1, st);
+    RS_HIP(hipStreamSynchronize(st));
+  }
+  for (int w = 0; w < 3; w++) {
+    mc->io_count[w] = (int)hk[w].size();
+    mc->io_const_col[w] = -1;
+    for (size_t c = 0; c < hk[w].size(); c++)
+      if (hk[w][c] == 0) mc->io_const_col[w] = hc[w][c];
+    const size_t n = std::max<size_t>(1, hk[w].size());
+    RS_HIP(hipMalloc(&mc->d_io_k[w], n * sizeof(int)));
+    RS_HIP(hipMalloc(&mc->d_io_c[w], n * sizeof(int)));
+    if (!hk[w].empty()) {
+      RS_HIP(hipMemcpy(mc->d_io_k[w], hk[w].data(), hk[w].size() * sizeof(int), hipMemcpyHostToDevice));
+      RS_HIP(hipMemcpy(mc->d_io_c[w], hc[w].data(), hc[w].size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+  }
+  mc->io_built = true;
+}
+
 // Witness map driver.  outs[k] (k = A_io,B_io,C_io,A_mid,B_mid,C_mid,H) may be null.
 void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const uint64_t *d1, const uint64_t *d2,
                  const uint64_t *d3, uint64_t *const outs[7], uint64_t *h_Z, hipStream_t st) {
@@ -731,19 +747,22 @@ void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const ui
   if (h_Z)
     for (int i = 0; i < ctx->L; i++) memcpy(h_Z + (size_t)i * (m + 1), P->limb[i].Z.data(), sizeof(uint64_t) * (m + 1));
   const bool needH = outs[6] != nullptr;
+  const bool shortcut = cs->n_inputs <= IO_SHORTCUT_MAX_INPUTS;
   bool need_io[3], need_full[3];
   for (int w = 0; w < 3; w++) {
     need_io[w] = outs[w] != nullptr || outs[3 + w] != nullptr;
-    need_full[w] = outs[3 + w] != nullptr || needH;
+    need_full[w] = outs[3 + w] != nullptr || (needH && w < 2);  // H needs A and B only
   }
-  // column-major workspace: slots 0..2 = io, 3..5 = full, 6 = H
+  // column-major workspace: slots 0..2 = io (fallback path only), 3..5 = full, 6 = H
   const size_t vec = S * M;
   double *colbuf = (double *)ws_get(ctx, 5, 7 * vec * sizeof(double));
   uint64_t *evalbuf = (uint64_t *)ws_get(ctx, 6, std::max<size_t>(m, 1) * S * sizeof(uint64_t));
   auto colv = [&](int k) { return colbuf + (size_t)k * vec; };
   const dim3 tgrid((unsigned)((S + 31) / 32), (unsigned)((M + 31) / 32));
+  const unsigned by = (unsigned)((S / 2 + 255) / 256);
+  if (shortcut) build_io_cache(ctx, cs, P, cp, st);
   for (int w = 0; w < 3; w++) {
-    if (need_io[w]) {
+    if (need_io[w] && !shortcut) {
       r1cs_evaluate_run(ctx, cs, w, RS_EVAL_IO, d_asg, evalbuf, st);
       hipLaunchKernelGGL(transpose_in_kernel, tgrid, dim3(256), 0, st, evalbuf, colv(w), m, S, M);
     }
@@ -753,57 +772,73 @@ void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const ui
     }
   }
   RS_HIP(hipGetLastError());
-  // one batched interpolation over every needed vector (skipped vectors cost nothing but are
-  // laid out contiguously, so launch per contiguous run)
+  // batched interpolation over contiguous runs of needed vectors
+  auto needed = [&](int k) { return k < 3 ? (need_io[k] && !shortcut) : need_full[k - 3]; };
   for (int k = 0; k < 6; k++) {
-    const bool need = k < 3 ? need_io[k] : need_full[k - 3];
-    if (!need) continue;
+    if (!needed(k)) continue;
     int e = k;
-    while (e + 1 < 6 && (e + 1 < 3 ? need_io[e + 1] : need_full[e + 1 - 3])) e++;
+    while (e + 1 < 6 && needed(e + 1)) e++;
     launch_interp(ctx, P, cp, colv(k), (size_t)(e - k + 1) * S, S, N, st);
     k = e;
   }
   if (needH) {
-    const size_t lds = padded_len(M) * sizeof(double);
+    const size_t lds = padded_len(2 * M) * sizeof(double);
     RS_HIP(hipFuncSetAttribute((const void *)h_columns_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(h_columns_kernel, dim3((unsigned)S), dim3(col_threads(M)), lds, st, colv(3), colv(4), colv(5),
-                       colv(6), P->logM, (unsigned)N, cp, d1, d2, d3);
+    hipLaunchKernelGGL(h_columns_kernel, dim3((unsigned)S), dim3(col_threads(2 * M)), lds, st, colv(3), colv(4), colv(6),
+                       P->logM, (int)m, (unsigned)N, cp, d1, d2, d3);
     RS_HIP(hipGetLastError());
   }
-  // constant-term correction for the mid vectors
-  double *d_const = nullptr;
-  bool any_const = false;
-  for (int w = 0; w < 3; w++) any_const = any_const || cs->has_const[w];
-  if (any_const) {
-    // [3][L][M] values -> interpolate as 3*L single columns
-    std::vector<double> hc((size_t)3 * ctx->L * M, 0.0);
-    for (int w = 0; w < 3; w++)
-      for (int i = 0; i < ctx->L; i++)
-        for (size_t r = 0; r < m; r++) hc[((size_t)w * ctx->L + i) * M + r] = (double)cs->h_const[w][(size_t)i * m + r];
-    d_const = (double *)ws_get(ctx, 4, hc.size() * sizeof(double));
-    RS_HIP(hipMemcpyAsync(d_const, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    RS_HIP(hipStreamSynchronize(st));  // hc goes out of scope
-    launch_interp(ctx, P, cp, d_const, (size_t)3 * ctx->L, (size_t)ctx->L, 1, st);
-  }
   const unsigned eb = (unsigned)std::min<size_t>((vec + 255) / 256, 256 * 16);
-  for (int w = 0; w < 3; w++) {
-    if (!outs[3 + w]) continue;
-    const double *cst = (d_const && cs->has_const[w]) ? d_const + (size_t)w * ctx->L * M : nullptr;
-    hipLaunchKernelGGL(mid_kernel, dim3(eb), dim3(256), 0, st, colv(3 + w), colv(w), cst, M, S, (unsigned)N, cp);
+  if (!shortcut) {
+    // fallback: interpolate the constant parts and combine in column-major form
+    double *d_const = nullptr;
+    bool any_const = false;
+    for (int w = 0; w < 3; w++) any_const = any_const || cs->has_const[w];
+    if (any_const) {
+      std::vector<double> hc((size_t)3 * ctx->L * M, 0.0);
+      for (int w = 0; w < 3; w++)
+        for (int i = 0; i < ctx->L; i++)
+          for (size_t r = 0; r < m; r++) hc[((size_t)w * ctx->L + i) * M + r] = (double)cs->h_const[w][(size_t)i * m + r];
+      d_const = (double *)ws_get(ctx, 4, hc.size() * sizeof(double));
+      RS_HIP(hipMemcpyAsync(d_const, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice, st));
+      RS_HIP(hipStreamSynchronize(st));  // hc goes out of scope
+      launch_interp(ctx, P, cp, d_const, (size_t)3 * ctx->L, (size_t)ctx->L, 1, st);
+    }
+    for (int w = 0; w < 3; w++) {
+      if (!outs[3 + w]) continue;
+      const double *cst = (d_const && cs->has_const[w]) ? d_const + (size_t)w * ctx->L * M : nullptr;
+      hipLaunchKernelGGL(mid_kernel, dim3(eb), dim3(256), 0, st, colv(3 + w), colv(w), cst, M, S, (unsigned)N, cp);
+    }
+    RS_HIP(hipGetLastError());
+    for (int k = 0; k < 6; k++)
+      if (outs[k]) hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(k), outs[k], m, S, M);
+  } else {
+    for (int w = 0; w < 3; w++) {
+      uint64_t *io_dst = outs[w] ? outs[w] : evalbuf;  // evalbuf is free again: all evaluations are transposed
+      if (need_io[w]) {
+        IoDesc io{cs->d_io_k[w], cs->d_io_c[w], cs->io_count[w]};
+        hipLaunchKernelGGL(io_coeff_kernel, dim3((unsigned)m, by), dim3(256), 0, st, io, cs->d_io_cols, d_asg, io_dst, ctx->N,
+                           ctx->L, M, ctx->d_qmod);
+      }
+      if (outs[3 + w]) {
+        hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(3 + w), outs[3 + w], m, S, M);
+        const double *cst = cs->io_const_col[w] >= 0 ? cs->d_io_cols + (size_t)cs->io_const_col[w] * ctx->L * M : nullptr;
+        const unsigned mb = (unsigned)std::min<size_t>((m * S / 2 + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(mid_tm_kernel, dim3(mb), dim3(256), 0, st, outs[3 + w], io_dst, cst, m, ctx->N, ctx->L, M, ctx->d_qmod);
+      }
+    }
   }
   RS_HIP(hipGetLastError());
-  for (int k = 0; k < 7; k++) {
-    if (!outs[k]) continue;
-    const size_t rows = std::min(m, M);  // H row m (only when m == M) is written below
-    hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(k), outs[k], k == 6 ? std::min(m + 1, M) : rows, S, M);
-  }
-  RS_HIP(hipGetLastError());
-  if (needH && m == M) {  // H[m] = d1*d2*Z[m] = d1*d2 (Z monic), zero without ZK
-    uint64_t *top = outs[6] + m * S;
-    if (d1)
-      RS_REQUIRE(rs_ring_mul(ctx, top, d1, d2, 1, (rs_stream)st) == RS_OK, rs_last_error());
-    else
-      RS_HIP(hipMemsetAsync(top, 0, S * sizeof(uint64_t), st));
+  if (needH) {
+    hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(6), outs[6], std::min(m + 1, M), S, M);
+    RS_HIP(hipGetLastError());
+    if (m == M) {  // H[m] = d1*d2*Z[m] = d1*d2 (Z monic), zero without ZK
+      uint64_t *top = outs[6] + m * S;
+      if (d1)
+        RS_REQUIRE(rs_ring_mul(ctx, top, d1, d2, 1, (rs_stream)st) == RS_OK, rs_last_error());
+      else
+        RS_HIP(hipMemsetAsync(top, 0, S * sizeof(uint64_t), st));
+    }
   }
 }
 
@@ -832,6 +867,9 @@ int rs_r1cs_create(rs_ctx *ctx, size_t m, size_t n_vars, size_t n_inputs, const 
     const size_t z = nnz[w];
     cs->nnz[w] = z;
     RS_REQUIRE(h_row_ptr[w][0] == 0 && h_row_ptr[w][m] == z, "row_ptr does not match nnz");
+    cs->h_row_ptr[w].assign(h_row_ptr[w], h_row_ptr[w] + m + 1);
+    cs->h_col[w].assign(h_col[w], h_col[w] + z);
+    cs->h_coeff[w].assign(h_coeff[w], h_coeff[w] + (size_t)ctx->L * z);
     cs->h_const[w].assign((size_t)ctx->L * m, 0);
     cs->has_const[w] = false;
     std::vector<double> cf((size_t)ctx->L * std::max<size_t>(z, 1), 0.0);
@@ -864,7 +902,10 @@ void rs_r1cs_destroy(rs_r1cs *cs) {
     if (cs->d_row_ptr[w]) (void)hipFree(cs->d_row_ptr[w]);
     if (cs->d_col[w]) (void)hipFree(cs->d_col[w]);
     if (cs->d_coeff[w]) (void)hipFree(cs->d_coeff[w]);
+    if (cs->d_io_k[w]) (void)hipFree(cs->d_io_k[w]);
+    if (cs->d_io_c[w]) (void)hipFree(cs->d_io_c[w]);
   }
+  if (cs->d_io_cols) (void)hipFree(cs->d_io_cols);
   delete cs;
 }
 

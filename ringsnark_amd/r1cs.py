@@ -51,7 +51,7 @@ def chain_r1cs(m: int, q: List[int]) -> R1CS:
     return from_rows(m, m + 2, 2, rows, q)
 
 
-def wide_r1cs(m: int, q: List[int], seed: int = 11, width: int = 8) -> R1CS:
+def wide_r1cs(m: int, q: List[int], seed: int = 11, width: int = 8, n_inputs: int = 2) -> R1CS:
     """(sum of `width` earlier variables with small signed coefficients, plus a constant)
     * (x_{i+1}) = x_{i+2}.  Exercises multi-term linear combinations, the constant-one column
     and negative coefficients."""
@@ -64,7 +64,7 @@ def wide_r1cs(m: int, q: List[int], seed: int = 11, width: int = 8) -> R1CS:
         rows["a"].append(terms)
         rows["b"].append([(i + 2, 1)])
         rows["c"].append([(i + 3, 1)])
-    return from_rows(m, m + 2, 2, rows, q)
+    return from_rows(m, m + 2, n_inputs, rows, q)
 
 
 def solve_forward(cs: R1CS, x0, x1, ring_mul, ring_lincomb):

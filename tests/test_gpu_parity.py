@@ -131,14 +131,18 @@ def test_grouped_msm_equals_sum_of_inner_products():
         assert (got[c, 1] == ctx.inner_product(crs, v[2])[0]).all()
 
 
-@pytest.mark.parametrize("name,m,kind", [("toy", 1, "chain"), ("toy", 2, "chain"), ("toy", 7, "wide"), ("toy", 16, "wide"),
-                                          ("toy", 100, "wide"), ("toy49", 33, "wide"), ("toy49", 64, "chain")])
+@pytest.mark.parametrize("name,m,kind", [("toy", 1, "chain"), ("toy", 2, "chain"), ("toy", 3, "wide"), ("toy", 7, "wide"),
+                                          ("toy", 16, "wide"), ("toy", 100, "wide"), ("toy", 100, "many_inputs"),
+                                          ("toy49", 33, "wide"), ("toy49", 64, "chain"), ("toy49", 90, "many_inputs")])
 def test_witness_map_matches_oracle(name, m, kind):
     from ringsnark_amd import _lib
     dev = dev_for(name)
     prm = dev.prm
     ctx = H.oracle_ctx(prm)
-    cs = R.wide_r1cs(m, prm.q) if kind == "wide" else R.chain_r1cs(m, prm.q)
+    if kind == "many_inputs":  # > 64 primary inputs: the generic io path (evaluate + interpolate)
+        cs = R.wide_r1cs(m, prm.q, n_inputs=70)
+    else:
+        cs = R.wide_r1cs(m, prm.q) if kind == "wide" else R.chain_r1cs(m, prm.q)
     asg = H.make_assignment(ctx, cs)
     dcs = dev.r1cs(cs)
     dasg = dev.put(asg)

@@ -612,6 +612,10 @@ int rs_set_tuning(const char *key, int value) {
     g_mac_variant = value;
   else if (std::string(key) == "mac_ablate")
     g_mac_ablate = value;
+  else if (std::string(key) == "witness_lds_logM") {
+    RS_REQUIRE(value >= 6 && value <= 13, "witness_lds_logM must be in [6, 13]");
+    g_witness_lds_logM = value;
+  }
   else
     throw Error(RS_ERR_INVALID, std::string("unknown tuning key ") + key);
   RS_API_END

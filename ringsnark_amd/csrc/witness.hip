@@ -154,8 +154,8 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
   P->M = (size_t)1 << P->logM;
   const size_t M = P->M;
   const int logM = P->logM;
-  if (M > 8192)
-    throw Error(RS_ERR_UNSUPPORTED, "witness map for more than 8192 constraints needs the multi-pass column transform, not built in this round");
+  if (logM > 20)
+    throw Error(RS_ERR_UNSUPPORTED, "witness map beyond 2^20 constraints is not supported");
   P->limb.resize(ctx->L);
   for (int li = 0; li < ctx->L; li++) {
     LimbPlan &lp = P->limb[li];
@@ -303,7 +303,7 @@ struct ColPlan {  // per-limb device pointers handed to the column kernels
   Mod mod;
   const double *tw, *itw, *invfact, *ehat, *dhat, *dlow, *shat, *ztab;
   uint32_t fwd_mask2, inv_mask2;
-  uint32_t fmask[16], imask[16];  // reduce masks for transforms of length 2^l
+  uint32_t fmask[24], imask[24];  // reduce masks for transforms of length 2^l
 };
 struct ColPlans {
   ColPlan l[RS_MAX_L];
@@ -342,6 +342,80 @@ __global__ void __launch_bounds__(256) transpose_out_kernel(const double *__rest
   }
 }
 
+// Newton -> monomial product tree on an LDS tile holding Bn = 2^logB consecutive Newton
+// coefficients of a column, starting at column position pos0 (a multiple of Bn); the tile's
+// second half [Bn, 2Bn) is scratch.  Runs levels 1..logB (node sizes 2..Bn).  Tables are
+// indexed by the position inside the whole column (length M = 2^logM).
+__device__ __forceinline__ void tree_levels_lds(double *s, int logB, int logM, int pos0, const ColPlan &P) {
+  const Mod mod = P.mod;
+  const int Bn = 1 << logB, M = 1 << logM;
+  // schoolbook levels: one thread per node of size 2^SCHOOL_LEVELS
+  {
+    const int lv = logB < SCHOOL_LEVELS ? logB : SCHOOL_LEVELS;
+    const int nn = 1 << lv;
+    const int dstride = M / 2 + 1;
+    for (int node = threadIdx.x; node < (Bn >> lv); node += blockDim.x) {
+      double v[1 << SCHOOL_LEVELS];
+#pragma unroll
+      for (int k = 0; k < (1 << SCHOOL_LEVELS); k++) v[k] = (k < nn) ? s[pidx(node * nn + k)] : 0.0;
+#pragma unroll
+      for (int l = 1; l <= SCHOOL_LEVELS; l++) {
+        if (l > lv) break;
+        const int n = 1 << l, h = n >> 1;
+#pragma unroll
+        for (int sub = 0; sub < ((1 << SCHOOL_LEVELS) >> l); sub++) {
+          if (sub * n >= nn) break;
+          const int gnode = ((pos0 + node * nn) >> l) + sub;  // node index at level l within the column
+          const double *dl = P.dlow + (size_t)l * dstride + (size_t)gnode * h;
+          double out[1 << SCHOOL_LEVELS];
+#pragma unroll
+          for (int k = 0; k < n; k++) out[k] = 0.0;
+          // D_left * F_right, D_left = x^h + sum dl[a] x^a
+#pragma unroll
+          for (int b = 0; b < h; b++) {
+            const double fr = v[sub * n + h + b];
+            out[h + b] += fr;
+#pragma unroll
+            for (int a = 0; a < h; a++) out[a + b] += mulmod(dl[a], fr, mod);
+          }
+#pragma unroll
+          for (int k = 0; k < n; k++) {
+            const double left = (k < h) ? v[sub * n + k] : 0.0;
+            v[sub * n + k] = reduce(out[k] + left, mod);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < (1 << SCHOOL_LEVELS); k++)
+        if (k < nn) s[pidx(node * nn + k)] = v[k];
+    }
+    __syncthreads();
+  }
+  // transform levels: B[node] = (F_right, 0) -> batched length-n transforms -> * spectrum of D_left
+  // -> inverse -> + F_left.  B is addressed through an offset tile (Bn is a multiple of 16 or < 16,
+  // so pidx(Bn + i) = pidx(Bn) + pidx(i)).
+  double *Bt = s + pidx(Bn);
+  for (int l = SCHOOL_LEVELS + 1; l <= logB; l++) {
+    const int n = 1 << l, h = n >> 1;
+    for (int i = threadIdx.x; i < Bn; i += blockDim.x) {
+      const int k = i & (n - 1);
+      Bt[pidx(i)] = (k < h) ? s[pidx(i + h)] : 0.0;
+    }
+    __syncthreads();
+    lds_bntt_fwd(Bt, logB, l, P.tw, mod, P.fmask[l]);
+    const double *dh = P.dhat + (size_t)l * M + pos0;
+    for (int i = threadIdx.x; i < Bn; i += blockDim.x) Bt[pidx(i)] = mulmod(reduce(Bt[pidx(i)], mod), dh[i], mod);
+    __syncthreads();
+    lds_bntt_inv(Bt, logB, l, P.itw, mod, P.imask[l]);
+    for (int i = threadIdx.x; i < Bn; i += blockDim.x) {
+      const int k = i & (n - 1);
+      const double left = (k < h) ? s[pidx(i)] : 0.0;
+      s[pidx(i)] = reduce(Bt[pidx(i)] + left, mod);
+    }
+    __syncthreads();
+  }
+}
+
 // One workgroup per column: values at 0..m-1 (cols[col][0..M)) -> monomial coefficients in place.
 // LDS: 2M padded doubles (A = [0,M) current polynomials, B = [M,2M) scratch).
 // Column c belongs to limb (c % S) / slots_per_limb (several vectors of S columns are batched).
@@ -371,74 +445,7 @@ interp_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned 
     s[pidx(j)] = (inv_nonzero != 0.0) ? reduce(s[pidx(j)], mod) : 0.0;
   }
   __syncthreads();
-  // 2a. schoolbook levels: one thread per node of size 2^SCHOOL_LEVELS
-  {
-    const int lv = logM < SCHOOL_LEVELS ? logM : SCHOOL_LEVELS;
-    const int nn = 1 << lv;
-    const int dstride = M / 2 + 1;
-    for (int node = threadIdx.x; node < (M >> lv); node += blockDim.x) {
-      double v[1 << SCHOOL_LEVELS];
-#pragma unroll
-      for (int k = 0; k < (1 << SCHOOL_LEVELS); k++) v[k] = (k < nn) ? s[pidx(node * nn + k)] : 0.0;
-#pragma unroll
-      for (int l = 1; l <= SCHOOL_LEVELS; l++) {
-        if (l > lv) break;
-        const int n = 1 << l, h = n >> 1;
-        // sub-nodes of this thread's node at level l
-#pragma unroll
-        for (int sub = 0; sub < ((1 << SCHOOL_LEVELS) >> l); sub++) {
-          if (sub * n >= nn) break;
-          const int gnode = (node * nn) / n + sub;  // global node index at level l
-          const double *dl = P.dlow + (size_t)l * dstride + (size_t)gnode * h;
-          double out[1 << SCHOOL_LEVELS];
-#pragma unroll
-          for (int k = 0; k < n; k++) out[k] = 0.0;
-          // D_left * F_right, D_left = x^h + sum dl[a] x^a
-#pragma unroll
-          for (int b = 0; b < h; b++) {
-            const double fr = v[sub * n + h + b];
-            out[h + b] += fr;
-#pragma unroll
-            for (int a = 0; a < h; a++) out[a + b] += mulmod(dl[a], fr, mod);
-          }
-#pragma unroll
-          for (int k = 0; k < n; k++) {
-            const double left = (k < h) ? v[sub * n + k] : 0.0;
-            v[sub * n + k] = reduce(out[k] + left, mod);
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < (1 << SCHOOL_LEVELS); k++)
-        if (k < nn) s[pidx(node * nn + k)] = v[k];
-    }
-    __syncthreads();
-  }
-  // 2b. transform levels
-  double *B = s;  // B region addressed as index M + i through pidx
-  for (int l = SCHOOL_LEVELS + 1; l <= logM; l++) {
-    const int n = 1 << l, h = n >> 1;
-    // B[node] = (F_right, 0)
-    for (int i = threadIdx.x; i < M; i += blockDim.x) {
-      const int k = i & (n - 1);
-      B[pidx(M + i)] = (k < h) ? s[pidx(i + h)] : 0.0;
-    }
-    __syncthreads();
-    // batched length-n transforms over the B half: shift the tile base so indices run 0..M-1
-    // (pidx is not shift-invariant, so transforms address B through an offset tile)
-    double *Bt = s + pidx(M);  // valid because M is a multiple of 16: pidx(M + i) = pidx(M) + pidx(i)
-    lds_bntt_fwd(Bt, logM, l, P.tw, mod, P.fmask[l]);
-    const double *dh = P.dhat + (size_t)l * M;
-    for (int i = threadIdx.x; i < M; i += blockDim.x) Bt[pidx(i)] = mulmod(reduce(Bt[pidx(i)], mod), dh[i], mod);
-    __syncthreads();
-    lds_bntt_inv(Bt, logM, l, P.itw, mod, P.imask[l]);
-    for (int i = threadIdx.x; i < M; i += blockDim.x) {
-      const int k = i & (n - 1);
-      const double left = (k < h) ? s[pidx(i)] : 0.0;
-      s[pidx(i)] = reduce(Bt[pidx(i)] + left, mod);
-    }
-    __syncthreads();
-  }
+  tree_levels_lds(s, logM, logM, 0, P);
   for (int j = threadIdx.x; j < M; j += blockDim.x) c[j] = canon(s[pidx(j)], mod);
 }
 
@@ -635,6 +642,151 @@ r1cs_eval_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restric
   reinterpret_cast<ulonglong2 *>(out + row * S)[pair] = o;
 }
 
+
+// =============================================================================================
+// Multi-pass column transforms for M > 2^g_witness_lds_logM (a column no longer fits one LDS tile).
+// A cyclic transform of length n = n1 * Bn over a column held in global memory is
+//     forward:  log2(n1) "cross" stages (gap >= Bn; twiddles depend on the block index only),
+//               then n1 independent length-Bn sub-transforms rooted at tree nodes n1 + b, in LDS;
+//     inverse:  the sub-transforms first, then the cross stages.
+// Both reuse the round functions of ntt_core.cuh (global-memory functors / `root`).
+// =============================================================================================
+struct TabPtrs {
+  const double *t[RS_MAX_L];
+};
+struct GlobalF64IO {
+  double *p;
+  __device__ __forceinline__ double load(int i) const { return p[i]; }
+  __device__ __forceinline__ void store(int i, double v) const { p[i] = v; }
+};
+
+// cross stages [s0, s0+R) of batched length-2^logsub transforms inside columns of length 2^logtot.
+// grid (x, columns)
+template <bool INV, int R>
+__global__ void __launch_bounds__(256)
+cross_kernel(double *__restrict__ X, int logtot, int logsub, int s0, size_t col0, unsigned S, unsigned slots_per_limb,
+             ColPlans plans) {
+  const size_t col = blockIdx.y;
+  const ColPlan &P = plans.l[((col0 + col) % S) / slots_per_limb];
+  const GlobalF64IO io{X + (col << logtot)};
+  const Lanes ln{(int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x)};
+  if (INV)
+    inv_round<R>(io, io, logtot, logsub, s0, P.itw, 1, P.mod, P.imask[logsub], ln);
+  else
+    fwd_round<R>(io, io, logtot, logsub, s0, P.tw, 1, P.mod, P.fmask[logsub], ln);
+}
+
+// Sub-transforms on blocks of Bn = 2^logB doubles.  MODE 0: forward, 1: inverse, 2: forward,
+// multiply by tab[(blk % tab_period) * Bn + j], inverse (fused).  Block blk belongs to column
+// blk / blocks_per_col; inside its transform (n1 = 2^log_n1 blocks) it is block blk % n1.
+template <int MODE>
+__global__ void __launch_bounds__(1024)
+sub_ntt_kernel(double *__restrict__ X, int logB, int log_n1, TabPtrs tabs, unsigned tab_period,
+               unsigned blocks_per_col, size_t col0, unsigned S, unsigned slots_per_limb, ColPlans plans) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int Bn = 1 << logB;
+  const size_t blk = blockIdx.x;
+  const size_t col = blk / blocks_per_col;
+  const int limb = (int)(((col0 + col) % S) / slots_per_limb);
+  const ColPlan &P = plans.l[limb];
+  const Mod mod = P.mod;
+  const int root = (1 << log_n1) + (int)(blk & ((1u << log_n1) - 1));
+  const int logn = logB + log_n1;
+  double *x = X + blk * (size_t)Bn;
+  for (int i = threadIdx.x; i < Bn; i += blockDim.x) s[pidx(i)] = x[i];
+  __syncthreads();
+  if (MODE == 0 || MODE == 2) lds_ntt_fwd<3>(s, logB, P.tw, root, mod, P.fmask[logn] >> log_n1);
+  if (MODE == 2) {
+    const double *tab = tabs.t[limb] + (size_t)(blk % tab_period) * Bn;
+    for (int i = threadIdx.x; i < Bn; i += blockDim.x) s[pidx(i)] = mulmod(reduce(s[pidx(i)], mod), tab[i], mod);
+    __syncthreads();
+  }
+  if (MODE == 1 || MODE == 2) lds_ntt_inv<3>(s, logB, P.itw, root, mod, P.imask[logn]);
+  for (int i = threadIdx.x; i < Bn; i += blockDim.x) x[i] = s[pidx(i)];
+}
+
+// product-tree levels 1..logB on every block of Bn Newton coefficients (grid = columns * M/Bn)
+__global__ void __launch_bounds__(1024)
+tree_block_kernel(double *__restrict__ X, int logM, int logB, size_t col0, unsigned S, unsigned slots_per_limb,
+                  ColPlans plans) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int Bn = 1 << logB;
+  const unsigned nb = 1u << (logM - logB);
+  const size_t col = blockIdx.x / nb;
+  const int pos0 = (int)(blockIdx.x % nb) * Bn;
+  const ColPlan &P = plans.l[((col0 + col) % S) / slots_per_limb];
+  double *x = X + (col << logM) + pos0;
+  for (int i = threadIdx.x; i < Bn; i += blockDim.x) s[pidx(i)] = x[i];
+  __syncthreads();
+  tree_levels_lds(s, logB, logM, pos0, P);
+  for (int i = threadIdx.x; i < Bn; i += blockDim.x) x[i] = s[pidx(i)];
+}
+
+// element-wise helpers of the multi-pass path; one launch covers `cols` columns
+enum EwOp { EW_SCALE_PAD, EW_TAKE_LOW, EW_FILL_RIGHT, EW_COMBINE, EW_PAD_CENTER, EW_MUL, EW_REV_TRUNC, EW_H_FINISH, EW_CANON };
+struct EwArgs {
+  double *dst;
+  const double *a, *b;
+  int logM, l, m;
+  unsigned S, slots_per_limb;
+  size_t col0;  // first column (for d1,d2,d3 indexing)
+  const uint64_t *d1, *d2, *d3;
+};
+template <int OP>
+__global__ void __launch_bounds__(256) ew_kernel(EwArgs e, size_t cols, ColPlans plans) {
+  const size_t M = (size_t)1 << e.logM, M2 = 2 * M;
+  const size_t len = (OP == EW_SCALE_PAD || OP == EW_PAD_CENTER || OP == EW_MUL || OP == EW_REV_TRUNC) ? M2 : M;
+  const size_t total = cols * len, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t col = i / len, k = i % len;
+    const ColPlan &P = plans.l[((e.col0 + col) % e.S) / e.slots_per_limb];
+    const Mod mod = P.mod;
+    if (OP == EW_SCALE_PAD) {  // dst[2M] = a[M] * invfact, zero padded
+      e.dst[i] = k < M ? mulmod(e.a[col * M + k], P.invfact[k], mod) : 0.0;
+    } else if (OP == EW_TAKE_LOW) {  // dst[M] = Newton coefficients k < m of a[2M]
+      e.dst[i] = (P.invfact[k] != 0.0) ? reduce(e.a[col * M2 + k], mod) : 0.0;
+    } else if (OP == EW_FILL_RIGHT) {  // dst[M]: per node of size 2^l, (F_right, 0)
+      const size_t n = (size_t)1 << e.l, h = n >> 1, kk = k & (n - 1);
+      e.dst[i] = kk < h ? e.a[col * M + k + h] : 0.0;
+    } else if (OP == EW_COMBINE) {  // dst[M] = a[M] (product) + F_left of dst
+      const size_t n = (size_t)1 << e.l, h = n >> 1, kk = k & (n - 1);
+      e.dst[i] = reduce(e.a[i] + (kk < h ? e.dst[i] : 0.0), mod);
+    } else if (OP == EW_PAD_CENTER) {  // dst[2M] = centred a[M], zero padded
+      e.dst[i] = k < M ? center(e.a[col * M + k], mod) : 0.0;
+    } else if (OP == EW_MUL) {  // dst[2M] *= a[2M]
+      e.dst[i] = mulmod(reduce(e.dst[i], mod), reduce(e.a[i], mod), mod);
+    } else if (OP == EW_REV_TRUNC) {  // dst[2M]: T_k = a[2m-2-k] for k < m-1
+      e.dst[i] = ((long long)k < (long long)e.m - 1) ? reduce(e.a[col * M2 + (size_t)(2 * e.m - 2) - k], mod) : 0.0;
+    } else if (OP == EW_H_FINISH) {  // dst[M] = H from U = a[2M], ZK patch from A = b (M), B = dst2 unused
+      double h = ((long long)k <= (long long)e.m - 2) ? reduce(e.a[col * M2 + (size_t)(e.m - 2) - k], mod) : 0.0;
+      e.dst[i] = h;
+    } else {  // EW_CANON
+      e.dst[i] = canon(e.a[i], mod);
+    }
+  }
+}
+// ZK patch of the multi-pass H: H += d2*A + d1*B + d1*d2*Z, H[0] -= d3; then canonical form.
+__global__ void __launch_bounds__(256)
+h_patch_kernel(double *__restrict__ H, const double *__restrict__ A, const double *__restrict__ B, int logM, size_t cols,
+               size_t col0, unsigned S, unsigned slots_per_limb, ColPlans plans, const uint64_t *__restrict__ d1,
+               const uint64_t *__restrict__ d2, const uint64_t *__restrict__ d3) {
+  const size_t M = (size_t)1 << logM, total = cols * M, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t col = i / M, k = i % M, gcol = (col0 + col) % S;
+    const ColPlan &P = plans.l[gcol / slots_per_limb];
+    const Mod mod = P.mod;
+    double h = H[i];
+    if (d1) {
+      const double e1 = center(from_u64(d1[gcol]), mod), e2 = center(from_u64(d2[gcol]), mod);
+      h += mulmod(e2, center(A[i], mod), mod) + mulmod(e1, center(B[i], mod), mod) + mulmod(mulmod(e1, e2, mod), P.ztab[k], mod);
+      if (k == 0) h -= center(from_u64(d3[gcol]), mod);
+    }
+    H[i] = canon(h, mod);
+  }
+}
+
 static ColPlans make_colplans(rs_ctx *ctx, const WitnessPlan *P) {
   ColPlans cp;
   memset(&cp, 0, sizeof(cp));
@@ -652,7 +804,7 @@ static ColPlans make_colplans(rs_ctx *ctx, const WitnessPlan *P) {
     c.ztab = lp.d_ztab;
     c.fwd_mask2 = lp.fwd_mask2;
     c.inv_mask2 = lp.inv_mask2;
-    for (int l = 0; l < 16; l++) {
+    for (int l = 0; l < 24; l++) {
       c.fmask[l] = fwd_reduce_mask(lp.p, l);
       c.imask[l] = inv_reduce_mask(lp.p, l);
     }
@@ -662,14 +814,189 @@ static ColPlans make_colplans(rs_ctx *ctx, const WitnessPlan *P) {
 
 static int col_threads(size_t M) { return (int)std::max<size_t>(64, std::min<size_t>(1024, M / 8)); }
 
+int g_witness_lds_logM = 13;  // columns up to 2^13 run entirely inside one LDS tile
+
+template <bool INV>
+static void launch_cross(double *X, size_t ncols, size_t col0, int logtot, int logsub, int logB, size_t S, size_t spl,
+                         const ColPlans &cp, hipStream_t st) {
+  // cross stages: forward stages [0, logsub-logB), inverse stages [logB, logsub)
+  const int ncross = logsub - logB;
+  const size_t groups = ((size_t)1 << logtot);
+  int done = 0;
+  while (done < ncross) {
+    const int R = pick_radix(ncross - done, 3);
+    const int s0 = INV ? logB + done : done;
+    const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>((groups >> R) / 256, 1024));
+    const dim3 grid(gx, (unsigned)ncols);
+    if (R == 3)
+      hipLaunchKernelGGL((cross_kernel<INV, 3>), grid, dim3(256), 0, st, X, logtot, logsub, s0, col0, (unsigned)S, (unsigned)spl, cp);
+    else if (R == 2)
+      hipLaunchKernelGGL((cross_kernel<INV, 2>), grid, dim3(256), 0, st, X, logtot, logsub, s0, col0, (unsigned)S, (unsigned)spl, cp);
+    else
+      hipLaunchKernelGGL((cross_kernel<INV, 1>), grid, dim3(256), 0, st, X, logtot, logsub, s0, col0, (unsigned)S, (unsigned)spl, cp);
+    done += R;
+  }
+  RS_HIP(hipGetLastError());
+}
+
+template <int MODE>
+static void launch_sub(double *X, size_t ncols, size_t col0, int logtot, int logsub, int logB, const TabPtrs *tabs,
+                       size_t tab_period, size_t S, size_t spl, const ColPlans &cp, hipStream_t st) {
+  const size_t lds = padded_len((size_t)1 << logB) * sizeof(double);
+  const size_t bpc = (size_t)1 << (logtot - logB);
+  static TabPtrs none{};
+  const TabPtrs &tp = tabs ? *tabs : none;
+  RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, ((size_t)1 << logB) / 8));
+  hipLaunchKernelGGL(sub_ntt_kernel<MODE>, dim3((unsigned)(ncols * bpc)), dim3(thr), lds, st, X, logB, logsub - logB, tp,
+                     (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp);
+  RS_HIP(hipGetLastError());
+}
+
+template <int OP>
+static void launch_ew(const EwArgs &e, size_t cols, size_t len, const ColPlans &cp, hipStream_t st) {
+  const size_t total = cols * len;
+  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 256 * 16));
+  hipLaunchKernelGGL(ew_kernel<OP>, dim3(blocks), dim3(256), 0, st, e, cols, cp);
+  RS_HIP(hipGetLastError());
+}
+
+// multi-pass interpolation of `ncols` columns X[ncols][M] in place; W: workspace [ncols][2M]
+static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, double *X, double *W, size_t ncols, size_t col0,
+                       size_t S, size_t spl, hipStream_t st) {
+  const int logM = P->logM, logB = std::min(g_witness_lds_logM, logM);
+  const size_t M = P->M;
+  EwArgs e{};
+  e.logM = logM;
+  e.m = (int)P->m;
+  e.S = (unsigned)S;
+  e.slots_per_limb = (unsigned)spl;
+  e.col0 = col0;
+  TabPtrs tp{};
+  // values -> Newton coefficients: one cyclic convolution of length 2M
+  e.dst = W;
+  e.a = X;
+  launch_ew<EW_SCALE_PAD>(e, ncols, 2 * M, cp, st);
+  launch_cross<false>(W, ncols, col0, logM + 1, logM + 1, logB, S, spl, cp, st);
+  for (int i = 0; i < ctx->L; i++) tp.t[i] = P->limb[i].d_ehat;
+  launch_sub<2>(W, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * M) >> logB, S, spl, cp, st);
+  launch_cross<true>(W, ncols, col0, logM + 1, logM + 1, logB, S, spl, cp, st);
+  e.dst = X;
+  e.a = W;
+  launch_ew<EW_TAKE_LOW>(e, ncols, M, cp, st);
+  // product tree: levels <= logB inside LDS blocks
+  {
+    const size_t lds = padded_len((size_t)2 << logB) * sizeof(double);
+    RS_HIP(hipFuncSetAttribute((const void *)tree_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, ((size_t)2 << logB) / 8));
+    hipLaunchKernelGGL(tree_block_kernel, dim3((unsigned)(ncols << (logM - logB))), dim3(thr), lds, st, X, logM, logB, col0,
+                       (unsigned)S, (unsigned)spl, cp);
+    RS_HIP(hipGetLastError());
+  }
+  // levels above: F_node = F_left + D_left * F_right with multi-pass transforms of length 2^l
+  for (int l = logB + 1; l <= logM; l++) {
+    e.l = l;
+    e.dst = W;
+    e.a = X;
+    launch_ew<EW_FILL_RIGHT>(e, ncols, M, cp, st);
+    launch_cross<false>(W, ncols, col0, logM, l, logB, S, spl, cp, st);
+    for (int i = 0; i < ctx->L; i++) tp.t[i] = P->limb[i].d_dhat + (size_t)l * M;
+    launch_sub<2>(W, ncols, col0, logM, l, logB, &tp, M >> logB, S, spl, cp, st);
+    launch_cross<true>(W, ncols, col0, logM, l, logB, S, spl, cp, st);
+    e.dst = X;
+    e.a = W;
+    launch_ew<EW_COMBINE>(e, ncols, M, cp, st);
+  }
+  e.dst = X;
+  e.a = X;
+  launch_ew<EW_CANON>(e, ncols, M, cp, st);
+}
+
+// multi-pass H = quo(A*B, Z) (+ ZK patch) for `ncols` columns; W1, W2: workspaces [ncols][2M]
+static void big_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const double *A, const double *B, double *H,
+                  double *W1, double *W2, size_t ncols, size_t col0, size_t S, size_t spl, const uint64_t *d1,
+                  const uint64_t *d2, const uint64_t *d3, hipStream_t st) {
+  const int logM = P->logM, logB = std::min(g_witness_lds_logM, logM);
+  const size_t M = P->M;
+  EwArgs e{};
+  e.logM = logM;
+  e.m = (int)P->m;
+  e.S = (unsigned)S;
+  e.slots_per_limb = (unsigned)spl;
+  e.col0 = col0;
+  TabPtrs tp{};
+  const double *src[2] = {A, B};
+  double *W[2] = {W1, W2};
+  for (int k = 0; k < 2; k++) {
+    e.dst = W[k];
+    e.a = src[k];
+    launch_ew<EW_PAD_CENTER>(e, ncols, 2 * M, cp, st);
+    launch_cross<false>(W[k], ncols, col0, logM + 1, logM + 1, logB, S, spl, cp, st);
+    launch_sub<0>(W[k], ncols, col0, logM + 1, logM + 1, logB, nullptr, 1, S, spl, cp, st);
+  }
+  e.dst = W1;
+  e.a = W2;
+  launch_ew<EW_MUL>(e, ncols, 2 * M, cp, st);
+  launch_sub<1>(W1, ncols, col0, logM + 1, logM + 1, logB, nullptr, 1, S, spl, cp, st);
+  launch_cross<true>(W1, ncols, col0, logM + 1, logM + 1, logB, S, spl, cp, st);
+  e.dst = W2;
+  e.a = W1;
+  launch_ew<EW_REV_TRUNC>(e, ncols, 2 * M, cp, st);
+  launch_cross<false>(W2, ncols, col0, logM + 1, logM + 1, logB, S, spl, cp, st);
+  for (int i = 0; i < ctx->L; i++) tp.t[i] = P->limb[i].d_shat;
+  launch_sub<2>(W2, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * M) >> logB, S, spl, cp, st);
+  launch_cross<true>(W2, ncols, col0, logM + 1, logM + 1, logB, S, spl, cp, st);
+  e.dst = H;
+  e.a = W2;
+  launch_ew<EW_H_FINISH>(e, ncols, M, cp, st);
+  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((ncols * M + 255) / 256, 256 * 16));
+  hipLaunchKernelGGL(h_patch_kernel, dim3(blocks), dim3(256), 0, st, H, A, B, logM, ncols, col0, (unsigned)S, (unsigned)spl, cp,
+                     d1, d2, d3);
+  RS_HIP(hipGetLastError());
+}
+
+static size_t big_chunk_cols(const WitnessPlan *P) {
+  // two [cols][2M] workspaces within ~6 GiB
+  const size_t per_col = 4 * P->M * sizeof(double);
+  return std::max<size_t>(1, ((size_t)6 << 30) / per_col);
+}
+
 static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, double *cols, size_t ncols, size_t S,
                           size_t slots_per_limb, hipStream_t st) {
-  (void)ctx;
-  const size_t lds = padded_len(2 * P->M) * sizeof(double);
-  RS_HIP(hipFuncSetAttribute((const void *)interp_columns_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(interp_columns_kernel, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds, st, cols, P->logM,
-                     (unsigned)S, (unsigned)slots_per_limb, cp);
-  RS_HIP(hipGetLastError());
+  if (P->logM <= g_witness_lds_logM) {
+    const size_t lds = padded_len(2 * P->M) * sizeof(double);
+    RS_HIP(hipFuncSetAttribute((const void *)interp_columns_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(interp_columns_kernel, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds, st, cols, P->logM,
+                       (unsigned)S, (unsigned)slots_per_limb, cp);
+    RS_HIP(hipGetLastError());
+    return;
+  }
+  const size_t chunk = std::min(ncols, big_chunk_cols(P));
+  double *W = (double *)ws_get(ctx, 12, chunk * 2 * P->M * sizeof(double));
+  for (size_t c0 = 0; c0 < ncols; c0 += chunk) {
+    const size_t nc = std::min(chunk, ncols - c0);
+    big_interp(ctx, P, cp, cols + c0 * P->M, W, nc, c0, S, slots_per_limb, st);
+  }
+}
+
+static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const double *A, const double *B, double *H,
+                     size_t S, size_t N, const uint64_t *d1, const uint64_t *d2, const uint64_t *d3, hipStream_t st) {
+  const size_t M = P->M;
+  if (P->logM <= g_witness_lds_logM) {
+    const size_t lds = padded_len(2 * M) * sizeof(double);
+    RS_HIP(hipFuncSetAttribute((const void *)h_columns_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(h_columns_kernel, dim3((unsigned)S), dim3(col_threads(2 * M)), lds, st, A, B, H, P->logM, (int)P->m,
+                       (unsigned)N, cp, d1, d2, d3);
+    RS_HIP(hipGetLastError());
+    return;
+  }
+  const size_t chunk = std::min(S, big_chunk_cols(P));
+  double *W1 = (double *)ws_get(ctx, 12, chunk * 2 * M * sizeof(double));
+  double *W2 = (double *)ws_get(ctx, 13, chunk * 2 * M * sizeof(double));
+  for (size_t c0 = 0; c0 < S; c0 += chunk) {
+    const size_t nc = std::min(chunk, S - c0);
+    big_h(ctx, P, cp, A + c0 * M, B + c0 * M, H + c0 * M, W1, W2, nc, c0, S, N, d1, d2, d3, st);
+  }
 }
 
 void r1cs_evaluate_run(rs_ctx *ctx, const rs_r1cs *cs, int which, int mode, const uint64_t *d_asg, uint64_t *d_out,
@@ -781,13 +1108,7 @@ void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const ui
     launch_interp(ctx, P, cp, colv(k), (size_t)(e - k + 1) * S, S, N, st);
     k = e;
   }
-  if (needH) {
-    const size_t lds = padded_len(2 * M) * sizeof(double);
-    RS_HIP(hipFuncSetAttribute((const void *)h_columns_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(h_columns_kernel, dim3((unsigned)S), dim3(col_threads(2 * M)), lds, st, colv(3), colv(4), colv(6),
-                       P->logM, (int)m, (unsigned)N, cp, d1, d2, d3);
-    RS_HIP(hipGetLastError());
-  }
+  if (needH) launch_h(ctx, P, cp, colv(3), colv(4), colv(6), S, N, d1, d2, d3, st);
   const unsigned eb = (unsigned)std::min<size_t>((vec + 255) / 256, 256 * 16);
   if (!shortcut) {
     // fallback: interpolate the constant parts and combine in column-major form

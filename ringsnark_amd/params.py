@@ -162,6 +162,8 @@ def preset(name: str) -> RingParams:
                            notes="C5 with the 54-bit BFVDefault(2048) prime replaced by a 49-bit one")
     if name == "toy":  # CPU-test scale
         return make_params(32, [30, 30], 64, [40, 40, 41], ring_factor=1 << 12, name="toy")
+    if name == "toy44":  # small ring, headline-size primes (= 1 mod 2^20): large-m witness-map tests
+        return make_params(32, [43, 44], 64, [43, 44, 44], ring_factor=1 << 20, name="toy44")
     if name == "toy49":  # stresses the 50-bit bound of the FP64 modmul path
         return make_params(64, [49, 49], 128, [49, 49, 49], ring_factor=1 << 12, name="toy49")
     raise KeyError(name)

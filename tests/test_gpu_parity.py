@@ -213,3 +213,101 @@ def test_rinocchio_prover_matches_oracle(name, m, zk):
     g = host(got)
     for k in range(9):
         assert (g[k] == exp[k]).all(), k
+
+
+def _set_tuning(key, value):
+    from ringsnark_amd import _lib
+    _lib.check(_lib.load().rs_set_tuning(key, value))
+
+
+@pytest.mark.parametrize("m,kind,zk", [(70, "wide", False), (300, "wide", True), (1000, "chain", True), (513, "many_inputs", False)])
+def test_witness_map_multipass_matches_oracle(m, kind, zk):
+    """The multi-pass (column does not fit one LDS tile) path, forced at small sizes by shrinking the
+    tile to 2^6 so the complete oracle comparison stays cheap."""
+    dev = dev_for("toy")
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    cs = {"wide": lambda: R.wide_r1cs(m, prm.q), "chain": lambda: R.chain_r1cs(m, prm.q),
+          "many_inputs": lambda: R.wide_r1cs(m, prm.q, n_inputs=70)}[kind]()
+    asg = H.make_assignment(ctx, cs)
+    ds = [ctx.random_ring(60 + k) for k in range(3)] if zk else [None] * 3
+    _set_tuning(b"witness_lds_logM", 6)
+    try:
+        w = dev.witness_map(dev.r1cs(cs), dev.put(asg), *[dev.put(d) if d is not None else None for d in ds])
+        got = {k: host(v) if k != "Z" else v for k, v in w.items()}
+    finally:
+        _set_tuning(b"witness_lds_logM", 13)
+    ocs = H.oracle_cs(cs)
+    for limb in range(prm.L):
+        dl = [np.ascontiguousarray(d[limb]) if d is not None else None for d in ds]
+        exp = O.witness_map(prm.q[limb], ocs, limb, np.ascontiguousarray(asg[:, limb, :]), *dl)
+        for k in ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H"):
+            assert (got[k][:, limb, :] == exp[k]).all(), (k, limb)
+        assert (got["Z"][limb] == exp["Z"]).all()
+
+
+def test_groth16_prover_multipass_matches_oracle():
+    dev = dev_for("toy")
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    m = 200
+    cs = R.wide_r1cs(m, prm.q)
+    asg = H.make_assignment(ctx, cs)
+    pk = dict(s_pows=ctx.random_enc(71, m + 1), delta_ts=ctx.random_enc(72, m + 1), delta_mid=ctx.random_enc(73, cs.n_aux),
+              alpha=ctx.random_enc(74), beta=ctx.random_enc(75))
+    exp, exp_empty = O.groth16_prove(ctx, H.oracle_cs(cs), pk, asg)
+    _set_tuning(b"witness_lds_logM", 7)
+    try:
+        got, empty = dev.groth16_prove(dev.r1cs(cs), {k: dev.put(v) for k, v in pk.items()}, dev.put(asg))
+        g = host(got)
+    finally:
+        _set_tuning(b"witness_lds_logM", 13)
+    assert empty == exp_empty and (g == exp).all()
+
+
+def _horner(coeffs, x, q):
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * x + int(c)) % q
+    return acc
+
+
+def test_witness_map_beyond_one_tile_full_size():
+    """m = 10000 > 8192 constraints with headline-size primes: the natural multi-pass path (2^13
+    tiles).  Checked against the oracle's O(n^2) interpolation on one slot, and on other slots through
+    size-independent properties: P(j) = y_j on the domain and H*Z = A*B - C at random points."""
+    dev = dev_for("toy44")
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    m = 10000
+    rng = np.random.RandomState(5)
+    y = ctx.random_ring(91, m)
+    got = host(dev.interpolate(dev.put(y)))
+    exp0 = O.interpolate(prm.q[0], np.ascontiguousarray(y[:, 0, :1]))
+    assert (got[:, 0, 0] == exp0[:, 0]).all()
+    for limb, slot in ((0, 7), (1, 0), (1, 31)):
+        q = prm.q[limb]
+        for j in [0, 1, m - 1] + [int(v) for v in rng.randint(0, m, 3)]:
+            assert _horner(got[:, limb, slot], j, q) == int(y[j, limb, slot])
+    # full witness map on the chain circuit
+    cs = R.chain_r1cs(m, prm.q)
+    asg = dev.ring_empty(m + 2)
+    asg[:2] = dev.put(ctx.random_ring(92, 2))
+    dev.chain_assignment(asg, m)
+    w = dev.witness_map(dev.r1cs(cs), asg)
+    A = (host(w["A_io"]).astype(object) + host(w["A_mid"]).astype(object))
+    B = (host(w["B_io"]).astype(object) + host(w["B_mid"]).astype(object))
+    C = (host(w["C_io"]).astype(object) + host(w["C_mid"]).astype(object))
+    Hh = host(w["H"])
+    a = host(asg)
+    for limb, slot in ((0, 3), (1, 17)):
+        q = prm.q[limb]
+        Z = w["Z"][limb]
+        for j in (0, 5, m - 1):  # A interpolates x_j, B x_{j+1}, C x_{j+2}
+            assert _horner(A[:, limb, slot] % q, j, q) == int(a[j, limb, slot])
+            assert _horner(B[:, limb, slot] % q, j, q) == int(a[j + 1, limb, slot])
+            assert _horner(C[:, limb, slot] % q, j, q) == int(a[j + 2, limb, slot])
+        for x in [int(v) for v in rng.randint(m, 2**40, 3)]:
+            lhs = _horner(Hh[:, limb, slot], x, q) * _horner(Z, x, q) % q
+            rhs = (_horner(A[:, limb, slot] % q, x, q) * _horner(B[:, limb, slot] % q, x, q) - _horner(C[:, limb, slot] % q, x, q)) % q
+            assert lhs == rhs

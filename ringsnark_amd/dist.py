@@ -41,6 +41,19 @@ class ShardPlan:
         return lo, min(T, lo + per)
 
 
+class TermWindow:
+    """A key vector of logical length T of which this rank stores only terms [lo, hi)."""
+
+    def __init__(self, store, lo, hi, T):
+        self.store, self.lo, self.hi, self.T = store, lo, hi, T
+
+    def __getitem__(self, sl):
+        assert isinstance(sl, slice) and sl.step is None
+        a, b = sl.start or 0, self.T if sl.stop is None else sl.stop
+        assert self.lo <= a <= b <= self.hi, "term range outside this rank's window"
+        return self.store[a - self.lo:b - self.lo]
+
+
 def make_plan(world, rank, L) -> ShardPlan:
     g_l = math.gcd(world, L)
     g_t = world // g_l

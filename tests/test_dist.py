@@ -123,3 +123,45 @@ def test_shard_plans():
             for i in p.limbs:
                 cover[i, lo:hi] += 1
         assert (cover == 1).all()
+
+
+def _gpu_worker(rank, world, port, m, q_override, tmp):
+    """Both ranks drive the REAL device backend on cuda:0 (gloo transports the collectives)."""
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from ringsnark_amd.device import Device, to_host
+        prm = P.preset("toy")
+        if q_override:
+            prm = P.RingParams(prm.N, prm.q[:q_override], prm.N_enc, prm.Q)
+        ctx_full = H.oracle_ctx(prm)
+        cs_full = R.wide_r1cs(m, prm.q)
+        asg = H.make_assignment(ctx_full, cs_full)
+        pk = dict(s_pows=ctx_full.random_enc(71, m + 1), delta_ts=ctx_full.random_enc(72, m + 1),
+                  delta_mid=ctx_full.random_enc(73, cs_full.n_aux), alpha=ctx_full.random_enc(74), beta=ctx_full.random_enc(75))
+        plan = RD.make_plan(world, rank, prm.L)
+        tg = RD.groups_for(plan)
+        prm_local = P.RingParams(prm.N, [prm.q[i] for i in plan.limbs], prm.N_enc, prm.Q)
+        dev = Device(prm_local, 0)
+        dcs = dev.r1cs(R.wide_r1cs(m, prm_local.q))
+        pk_local = {}
+        for k, v in pk.items():
+            if v.ndim == 5:  # key vector: keep only this rank's limbs AND its term window
+                lo, hi = plan.term_range(v.shape[0])
+                pk_local[k] = RD.TermWindow(dev.put(np.ascontiguousarray(v[lo:hi][:, plan.limbs])), lo, hi, v.shape[0])
+            else:
+                pk_local[k] = dev.put(np.ascontiguousarray(v[plan.limbs]))
+        got = RD.groth16_prove_sharded(RD.DeviceBackend(dev), plan, tg, dcs, pk_local, dev.put(np.ascontiguousarray(asg[:, plan.limbs])),
+                                       m, cs_full.n_inputs, cs_full.n_aux)
+        if rank == 0:
+            exp, _ = O.groth16_prove(ctx_full, H.oracle_cs(cs_full), pk, asg)
+            open(tmp, "w").write("ok" if bool((to_host(got) == exp).all()) else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q_override", [None, 1])
+def test_sharded_groth16_on_device_backend(tmp_path, q_override):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_gpu_worker, args=(2, _free_port(), 9, q_override, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"

@@ -25,11 +25,24 @@ __host__ __device__ __forceinline__ int pidx(int i) { return i + (i >> PAD_SHIFT
 __host__ __device__ inline size_t padded_len(size_t n) { return n + (n >> PAD_SHIFT); }
 
 // element accessors for a round: LDS tile (padded) or caller-supplied functors
+// A round addresses its 2^R elements as base + e*step.  For the padded LDS tile the padded address
+// splits into pidx(base) + poff(e) with poff uniform across the wave (round_poff below), so an
+// access costs one vector add instead of a shift-add-add; functors that ignore padding (global
+// memory) just use base + e*step.
 struct LdsIO {
   double *s;
-  __device__ __forceinline__ double load(int i) const { return s[pidx(i)]; }
-  __device__ __forceinline__ void store(int i, double v) const { s[pidx(i)] = v; }
+  __device__ __forceinline__ int pbase(int base) const { return pidx(base); }
+  __device__ __forceinline__ double load(int, int pb, int, int poff) const { return s[pb + poff]; }
+  __device__ __forceinline__ void store(int, int pb, int, int poff, double v) const { s[pb + poff] = v; }
 };
+// padded offset of element offset eoff = e*step inside a radix group of E elements (see the
+// case analysis in DESIGN.md "NTT core"): exact because a group never straddles a 16-slot pad
+// boundary in a way that depends on the lane.
+__device__ __forceinline__ int round_poff(int eoff, int step, int E) {
+  if (step >= 16) return eoff + (eoff >> PAD_SHIFT);
+  if (E * step >= 16) return eoff + (eoff >> PAD_SHIFT);
+  return eoff;
+}
 
 // number of stages of the next round when `rem` stages remain: spread evenly over the minimum
 // number of rounds
@@ -62,15 +75,20 @@ __device__ __forceinline__ void fwd_round(const In in, const Out out, int logtot
                                           uint32_t red_mask, const Lanes ln = block_lanes()) {
   constexpr int E = 1 << R;
   const int lstep = logsub - s0 - R;  // log2 of the smallest gap in this round
-  const int sstep = 1 << lstep;
+  const int sstep_ = 1 << lstep;
   const int ngroups = (1 << logtot) >> R;
-  for (int grp = ln.tid; grp < ngroups; grp += ln.nthr) {
+  for (int grp_ = ln.tid; grp_ < ngroups; grp_ += ln.nthr) {
+    // Opaque copies: inside a caller's loop every address below is loop invariant, and hoisting
+    // all of them (dozens per round, several rounds) costs far more registers than recomputing.
+    int grp = grp_, sstep = sstep_;
+    asm volatile("" : "+v"(grp), "+s"(sstep));
     const int lo = grp & (sstep - 1), hi_all = grp >> lstep;
     const int hi = hi_all & ((1 << s0) - 1);
     const int base = (hi_all << (logsub - s0)) + lo;
     double v[E];
+    const int pbi = in.pbase(base), pbo = out.pbase(base);
 #pragma unroll
-    for (int e = 0; e < E; e++) v[e] = in.load(base + e * sstep);
+    for (int e = 0; e < E; e++) v[e] = in.load(base, pbi, e * sstep, round_poff(e * sstep, sstep, E));
 #pragma unroll
     for (int k = 0; k < R; k++) {
       if ((red_mask >> (s0 + k)) & 1u) {
@@ -93,7 +111,7 @@ __device__ __forceinline__ void fwd_round(const In in, const Out out, int logtot
       }
     }
 #pragma unroll
-    for (int e = 0; e < E; e++) out.store(base + e * sstep, v[e]);
+    for (int e = 0; e < E; e++) out.store(base, pbo, e * sstep, round_poff(e * sstep, sstep, E), v[e]);
   }
 }
 
@@ -157,16 +175,19 @@ __device__ __forceinline__ void inv_round(const In in, const Out out, int logtot
                                           const double *__restrict__ itw, int root, const Mod mod,
                                           uint32_t red_mask, const Lanes ln = block_lanes()) {
   constexpr int E = 1 << R;
-  const int g0 = 1 << u0;
+  const int g0_ = 1 << u0;
   const int ngroups = (1 << logtot) >> R;
   const int gpb_log = logsub - u0 - R;  // log2 of radix groups per sub-transform (per lo)
-  for (int grp = ln.tid; grp < ngroups; grp += ln.nthr) {
+  for (int grp_ = ln.tid; grp_ < ngroups; grp_ += ln.nthr) {
+    int grp = grp_, g0 = g0_;
+    asm volatile("" : "+v"(grp), "+s"(g0));
     const int lo = grp & (g0 - 1), hi_all = grp >> u0;
     const int hi = hi_all & ((1 << gpb_log) - 1);
     const int base = (hi_all << (u0 + R)) + lo;
     double v[E];
+    const int pbi = in.pbase(base), pbo = out.pbase(base);
 #pragma unroll
-    for (int e = 0; e < E; e++) v[e] = in.load(base + e * g0);
+    for (int e = 0; e < E; e++) v[e] = in.load(base, pbi, e * g0, round_poff(e * g0, g0, E));
 #pragma unroll
     for (int k = 0; k < R; k++) {
       if ((red_mask >> (u0 + k)) & 1u) {
@@ -185,7 +206,7 @@ __device__ __forceinline__ void inv_round(const In in, const Out out, int logtot
       }
     }
 #pragma unroll
-    for (int e = 0; e < E; e++) out.store(base + e * g0, v[e]);
+    for (int e = 0; e < E; e++) out.store(base, pbo, e * g0, round_poff(e * g0, g0, E), v[e]);
   }
 }
 
@@ -252,8 +273,9 @@ __device__ __forceinline__ void lds_bntt_inv(double *s, int logtot, int logsub, 
 // on multiples of 16).
 struct LdsBlockIO {
   double *s;  // s + pidx(block_offset)
-  __device__ __forceinline__ double load(int i) const { return s[pidx(i)]; }
-  __device__ __forceinline__ void store(int i, double v) const { s[pidx(i)] = v; }
+  __device__ __forceinline__ int pbase(int base) const { return pidx(base); }
+  __device__ __forceinline__ double load(int, int pb, int, int poff) const { return s[pb + poff]; }
+  __device__ __forceinline__ void store(int, int pb, int, int poff, double v) const { s[pb + poff] = v; }
 };
 
 // Forward.  first_in feeds the cross-wave round (global or LDS); the result of the private rounds

@@ -95,18 +95,20 @@ void free_table(NttTable &t) {
 // ---------------------------------------------------------------------------------------------
 struct GlobalU64In {
   const uint64_t *p;
-  __device__ __forceinline__ double load(int i) const { return from_u64(p[i]); }
-  __device__ __forceinline__ void store(int, double) const {}
+  __device__ __forceinline__ int pbase(int) const { return 0; }
+  __device__ __forceinline__ double load(int base, int, int eoff, int) const { return from_u64(p[base + eoff]); }
+  __device__ __forceinline__ void store(int, int, int, int, double) const {}
 };
 template <bool SCALE>
 struct GlobalCanonOut {
   uint64_t *p;
   Mod mod;
   double ninv;
-  __device__ __forceinline__ double load(int) const { return 0.0; }
-  __device__ __forceinline__ void store(int i, double v) const {
+  __device__ __forceinline__ int pbase(int) const { return 0; }
+  __device__ __forceinline__ double load(int, int, int, int) const { return 0.0; }
+  __device__ __forceinline__ void store(int base, int, int eoff, int, double v) const {
     if (SCALE) v = mulmod(reduce(v, mod), ninv, mod);
-    p[i] = to_u64(canon(v, mod));
+    p[base + eoff] = to_u64(canon(v, mod));
   }
 };
 

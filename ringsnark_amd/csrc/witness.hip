@@ -656,8 +656,9 @@ struct TabPtrs {
 };
 struct GlobalF64IO {
   double *p;
-  __device__ __forceinline__ double load(int i) const { return p[i]; }
-  __device__ __forceinline__ void store(int i, double v) const { p[i] = v; }
+  __device__ __forceinline__ int pbase(int) const { return 0; }
+  __device__ __forceinline__ double load(int base, int, int eoff, int) const { return p[base + eoff]; }
+  __device__ __forceinline__ void store(int base, int, int eoff, int, double v) const { p[base + eoff] = v; }
 };
 
 // cross stages [s0, s0+R) of batched length-2^logsub transforms inside columns of length 2^logtot.

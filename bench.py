@@ -173,8 +173,16 @@ def main():
         if timings["msm_mac_ms"] > 0:
             achieved = nbytes / (timings["msm_mac_ms"] * 1e-3) / 1e9
             nlaunch = max(1, timings["msm_mac_launches"])
+            # HBM traffic of the same kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB units;
+            # tools/pmc_summary.py), collected offline with rocprofv3 --pmc on this exact configuration
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s_m%d.json" % (prm.name, m))
+            if os.path.exists(pmc):
+                k = json.load(open(pmc))["kernels"].get("rs::mac_kernel_v2<512>")
+                if k:
+                    traffic = int(k["hbm_bytes"] / k["launches_per_proof"])
             roofline = {"bound": "hbm", "kernel": "mac_kernel_v2", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "launches": nlaunch, "avg_launch_ms": round(timings["msm_mac_ms"] / nlaunch, 3),
                         "algorithmic_bytes_per_launch": nbytes // nlaunch}
 

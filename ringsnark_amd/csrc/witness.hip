@@ -342,6 +342,52 @@ __global__ void __launch_bounds__(256) transpose_out_kernel(const double *__rest
   }
 }
 
+// Product-tree levels 1..SCHOOL_LEVELS by schoolbook products in registers, on 2^logB consecutive
+// Newton coefficients at column position pos0 held in the (offset) tile s; one thread per node of
+// size 2^SCHOOL_LEVELS, executed by the lanes `ln` (a workgroup or one wave).
+__device__ __forceinline__ void school_levels_lds(double *s, int logB, int logM, int pos0, const ColPlan &P, const Lanes ln) {
+  const Mod mod = P.mod;
+  const int Bn = 1 << logB, M = 1 << logM;
+  const int lv = logB < SCHOOL_LEVELS ? logB : SCHOOL_LEVELS;
+  const int nn = 1 << lv;
+  const int dstride = M / 2 + 1;
+  for (int node = ln.tid; node < (Bn >> lv); node += ln.nthr) {
+    double v[1 << SCHOOL_LEVELS];
+#pragma unroll
+    for (int k = 0; k < (1 << SCHOOL_LEVELS); k++) v[k] = (k < nn) ? s[pidx(node * nn + k)] : 0.0;
+#pragma unroll
+    for (int l = 1; l <= SCHOOL_LEVELS; l++) {
+      if (l > lv) break;
+      const int n = 1 << l, h = n >> 1;
+#pragma unroll
+      for (int sub = 0; sub < ((1 << SCHOOL_LEVELS) >> l); sub++) {
+        if (sub * n >= nn) break;
+        const int gnode = ((pos0 + node * nn) >> l) + sub;  // node index at level l within the column
+        const double *dl = P.dlow + (size_t)l * dstride + (size_t)gnode * h;
+        double out[1 << SCHOOL_LEVELS];
+#pragma unroll
+        for (int k = 0; k < n; k++) out[k] = 0.0;
+        // D_left * F_right, D_left = x^h + sum dl[a] x^a
+#pragma unroll
+        for (int b = 0; b < h; b++) {
+          const double fr = v[sub * n + h + b];
+          out[h + b] += fr;
+#pragma unroll
+          for (int a = 0; a < h; a++) out[a + b] += mulmod(dl[a], fr, mod);
+        }
+#pragma unroll
+        for (int k = 0; k < n; k++) {
+          const double left = (k < h) ? v[sub * n + k] : 0.0;
+          v[sub * n + k] = reduce(out[k] + left, mod);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < (1 << SCHOOL_LEVELS); k++)
+      if (k < nn) s[pidx(node * nn + k)] = v[k];
+  }
+}
+
 // Newton -> monomial product tree on an LDS tile holding Bn = 2^logB consecutive Newton
 // coefficients of a column, starting at column position pos0 (a multiple of Bn); the tile's
 // second half [Bn, 2Bn) is scratch.  Runs levels 1..logB (node sizes 2..Bn).  Tables are
@@ -349,48 +395,8 @@ __global__ void __launch_bounds__(256) transpose_out_kernel(const double *__rest
 __device__ __forceinline__ void tree_levels_lds(double *s, int logB, int logM, int pos0, const ColPlan &P) {
   const Mod mod = P.mod;
   const int Bn = 1 << logB, M = 1 << logM;
-  // schoolbook levels: one thread per node of size 2^SCHOOL_LEVELS
-  {
-    const int lv = logB < SCHOOL_LEVELS ? logB : SCHOOL_LEVELS;
-    const int nn = 1 << lv;
-    const int dstride = M / 2 + 1;
-    for (int node = threadIdx.x; node < (Bn >> lv); node += blockDim.x) {
-      double v[1 << SCHOOL_LEVELS];
-#pragma unroll
-      for (int k = 0; k < (1 << SCHOOL_LEVELS); k++) v[k] = (k < nn) ? s[pidx(node * nn + k)] : 0.0;
-#pragma unroll
-      for (int l = 1; l <= SCHOOL_LEVELS; l++) {
-        if (l > lv) break;
-        const int n = 1 << l, h = n >> 1;
-#pragma unroll
-        for (int sub = 0; sub < ((1 << SCHOOL_LEVELS) >> l); sub++) {
-          if (sub * n >= nn) break;
-          const int gnode = ((pos0 + node * nn) >> l) + sub;  // node index at level l within the column
-          const double *dl = P.dlow + (size_t)l * dstride + (size_t)gnode * h;
-          double out[1 << SCHOOL_LEVELS];
-#pragma unroll
-          for (int k = 0; k < n; k++) out[k] = 0.0;
-          // D_left * F_right, D_left = x^h + sum dl[a] x^a
-#pragma unroll
-          for (int b = 0; b < h; b++) {
-            const double fr = v[sub * n + h + b];
-            out[h + b] += fr;
-#pragma unroll
-            for (int a = 0; a < h; a++) out[a + b] += mulmod(dl[a], fr, mod);
-          }
-#pragma unroll
-          for (int k = 0; k < n; k++) {
-            const double left = (k < h) ? v[sub * n + k] : 0.0;
-            v[sub * n + k] = reduce(out[k] + left, mod);
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < (1 << SCHOOL_LEVELS); k++)
-        if (k < nn) s[pidx(node * nn + k)] = v[k];
-    }
-    __syncthreads();
-  }
+  school_levels_lds(s, logB, logM, pos0, P, block_lanes());
+  __syncthreads();
   // transform levels: B[node] = (F_right, 0) -> batched length-n transforms -> * spectrum of D_left
   // -> inverse -> + F_left.  B is addressed through an offset tile (Bn is a multiple of 16 or < 16,
   // so pidx(Bn + i) = pidx(Bn) + pidx(i)).
@@ -447,6 +453,118 @@ interp_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned 
   __syncthreads();
   tree_levels_lds(s, logM, logM, 0, P);
   for (int j = threadIdx.x; j < M; j += blockDim.x) c[j] = canon(s[pidx(j)], mod);
+}
+
+
+// values at 0..m-1 -> Newton coefficients (first half of interp_columns_kernel), in place.
+__global__ void __launch_bounds__(1024)
+newton_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned slots_per_limb, ColPlans plans) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int M = 1 << logM;
+  const size_t col = blockIdx.x;
+  const ColPlan &P = plans.l[(col % S) / slots_per_limb];
+  const Mod mod = P.mod;
+  double *c = cols + col * (size_t)M;
+  for (int j = threadIdx.x; j < M; j += blockDim.x) {
+    s[pidx(j)] = mulmod(c[j], P.invfact[j], mod);
+    s[pidx(M + j)] = 0.0;
+  }
+  __syncthreads();
+  lds_ntt_fwd<4>(s, logM + 1, P.tw, 1, mod, P.fwd_mask2);
+  for (int j = threadIdx.x; j < 2 * M; j += blockDim.x) s[pidx(j)] = mulmod(reduce(s[pidx(j)], mod), P.ehat[j], mod);
+  __syncthreads();
+  lds_ntt_inv<4>(s, logM + 1, P.itw, 1, mod, P.inv_mask2);
+  for (int j = threadIdx.x; j < M; j += blockDim.x) c[j] = (P.invfact[j] != 0.0) ? reduce(s[pidx(j)], mod) : 0.0;
+}
+
+// Newton -> monomial, one column per workgroup, tile = M doubles only (two workgroups per CU):
+// a level's F_left values wait in registers while the node regions are overwritten in place with
+// (F_right, 0), transformed, multiplied by the spectrum of D_left and transformed back.  Wave w
+// owns block w of M/W coefficients; every level whose nodes fit a block (n <= M/W) runs without a
+// single workgroup barrier.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS, THREADS / 128)  // two workgroups per CU
+tree_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned slots_per_limb, ColPlans plans) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  constexpr int LOGW = THREADS == 512 ? 3 : (THREADS == 256 ? 2 : (THREADS == 128 ? 1 : 0));
+  constexpr int EPT = 16;  // coefficients per lane: M / THREADS <= 16
+  const int M = 1 << logM;
+  const size_t col = blockIdx.x;
+  const ColPlan &P = plans.l[(col % S) / slots_per_limb];
+  const Mod mod = P.mod;
+  double *c = cols + col * (size_t)M;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int logb = logM - LOGW, bsz = 1 << logb, off = wave << logb;
+  const int per = bsz >> 6;  // own positions: off + lane + 64*j, j < per
+  double *sb = s + pidx(off);
+  const LdsBlockIO blk{sb};
+  const Lanes wl = wave_lanes();
+#pragma unroll
+  for (int j = 0; j < EPT; j++)
+    if (j < per) sb[pidx(lane + 64 * j)] = c[off + lane + 64 * j];
+  wave_sync();
+  school_levels_lds(sb, logb, logM, off, P, wl);
+  wave_sync();
+  for (int l = SCHOOL_LEVELS + 1; l <= logM; l++) {
+    const int n = 1 << l, h = n >> 1;
+    const bool priv = l <= logb;
+    double r[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++)
+      if (j < per) r[j] = sb[pidx(lane + 64 * j)];
+    if (priv) wave_sync(); else __syncthreads();
+    // node regions <- (F_right, 0); F_left stays in r
+#pragma unroll
+    for (int j = 0; j < EPT; j++)
+      if (j < per) {
+        const int i = off + lane + 64 * j;
+        if ((i & (n - 1)) >= h) {
+          s[pidx(i - h)] = r[j];
+          s[pidx(i)] = 0.0;
+        }
+      }
+    if (priv) wave_sync(); else __syncthreads();
+    if (priv) {
+      for (int st = 0; st < l;) {
+        const int R = pick_radix(l - st, 3);
+        fwd_round_dispatch<3>(R, blk, blk, logb, l, st, P.tw, 1, mod, P.fmask[l], wl);
+        wave_sync();
+        st += R;
+      }
+    } else {
+      lds_bntt_fwd<3>(s, logM, l, P.tw, mod, P.fmask[l]);
+    }
+    const double *dh = P.dhat + (size_t)l * M + off;
+#pragma unroll
+    for (int j = 0; j < EPT; j++)
+      if (j < per) {
+        const int pi = pidx(lane + 64 * j);
+        sb[pi] = mulmod(reduce(sb[pi], mod), dh[lane + 64 * j], mod);
+      }
+    if (priv) wave_sync(); else __syncthreads();
+    if (priv) {
+      for (int st = 0; st < l;) {
+        const int R = pick_radix(l - st, 3);
+        inv_round_dispatch<3>(R, blk, blk, logb, l, st, P.itw, 1, mod, P.imask[l], wl);
+        wave_sync();
+        st += R;
+      }
+    } else {
+      lds_bntt_inv<3>(s, logM, l, P.itw, mod, P.imask[l]);
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; j++)
+      if (j < per) {
+        const int i = off + lane + 64 * j, pi = pidx(lane + 64 * j);
+        sb[pi] = reduce(sb[pi] + (((i & (n - 1)) < h) ? r[j] : 0.0), mod);
+      }
+    if (priv) wave_sync(); else __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < EPT; j++)
+    if (j < per) c[off + lane + 64 * j] = canon(sb[pidx(lane + 64 * j)], mod);
 }
 
 
@@ -816,6 +934,7 @@ static ColPlans make_colplans(rs_ctx *ctx, const WitnessPlan *P) {
 static int col_threads(size_t M) { return (int)std::max<size_t>(64, std::min<size_t>(1024, M / 8)); }
 
 int g_witness_lds_logM = 13;  // columns up to 2^13 run entirely inside one LDS tile
+int g_witness_split = 1;      // 1: separate Newton-convolution and product-tree launches (M >= 1024)
 
 template <bool INV>
 static void launch_cross(double *X, size_t ncols, size_t col0, int logtot, int logsub, int logB, size_t S, size_t spl,
@@ -964,6 +1083,30 @@ static size_t big_chunk_cols(const WitnessPlan *P) {
 
 static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, double *cols, size_t ncols, size_t S,
                           size_t slots_per_limb, hipStream_t st) {
+  if (P->logM <= g_witness_lds_logM && P->logM >= 10 && g_witness_split) {
+    // two launches: the convolution needs a 2M tile (one workgroup per CU), the product tree only M
+    const size_t lds2 = padded_len(2 * P->M) * sizeof(double), lds1 = padded_len(P->M) * sizeof(double);
+    RS_HIP(hipFuncSetAttribute((const void *)newton_columns_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    hipLaunchKernelGGL(newton_columns_kernel, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds2, st, cols, P->logM,
+                       (unsigned)S, (unsigned)slots_per_limb, cp);
+    const int thr = (int)std::max<size_t>(64, std::min<size_t>(512, P->M / 16));
+    if (thr == 512) {
+      RS_HIP(hipFuncSetAttribute((const void *)tree_columns_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+      hipLaunchKernelGGL(tree_columns_kernel<512>, dim3((unsigned)ncols), dim3(512), lds1, st, cols, P->logM, (unsigned)S,
+                         (unsigned)slots_per_limb, cp);
+    } else if (thr == 256) {
+      hipLaunchKernelGGL(tree_columns_kernel<256>, dim3((unsigned)ncols), dim3(256), lds1, st, cols, P->logM, (unsigned)S,
+                         (unsigned)slots_per_limb, cp);
+    } else if (thr == 128) {
+      hipLaunchKernelGGL(tree_columns_kernel<128>, dim3((unsigned)ncols), dim3(128), lds1, st, cols, P->logM, (unsigned)S,
+                         (unsigned)slots_per_limb, cp);
+    } else {
+      hipLaunchKernelGGL(tree_columns_kernel<64>, dim3((unsigned)ncols), dim3(64), lds1, st, cols, P->logM, (unsigned)S,
+                         (unsigned)slots_per_limb, cp);
+    }
+    RS_HIP(hipGetLastError());
+    return;
+  }
   if (P->logM <= g_witness_lds_logM) {
     const size_t lds = padded_len(2 * P->M) * sizeof(double);
     RS_HIP(hipFuncSetAttribute((const void *)interp_columns_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -133,6 +133,7 @@ def test_grouped_msm_equals_sum_of_inner_products():
 
 @pytest.mark.parametrize("name,m,kind", [("toy", 1, "chain"), ("toy", 2, "chain"), ("toy", 3, "wide"), ("toy", 7, "wide"),
                                           ("toy", 16, "wide"), ("toy", 100, "wide"), ("toy", 100, "many_inputs"),
+                                          ("toy", 600, "wide"),  # M = 1024: split Newton / in-place product-tree kernels
                                           ("toy49", 33, "wide"), ("toy49", 64, "chain"), ("toy49", 90, "many_inputs")])
 def test_witness_map_matches_oracle(name, m, kind):
     from ringsnark_amd import _lib

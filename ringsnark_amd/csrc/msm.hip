@@ -32,6 +32,11 @@ namespace rs {
 constexpr int MAX_GROUP_VECS = 4;
 constexpr int MAX_GROUPS = 6;
 
+struct TileBlockFactory {
+  double *s;
+  __device__ __forceinline__ LdsBlockIO operator()(int off) const { return LdsBlockIO{s + pidx(off)}; }
+};
+
 struct PlainGroup {
   const uint64_t *coeff[MAX_GROUP_VECS];
   const uint8_t *kinds[MAX_GROUP_VECS];
@@ -56,6 +61,10 @@ plain_center_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t
   const PlainGroup &G = args.g[g];
   const NttTable tab = plain_tabs[limb];
   const Mod mod = tab.mod;
+  // wave-private inverse transform when every wave gets a block of >= 256 coefficients
+  int logw = 0;
+  while ((64 << logw) < (int)blockDim.x) logw++;
+  const bool wp = logn - logw >= 8 && logw >= 1 && logw <= 4;
   double acc[EPT];
 #pragma unroll
   for (int k = 0; k < EPT; k++) acc[k] = 0.0;
@@ -80,7 +89,10 @@ plain_center_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t
     }
     if (!__syncthreads_or(nz)) continue;  // is_zero term (this limb): contributes nothing
     if (threadIdx.x == 0 && G.nz[v]) atomicOr(&G.nz[v][t], 1u);
-    lds_ntt_inv(s, logn, tab.d_itw, 1, mod, tab.inv_red_mask);
+    if (wp)
+      lds_ntt_inv_wp<4, TileBlockFactory, LdsIO, 3>(s, TileBlockFactory{s}, LdsIO{s}, logn, logw, tab.d_itw, mod, tab.inv_red_mask);
+    else
+      lds_ntt_inv(s, logn, tab.d_itw, 1, mod, tab.inv_red_mask);
 #pragma unroll
     for (int k = 0; k < EPT; k++) {
       const int p = threadIdx.x + k * blockDim.x;
@@ -250,10 +262,6 @@ mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff
 //   * the transform is the wave-private form (ntt_core.cuh): one cross-wave round, then each of the
 //     16 waves finishes its own 512-element block and multiplies exactly that block into its
 //     accumulators -- two workgroup barriers per term instead of seven.
-struct TileBlockFactory {
-  double *s;
-  __device__ __forceinline__ LdsBlockIO operator()(int off) const { return LdsBlockIO{s + pidx(off)}; }
-};
 struct MacArgs2 {
   const double *C;      // [tile_terms][L][n] plaintext rows of the group
   const uint64_t *crs;  // first ciphertext of the tile
@@ -549,8 +557,10 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
   uint64_t *d_partial = (uint64_t *)ws_get(ctx, 1, (size_t)n_chunks * n_sets * enc_words * sizeof(uint64_t));
   const size_t lds = padded_len((size_t)n) * sizeof(double);
   const int thr = tile_threads(ctx->logN_enc);
-  const bool big = n > 8192;  // 16 elements per thread; one accumulator set per MAC launch
-  if (big)
+  const bool big = n > 8192;  // one accumulator set per MAC launch
+  const bool plain16 = n >= 2048;  // 16 coefficients per thread, wave-private inverse transform
+  const int plain_thr = plain16 ? n / 16 : thr;
+  if (plain16)
     RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   else
     RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -567,8 +577,8 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
   int tile_idx = 0;
   for (size_t t0 = 0; t0 < Tmax; t0 += tile_terms, tile_idx++) {
     const size_t tt = std::min(tile_terms, Tmax - t0);
-    if (big)
-      hipLaunchKernelGGL(plain_center_kernel<16>, dim3((unsigned)tt, L, n_groups), dim3(thr), lds, st, pa, d_C,
+    if (plain16)
+      hipLaunchKernelGGL(plain_center_kernel<16>, dim3((unsigned)tt, L, n_groups), dim3(plain_thr), lds, st, pa, d_C,
                          (unsigned long long)t0, (unsigned long long)tile_terms, ctx->N, L, ctx->logN_enc,
                          ctx->d_index_map, sc.d_plain_tabs);
     else

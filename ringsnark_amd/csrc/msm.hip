@@ -356,7 +356,7 @@ mac_kernel_v2(MacArgs2 a, int L, int K, int logn, const NttTable *__restrict__ c
       for (int k = 0; k < PP; k++)
         if (64 * k + lane < bpairs) cn[k] = crow[pbase + 64 * k];
     }
-    if (!(a.ablate & 1)) lds_ntt_fwd_wp<4, LdsIO, TileBlockFactory, 3>(s, lds, bf, logn, LOGW, twl, mod, red_mask);
+    if (!(a.ablate & 1)) lds_ntt_fwd_wp<4, LdsIO, TileBlockFactory, 3, true>(s, lds, bf, logn, LOGW, twl, mod, red_mask);
 #pragma unroll
     for (int k = 0; k < PP; k++)
       if (64 * k + lane < bpairs) {

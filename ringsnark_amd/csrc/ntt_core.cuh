@@ -58,9 +58,10 @@ __host__ __device__ __forceinline__ int pick_radix(int rem, int maxr) {
 // Who executes a round: the whole workgroup (default) or one wave on its own sub-block.
 struct Lanes {
   int tid, nthr;
+  bool opaque;  // recompute addresses inside the round (for rounds that sit in a caller's loop)
 };
-__device__ __forceinline__ Lanes block_lanes() { return Lanes{(int)threadIdx.x, (int)blockDim.x}; }
-__device__ __forceinline__ Lanes wave_lanes() { return Lanes{(int)(threadIdx.x & 63), 64}; }
+__device__ __forceinline__ Lanes block_lanes() { return Lanes{(int)threadIdx.x, (int)blockDim.x, false}; }
+__device__ __forceinline__ Lanes wave_lanes(bool opaque = false) { return Lanes{(int)(threadIdx.x & 63), 64, opaque}; }
 // wave-scope ordering of LDS traffic: DS operations of one wave execute in issue order, so a
 // compiler-level fence is all that is needed between a wave-private exchange's writes and reads.
 __device__ __forceinline__ void wave_sync() {
@@ -81,7 +82,7 @@ __device__ __forceinline__ void fwd_round(const In in, const Out out, int logtot
     // Opaque copies: inside a caller's loop every address below is loop invariant, and hoisting
     // all of them (dozens per round, several rounds) costs far more registers than recomputing.
     int grp = grp_, sstep = sstep_;
-    asm volatile("" : "+v"(grp), "+s"(sstep));
+    if (ln.opaque) asm volatile("" : "+v"(grp), "+s"(sstep));
     const int lo = grp & (sstep - 1), hi_all = grp >> lstep;
     const int hi = hi_all & ((1 << s0) - 1);
     const int base = (hi_all << (logsub - s0)) + lo;
@@ -180,7 +181,7 @@ __device__ __forceinline__ void inv_round(const In in, const Out out, int logtot
   const int gpb_log = logsub - u0 - R;  // log2 of radix groups per sub-transform (per lo)
   for (int grp_ = ln.tid; grp_ < ngroups; grp_ += ln.nthr) {
     int grp = grp_, g0 = g0_;
-    asm volatile("" : "+v"(grp), "+s"(g0));
+    if (ln.opaque) asm volatile("" : "+v"(grp), "+s"(g0));
     const int lo = grp & (g0 - 1), hi_all = grp >> u0;
     const int hi = hi_all & ((1 << gpb_log) - 1);
     const int base = (hi_all << (u0 + R)) + lo;
@@ -282,17 +283,18 @@ struct LdsBlockIO {
 // goes to last_out, addressed with block-local indices + the wave's block offset added by the
 // functor's owner (see WaveOut below).  Ends WITHOUT a workgroup barrier: each wave's block is
 // complete (for that wave) on return.
-template <int MAXR, class In, class OutFactory, int CROSSR = 4>
+template <int MAXR, class In, class OutFactory, int CROSSR = 4, bool OPAQUE = false>
 __device__ __forceinline__ void lds_ntt_fwd_wp(double *s, const In first_in, const OutFactory make_out, int logn, int logw,
                                                const double *__restrict__ tw, const Mod mod, uint32_t red_mask) {
   const LdsIO lds{s};
   // cross-wave rounds: logw stages in rounds of at most CROSSR (each ends with a barrier)
   for (int st = 0; st < logw;) {
     const int R = pick_radix(logw - st, CROSSR);
+    const Lanes bl{(int)threadIdx.x, (int)blockDim.x, OPAQUE};
     if (st == 0)
-      fwd_round_dispatch<CROSSR>(R, first_in, lds, logn, logn, st, tw, 1, mod, red_mask);
+      fwd_round_dispatch<CROSSR>(R, first_in, lds, logn, logn, st, tw, 1, mod, red_mask, bl);
     else
-      fwd_round_dispatch<CROSSR>(R, lds, lds, logn, logn, st, tw, 1, mod, red_mask);
+      fwd_round_dispatch<CROSSR>(R, lds, lds, logn, logn, st, tw, 1, mod, red_mask, bl);
     __syncthreads();
     st += R;
   }
@@ -302,7 +304,7 @@ __device__ __forceinline__ void lds_ntt_fwd_wp(double *s, const In first_in, con
   const LdsBlockIO blk{s + pidx(off)};
   const int root = (1 << logw) + wave;
   const uint32_t mask = red_mask >> logw;
-  const Lanes ln = wave_lanes();
+  const Lanes ln = wave_lanes(OPAQUE);
   int st = 0;
   while (st < logb) {
     const int R = pick_radix(logb - st, MAXR);

@@ -243,7 +243,85 @@ static void launch_ntt_wp(const NttTable &t, uint64_t *d_data, size_t batch, hip
   RS_HIP(hipGetLastError());
 }
 
-int g_ntt_variant = 8;  // tuning knob (rs_set_tuning("ntt_variant", v)): see launch_ntt
+
+// Persistent, software-pipelined forward transform (the streaming form of ntt_kernel_wp): one
+// workgroup per CU loops over polynomials of one prime.  The twiddle table lives in LDS next to
+// the tile, so the loop's only vector-memory traffic is the data itself, and the NEXT polynomial is
+// loaded into registers (in the first round's radix-4 access pattern) while the current one is
+// transformed.  1024 threads: two cross-wave radix-4 rounds, then nine wave-private stages per
+// 512-point block, then each wave streams its block out.
+template <int G>  // radix-4 groups per thread in the first round: n / 4096
+__global__ void __launch_bounds__(1024)
+ntt_fwd_stream_kernel(uint64_t *__restrict__ data, unsigned long long batch, int logn, const double *__restrict__ tw, Mod mod,
+                      uint32_t red_mask) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int n = 1 << logn;
+  double *twl = s + padded_len((size_t)n);
+  for (int i = threadIdx.x; i < n; i += 1024) twl[i] = tw[i];
+  const int q = n >> 2;  // gap of the first radix-4 round
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int logb = logn - 4, bsz = 1 << logb, off = wave << logb;
+  const LdsIO lds{s};
+  const LdsBlockIO blk{s + pidx(off)};
+  const Lanes wl = wave_lanes(true);
+  uint64_t pre[G][4];
+  unsigned long long p = blockIdx.x;
+  if (p < batch) {
+    const uint64_t *src = data + p * (size_t)n;
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) pre[g][e] = src[threadIdx.x + g * 1024 + e * q];
+  }
+  __syncthreads();
+  const double w1 = twl[1], w2 = twl[2], w3 = twl[3];
+  for (; p < batch; p += gridDim.x) {
+    // stages 0,1 from registers (root 1: twiddles tw[1]; tw[2], tw[3])
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const int base = threadIdx.x + g * 1024;
+      double v0 = from_u64(pre[g][0]), v1 = from_u64(pre[g][1]), v2 = from_u64(pre[g][2]), v3 = from_u64(pre[g][3]);
+      double t = mulmod(v2, w1, mod), u = mulmod(v3, w1, mod);
+      double a0 = v0 + t, a2 = v0 - t, a1 = v1 + u, a3 = v1 - u;
+      t = mulmod(a1, w2, mod);
+      u = mulmod(a3, w3, mod);
+      const int pb = pidx(base), po = q + (q >> PAD_SHIFT);
+      s[pb] = a0 + t;
+      s[pb + po] = a0 - t;
+      s[pb + 2 * po] = a2 + u;
+      s[pb + 3 * po] = a2 - u;
+    }
+    __syncthreads();
+    const unsigned long long pn = p + gridDim.x;
+    if (pn < batch) {
+      const uint64_t *src = data + pn * (size_t)n;
+#pragma unroll
+      for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) pre[g][e] = src[threadIdx.x + g * 1024 + e * q];
+    }
+    fwd_round<2>(lds, lds, logn, logn, 2, twl, 1, mod, red_mask, Lanes{(int)threadIdx.x, 1024, true});
+    __syncthreads();
+    for (int st = 0; st < logb;) {
+      const int R = pick_radix(logb - st, 3);
+      fwd_round_dispatch<3>(R, blk, blk, logb, logb, st, twl, 16 + wave, mod, red_mask >> 4, wl);
+      wave_sync();
+      st += R;
+    }
+    ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(data + p * (size_t)n + off);
+    for (int i = lane; i < (bsz >> 1); i += 64) {
+      const int pi = pidx(off + 2 * i);
+      ulonglong2 o;
+      o.x = to_u64(canon(s[pi], mod));
+      o.y = to_u64(canon(s[pi + 1], mod));
+      dst[i] = o;
+    }
+    __syncthreads();
+  }
+}
+
+int g_ntt_variant = 12;  // tuning knob (rs_set_tuning("ntt_variant", v)): see launch_ntt
 
 template <bool INV, int MAXR, bool DIN, bool DOUT, int THREADS>
 static void launch_ntt_variant(const NttTable &t, uint64_t *d_data, size_t batch, hipStream_t st) {
@@ -267,10 +345,26 @@ void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, 
     else                                                                               \
       launch_ntt_variant<false, MAXR, DIN_F, DOUT_F, THR>(t, d_data, batch, st);       \
     break;
+  if (g_ntt_variant == 12 && !inverse && t.logn >= 12 && t.logn <= 13 && t.fwd_red_mask < 4) {
+    const size_t lds = (padded_len((size_t)1 << t.logn) + ((size_t)1 << t.logn)) * sizeof(double);
+    const unsigned grid = (unsigned)std::min<size_t>(batch, 256);
+    if (t.logn == 13) {
+      RS_HIP(hipFuncSetAttribute((const void *)ntt_fwd_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(ntt_fwd_stream_kernel<2>, dim3(grid), dim3(1024), lds, st, d_data, (unsigned long long)batch, t.logn,
+                         t.d_tw, t.mod, t.fwd_red_mask);
+    } else {
+      RS_HIP(hipFuncSetAttribute((const void *)ntt_fwd_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(ntt_fwd_stream_kernel<1>, dim3(grid), dim3(1024), lds, st, d_data, (unsigned long long)batch, t.logn,
+                         t.d_tw, t.mod, t.fwd_red_mask);
+    }
+    RS_HIP(hipGetLastError());
+    return;
+  }
   const bool wp_ok = t.logn >= 11;  // wave-private blocks need n / W >= 128
-  if (wp_ok && g_ntt_variant >= 8 && g_ntt_variant <= 11) {
+  if (wp_ok && g_ntt_variant >= 8 && g_ntt_variant <= 12) {
     switch (g_ntt_variant) {
       case 8:
+      case 12:  // streaming forward kernel not applicable (inverse, or shape): wave-private kernel
         inverse ? launch_ntt_wp<true, 4, 512>(t, d_data, batch, st) : launch_ntt_wp<false, 4, 512>(t, d_data, batch, st);
         break;
       case 9:

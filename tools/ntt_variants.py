@@ -19,7 +19,7 @@ prm = P.preset(name); dev = Device(prm); lib = _lib.load()
 batch = 8192
 src = torch.empty((batch, prm.N_enc), dtype=torch.int64, device=dev.device); src.random_(0, prm.Q[0])
 ref_f = ref_i = None
-for v in [int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else range(12))]:
+for v in [int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else range(13))]:
     _lib.check(lib.rs_set_tuning(b"ntt_variant", v))
     d = src.clone(); dev.ntt(d, _lib.RS_MOD_COEFF, 0); f = d.clone()
     dev.ntt(d, _lib.RS_MOD_COEFF, 0, inverse=True)

@@ -285,16 +285,17 @@ struct LdsBlockIO {
 // complete (for that wave) on return.
 template <int MAXR, class In, class OutFactory, int CROSSR = 4, bool OPAQUE = false>
 __device__ __forceinline__ void lds_ntt_fwd_wp(double *s, const In first_in, const OutFactory make_out, int logn, int logw,
-                                               const double *__restrict__ tw, const Mod mod, uint32_t red_mask) {
+                                               const double *__restrict__ tw, const Mod mod, uint32_t red_mask,
+                                               int root0 = 1) {
   const LdsIO lds{s};
   // cross-wave rounds: logw stages in rounds of at most CROSSR (each ends with a barrier)
   for (int st = 0; st < logw;) {
     const int R = pick_radix(logw - st, CROSSR);
     const Lanes bl{(int)threadIdx.x, (int)blockDim.x, OPAQUE};
     if (st == 0)
-      fwd_round_dispatch<CROSSR>(R, first_in, lds, logn, logn, st, tw, 1, mod, red_mask, bl);
+      fwd_round_dispatch<CROSSR>(R, first_in, lds, logn, logn, st, tw, root0, mod, red_mask, bl);
     else
-      fwd_round_dispatch<CROSSR>(R, lds, lds, logn, logn, st, tw, 1, mod, red_mask, bl);
+      fwd_round_dispatch<CROSSR>(R, lds, lds, logn, logn, st, tw, root0, mod, red_mask, bl);
     __syncthreads();
     st += R;
   }
@@ -302,7 +303,7 @@ __device__ __forceinline__ void lds_ntt_fwd_wp(double *s, const In first_in, con
   const int logb = logn - logw;
   const int off = wave << logb;
   const LdsBlockIO blk{s + pidx(off)};
-  const int root = (1 << logw) + wave;
+  const int root = (root0 << logw) + wave;
   const uint32_t mask = red_mask >> logw;
   const Lanes ln = wave_lanes(OPAQUE);
   int st = 0;
@@ -321,7 +322,8 @@ __device__ __forceinline__ void lds_ntt_fwd_wp(double *s, const In first_in, con
 // round writes to last_out.  Ends with a workgroup barrier after the cross-wave round.
 template <int MAXR, class InFactory, class Out, int CROSSR = 4>
 __device__ __forceinline__ void lds_ntt_inv_wp(double *s, const InFactory make_in, const Out last_out, int logn, int logw,
-                                               const double *__restrict__ itw, const Mod mod, uint32_t red_mask) {
+                                               const double *__restrict__ itw, const Mod mod, uint32_t red_mask,
+                                               int root0 = 1) {
   const LdsIO lds{s};
   const int wave = threadIdx.x >> 6;
   const int logb = logn - logw;
@@ -329,7 +331,7 @@ __device__ __forceinline__ void lds_ntt_inv_wp(double *s, const InFactory make_i
   const LdsBlockIO blk{s + pidx(off)};
   // inverse stage u of the block == inverse stage u of the whole transform; group index inside the
   // block's subtree: node = M_block * (W + wave) + i  with M_block groups per block at that stage
-  const int root = (1 << logw) + wave;
+  const int root = (root0 << logw) + wave;
   const Lanes ln = wave_lanes();
   int st = 0;
   while (st < logb) {
@@ -345,9 +347,9 @@ __device__ __forceinline__ void lds_ntt_inv_wp(double *s, const InFactory make_i
   for (int st = 0; st < logw;) {
     const int R = pick_radix(logw - st, CROSSR);
     if (st + R >= logw)
-      inv_round_dispatch<CROSSR>(R, lds, last_out, logn, logn, logb + st, itw, 1, mod, red_mask);
+      inv_round_dispatch<CROSSR>(R, lds, last_out, logn, logn, logb + st, itw, root0, mod, red_mask);
     else
-      inv_round_dispatch<CROSSR>(R, lds, lds, logn, logn, logb + st, itw, 1, mod, red_mask);
+      inv_round_dispatch<CROSSR>(R, lds, lds, logn, logn, logb + st, itw, root0, mod, red_mask);
     __syncthreads();
     st += R;
   }

@@ -485,18 +485,22 @@ newton_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned 
 // single workgroup barrier.
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS, THREADS / 128)  // two workgroups per CU
-tree_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned slots_per_limb, ColPlans plans) {
+tree_columns_kernel(double *__restrict__ cols, int logM, int logT, size_t col0, unsigned S, unsigned slots_per_limb,
+                    ColPlans plans) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   constexpr int LOGW = THREADS == 512 ? 3 : (THREADS == 256 ? 2 : (THREADS == 128 ? 1 : 0));
-  constexpr int EPT = 16;  // coefficients per lane: M / THREADS <= 16
+  constexpr int EPT = 16;  // coefficients per lane: T / THREADS <= 16
   const int M = 1 << logM;
-  const size_t col = blockIdx.x;
-  const ColPlan &P = plans.l[(col % S) / slots_per_limb];
+  // workgroup = one tile of T = 2^logT coefficients: levels 1..logT of the tree below position pos0
+  const unsigned nb = 1u << (logM - logT);
+  const size_t col = blockIdx.x / nb;
+  const int pos0 = (int)(blockIdx.x % nb) << logT;
+  const ColPlan &P = plans.l[((col0 + col) % S) / slots_per_limb];
   const Mod mod = P.mod;
-  double *c = cols + col * (size_t)M;
+  double *c = cols + col * (size_t)M + pos0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int logb = logM - LOGW, bsz = 1 << logb, off = wave << logb;
+  const int logb = logT - LOGW, bsz = 1 << logb, off = wave << logb;
   const int per = bsz >> 6;  // own positions: off + lane + 64*j, j < per
   double *sb = s + pidx(off);
   const LdsBlockIO blk{sb};
@@ -505,9 +509,9 @@ tree_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned sl
   for (int j = 0; j < EPT; j++)
     if (j < per) sb[pidx(lane + 64 * j)] = c[off + lane + 64 * j];
   wave_sync();
-  school_levels_lds(sb, logb, logM, off, P, wl);
+  school_levels_lds(sb, logb, logM, pos0 + off, P, wl);
   wave_sync();
-  for (int l = SCHOOL_LEVELS + 1; l <= logM; l++) {
+  for (int l = SCHOOL_LEVELS + 1; l <= logT; l++) {
     const int n = 1 << l, h = n >> 1;
     const bool priv = l <= logb;
     double r[EPT];
@@ -534,9 +538,9 @@ tree_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned sl
         st += R;
       }
     } else {
-      lds_bntt_fwd<3>(s, logM, l, P.tw, mod, P.fmask[l]);
+      lds_bntt_fwd<3>(s, logT, l, P.tw, mod, P.fmask[l]);
     }
-    const double *dh = P.dhat + (size_t)l * M + off;
+    const double *dh = P.dhat + (size_t)l * M + pos0 + off;
 #pragma unroll
     for (int j = 0; j < EPT; j++)
       if (j < per) {
@@ -552,7 +556,7 @@ tree_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned sl
         st += R;
       }
     } else {
-      lds_bntt_inv<3>(s, logM, l, P.itw, mod, P.imask[l]);
+      lds_bntt_inv<3>(s, logT, l, P.itw, mod, P.imask[l]);
     }
 #pragma unroll
     for (int j = 0; j < EPT; j++)
@@ -772,6 +776,10 @@ r1cs_eval_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restric
 struct TabPtrs {
   const double *t[RS_MAX_L];
 };
+struct ColBlockFactory {
+  double *s;
+  __device__ __forceinline__ LdsBlockIO operator()(int off) const { return LdsBlockIO{s + pidx(off)}; }
+};
 struct GlobalF64IO {
   double *p;
   __device__ __forceinline__ int pbase(int) const { return 0; }
@@ -779,24 +787,90 @@ struct GlobalF64IO {
   __device__ __forceinline__ void store(int base, int, int eoff, int, double v) const { p[base + eoff] = v; }
 };
 
+// ---- cross passes with fused sources and sinks ----------------------------------------------------
+// The first forward pass of a transform reads its input through a source functor (padding,
+// scaling, centring, node splitting, reversal happen on the fly, from the caller's buffer); the
+// last inverse pass hands its output to a sink functor (truncation, node recombination, H
+// extraction).  Every other pass works in place on the workspace.  This removes the separate
+// element-wise launches (and their HBM round trips) around every multi-pass transform.
+enum CrossSrc { CS_PLAIN = 0, CS_SCALE_PAD, CS_FILL_RIGHT, CS_PAD_CENTER, CS_REV_TRUNC };
+enum CrossDst { CD_PLAIN = 0, CD_TAKE_LOW, CD_COMBINE, CD_COMBINE_CANON, CD_H_FINISH };
+struct CrossArgs {
+  double *W;          // workspace columns [ncols][2^logtot]
+  const double *src;  // source columns (CS_*): [ncols][M] (CS_REV_TRUNC: [ncols][2M])
+  double *dst;        // sink columns (CD_*): [ncols][M]
+  int logtot, logsub, s0, logM, l, m;
+  size_t col0;
+  unsigned S, slots_per_limb;
+};
+template <int SRC>
+struct CrossIn {
+  const double *p;  // this column of the source
+  const double *invfact;
+  Mod mod;
+  int M, m, n, h;
+  __device__ __forceinline__ int pbase(int) const { return 0; }
+  __device__ __forceinline__ double load(int base, int, int eoff, int) const {
+    const int k = base + eoff;
+    if (SRC == CS_SCALE_PAD) return k < M ? mulmod(p[k], invfact[k], mod) : 0.0;  // values * 1/k!, zero padded
+    if (SRC == CS_FILL_RIGHT) return (k & (n - 1)) < h ? p[k + h] : 0.0;         // per node: (F_right, 0)
+    if (SRC == CS_PAD_CENTER) return k < M ? center(p[k], mod) : 0.0;
+    if (SRC == CS_REV_TRUNC) return k < m - 1 ? reduce(p[2 * m - 2 - k], mod) : 0.0;  // T_k = P_{2m-2-k}, k < m-1
+    return p[k];
+  }
+};
+template <int DST>
+struct CrossOut {
+  double *p;  // this column of the sink
+  const double *invfact;
+  Mod mod;
+  int M, m, n, h;
+  __device__ __forceinline__ int pbase(int) const { return 0; }
+  __device__ __forceinline__ void store(int base, int, int eoff, int, double v) const {
+    const int k = base + eoff;
+    if (DST == CD_TAKE_LOW) {  // Newton coefficients k < m of the length-2M convolution
+      if (k < M) p[k] = (invfact[k] != 0.0) ? reduce(v, mod) : 0.0;
+    } else if (DST == CD_COMBINE || DST == CD_COMBINE_CANON) {  // F_node = (F_left, 0) + D_left * F_right
+      const double f = reduce(v + ((k & (n - 1)) < h ? p[k] : 0.0), mod);
+      p[k] = DST == CD_COMBINE_CANON ? canon(f, mod) : f;
+    } else if (DST == CD_H_FINISH) {  // H_j = U_{m-2-j}; positions j > m-2 are cleared by h_patch_kernel
+      if (k <= m - 2) p[m - 2 - k] = reduce(v, mod);
+    } else {
+      p[k] = v;
+    }
+  }
+};
+
 // cross stages [s0, s0+R) of batched length-2^logsub transforms inside columns of length 2^logtot.
-// grid (x, columns)
-template <bool INV, int R>
-__global__ void __launch_bounds__(256)
-cross_kernel(double *__restrict__ X, int logtot, int logsub, int s0, size_t col0, unsigned S, unsigned slots_per_limb,
-             ColPlans plans) {
+// grid (x, columns).  MODE: CrossSrc for forward passes, CrossDst for inverse passes.
+template <bool INV, int R, int MODE>
+__global__ void __launch_bounds__(256) cross_kernel(CrossArgs a, ColPlans plans) {
   const size_t col = blockIdx.y;
-  const ColPlan &P = plans.l[((col0 + col) % S) / slots_per_limb];
-  const GlobalF64IO io{X + (col << logtot)};
+  const ColPlan &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const GlobalF64IO io{a.W + (col << a.logtot)};
   const Lanes ln{(int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x)};
-  if (INV)
-    inv_round<R>(io, io, logtot, logsub, s0, P.itw, 1, P.mod, P.imask[logsub], ln);
-  else
-    fwd_round<R>(io, io, logtot, logsub, s0, P.tw, 1, P.mod, P.fmask[logsub], ln);
+  const int M = 1 << a.logM, n = 1 << a.l;
+  if (INV) {
+    if (MODE == CD_PLAIN) {
+      inv_round<R>(io, io, a.logtot, a.logsub, a.s0, P.itw, 1, P.mod, P.imask[a.logsub], ln);
+    } else {
+      const CrossOut<MODE> out{a.dst + (col << a.logM), P.invfact, P.mod, M, a.m, n, n >> 1};
+      inv_round<R>(io, out, a.logtot, a.logsub, a.s0, P.itw, 1, P.mod, P.imask[a.logsub], ln);
+    }
+  } else {
+    if (MODE == CS_PLAIN) {
+      fwd_round<R>(io, io, a.logtot, a.logsub, a.s0, P.tw, 1, P.mod, P.fmask[a.logsub], ln);
+    } else {
+      const size_t stride = MODE == CS_REV_TRUNC ? (size_t)2 << a.logM : (size_t)1 << a.logM;
+      const CrossIn<MODE> in{a.src + col * stride, P.invfact, P.mod, M, a.m, n, n >> 1};
+      fwd_round<R>(in, io, a.logtot, a.logsub, a.s0, P.tw, 1, P.mod, P.fmask[a.logsub], ln);
+    }
+  }
 }
 
 // Sub-transforms on blocks of Bn = 2^logB doubles.  MODE 0: forward, 1: inverse, 2: forward,
-// multiply by tab[(blk % tab_period) * Bn + j], inverse (fused).  Block blk belongs to column
+// multiply by tab[(blk % tab_period) * Bn + j], inverse (fused); 3: like 2 with a per-column table
+// (another workspace of the same shape, lazily reduced): tab[blk * Bn + j].  Block blk belongs to column
 // blk / blocks_per_col; inside its transform (n1 = 2^log_n1 blocks) it is block blk % n1.
 template <int MODE>
 __global__ void __launch_bounds__(1024)
@@ -815,80 +889,42 @@ sub_ntt_kernel(double *__restrict__ X, int logB, int log_n1, TabPtrs tabs, unsig
   double *x = X + blk * (size_t)Bn;
   for (int i = threadIdx.x; i < Bn; i += blockDim.x) s[pidx(i)] = x[i];
   __syncthreads();
-  if (MODE == 0 || MODE == 2) lds_ntt_fwd<3>(s, logB, P.tw, root, mod, P.fmask[logn] >> log_n1);
+  int logw = 0;
+  while ((64 << logw) < (int)blockDim.x) logw++;
+  const bool wp = logw >= 1 && logw <= 4 && logB - logw >= 8;
+  const ColBlockFactory bf{s};
+  const LdsIO lds{s};
+  if (MODE == 0 || MODE >= 2) {
+    if (wp) {
+      lds_ntt_fwd_wp<4, LdsIO, ColBlockFactory, 3>(s, lds, bf, logB, logw, P.tw, mod, P.fmask[logn] >> log_n1, root);
+      __syncthreads();
+    } else {
+      lds_ntt_fwd<3>(s, logB, P.tw, root, mod, P.fmask[logn] >> log_n1);
+    }
+  }
   if (MODE == 2) {
     const double *tab = tabs.t[limb] + (size_t)(blk % tab_period) * Bn;
     for (int i = threadIdx.x; i < Bn; i += blockDim.x) s[pidx(i)] = mulmod(reduce(s[pidx(i)], mod), tab[i], mod);
     __syncthreads();
   }
-  if (MODE == 1 || MODE == 2) lds_ntt_inv<3>(s, logB, P.itw, root, mod, P.imask[logn]);
-  for (int i = threadIdx.x; i < Bn; i += blockDim.x) x[i] = s[pidx(i)];
-}
-
-// product-tree levels 1..logB on every block of Bn Newton coefficients (grid = columns * M/Bn)
-__global__ void __launch_bounds__(1024)
-tree_block_kernel(double *__restrict__ X, int logM, int logB, size_t col0, unsigned S, unsigned slots_per_limb,
-                  ColPlans plans) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *s = reinterpret_cast<double *>(smem);
-  const int Bn = 1 << logB;
-  const unsigned nb = 1u << (logM - logB);
-  const size_t col = blockIdx.x / nb;
-  const int pos0 = (int)(blockIdx.x % nb) * Bn;
-  const ColPlan &P = plans.l[((col0 + col) % S) / slots_per_limb];
-  double *x = X + (col << logM) + pos0;
-  for (int i = threadIdx.x; i < Bn; i += blockDim.x) s[pidx(i)] = x[i];
-  __syncthreads();
-  tree_levels_lds(s, logB, logM, pos0, P);
-  for (int i = threadIdx.x; i < Bn; i += blockDim.x) x[i] = s[pidx(i)];
-}
-
-// element-wise helpers of the multi-pass path; one launch covers `cols` columns
-enum EwOp { EW_SCALE_PAD, EW_TAKE_LOW, EW_FILL_RIGHT, EW_COMBINE, EW_PAD_CENTER, EW_MUL, EW_REV_TRUNC, EW_H_FINISH, EW_CANON };
-struct EwArgs {
-  double *dst;
-  const double *a, *b;
-  int logM, l, m;
-  unsigned S, slots_per_limb;
-  size_t col0;  // first column (for d1,d2,d3 indexing)
-  const uint64_t *d1, *d2, *d3;
-};
-template <int OP>
-__global__ void __launch_bounds__(256) ew_kernel(EwArgs e, size_t cols, ColPlans plans) {
-  const size_t M = (size_t)1 << e.logM, M2 = 2 * M;
-  const size_t len = (OP == EW_SCALE_PAD || OP == EW_PAD_CENTER || OP == EW_MUL || OP == EW_REV_TRUNC) ? M2 : M;
-  const size_t total = cols * len, stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const size_t col = i / len, k = i % len;
-    const ColPlan &P = plans.l[((e.col0 + col) % e.S) / e.slots_per_limb];
-    const Mod mod = P.mod;
-    if (OP == EW_SCALE_PAD) {  // dst[2M] = a[M] * invfact, zero padded
-      e.dst[i] = k < M ? mulmod(e.a[col * M + k], P.invfact[k], mod) : 0.0;
-    } else if (OP == EW_TAKE_LOW) {  // dst[M] = Newton coefficients k < m of a[2M]
-      e.dst[i] = (P.invfact[k] != 0.0) ? reduce(e.a[col * M2 + k], mod) : 0.0;
-    } else if (OP == EW_FILL_RIGHT) {  // dst[M]: per node of size 2^l, (F_right, 0)
-      const size_t n = (size_t)1 << e.l, h = n >> 1, kk = k & (n - 1);
-      e.dst[i] = kk < h ? e.a[col * M + k + h] : 0.0;
-    } else if (OP == EW_COMBINE) {  // dst[M] = a[M] (product) + F_left of dst
-      const size_t n = (size_t)1 << e.l, h = n >> 1, kk = k & (n - 1);
-      e.dst[i] = reduce(e.a[i] + (kk < h ? e.dst[i] : 0.0), mod);
-    } else if (OP == EW_PAD_CENTER) {  // dst[2M] = centred a[M], zero padded
-      e.dst[i] = k < M ? center(e.a[col * M + k], mod) : 0.0;
-    } else if (OP == EW_MUL) {  // dst[2M] *= a[2M]
-      e.dst[i] = mulmod(reduce(e.dst[i], mod), reduce(e.a[i], mod), mod);
-    } else if (OP == EW_REV_TRUNC) {  // dst[2M]: T_k = a[2m-2-k] for k < m-1
-      e.dst[i] = ((long long)k < (long long)e.m - 1) ? reduce(e.a[col * M2 + (size_t)(2 * e.m - 2) - k], mod) : 0.0;
-    } else if (OP == EW_H_FINISH) {  // dst[M] = H from U = a[2M], ZK patch from A = b (M), B = dst2 unused
-      double h = ((long long)k <= (long long)e.m - 2) ? reduce(e.a[col * M2 + (size_t)(e.m - 2) - k], mod) : 0.0;
-      e.dst[i] = h;
-    } else {  // EW_CANON
-      e.dst[i] = canon(e.a[i], mod);
-    }
+  if (MODE == 3) {
+    const double *tab = tabs.t[0] + blk * (size_t)Bn;
+    for (int i = threadIdx.x; i < Bn; i += blockDim.x)
+      s[pidx(i)] = mulmod(reduce(s[pidx(i)], mod), reduce(tab[i], mod), mod);
+    __syncthreads();
   }
+  if (MODE >= 1) {
+    if (wp)
+      lds_ntt_inv_wp<4, ColBlockFactory, LdsIO, 3>(s, bf, lds, logB, logw, P.itw, mod, P.imask[logn], root);
+    else
+      lds_ntt_inv<3>(s, logB, P.itw, root, mod, P.imask[logn]);
+  }
+  for (int i = threadIdx.x; i < Bn; i += blockDim.x) x[i] = s[pidx(i)];
 }
+
 // ZK patch of the multi-pass H: H += d2*A + d1*B + d1*d2*Z, H[0] -= d3; then canonical form.
 __global__ void __launch_bounds__(256)
-h_patch_kernel(double *__restrict__ H, const double *__restrict__ A, const double *__restrict__ B, int logM, size_t cols,
+h_patch_kernel(double *__restrict__ H, const double *__restrict__ A, const double *__restrict__ B, int logM, int m, size_t cols,
                size_t col0, unsigned S, unsigned slots_per_limb, ColPlans plans, const uint64_t *__restrict__ d1,
                const uint64_t *__restrict__ d2, const uint64_t *__restrict__ d3) {
   const size_t M = (size_t)1 << logM, total = cols * M, stride = (size_t)gridDim.x * blockDim.x;
@@ -896,7 +932,7 @@ h_patch_kernel(double *__restrict__ H, const double *__restrict__ A, const doubl
     const size_t col = i / M, k = i % M, gcol = (col0 + col) % S;
     const ColPlan &P = plans.l[gcol / slots_per_limb];
     const Mod mod = P.mod;
-    double h = H[i];
+    double h = ((long long)k <= (long long)m - 2) ? H[i] : 0.0;
     if (d1) {
       const double e1 = center(from_u64(d1[gcol]), mod), e2 = center(from_u64(d2[gcol]), mod);
       h += mulmod(e2, center(A[i], mod), mod) + mulmod(e1, center(B[i], mod), mod) + mulmod(mulmod(e1, e2, mod), P.ztab[k], mod);
@@ -936,24 +972,57 @@ static int col_threads(size_t M) { return (int)std::max<size_t>(64, std::min<siz
 int g_witness_lds_logM = 13;  // columns up to 2^13 run entirely inside one LDS tile
 int g_witness_split = 1;      // 1: separate Newton-convolution and product-tree launches (M >= 1024)
 
-template <bool INV>
-static void launch_cross(double *X, size_t ncols, size_t col0, int logtot, int logsub, int logB, size_t S, size_t spl,
-                         const ColPlans &cp, hipStream_t st) {
-  // cross stages: forward stages [0, logsub-logB), inverse stages [logB, logsub)
-  const int ncross = logsub - logB;
-  const size_t groups = ((size_t)1 << logtot);
+// Newton -> monomial levels 1..logT on tiles of 2^logT coefficients of [ncols][M] columns
+static void launch_tree_tiles(double *cols, size_t ncols, size_t col0, int logM, int logT, size_t S, size_t slots_per_limb,
+                              const ColPlans &cp, hipStream_t st) {
+  const size_t T = (size_t)1 << logT;
+  const size_t lds1 = padded_len(T) * sizeof(double);
+  const unsigned grid = (unsigned)(ncols << (logM - logT));
+  const int thr = (int)std::max<size_t>(64, std::min<size_t>(512, T / 16));
+  RS_REQUIRE(T / thr <= 16 && logT >= 6, "tree tile out of range");
+#define RS_TREE_LAUNCH(THR)                                                                                          \
+  do {                                                                                                               \
+    RS_HIP(hipFuncSetAttribute((const void *)tree_columns_kernel<THR>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                               (int)lds1));                                                                          \
+    hipLaunchKernelGGL(tree_columns_kernel<THR>, dim3(grid), dim3(THR), lds1, st, cols, logM, logT, col0, (unsigned)S, \
+                       (unsigned)slots_per_limb, cp);                                                                \
+  } while (0)
+  if (thr == 512) RS_TREE_LAUNCH(512);
+  else if (thr == 256) RS_TREE_LAUNCH(256);
+  else if (thr == 128) RS_TREE_LAUNCH(128);
+  else RS_TREE_LAUNCH(64);
+#undef RS_TREE_LAUNCH
+  RS_HIP(hipGetLastError());
+}
+
+template <bool INV, int MODE>
+static void launch_cross_pass(int R, const dim3 &grid, const CrossArgs &a, const ColPlans &cp, hipStream_t st) {
+  switch (R) {
+    case 4: hipLaunchKernelGGL((cross_kernel<INV, 4, MODE>), grid, dim3(256), 0, st, a, cp); break;
+    case 3: hipLaunchKernelGGL((cross_kernel<INV, 3, MODE>), grid, dim3(256), 0, st, a, cp); break;
+    case 2: hipLaunchKernelGGL((cross_kernel<INV, 2, MODE>), grid, dim3(256), 0, st, a, cp); break;
+    default: hipLaunchKernelGGL((cross_kernel<INV, 1, MODE>), grid, dim3(256), 0, st, a, cp); break;
+  }
+}
+
+// Cross stages of the length-2^logsub transforms in W[ncols][2^logtot]: forward stages
+// [0, logsub-logB) (the first pass reads through source MODE from a.src), or inverse stages
+// [logB, logsub) (the last pass writes through sink MODE to a.dst).
+template <bool INV, int MODE>
+static void launch_cross(CrossArgs a, size_t ncols, int logB, const ColPlans &cp, hipStream_t st) {
+  const int ncross = a.logsub - logB;
+  const size_t groups = ((size_t)1 << a.logtot);
   int done = 0;
   while (done < ncross) {
-    const int R = pick_radix(ncross - done, 3);
-    const int s0 = INV ? logB + done : done;
+    const int R = pick_radix(ncross - done, 4);
+    a.s0 = INV ? logB + done : done;
     const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>((groups >> R) / 256, 1024));
     const dim3 grid(gx, (unsigned)ncols);
-    if (R == 3)
-      hipLaunchKernelGGL((cross_kernel<INV, 3>), grid, dim3(256), 0, st, X, logtot, logsub, s0, col0, (unsigned)S, (unsigned)spl, cp);
-    else if (R == 2)
-      hipLaunchKernelGGL((cross_kernel<INV, 2>), grid, dim3(256), 0, st, X, logtot, logsub, s0, col0, (unsigned)S, (unsigned)spl, cp);
+    const bool special = INV ? (done + R >= ncross) : (done == 0);
+    if (special)
+      launch_cross_pass<INV, MODE>(R, grid, a, cp, st);
     else
-      hipLaunchKernelGGL((cross_kernel<INV, 1>), grid, dim3(256), 0, st, X, logtot, logsub, s0, col0, (unsigned)S, (unsigned)spl, cp);
+      launch_cross_pass<INV, 0>(R, grid, a, cp, st);
     done += R;
   }
   RS_HIP(hipGetLastError());
@@ -967,17 +1036,9 @@ static void launch_sub(double *X, size_t ncols, size_t col0, int logtot, int log
   static TabPtrs none{};
   const TabPtrs &tp = tabs ? *tabs : none;
   RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, ((size_t)1 << logB) / 8));
+  const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, ((size_t)1 << logB) / 16));
   hipLaunchKernelGGL(sub_ntt_kernel<MODE>, dim3((unsigned)(ncols * bpc)), dim3(thr), lds, st, X, logB, logsub - logB, tp,
                      (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp);
-  RS_HIP(hipGetLastError());
-}
-
-template <int OP>
-static void launch_ew(const EwArgs &e, size_t cols, size_t len, const ColPlans &cp, hipStream_t st) {
-  const size_t total = cols * len;
-  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 256 * 16));
-  hipLaunchKernelGGL(ew_kernel<OP>, dim3(blocks), dim3(256), 0, st, e, cols, cp);
   RS_HIP(hipGetLastError());
 }
 
@@ -986,50 +1047,38 @@ static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, do
                        size_t S, size_t spl, hipStream_t st) {
   const int logM = P->logM, logB = std::min(g_witness_lds_logM, logM);
   const size_t M = P->M;
-  EwArgs e{};
-  e.logM = logM;
-  e.m = (int)P->m;
-  e.S = (unsigned)S;
-  e.slots_per_limb = (unsigned)spl;
-  e.col0 = col0;
+  CrossArgs a{};
+  a.W = W;
+  a.src = X;
+  a.dst = X;
+  a.logM = logM;
+  a.l = 1;
+  a.m = (int)P->m;
+  a.S = (unsigned)S;
+  a.slots_per_limb = (unsigned)spl;
+  a.col0 = col0;
   TabPtrs tp{};
   // values -> Newton coefficients: one cyclic convolution of length 2M
-  e.dst = W;
-  e.a = X;
-  launch_ew<EW_SCALE_PAD>(e, ncols, 2 * M, cp, st);
-  launch_cross<false>(W, ncols, col0, logM + 1, logM + 1, logB, S, spl, cp, st);
+  a.logtot = a.logsub = logM + 1;
+  launch_cross<false, CS_SCALE_PAD>(a, ncols, logB, cp, st);
   for (int i = 0; i < ctx->L; i++) tp.t[i] = P->limb[i].d_ehat;
   launch_sub<2>(W, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * M) >> logB, S, spl, cp, st);
-  launch_cross<true>(W, ncols, col0, logM + 1, logM + 1, logB, S, spl, cp, st);
-  e.dst = X;
-  e.a = W;
-  launch_ew<EW_TAKE_LOW>(e, ncols, M, cp, st);
-  // product tree: levels <= logB inside LDS blocks
-  {
-    const size_t lds = padded_len((size_t)2 << logB) * sizeof(double);
-    RS_HIP(hipFuncSetAttribute((const void *)tree_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, ((size_t)2 << logB) / 8));
-    hipLaunchKernelGGL(tree_block_kernel, dim3((unsigned)(ncols << (logM - logB))), dim3(thr), lds, st, X, logM, logB, col0,
-                       (unsigned)S, (unsigned)spl, cp);
-    RS_HIP(hipGetLastError());
-  }
+  launch_cross<true, CD_TAKE_LOW>(a, ncols, logB, cp, st);
+  // product tree: levels <= logB inside LDS tiles
+  launch_tree_tiles(X, ncols, col0, logM, logB, S, spl, cp, st);
   // levels above: F_node = F_left + D_left * F_right with multi-pass transforms of length 2^l
+  a.logtot = logM;
   for (int l = logB + 1; l <= logM; l++) {
-    e.l = l;
-    e.dst = W;
-    e.a = X;
-    launch_ew<EW_FILL_RIGHT>(e, ncols, M, cp, st);
-    launch_cross<false>(W, ncols, col0, logM, l, logB, S, spl, cp, st);
+    a.l = l;
+    a.logsub = l;
+    launch_cross<false, CS_FILL_RIGHT>(a, ncols, logB, cp, st);
     for (int i = 0; i < ctx->L; i++) tp.t[i] = P->limb[i].d_dhat + (size_t)l * M;
     launch_sub<2>(W, ncols, col0, logM, l, logB, &tp, M >> logB, S, spl, cp, st);
-    launch_cross<true>(W, ncols, col0, logM, l, logB, S, spl, cp, st);
-    e.dst = X;
-    e.a = W;
-    launch_ew<EW_COMBINE>(e, ncols, M, cp, st);
+    if (l == logM)
+      launch_cross<true, CD_COMBINE_CANON>(a, ncols, logB, cp, st);
+    else
+      launch_cross<true, CD_COMBINE>(a, ncols, logB, cp, st);
   }
-  e.dst = X;
-  e.a = X;
-  launch_ew<EW_CANON>(e, ncols, M, cp, st);
 }
 
 // multi-pass H = quo(A*B, Z) (+ ZK patch) for `ncols` columns; W1, W2: workspaces [ncols][2M]
@@ -1038,39 +1087,36 @@ static void big_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const d
                   const uint64_t *d2, const uint64_t *d3, hipStream_t st) {
   const int logM = P->logM, logB = std::min(g_witness_lds_logM, logM);
   const size_t M = P->M;
-  EwArgs e{};
-  e.logM = logM;
-  e.m = (int)P->m;
-  e.S = (unsigned)S;
-  e.slots_per_limb = (unsigned)spl;
-  e.col0 = col0;
+  CrossArgs a{};
+  a.logM = logM;
+  a.l = 1;
+  a.m = (int)P->m;
+  a.S = (unsigned)S;
+  a.slots_per_limb = (unsigned)spl;
+  a.col0 = col0;
+  a.logtot = a.logsub = logM + 1;
   TabPtrs tp{};
-  const double *src[2] = {A, B};
-  double *W[2] = {W1, W2};
-  for (int k = 0; k < 2; k++) {
-    e.dst = W[k];
-    e.a = src[k];
-    launch_ew<EW_PAD_CENTER>(e, ncols, 2 * M, cp, st);
-    launch_cross<false>(W[k], ncols, col0, logM + 1, logM + 1, logB, S, spl, cp, st);
-    launch_sub<0>(W[k], ncols, col0, logM + 1, logM + 1, logB, nullptr, 1, S, spl, cp, st);
-  }
-  e.dst = W1;
-  e.a = W2;
-  launch_ew<EW_MUL>(e, ncols, 2 * M, cp, st);
-  launch_sub<1>(W1, ncols, col0, logM + 1, logM + 1, logB, nullptr, 1, S, spl, cp, st);
-  launch_cross<true>(W1, ncols, col0, logM + 1, logM + 1, logB, S, spl, cp, st);
-  e.dst = W2;
-  e.a = W1;
-  launch_ew<EW_REV_TRUNC>(e, ncols, 2 * M, cp, st);
-  launch_cross<false>(W2, ncols, col0, logM + 1, logM + 1, logB, S, spl, cp, st);
+  // W1 = spectrum of A; W2 = A * B (spectrum product inside the sub-transform kernel of B)
+  a.W = W1;
+  a.src = A;
+  launch_cross<false, CS_PAD_CENTER>(a, ncols, logB, cp, st);
+  launch_sub<0>(W1, ncols, col0, logM + 1, logM + 1, logB, nullptr, 1, S, spl, cp, st);
+  a.W = W2;
+  a.src = B;
+  launch_cross<false, CS_PAD_CENTER>(a, ncols, logB, cp, st);
+  tp.t[0] = W1;
+  launch_sub<3>(W2, ncols, col0, logM + 1, logM + 1, logB, &tp, 1, S, spl, cp, st);
+  launch_cross<true, CD_PLAIN>(a, ncols, logB, cp, st);
+  // U = rev(P) * rev(Z)^-1 mod x^(m-1)
+  a.W = W1;
+  a.src = W2;
+  launch_cross<false, CS_REV_TRUNC>(a, ncols, logB, cp, st);
   for (int i = 0; i < ctx->L; i++) tp.t[i] = P->limb[i].d_shat;
-  launch_sub<2>(W2, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * M) >> logB, S, spl, cp, st);
-  launch_cross<true>(W2, ncols, col0, logM + 1, logM + 1, logB, S, spl, cp, st);
-  e.dst = H;
-  e.a = W2;
-  launch_ew<EW_H_FINISH>(e, ncols, M, cp, st);
+  launch_sub<2>(W1, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * M) >> logB, S, spl, cp, st);
+  a.dst = H;
+  launch_cross<true, CD_H_FINISH>(a, ncols, logB, cp, st);
   const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((ncols * M + 255) / 256, 256 * 16));
-  hipLaunchKernelGGL(h_patch_kernel, dim3(blocks), dim3(256), 0, st, H, A, B, logM, ncols, col0, (unsigned)S, (unsigned)spl, cp,
+  hipLaunchKernelGGL(h_patch_kernel, dim3(blocks), dim3(256), 0, st, H, A, B, logM, (int)P->m, ncols, col0, (unsigned)S, (unsigned)spl, cp,
                      d1, d2, d3);
   RS_HIP(hipGetLastError());
 }
@@ -1085,25 +1131,11 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp,
                           size_t slots_per_limb, hipStream_t st) {
   if (P->logM <= g_witness_lds_logM && P->logM >= 10 && g_witness_split) {
     // two launches: the convolution needs a 2M tile (one workgroup per CU), the product tree only M
-    const size_t lds2 = padded_len(2 * P->M) * sizeof(double), lds1 = padded_len(P->M) * sizeof(double);
+    const size_t lds2 = padded_len(2 * P->M) * sizeof(double);
     RS_HIP(hipFuncSetAttribute((const void *)newton_columns_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     hipLaunchKernelGGL(newton_columns_kernel, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds2, st, cols, P->logM,
                        (unsigned)S, (unsigned)slots_per_limb, cp);
-    const int thr = (int)std::max<size_t>(64, std::min<size_t>(512, P->M / 16));
-    if (thr == 512) {
-      RS_HIP(hipFuncSetAttribute((const void *)tree_columns_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-      hipLaunchKernelGGL(tree_columns_kernel<512>, dim3((unsigned)ncols), dim3(512), lds1, st, cols, P->logM, (unsigned)S,
-                         (unsigned)slots_per_limb, cp);
-    } else if (thr == 256) {
-      hipLaunchKernelGGL(tree_columns_kernel<256>, dim3((unsigned)ncols), dim3(256), lds1, st, cols, P->logM, (unsigned)S,
-                         (unsigned)slots_per_limb, cp);
-    } else if (thr == 128) {
-      hipLaunchKernelGGL(tree_columns_kernel<128>, dim3((unsigned)ncols), dim3(128), lds1, st, cols, P->logM, (unsigned)S,
-                         (unsigned)slots_per_limb, cp);
-    } else {
-      hipLaunchKernelGGL(tree_columns_kernel<64>, dim3((unsigned)ncols), dim3(64), lds1, st, cols, P->logM, (unsigned)S,
-                         (unsigned)slots_per_limb, cp);
-    }
+    launch_tree_tiles(cols, ncols, 0, P->logM, P->logM, S, slots_per_limb, cp, st);
     RS_HIP(hipGetLastError());
     return;
   }

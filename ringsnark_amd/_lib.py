@@ -8,6 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librs_hip.so")
+LIB_PATH = os.environ.get("RINGSNARK_AMD_LIB", LIB_PATH)  # developer override: A/B builds of the same ABI
 
 RS_OK, RS_ERR_INVALID, RS_ERR_HIP, RS_ERR_UNSUPPORTED, RS_ERR_NOT_INVERTIBLE = 0, 1, 2, 3, 4
 RS_MOD_PLAIN, RS_MOD_COEFF = 0, 1

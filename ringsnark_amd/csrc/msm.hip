@@ -196,7 +196,7 @@ mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff
         const double2 v = src[pp];
         const int pi = pidx(2 * pp);
         s[pi] = reduce(v.x, mod);
-        s[pi + 1] = reduce(v.y, mod);
+        s[pnext(pi)] = reduce(v.y, mod);
       }
       __syncthreads();
       lds_ntt_fwd(s, logn, tab.d_tw, 1, mod, tab.fwd_red_mask);
@@ -205,7 +205,7 @@ mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff
         const int pp = threadIdx.x + k * blockDim.x;
         if (pp < (n >> 1)) {
           const int pi = pidx(2 * pp);
-          double u0 = s[pi], u1 = s[pi + 1];
+          double u0 = s[pi], u1 = s[pnext(pi)];
           if (a.reduce_u) {
             u0 = reduce(u0, mod);
             u1 = reduce(u1, mod);
@@ -262,6 +262,12 @@ mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff
 //   * the transform is the wave-private form (ntt_core.cuh): one cross-wave round, then each of the
 //     16 waves finishes its own 512-element block and multiplies exactly that block into its
 //     accumulators -- two workgroup barriers per term instead of seven.
+// radix of the wave-private rounds inside mac_kernel_v2: 3 keeps the kernel free of VGPR spills (a
+// scratch reload inside the term loop costs an s_waitcnt vmcnt(0), which drains the prefetched
+// ciphertext loads and serialises stream and transform)
+#ifndef RS_MAC_MAXR
+#define RS_MAC_MAXR 3
+#endif
 struct MacArgs2 {
   const double *C;      // [tile_terms][L][n] plaintext rows of the group
   const uint64_t *crs;  // first ciphertext of the tile
@@ -334,7 +340,7 @@ mac_kernel_v2(MacArgs2 a, int L, int K, int logn, const NttTable *__restrict__ c
       if (64 * k + lane < bpairs) {
         const int pi = pidx(2 * (pbase + 64 * k));
         s[pi] = reduce(cn[k].x, mod);
-        s[pi + 1] = reduce(cn[k].y, mod);
+        s[pnext(pi)] = reduce(cn[k].y, mod);
       }
     __syncthreads();
     // stream: this term's ciphertext words and the next plaintext row, in flight during the transform
@@ -356,12 +362,12 @@ mac_kernel_v2(MacArgs2 a, int L, int K, int logn, const NttTable *__restrict__ c
       for (int k = 0; k < PP; k++)
         if (64 * k + lane < bpairs) cn[k] = crow[pbase + 64 * k];
     }
-    if (!(a.ablate & 1)) lds_ntt_fwd_wp<4, LdsIO, TileBlockFactory, 3, true>(s, lds, bf, logn, LOGW, twl, mod, red_mask);
+    if (!(a.ablate & 1)) lds_ntt_fwd_wp<RS_MAC_MAXR, LdsIO, TileBlockFactory, 3, true>(s, lds, bf, logn, LOGW, twl, mod, red_mask);
 #pragma unroll
     for (int k = 0; k < PP; k++)
       if (64 * k + lane < bpairs) {
         const int pi = pidx(2 * (pbase + 64 * k));
-        double u0 = s[pi], u1 = s[pi + 1];
+        double u0 = s[pi], u1 = s[pnext(pi)];
         if (a.reduce_u) {
           u0 = reduce(u0, mod);
           u1 = reduce(u1, mod);

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(THREADS) ntt_kernel(uint64_t *__restrict__ dat
       const ulonglong2 v = src[i];
       const int pi = pidx(2 * i);
       s[pi] = from_u64(v.x);
-      s[pi + 1] = from_u64(v.y);
+      s[pnext(pi)] = from_u64(v.y);
     }
     __syncthreads();
   }
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(THREADS) ntt_kernel(uint64_t *__restrict__ dat
     ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(poly);
     for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
       const int pi = pidx(2 * i);
-      double a = s[pi], b = s[pi + 1];
+      double a = s[pi], b = s[pnext(pi)];
       if (INV) {
         a = mulmod(reduce(a, mod), ninv, mod);
         b = mulmod(reduce(b, mod), ninv, mod);
@@ -189,8 +189,8 @@ struct BlockFactory {
   double *s;
   __device__ __forceinline__ LdsBlockIO operator()(int off) const { return LdsBlockIO{s + pidx(off)}; }
 };
-template <bool INV, int MAXR, int THREADS>
-__global__ void __launch_bounds__(THREADS) ntt_kernel_wp(uint64_t *__restrict__ data, int logn, int logw,
+template <bool INV, int MAXR, int THREADS, int MINW = 1>
+__global__ void __launch_bounds__(THREADS, MINW) ntt_kernel_wp(uint64_t *__restrict__ data, int logn, int logw,
                                                          const double *__restrict__ tw, Mod mod, double ninv,
                                                          uint32_t red_mask, int repeat) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(THREADS) ntt_kernel_wp(uint64_t *__restrict__ 
       const int pi = pidx(off + 2 * i);
       ulonglong2 o;
       o.x = to_u64(canon(s[pi], mod));
-      o.y = to_u64(canon(s[pi + 1], mod));
+      o.y = to_u64(canon(s[pnext(pi)], mod));
       dst[i] = o;
     }
   } else {
@@ -224,19 +224,19 @@ __global__ void __launch_bounds__(THREADS) ntt_kernel_wp(uint64_t *__restrict__ 
       const ulonglong2 v = src[i];
       const int pi = pidx(off + 2 * i);
       s[pi] = from_u64(v.x);
-      s[pi + 1] = from_u64(v.y);
+      s[pnext(pi)] = from_u64(v.y);
     }
     wave_sync();
     lds_ntt_inv_wp<MAXR>(s, bf, GlobalCanonOut<true>{poly, mod, ninv}, logn, logw, tw, mod, red_mask);
   }
 }
 
-template <bool INV, int MAXR, int THREADS>
+template <bool INV, int MAXR, int THREADS, int MINW = 1>
 static void launch_ntt_wp(const NttTable &t, uint64_t *d_data, size_t batch, hipStream_t st) {
   const size_t lds = padded_len((size_t)1 << t.logn) * sizeof(double);
   int logw = 0;
   while ((64 << logw) < THREADS) logw++;
-  auto kern = ntt_kernel_wp<INV, MAXR, THREADS>;
+  auto kern = ntt_kernel_wp<INV, MAXR, THREADS, MINW>;
   RS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(THREADS), lds, st, d_data, t.logn, logw, INV ? t.d_itw : t.d_tw,
                      t.mod, t.ninv, INV ? t.inv_red_mask : t.fwd_red_mask, g_ntt_repeat);
@@ -286,11 +286,11 @@ ntt_fwd_stream_kernel(uint64_t *__restrict__ data, unsigned long long batch, int
       double a0 = v0 + t, a2 = v0 - t, a1 = v1 + u, a3 = v1 - u;
       t = mulmod(a1, w2, mod);
       u = mulmod(a3, w3, mod);
-      const int pb = pidx(base), po = q + (q >> PAD_SHIFT);
+      const int pb = pidx(base);  // base < q: the quarter offsets occupy disjoint bits
       s[pb] = a0 + t;
-      s[pb + po] = a0 - t;
-      s[pb + 2 * po] = a2 + u;
-      s[pb + 3 * po] = a2 - u;
+      s[pcomb(pb, pidx(q))] = a0 - t;
+      s[pcomb(pb, pidx(2 * q))] = a2 + u;
+      s[pcomb(pb, pidx(3 * q))] = a2 - u;
     }
     __syncthreads();
     const unsigned long long pn = p + gridDim.x;
@@ -314,7 +314,7 @@ ntt_fwd_stream_kernel(uint64_t *__restrict__ data, unsigned long long batch, int
       const int pi = pidx(off + 2 * i);
       ulonglong2 o;
       o.x = to_u64(canon(s[pi], mod));
-      o.y = to_u64(canon(s[pi + 1], mod));
+      o.y = to_u64(canon(s[pnext(pi)], mod));
       dst[i] = o;
     }
     __syncthreads();
@@ -360,8 +360,9 @@ void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, 
     RS_HIP(hipGetLastError());
     return;
   }
-  const bool wp_ok = t.logn >= 11;  // wave-private blocks need n / W >= 128
-  if (wp_ok && g_ntt_variant >= 8 && g_ntt_variant <= 12) {
+  const int wp_waves = (g_ntt_variant == 9 || g_ntt_variant == 13) ? 16 : (g_ntt_variant == 10 ? 4 : 8);
+  const bool wp_ok = (1 << t.logn) >= wp_waves * LDS_BLOCK_MIN;  // wave-private blocks need n / W >= LDS_BLOCK_MIN
+  if (wp_ok && g_ntt_variant >= 8 && g_ntt_variant <= 13) {
     switch (g_ntt_variant) {
       case 8:
       case 12:  // streaming forward kernel not applicable (inverse, or shape): wave-private kernel
@@ -369,6 +370,9 @@ void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, 
         break;
       case 9:
         inverse ? launch_ntt_wp<true, 3, 1024>(t, d_data, batch, st) : launch_ntt_wp<false, 3, 1024>(t, d_data, batch, st);
+        break;
+      case 13:  // radix-8 rounds at 8 waves per SIMD (<= 64 VGPRs), two workgroups per CU
+        inverse ? launch_ntt_wp<true, 3, 1024, 8>(t, d_data, batch, st) : launch_ntt_wp<false, 3, 1024, 8>(t, d_data, batch, st);
         break;
       case 10:
         inverse ? launch_ntt_wp<true, 5, 256>(t, d_data, batch, st) : launch_ntt_wp<false, 5, 256>(t, d_data, batch, st);

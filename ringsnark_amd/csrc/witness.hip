@@ -392,15 +392,15 @@ __device__ __forceinline__ void school_levels_lds(double *s, int logB, int logM,
 // coefficients of a column, starting at column position pos0 (a multiple of Bn); the tile's
 // second half [Bn, 2Bn) is scratch.  Runs levels 1..logB (node sizes 2..Bn).  Tables are
 // indexed by the position inside the whole column (length M = 2^logM).
+__host__ __device__ __forceinline__ int tree_scratch_offset(int Bn) { return Bn >= LDS_BLOCK_MIN ? Bn : LDS_BLOCK_MIN; }
 __device__ __forceinline__ void tree_levels_lds(double *s, int logB, int logM, int pos0, const ColPlan &P) {
   const Mod mod = P.mod;
   const int Bn = 1 << logB, M = 1 << logM;
   school_levels_lds(s, logB, logM, pos0, P, block_lanes());
   __syncthreads();
   // transform levels: B[node] = (F_right, 0) -> batched length-n transforms -> * spectrum of D_left
-  // -> inverse -> + F_left.  B is addressed through an offset tile (Bn is a multiple of 16 or < 16,
-  // so pidx(Bn + i) = pidx(Bn) + pidx(i)).
-  double *Bt = s + pidx(Bn);
+  // -> inverse -> + F_left.  B is an offset tile starting at a multiple of LDS_BLOCK_MIN.
+  double *Bt = s + tree_scratch_offset(Bn);
   for (int l = SCHOOL_LEVELS + 1; l <= logB; l++) {
     const int n = 1 << l, h = n >> 1;
     for (int i = threadIdx.x; i < Bn; i += blockDim.x) {
@@ -1140,7 +1140,8 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp,
     return;
   }
   if (P->logM <= g_witness_lds_logM) {
-    const size_t lds = padded_len(2 * P->M) * sizeof(double);
+    // the 2M convolution tile, or the product tree's tile + scratch when M is below the LDS block size
+    const size_t lds = std::max(padded_len(2 * P->M), padded_len(tree_scratch_offset((int)P->M) + P->M)) * sizeof(double);
     RS_HIP(hipFuncSetAttribute((const void *)interp_columns_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(interp_columns_kernel, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds, st, cols, P->logM,
                        (unsigned)S, (unsigned)slots_per_limb, cp);

@@ -400,7 +400,7 @@ __device__ __forceinline__ void tree_levels_lds(double *s, int logB, int logM, i
   __syncthreads();
   // transform levels: B[node] = (F_right, 0) -> batched length-n transforms -> * spectrum of D_left
   // -> inverse -> + F_left.  B is an offset tile starting at a multiple of LDS_BLOCK_MIN.
-  double *Bt = s + tree_scratch_offset(Bn);
+  double *Bt = s + pidx(tree_scratch_offset(Bn));
   for (int l = SCHOOL_LEVELS + 1; l <= logB; l++) {
     const int n = 1 << l, h = n >> 1;
     for (int i = threadIdx.x; i < Bn; i += blockDim.x) {

@@ -48,6 +48,10 @@ struct PlainArgs {
   PlainGroup g[MAX_GROUPS];
 };
 
+// radix of the wave-private rounds: 3 keeps the accumulators + a round inside 128 VGPRs (no scratch)
+#ifndef RS_PLAIN_MAXR
+#define RS_PLAIN_MAXR 3
+#endif
 // grid (terms in tile, L, groups); EPT = max elements per thread (16 only for N_enc = 16384)
 template <int EPT>
 __global__ void __launch_bounds__(1024)
@@ -78,8 +82,10 @@ plain_center_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t
       }
       continue;
     }
-    for (int p = threadIdx.x; p < n; p += blockDim.x) s[pidx(p)] = 0.0;
-    __syncthreads();
+    if (N < n) {  // slots beyond N stay zero (seal_ring.tcc:350-351); with N == n the scatter covers the tile
+      for (int p = threadIdx.x; p < n; p += blockDim.x) s[pidx(p)] = 0.0;
+      __syncthreads();
+    }
     const uint64_t *src = G.coeff[v] + ((size_t)t * L + limb) * (size_t)N;
     bool nz = false;
     for (int x = threadIdx.x; x < N; x += blockDim.x) {
@@ -90,7 +96,7 @@ plain_center_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t
     if (!__syncthreads_or(nz)) continue;  // is_zero term (this limb): contributes nothing
     if (threadIdx.x == 0 && G.nz[v]) atomicOr(&G.nz[v][t], 1u);
     if (wp)
-      lds_ntt_inv_wp<4, TileBlockFactory, LdsIO, 3>(s, TileBlockFactory{s}, LdsIO{s}, logn, logw, tab.d_itw, mod, tab.inv_red_mask);
+      lds_ntt_inv_wp<RS_PLAIN_MAXR, TileBlockFactory, LdsIO, 3>(s, TileBlockFactory{s}, LdsIO{s}, logn, logw, tab.d_itw, mod, tab.inv_red_mask);
     else
       lds_ntt_inv(s, logn, tab.d_itw, 1, mod, tab.inv_red_mask);
 #pragma unroll

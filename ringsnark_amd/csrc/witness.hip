@@ -514,16 +514,20 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT, size_t col0, 
   for (int l = SCHOOL_LEVELS + 1; l <= logT; l++) {
     const int n = 1 << l, h = n >> 1;
     const bool priv = l <= logb;
+    // fresh copy per level: otherwise the 16 tile addresses are hoisted out of the level loop,
+    // spilled, and every use becomes a serialised scratch reload (s_waitcnt vmcnt(0))
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
     double r[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; j++)
-      if (j < per) r[j] = sb[pidx(lane + 64 * j)];
+      if (j < per) r[j] = sb[pidx(ln + 64 * j)];
     if (priv) wave_sync(); else __syncthreads();
     // node regions <- (F_right, 0); F_left stays in r
 #pragma unroll
     for (int j = 0; j < EPT; j++)
       if (j < per) {
-        const int i = off + lane + 64 * j;
+        const int i = off + ln + 64 * j;
         if ((i & (n - 1)) >= h) {
           s[pidx(i - h)] = r[j];
           s[pidx(i)] = 0.0;
@@ -544,8 +548,8 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT, size_t col0, 
 #pragma unroll
     for (int j = 0; j < EPT; j++)
       if (j < per) {
-        const int pi = pidx(lane + 64 * j);
-        sb[pi] = mulmod(reduce(sb[pi], mod), dh[lane + 64 * j], mod);
+        const int pi = pidx(ln + 64 * j);
+        sb[pi] = mulmod(reduce(sb[pi], mod), dh[ln + 64 * j], mod);
       }
     if (priv) wave_sync(); else __syncthreads();
     if (priv) {
@@ -561,7 +565,7 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT, size_t col0, 
 #pragma unroll
     for (int j = 0; j < EPT; j++)
       if (j < per) {
-        const int i = off + lane + 64 * j, pi = pidx(lane + 64 * j);
+        const int i = off + ln + 64 * j, pi = pidx(ln + 64 * j);
         sb[pi] = reduce(sb[pi] + (((i & (n - 1)) < h) ? r[j] : 0.0), mod);
       }
     if (priv) wave_sync(); else __syncthreads();
@@ -598,9 +602,11 @@ h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, do
     }
     __syncthreads();
     lds_ntt_fwd<4>(s, logM + 1, P.tw, 1, mod, P.fwd_mask2);
+    int tid = threadIdx.x;  // fresh copy per pass: keeps the 16 tile addresses from being hoisted and spilled
+    asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      const int p = threadIdx.x + k * blockDim.x;
+      const int p = tid + k * blockDim.x;
       if (p < M2) {
         const double v = reduce(s[pidx(p)], mod);
         r[k] = pass ? mulmod(r[k], v, mod) : v;

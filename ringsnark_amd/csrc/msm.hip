@@ -333,18 +333,27 @@ mac_kernel_v2(MacArgs2 a, int L, int K, int logn, const NttTable *__restrict__ c
   int since = 0;
   const double2 *crow = reinterpret_cast<const double2 *>(a.C + ((size_t)tbeg * L + limb) * (size_t)n);
   const uint64_t *ctp = a.crs + (size_t)tbeg * enc_words + slab;
+  // 512 threads: the next plaintext row is prefetched across the transform; 1024 threads (half the
+  // registers per lane, twice the waves to hide the L2 latency): loaded where it is used
+  constexpr bool PREFETCH_C = THREADS == 512;
   double2 cn[PP];
-  if (tbeg < tend) {
+  if (PREFETCH_C && tbeg < tend) {
 #pragma unroll
     for (int k = 0; k < PP; k++)
       if (64 * k + lane < bpairs) cn[k] = crow[pbase + 64 * k];
   }
   for (unsigned long long t = tbeg; t < tend; t++) {
-    // plaintext row (already in registers) -> tile, reduced mod Q_j
+    const int pbl = pbase;
+    if (!PREFETCH_C) {
+#pragma unroll
+      for (int k = 0; k < PP; k++)
+        if (64 * k + lane < bpairs) cn[k] = crow[pbase + 64 * k];
+    }
+    // plaintext row -> tile, reduced mod Q_j
 #pragma unroll
     for (int k = 0; k < PP; k++)
       if (64 * k + lane < bpairs) {
-        const int pi = pidx(2 * (pbase + 64 * k));
+        const int pi = pidx(2 * (pbl + 64 * k));
         s[pi] = reduce(cn[k].x, mod);
         s[pnext(pi)] = reduce(cn[k].y, mod);
       }
@@ -363,7 +372,7 @@ mac_kernel_v2(MacArgs2 a, int L, int K, int logn, const NttTable *__restrict__ c
         }
     crow += (size_t)L * (n >> 1);
     ctp += enc_words;
-    if (t + 1 < tend && !(a.ablate & 4)) {
+    if (PREFETCH_C && t + 1 < tend && !(a.ablate & 4)) {
 #pragma unroll
       for (int k = 0; k < PP; k++)
         if (64 * k + lane < bpairs) cn[k] = crow[pbase + 64 * k];
@@ -372,7 +381,7 @@ mac_kernel_v2(MacArgs2 a, int L, int K, int logn, const NttTable *__restrict__ c
 #pragma unroll
     for (int k = 0; k < PP; k++)
       if (64 * k + lane < bpairs) {
-        const int pi = pidx(2 * (pbase + 64 * k));
+        const int pi = pidx(2 * (pbl + 64 * k));
         double u0 = s[pi], u1 = s[pnext(pi)];
         if (a.reduce_u) {
           u0 = reduce(u0, mod);
@@ -490,10 +499,19 @@ static void launch_mac(rs_ctx *ctx, const MacArgs &a, const MsmScratch &sc, hipS
   RS_HIP(hipGetLastError());
 }
 
+extern int g_mac_variant;
 static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   const size_t lds = (padded_len((size_t)ctx->N_enc) + (size_t)ctx->N_enc) * sizeof(double);
   const int rows = a.n_chunks * ctx->L;
   const unsigned blocks = (unsigned)(((rows + 7) / 8) * 8 * ctx->K);
+  if (g_mac_variant == 3 && ctx->N_enc >= 4096) {  // experiment: 16 waves of 128 VGPRs (4 waves per SIMD)
+    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (e0) RS_HIP(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(mac_kernel_v2<1024>, dim3(blocks), dim3(1024), lds, st, a, ctx->L, ctx->K, ctx->logN_enc, sc.d_coeff_tabs);
+    if (e1) RS_HIP(hipEventRecord(e1, st));
+    RS_HIP(hipGetLastError());
+    return;
+  }
   RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (e0) RS_HIP(hipEventRecord(e0, st));
   hipLaunchKernelGGL(mac_kernel_v2<512>, dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K, ctx->logN_enc, sc.d_coeff_tabs);

@@ -478,6 +478,28 @@ newton_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned 
   for (int j = threadIdx.x; j < M; j += blockDim.x) c[j] = (P.invfact[j] != 0.0) ? reduce(s[pidx(j)], mod) : 0.0;
 }
 
+// Source / sink functors of the product tree's wave-private levels (block-local indices).
+// First forward round of a level-l transform: element offset eoff inside the node is a left
+// position iff eoff < h; the transform's input there is F_right (the node's right half), zero above.
+struct TreeRightIn {
+  const double *sb;
+  int h;
+  __device__ __forceinline__ int pbase(int base) const { return base; }
+  __device__ __forceinline__ double load(int base, int, int eoff, int) const {
+    return eoff < h ? sb[pidx(base + eoff + h)] : 0.0;
+  }
+};
+// Last forward round: spectrum of F_right times the precomputed spectrum of D_left.
+struct TreeMulOut {
+  double *sb;
+  const double *dh;  // level table at this block
+  Mod mod;
+  __device__ __forceinline__ int pbase(int base) const { return pidx(base); }
+  __device__ __forceinline__ void store(int base, int pb, int eoff, int poff, double v) const {
+    sb[pcomb(pb, poff)] = mulmod(reduce(v, mod), dh[base + eoff], mod);
+  }
+};
+
 // Newton -> monomial, one column per workgroup, tile = M doubles only (two workgroups per CU):
 // a level's F_left values wait in registers while the node regions are overwritten in place with
 // (F_right, 0), transformed, multiplied by the spectrum of D_left and transformed back.  Wave w
@@ -518,41 +540,29 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT, size_t col0, 
     // spilled, and every use becomes a serialised scratch reload (s_waitcnt vmcnt(0))
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    double r[EPT];
+    double r[EPT];  // this lane's old coefficients; the F_left ones are added back at the end
 #pragma unroll
     for (int j = 0; j < EPT; j++)
       if (j < per) r[j] = sb[pidx(ln + 64 * j)];
-    if (priv) wave_sync(); else __syncthreads();
-    // node regions <- (F_right, 0); F_left stays in r
-#pragma unroll
-    for (int j = 0; j < EPT; j++)
-      if (j < per) {
-        const int i = off + ln + 64 * j;
-        if ((i & (n - 1)) >= h) {
-          s[pidx(i - h)] = r[j];
-          s[pidx(i)] = 0.0;
-        }
-      }
-    if (priv) wave_sync(); else __syncthreads();
+    const double *dh = P.dhat + (size_t)l * M + pos0 + off;
     if (priv) {
+      // Nodes inside the wave's block, no workgroup barrier.  The first forward round reads
+      // (F_right, 0) straight out of the right halves, the last one multiplies by the spectrum of
+      // D_left on its way back to the tile: no separate split and pointwise passes.
+      wave_sync();
+      const TreeRightIn rin{sb, h};
+      const TreeMulOut mout{sb, dh, mod};
       for (int st = 0; st < l;) {
         const int R = pick_radix(l - st, 3);
-        fwd_round_dispatch<3>(R, blk, blk, logb, l, st, P.tw, 1, mod, P.fmask[l], wl);
+        if (st == 0)
+          fwd_round_dispatch<3>(R, rin, blk, logb, l, st, P.tw, 1, mod, P.fmask[l], wl);
+        else if (st + R >= l)
+          fwd_round_dispatch<3>(R, blk, mout, logb, l, st, P.tw, 1, mod, P.fmask[l], wl);
+        else
+          fwd_round_dispatch<3>(R, blk, blk, logb, l, st, P.tw, 1, mod, P.fmask[l], wl);
         wave_sync();
         st += R;
       }
-    } else {
-      lds_bntt_fwd<3>(s, logT, l, P.tw, mod, P.fmask[l]);
-    }
-    const double *dh = P.dhat + (size_t)l * M + pos0 + off;
-#pragma unroll
-    for (int j = 0; j < EPT; j++)
-      if (j < per) {
-        const int pi = pidx(ln + 64 * j);
-        sb[pi] = mulmod(reduce(sb[pi], mod), dh[ln + 64 * j], mod);
-      }
-    if (priv) wave_sync(); else __syncthreads();
-    if (priv) {
       for (int st = 0; st < l;) {
         const int R = pick_radix(l - st, 3);
         inv_round_dispatch<3>(R, blk, blk, logb, l, st, P.itw, 1, mod, P.imask[l], wl);
@@ -560,6 +570,26 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT, size_t col0, 
         st += R;
       }
     } else {
+      __syncthreads();
+      // node regions <- (F_right, 0); F_left stays in r
+#pragma unroll
+      for (int j = 0; j < EPT; j++)
+        if (j < per) {
+          const int i = off + ln + 64 * j;
+          if ((i & (n - 1)) >= h) {
+            s[pidx(i - h)] = r[j];
+            s[pidx(i)] = 0.0;
+          }
+        }
+      __syncthreads();
+      lds_bntt_fwd<3>(s, logT, l, P.tw, mod, P.fmask[l]);
+#pragma unroll
+      for (int j = 0; j < EPT; j++)
+        if (j < per) {
+          const int pi = pidx(ln + 64 * j);
+          sb[pi] = mulmod(reduce(sb[pi], mod), dh[ln + 64 * j], mod);
+        }
+      __syncthreads();
       lds_bntt_inv<3>(s, logT, l, P.itw, mod, P.imask[l]);
     }
 #pragma unroll

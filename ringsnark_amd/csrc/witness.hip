@@ -570,26 +570,9 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT, size_t col0, 
         st += R;
       }
     } else {
+      // nodes span several waves: same fusion, workgroup-wide rounds (tile indices)
       __syncthreads();
-      // node regions <- (F_right, 0); F_left stays in r
-#pragma unroll
-      for (int j = 0; j < EPT; j++)
-        if (j < per) {
-          const int i = off + ln + 64 * j;
-          if ((i & (n - 1)) >= h) {
-            s[pidx(i - h)] = r[j];
-            s[pidx(i)] = 0.0;
-          }
-        }
-      __syncthreads();
-      lds_bntt_fwd<3>(s, logT, l, P.tw, mod, P.fmask[l]);
-#pragma unroll
-      for (int j = 0; j < EPT; j++)
-        if (j < per) {
-          const int pi = pidx(ln + 64 * j);
-          sb[pi] = mulmod(reduce(sb[pi], mod), dh[ln + 64 * j], mod);
-        }
-      __syncthreads();
+      lds_ntt_fwd_io<3>(s, TreeRightIn{s, h}, TreeMulOut{s, dh - off, mod}, logT, l, P.tw, 1, mod, P.fmask[l]);
       lds_bntt_inv<3>(s, logT, l, P.itw, mod, P.imask[l]);
     }
 #pragma unroll

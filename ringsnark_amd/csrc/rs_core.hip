@@ -714,6 +714,8 @@ int rs_set_tuning(const char *key, int value) {
     g_mac_ablate = value;
   else if (std::string(key) == "witness_split")
     g_witness_split = value;
+  else if (std::string(key) == "witness_tree_ct")
+    g_witness_tree_ct = value;
   else if (std::string(key) == "witness_lds_logM") {
     RS_REQUIRE(value >= 6 && value <= 13, "witness_lds_logM must be in [6, 13]");
     g_witness_lds_logM = value;

@@ -122,6 +122,7 @@ inline hipStream_t S(rs_stream s) { return (hipStream_t)s; }
 void msm_scratch_release(rs_ctx *ctx);  // msm.hip
 extern int g_mac_variant, g_mac_ablate;  // msm.hip tuning knobs
 extern int g_witness_split;               // witness.hip: split interpolation into two launches
+extern int g_witness_tree_ct;             // witness.hip: level-unrolled product-tree kernel
 extern int g_witness_lds_logM;           // witness.hip: largest column (log2) handled inside one LDS tile
 void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st);
 }  // namespace rs

@@ -505,10 +505,13 @@ struct TreeMulOut {
 // (F_right, 0), transformed, multiplied by the spectrum of D_left and transformed back.  Wave w
 // owns block w of M/W coefficients; every level whose nodes fit a block (n <= M/W) runs without a
 // single workgroup barrier.
-template <int THREADS>
+// LOGT_CT != 0: the tile size is a compile-time constant and the level loop is unrolled, so every
+// round of every level is specialised (constant gaps, radices and masks of addresses).
+template <int THREADS, int LOGT_CT = 0>
 __global__ void __launch_bounds__(THREADS, THREADS / 128)  // two workgroups per CU
-tree_columns_kernel(double *__restrict__ cols, int logM, int logT, size_t col0, unsigned S, unsigned slots_per_limb,
+tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t col0, unsigned S, unsigned slots_per_limb,
                     ColPlans plans) {
+  const int logT = LOGT_CT ? LOGT_CT : logT_arg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   constexpr int LOGW = THREADS == 512 ? 3 : (THREADS == 256 ? 2 : (THREADS == 128 ? 1 : 0));
@@ -533,7 +536,9 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT, size_t col0, 
   wave_sync();
   school_levels_lds(sb, logb, logM, pos0 + off, P, wl);
   wave_sync();
-  for (int l = SCHOOL_LEVELS + 1; l <= logT; l++) {
+#pragma unroll
+  for (int l = SCHOOL_LEVELS + 1; l <= (LOGT_CT ? LOGT_CT : 20); l++) {
+    if (l > logT) break;
     const int n = 1 << l, h = n >> 1;
     const bool priv = l <= logb;
     // fresh copy per level: otherwise the 16 tile addresses are hoisted out of the level loop,
@@ -989,6 +994,7 @@ static ColPlans make_colplans(rs_ctx *ctx, const WitnessPlan *P) {
 static int col_threads(size_t M) { return (int)std::max<size_t>(64, std::min<size_t>(1024, M / 8)); }
 
 int g_witness_lds_logM = 13;  // columns up to 2^13 run entirely inside one LDS tile
+int g_witness_tree_ct = 1;    // 1: level-unrolled product-tree kernel for 2^13 tiles
 int g_witness_split = 1;      // 1: separate Newton-convolution and product-tree launches (M >= 1024)
 
 // Newton -> monomial levels 1..logT on tiles of 2^logT coefficients of [ncols][M] columns
@@ -1006,7 +1012,11 @@ static void launch_tree_tiles(double *cols, size_t ncols, size_t col0, int logM,
     hipLaunchKernelGGL(tree_columns_kernel<THR>, dim3(grid), dim3(THR), lds1, st, cols, logM, logT, col0, (unsigned)S, \
                        (unsigned)slots_per_limb, cp);                                                                \
   } while (0)
-  if (thr == 512) RS_TREE_LAUNCH(512);
+  if (thr == 512 && logT == 13 && g_witness_tree_ct) {
+    RS_HIP(hipFuncSetAttribute((const void *)tree_columns_kernel<512, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    hipLaunchKernelGGL((tree_columns_kernel<512, 13>), dim3(grid), dim3(512), lds1, st, cols, logM, logT, col0, (unsigned)S,
+                       (unsigned)slots_per_limb, cp);
+  } else if (thr == 512) RS_TREE_LAUNCH(512);
   else if (thr == 256) RS_TREE_LAUNCH(256);
   else if (thr == 128) RS_TREE_LAUNCH(128);
   else RS_TREE_LAUNCH(64);

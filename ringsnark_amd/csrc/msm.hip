@@ -282,14 +282,18 @@ struct MacArgs2 {
   unsigned long long terms;  // valid terms in this tile
   int terms_per_chunk, n_chunks;
   int accumulate, acc_period, reduce_u;
-  int ablate;  // experiment knob: 1 = skip the transform, 2 = skip the ciphertext loads, 4 = skip the C loads
 };
 // THREADS = 512: 8 waves, 256 VGPRs per lane -> the whole ciphertext of term t AND the plaintext
 // row of term t+1 are prefetched into registers, 8 coefficient pairs per lane, radix-16 private
 // rounds.  (A 1024-thread shape has half the registers per lane and spills.)
-template <int THREADS>
+// LOGN_CT != 0: transform length fixed at compile time (rounds specialised).  ABLATE (experiments,
+// tools/mac_ablate.py): 1 = skip the transform, 2 = skip the ciphertext loads, 4 = skip the C loads;
+// a compile-time parameter because a run-time branch around each load makes the compiler wait for
+// every load right where it is issued.
+template <int THREADS, int LOGN_CT = 0, int ABLATE = 0>
 __global__ void __launch_bounds__(THREADS)
-mac_kernel_v2(MacArgs2 a, int L, int K, int logn, const NttTable *__restrict__ coeff_tabs) {
+mac_kernel_v2(MacArgs2 a, int L, int K, int logn_arg, const NttTable *__restrict__ coeff_tabs) {
+  const int logn = LOGN_CT ? LOGN_CT : logn_arg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   constexpr int LOGW = THREADS == 512 ? 3 : 4;
@@ -365,19 +369,23 @@ mac_kernel_v2(MacArgs2 a, int L, int K, int logn, const NttTable *__restrict__ c
 #pragma unroll
       for (int k = 0; k < PP; k++)
         if (64 * k + lane < bpairs) {
-          if (a.ablate & 2)
+          if (ABLATE & 2)
             ct[c][k] = make_ulonglong2(12345ull + k, 6789ull + c);
           else
             ct[c][k] = reinterpret_cast<const ulonglong2 *>(ctp + c * comp)[pbase + 64 * k];
         }
     crow += (size_t)L * (n >> 1);
     ctp += enc_words;
-    if (PREFETCH_C && t + 1 < tend && !(a.ablate & 4)) {
+    if (PREFETCH_C && t + 1 < tend && !(ABLATE & 4)) {
 #pragma unroll
       for (int k = 0; k < PP; k++)
         if (64 * k + lane < bpairs) cn[k] = crow[pbase + 64 * k];
     }
-    if (!(a.ablate & 1)) lds_ntt_fwd_wp<RS_MAC_MAXR, LdsIO, TileBlockFactory, 3, true>(s, lds, bf, logn, LOGW, twl, mod, red_mask);
+    // the loads above must be ISSUED before the transform (the scheduler would otherwise sink them
+    // next to their uses, after the transform, to save registers)
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(ABLATE & 1)) lds_ntt_fwd_wp<RS_MAC_MAXR, LdsIO, TileBlockFactory, 3, true>(s, lds, bf, logn, LOGW, twl, mod, red_mask);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < PP; k++)
       if (64 * k + lane < bpairs) {
@@ -499,16 +507,36 @@ static void launch_mac(rs_ctx *ctx, const MacArgs &a, const MsmScratch &sc, hipS
   RS_HIP(hipGetLastError());
 }
 
-extern int g_mac_variant;
+extern int g_mac_variant, g_mac_ablate;
 static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   const size_t lds = (padded_len((size_t)ctx->N_enc) + (size_t)ctx->N_enc) * sizeof(double);
   const int rows = a.n_chunks * ctx->L;
   const unsigned blocks = (unsigned)(((rows + 7) / 8) * 8 * ctx->K);
-  if (g_mac_variant == 3 && ctx->N_enc >= 4096) {  // experiment: 16 waves of 128 VGPRs (4 waves per SIMD)
-    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (g_mac_variant == 3 && ctx->logN_enc == 13) {  // 16 waves of 128 VGPRs (4 waves per SIMD), plaintext row not prefetched
+    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<1024, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (e0) RS_HIP(hipEventRecord(e0, st));
-    hipLaunchKernelGGL(mac_kernel_v2<1024>, dim3(blocks), dim3(1024), lds, st, a, ctx->L, ctx->K, ctx->logN_enc, sc.d_coeff_tabs);
+    hipLaunchKernelGGL((mac_kernel_v2<1024, 13>), dim3(blocks), dim3(1024), lds, st, a, ctx->L, ctx->K, ctx->logN_enc, sc.d_coeff_tabs);
     if (e1) RS_HIP(hipEventRecord(e1, st));
+    RS_HIP(hipGetLastError());
+    return;
+  }
+  if (ctx->logN_enc == 13 && g_mac_variant != 4) {
+#define RS_MAC_LAUNCH(AB)                                                                                             \
+  do {                                                                                                                \
+    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<512, 13, AB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)lds));                                                                           \
+    if (e0) RS_HIP(hipEventRecord(e0, st));                                                                           \
+    hipLaunchKernelGGL((mac_kernel_v2<512, 13, AB>), dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K,             \
+                       ctx->logN_enc, sc.d_coeff_tabs);                                                               \
+    if (e1) RS_HIP(hipEventRecord(e1, st));                                                                           \
+  } while (0)
+    switch (g_mac_ablate) {
+      case 1: RS_MAC_LAUNCH(1); break;
+      case 2: RS_MAC_LAUNCH(2); break;
+      case 6: RS_MAC_LAUNCH(6); break;
+      default: RS_MAC_LAUNCH(0); break;
+    }
+#undef RS_MAC_LAUNCH
     RS_HIP(hipGetLastError());
     return;
   }
@@ -520,7 +548,7 @@ static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, 
 }
 
 int g_mac_ablate = 0;
-int g_mac_variant = 2;  // 2: streaming kernel where applicable; 1: always the generic kernel
+int g_mac_variant = 3;  // 3: streaming kernel, 1024-thread shape at N_enc = 8192 (else as 2); 2: 512-thread streaming kernel; 1: generic kernel
 
 // Core grouped MSM.  addends: optional per-output (n_crs * n_groups) device pointers to encoding
 // elements added to the result (pk.alpha / pk.beta of groth16.tcc:95,103).
@@ -672,7 +700,6 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
         a2.accumulate = base.accumulate;
         a2.acc_period = base.acc_period;
         a2.reduce_u = base.reduce_u;
-        a2.ablate = g_mac_ablate;
         launch_mac_v2(ctx, a2, sc, st, e0, e1);
         if (e0) {
           RS_HIP(hipEventSynchronize(e1));

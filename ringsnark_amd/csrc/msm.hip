@@ -53,10 +53,11 @@ struct PlainArgs {
 #define RS_PLAIN_MAXR 3
 #endif
 // grid (terms in tile, L, groups); EPT = max elements per thread (16 only for N_enc = 16384)
-template <int EPT>
+template <int EPT, int LOGN_CT = 0>  // LOGN_CT != 0: transform length fixed at compile time (rounds specialised)
 __global__ void __launch_bounds__(1024)
 plain_center_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t0, unsigned long long tile_terms,
-                    int N, int L, int logn, const uint32_t *__restrict__ index_map, const NttTable *__restrict__ plain_tabs) {
+                    int N, int L, int logn_arg, const uint32_t *__restrict__ index_map, const NttTable *__restrict__ plain_tabs) {
+  const int logn = LOGN_CT ? LOGN_CT : logn_arg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   const int n = 1 << logn;
@@ -618,7 +619,10 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
   const bool big = n > 8192;  // one accumulator set per MAC launch
   const bool plain16 = n >= 2048;  // 16 coefficients per thread, wave-private inverse transform
   const int plain_thr = plain16 ? n / 16 : thr;
-  if (plain16)
+  const bool plain13 = false;  // measured: no gain from a compile-time length here
+  if (plain13)
+    RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<16, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  else if (plain16)
     RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   else
     RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -635,7 +639,11 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
   int tile_idx = 0;
   for (size_t t0 = 0; t0 < Tmax; t0 += tile_terms, tile_idx++) {
     const size_t tt = std::min(tile_terms, Tmax - t0);
-    if (plain16)
+    if (plain13)
+      hipLaunchKernelGGL((plain_center_kernel<16, 13>), dim3((unsigned)tt, L, n_groups), dim3(plain_thr), lds, st, pa, d_C,
+                         (unsigned long long)t0, (unsigned long long)tile_terms, ctx->N, L, ctx->logN_enc,
+                         ctx->d_index_map, sc.d_plain_tabs);
+    else if (plain16)
       hipLaunchKernelGGL(plain_center_kernel<16>, dim3((unsigned)tt, L, n_groups), dim3(plain_thr), lds, st, pa, d_C,
                          (unsigned long long)t0, (unsigned long long)tile_terms, ctx->N, L, ctx->logN_enc,
                          ctx->d_index_map, sc.d_plain_tabs);

@@ -457,8 +457,10 @@ interp_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned 
 
 
 // values at 0..m-1 -> Newton coefficients (first half of interp_columns_kernel), in place.
+template <int LOGM_CT = 0>  // != 0: column length fixed at compile time (rounds specialised)
 __global__ void __launch_bounds__(1024)
-newton_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned slots_per_limb, ColPlans plans) {
+newton_columns_kernel(double *__restrict__ cols, int logM_arg, unsigned S, unsigned slots_per_limb, ColPlans plans) {
+  const int logM = LOGM_CT ? LOGM_CT : logM_arg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   const int M = 1 << logM;
@@ -600,12 +602,14 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
 //     rev(H) = rev(P) * rev(Z)^-1  mod x^(m-1)
 // i.e. five length-2M cyclic transforms per column against the precomputed spectrum `shat`.
 // A, B: [cols][M] canonical doubles; H: [cols][M].  d1,d2,d3: ring elements [L][N] (u64) or NULL.
+template <int LOGM_CT = 0>
 __global__ void __launch_bounds__(1024)
-h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, double *__restrict__ H, int logM, int m,
+h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, double *__restrict__ H, int logM_arg, int m,
                  unsigned slots_per_limb, ColPlans plans, const uint64_t *__restrict__ d1,
                  const uint64_t *__restrict__ d2, const uint64_t *__restrict__ d3) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
+  const int logM = LOGM_CT ? LOGM_CT : logM_arg;
   const int M = 1 << logM, M2 = 2 * M;
   const size_t col = blockIdx.x;
   const ColPlan &P = plans.l[col / slots_per_limb];
@@ -1161,9 +1165,15 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp,
   if (P->logM <= g_witness_lds_logM && P->logM >= 10 && g_witness_split) {
     // two launches: the convolution needs a 2M tile (one workgroup per CU), the product tree only M
     const size_t lds2 = padded_len(2 * P->M) * sizeof(double);
-    RS_HIP(hipFuncSetAttribute((const void *)newton_columns_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    hipLaunchKernelGGL(newton_columns_kernel, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds2, st, cols, P->logM,
-                       (unsigned)S, (unsigned)slots_per_limb, cp);
+    if (P->logM == 13) {
+      RS_HIP(hipFuncSetAttribute((const void *)newton_columns_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      hipLaunchKernelGGL(newton_columns_kernel<13>, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds2, st, cols, P->logM,
+                         (unsigned)S, (unsigned)slots_per_limb, cp);
+    } else {
+      RS_HIP(hipFuncSetAttribute((const void *)newton_columns_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      hipLaunchKernelGGL(newton_columns_kernel<0>, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds2, st, cols, P->logM,
+                         (unsigned)S, (unsigned)slots_per_limb, cp);
+    }
     launch_tree_tiles(cols, ncols, 0, P->logM, P->logM, S, slots_per_limb, cp, st);
     RS_HIP(hipGetLastError());
     return;
@@ -1190,9 +1200,15 @@ static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, cons
   const size_t M = P->M;
   if (P->logM <= g_witness_lds_logM) {
     const size_t lds = padded_len(2 * M) * sizeof(double);
-    RS_HIP(hipFuncSetAttribute((const void *)h_columns_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(h_columns_kernel, dim3((unsigned)S), dim3(col_threads(2 * M)), lds, st, A, B, H, P->logM, (int)P->m,
-                       (unsigned)N, cp, d1, d2, d3);
+    if (false && P->logM == 13) {  // measured: the specialised H kernel spills (r[16] + unrolled rounds) and is 3 % slower
+      RS_HIP(hipFuncSetAttribute((const void *)h_columns_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(h_columns_kernel<13>, dim3((unsigned)S), dim3(col_threads(2 * M)), lds, st, A, B, H, P->logM, (int)P->m,
+                         (unsigned)N, cp, d1, d2, d3);
+    } else {
+      RS_HIP(hipFuncSetAttribute((const void *)h_columns_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(h_columns_kernel<0>, dim3((unsigned)S), dim3(col_threads(2 * M)), lds, st, A, B, H, P->logM, (int)P->m,
+                         (unsigned)N, cp, d1, d2, d3);
+    }
     RS_HIP(hipGetLastError());
     return;
   }

@@ -308,6 +308,10 @@ struct ColPlan {  // per-limb device pointers handed to the column kernels
 struct ColPlans {
   ColPlan l[RS_MAX_L];
 };
+struct ColBlockFactory {
+  double *s;
+  __device__ __forceinline__ LdsBlockIO operator()(int off) const { return LdsBlockIO{s + pidx(off)}; }
+};
 
 // [rows][S] u64 (term-major, S = L*N) -> [S][M] f64 (column-major), rows >= m zero-filled.
 __global__ void __launch_bounds__(256) transpose_in_kernel(const uint64_t *__restrict__ src, double *__restrict__ dst,
@@ -509,7 +513,14 @@ struct TreeMulOut {
 // single workgroup barrier.
 // LOGT_CT != 0: the tile size is a compile-time constant and the level loop is unrolled, so every
 // round of every level is specialised (constant gaps, radices and masks of addresses).
-template <int THREADS, int LOGT_CT = 0>
+// NEWTON (single-tile columns only, logT == logM): the tile starts as VALUES at the nodes and the
+// kernel first converts them to Newton coefficients, f = low half of g * e with g_j = y_j / j!,
+// e_i = (-1)^i / i!.  The length-2M cyclic convolution is never formed: the 2M-point transform of a
+// zero-padded input is the pair of M-point sub-transforms rooted at decimation-tree nodes 2 (the
+// cyclic one: bins [0, M) of the table `ehat`) and 3 (the negacyclic one: bins [M, 2M)), and the low
+// half of the inverse is the SUM of the two M-point inverses -- two passes over an M-sized tile, so
+// the whole interpolation of a column runs in ONE launch at two workgroups per CU.
+template <int THREADS, int LOGT_CT = 0, bool NEWTON = false>
 __global__ void __launch_bounds__(THREADS, THREADS / 128)  // two workgroups per CU
 tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t col0, unsigned S, unsigned slots_per_limb,
                     ColPlans plans) {
@@ -532,9 +543,59 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
   double *sb = s + pidx(off);
   const LdsBlockIO blk{sb};
   const Lanes wl = wave_lanes();
+  if (NEWTON) {
+    const ColBlockFactory bf{s};
+    const LdsIO lds{s};
+    double u[EPT];
 #pragma unroll
-  for (int j = 0; j < EPT; j++)
-    if (j < per) sb[pidx(lane + 64 * j)] = c[off + lane + 64 * j];
+    for (int half = 0; half < 2; half++) {
+      // tile <- g (recomputed from the column for the second pass: the first one overwrote it).
+      // `ln`: fresh copies of the lane index keep the 16 tile addresses of each phase from being
+      // hoisted over the transforms, spilled and reloaded one by one.
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+#pragma unroll
+      for (int j = 0; j < EPT; j++)
+        if (j < per) {
+          const int k = off + ln + 64 * j;
+          sb[pidx(ln + 64 * j)] = mulmod(c[k], P.invfact[k], mod);
+        }
+      __syncthreads();
+      lds_ntt_fwd_wp<3, LdsIO, ColBlockFactory, 3>(s, lds, bf, logT, LOGW, P.tw, mod, P.fwd_mask2 >> 1, 2 + half);
+      const double *eh = P.ehat + (size_t)half * M + off;
+      ln = lane;
+      asm volatile("" : "+v"(ln));
+#pragma unroll
+      for (int j = 0; j < EPT; j++)
+        if (j < per) {
+          const int pi = pidx(ln + 64 * j);
+          sb[pi] = mulmod(reduce(sb[pi], mod), eh[ln + 64 * j], mod);
+        }
+      wave_sync();
+      lds_ntt_inv_wp<3, ColBlockFactory, LdsIO, 3>(s, bf, lds, logT, LOGW, P.itw, mod, P.inv_mask2, 2 + half);
+      if (half == 0) {
+        ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int j = 0; j < EPT; j++)
+          if (j < per) u[j] = sb[pidx(ln + 64 * j)];
+        __syncthreads();  // every wave has saved its block before the tile is refilled
+      }
+    }
+    // Newton coefficients k < m; the convolution tail is discarded
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int j = 0; j < EPT; j++)
+      if (j < per) {
+        const int pi = pidx(ln + 64 * j);
+        sb[pi] = (P.invfact[off + ln + 64 * j] != 0.0) ? reduce(u[j] + sb[pi], mod) : 0.0;
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < EPT; j++)
+      if (j < per) sb[pidx(lane + 64 * j)] = c[off + lane + 64 * j];
+  }
   wave_sync();
   school_levels_lds(sb, logb, logM, pos0 + off, P, wl);
   wave_sync();
@@ -804,10 +865,6 @@ r1cs_eval_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restric
 struct TabPtrs {
   const double *t[RS_MAX_L];
 };
-struct ColBlockFactory {
-  double *s;
-  __device__ __forceinline__ LdsBlockIO operator()(int off) const { return LdsBlockIO{s + pidx(off)}; }
-};
 struct GlobalF64IO {
   double *p;
   __device__ __forceinline__ int pbase(int) const { return 0; }
@@ -999,32 +1056,42 @@ static int col_threads(size_t M) { return (int)std::max<size_t>(64, std::min<siz
 
 int g_witness_lds_logM = 13;  // columns up to 2^13 run entirely inside one LDS tile
 int g_witness_tree_ct = 1;    // 1: level-unrolled product-tree kernel for 2^13 tiles
-int g_witness_split = 1;      // 1: separate Newton-convolution and product-tree launches (M >= 1024)
+int g_witness_split = 2;      // M >= 1024 -- 2: fused Newton + tree kernel on an M tile; 1: Newton (2M tile) + tree launches; 0: one 2M-tile kernel
 
-// Newton -> monomial levels 1..logT on tiles of 2^logT coefficients of [ncols][M] columns
+// Newton -> monomial levels 1..logT on tiles of 2^logT coefficients of [ncols][M] columns; with
+// `newton` (logT == logM) the tiles hold values and the Newton conversion runs first, in the same launch
 static void launch_tree_tiles(double *cols, size_t ncols, size_t col0, int logM, int logT, size_t S, size_t slots_per_limb,
-                              const ColPlans &cp, hipStream_t st) {
+                              const ColPlans &cp, hipStream_t st, bool newton = false) {
   const size_t T = (size_t)1 << logT;
   const size_t lds1 = padded_len(T) * sizeof(double);
   const unsigned grid = (unsigned)(ncols << (logM - logT));
   const int thr = (int)std::max<size_t>(64, std::min<size_t>(512, T / 16));
   RS_REQUIRE(T / thr <= 16 && logT >= 6, "tree tile out of range");
-#define RS_TREE_LAUNCH(THR)                                                                                          \
-  do {                                                                                                               \
-    RS_HIP(hipFuncSetAttribute((const void *)tree_columns_kernel<THR>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                               (int)lds1));                                                                          \
-    hipLaunchKernelGGL(tree_columns_kernel<THR>, dim3(grid), dim3(THR), lds1, st, cols, logM, logT, col0, (unsigned)S, \
-                       (unsigned)slots_per_limb, cp);                                                                \
+  RS_REQUIRE(!newton || logT == logM, "fused Newton conversion needs single-tile columns");
+#define RS_TREE_LAUNCH_K(KERN)                                                                                   \
+  do {                                                                                                           \
+    RS_HIP(hipFuncSetAttribute((const void *)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));     \
+    hipLaunchKernelGGL(KERN, dim3(grid), dim3(thr), lds1, st, cols, logM, logT, col0, (unsigned)S,               \
+                       (unsigned)slots_per_limb, cp);                                                            \
+  } while (0)
+#define RS_TREE_LAUNCH(THR)                                          \
+  do {                                                               \
+    if (newton)                                                      \
+      RS_TREE_LAUNCH_K((tree_columns_kernel<THR, 0, true>));         \
+    else                                                             \
+      RS_TREE_LAUNCH_K((tree_columns_kernel<THR, 0, false>));        \
   } while (0)
   if (thr == 512 && logT == 13 && g_witness_tree_ct) {
-    RS_HIP(hipFuncSetAttribute((const void *)tree_columns_kernel<512, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    hipLaunchKernelGGL((tree_columns_kernel<512, 13>), dim3(grid), dim3(512), lds1, st, cols, logM, logT, col0, (unsigned)S,
-                       (unsigned)slots_per_limb, cp);
+    if (newton)
+      RS_TREE_LAUNCH_K((tree_columns_kernel<512, 13, true>));
+    else
+      RS_TREE_LAUNCH_K((tree_columns_kernel<512, 13, false>));
   } else if (thr == 512) RS_TREE_LAUNCH(512);
   else if (thr == 256) RS_TREE_LAUNCH(256);
   else if (thr == 128) RS_TREE_LAUNCH(128);
   else RS_TREE_LAUNCH(64);
 #undef RS_TREE_LAUNCH
+#undef RS_TREE_LAUNCH_K
   RS_HIP(hipGetLastError());
 }
 
@@ -1162,8 +1229,14 @@ static size_t big_chunk_cols(const WitnessPlan *P) {
 
 static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, double *cols, size_t ncols, size_t S,
                           size_t slots_per_limb, hipStream_t st) {
-  if (P->logM <= g_witness_lds_logM && P->logM >= 10 && g_witness_split) {
-    // two launches: the convolution needs a 2M tile (one workgroup per CU), the product tree only M
+  if (P->logM <= g_witness_lds_logM && P->logM >= 10 && g_witness_split == 2) {
+    // one launch, tile = M, two workgroups per CU: Newton conversion by the two rooted M-point
+    // sub-transforms, then the product tree in place
+    launch_tree_tiles(cols, ncols, 0, P->logM, P->logM, S, slots_per_limb, cp, st, true);
+    return;
+  }
+  if (P->logM <= g_witness_lds_logM && P->logM >= 10 && g_witness_split == 1) {
+    // two launches: the length-2M convolution in a 2M tile (one workgroup per CU), then the product tree
     const size_t lds2 = padded_len(2 * P->M) * sizeof(double);
     if (P->logM == 13) {
       RS_HIP(hipFuncSetAttribute((const void *)newton_columns_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));

@@ -740,6 +740,175 @@ h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, do
   }
 }
 
+// H on an M-sized tile (M >= 1024), two workgroups per CU, wave-private transforms.  Every
+// length-2M transform of h_columns_kernel has a zero-padded input, so it is the pair of M-point
+// sub-transforms rooted at decimation-tree nodes 2 and 3 (bins [0, M) and [M, 2M) of the spectra
+// `shat`), and the inverse's low / high halves are the sum / difference of the two M-point inverses:
+//     P = A*B:  u = inv2(fwd2 A . fwd2 B), v = inv3(fwd3 A . fwd3 B),  P_low = u + v, P_high = u - v
+//     U = T*S mod x^(m-1):  U = inv2(fwd2 T . shat[0,M)) + inv3(fwd3 T . shat[M,2M))
+// Ten M-point transforms instead of five 2M-point ones, none of them with all-workgroup barriers
+// between rounds.  Lane l of wave w owns positions off + l + 64 j; `u` is parked in the output
+// column (L2) while the second half runs.
+template <int THREADS, int LOGM_CT = 0>
+__global__ void __launch_bounds__(THREADS, THREADS / 128)
+h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, double *__restrict__ H, int logM_arg, int m,
+              unsigned slots_per_limb, ColPlans plans, const uint64_t *__restrict__ d1, const uint64_t *__restrict__ d2,
+              const uint64_t *__restrict__ d3) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  constexpr int LOGW = THREADS == 512 ? 3 : (THREADS == 256 ? 2 : (THREADS == 128 ? 1 : 0));
+  constexpr int EPT = 16;
+  const int logM = LOGM_CT ? LOGM_CT : logM_arg;
+  const int M = 1 << logM;
+  const size_t col = blockIdx.x;
+  const ColPlan &P = plans.l[col / slots_per_limb];
+  const Mod mod = P.mod;
+  const double *srcA = A + col * (size_t)M, *srcB = Bc + col * (size_t)M;
+  double *dst = H + col * (size_t)M;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int logb = logM - LOGW, off = wave << logb;
+  double *sb = s + pidx(off);
+  const ColBlockFactory bf{s};
+  const LdsIO lds{s};
+  const uint32_t fmask = P.fwd_mask2 >> 1, imask = P.inv_mask2;
+  // `ln`: fresh copies of the lane index keep each phase's 16 tile addresses from being hoisted over
+  // the transforms, spilled and reloaded one by one
+#define RS_FRESH_LANE() \
+  int ln = lane;        \
+  asm volatile("" : "+v"(ln))
+  double r[EPT];
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    {
+      RS_FRESH_LANE();
+#pragma unroll
+      for (int j = 0; j < EPT; j++) sb[pidx(ln + 64 * j)] = center(srcA[off + ln + 64 * j], mod);
+    }
+    __syncthreads();
+    lds_ntt_fwd_wp<3, LdsIO, ColBlockFactory, 3>(s, lds, bf, logM, LOGW, P.tw, mod, fmask, 2 + half);
+    {
+      RS_FRESH_LANE();
+#pragma unroll
+      for (int j = 0; j < EPT; j++) r[j] = reduce(sb[pidx(ln + 64 * j)], mod);
+    }
+    __syncthreads();  // every wave has its slice of the spectrum of A before the tile is refilled
+    {
+      RS_FRESH_LANE();
+#pragma unroll
+      for (int j = 0; j < EPT; j++) sb[pidx(ln + 64 * j)] = center(srcB[off + ln + 64 * j], mod);
+    }
+    __syncthreads();
+    lds_ntt_fwd_wp<3, LdsIO, ColBlockFactory, 3>(s, lds, bf, logM, LOGW, P.tw, mod, fmask, 2 + half);
+    {
+      RS_FRESH_LANE();
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const int pi = pidx(ln + 64 * j);
+        sb[pi] = mulmod(r[j], reduce(sb[pi], mod), mod);
+      }
+    }
+    wave_sync();
+    lds_ntt_inv_wp<3, ColBlockFactory, LdsIO, 3>(s, bf, lds, logM, LOGW, P.itw, mod, imask, 2 + half);
+    if (half == 0) {
+      RS_FRESH_LANE();
+#pragma unroll
+      for (int j = 0; j < EPT; j++) dst[off + ln + 64 * j] = reduce(sb[pidx(ln + 64 * j)], mod);  // park u
+      __syncthreads();
+    }
+  }
+  // T_k = P_{2m-2-k}, k < m-1, zero-padded, scattered into the tile from the own slices of
+  // P_low = u + v (index i) and P_high = u - v (index i + M)
+  {
+    RS_FRESH_LANE();
+#pragma unroll
+    for (int j = 0; j < EPT; j++) r[j] = reduce(sb[pidx(ln + 64 * j)], mod);  // v
+  }
+  __syncthreads();
+  {
+    RS_FRESH_LANE();
+#pragma unroll
+    for (int j = 0; j < EPT; j++) sb[pidx(ln + 64 * j)] = 0.0;
+  }
+  __syncthreads();
+  {
+    RS_FRESH_LANE();
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      const int i = off + ln + 64 * j;
+      const double u = dst[i];
+      const int klo = 2 * m - 2 - i, khi = klo - M;
+      if (klo >= 0 && klo < m - 1) s[pidx(klo)] = reduce(u + r[j], mod);
+      if (khi >= 0 && khi < m - 1) s[pidx(khi)] = reduce(u - r[j], mod);
+    }
+  }
+  __syncthreads();
+  {
+    RS_FRESH_LANE();
+#pragma unroll
+    for (int j = 0; j < EPT; j++) r[j] = sb[pidx(ln + 64 * j)];  // own slice of T, for the second half
+  }
+  double uu[EPT];
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    if (half == 1) {
+      RS_FRESH_LANE();
+#pragma unroll
+      for (int j = 0; j < EPT; j++) sb[pidx(ln + 64 * j)] = r[j];
+      __syncthreads();
+    }
+    lds_ntt_fwd_wp<3, LdsIO, ColBlockFactory, 3>(s, lds, bf, logM, LOGW, P.tw, mod, fmask, 2 + half);
+    {
+      RS_FRESH_LANE();
+      const double *sh = P.shat + (size_t)half * M + off;
+#pragma unroll
+      for (int j = 0; j < EPT; j++) {
+        const int pi = pidx(ln + 64 * j);
+        sb[pi] = mulmod(reduce(sb[pi], mod), sh[ln + 64 * j], mod);
+      }
+    }
+    wave_sync();
+    lds_ntt_inv_wp<3, ColBlockFactory, LdsIO, 3>(s, bf, lds, logM, LOGW, P.itw, mod, imask, 2 + half);
+    if (half == 0) {
+      RS_FRESH_LANE();
+#pragma unroll
+      for (int j = 0; j < EPT; j++) uu[j] = sb[pidx(ln + 64 * j)];
+      __syncthreads();
+    }
+  }
+  // U = uu + tile (own slice) back into the tile, then H_j = U_{m-2-j} + ZK patch
+  {
+    RS_FRESH_LANE();
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      const int pi = pidx(ln + 64 * j);
+      sb[pi] = reduce(uu[j] + sb[pi], mod);
+    }
+  }
+  __syncthreads();
+  double e1 = 0.0, e2 = 0.0, e3 = 0.0, e12 = 0.0;
+  const bool zk = d1 != nullptr;
+  if (zk) {
+    e1 = center(from_u64(d1[col]), mod);
+    e2 = center(from_u64(d2[col]), mod);
+    e3 = center(from_u64(d3[col]), mod);
+    e12 = mulmod(e1, e2, mod);
+  }
+  {
+    RS_FRESH_LANE();
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      const int k = off + ln + 64 * j;
+      double h = (k <= m - 2) ? s[pidx(m - 2 - k)] : 0.0;
+      if (zk) {
+        h += mulmod(e2, center(srcA[k], mod), mod) + mulmod(e1, center(srcB[k], mod), mod) + mulmod(e12, P.ztab[k], mod);
+        if (k == 0) h -= e3;
+      }
+      dst[k] = canon(h, mod);
+    }
+  }
+#undef RS_FRESH_LANE
+}
+
 // Input/primary coefficient vectors without interpolation (io shortcut): interpolation is linear
 // and the io evaluations depend on the n_inputs primary variables only, so
 //     X_io[t] = Lconst[t] + sum_{k <= n_inputs} x_k (*) L_k[t],   L_k = interp(column k of X)
@@ -1271,6 +1440,24 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp,
 static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const double *A, const double *B, double *H,
                      size_t S, size_t N, const uint64_t *d1, const uint64_t *d2, const uint64_t *d3, hipStream_t st) {
   const size_t M = P->M;
+  if (P->logM <= g_witness_lds_logM && P->logM >= 10 && g_witness_split == 2) {
+    const size_t lds1 = padded_len(M) * sizeof(double);
+    const int thr = (int)(M / 16);
+#define RS_H_LAUNCH(KERN)                                                                                          \
+  do {                                                                                                             \
+    RS_HIP(hipFuncSetAttribute((const void *)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));       \
+    hipLaunchKernelGGL(KERN, dim3((unsigned)S), dim3(thr), lds1, st, A, B, H, P->logM, (int)P->m, (unsigned)N, cp, \
+                       d1, d2, d3);                                                                                \
+  } while (0)
+    if (thr == 512 && g_witness_tree_ct) RS_H_LAUNCH((h_tile_kernel<512, 13>));
+    else if (thr == 512) RS_H_LAUNCH((h_tile_kernel<512, 0>));
+    else if (thr == 256) RS_H_LAUNCH((h_tile_kernel<256, 0>));
+    else if (thr == 128) RS_H_LAUNCH((h_tile_kernel<128, 0>));
+    else RS_H_LAUNCH((h_tile_kernel<64, 0>));
+#undef RS_H_LAUNCH
+    RS_HIP(hipGetLastError());
+    return;
+  }
   if (P->logM <= g_witness_lds_logM) {
     const size_t lds = padded_len(2 * M) * sizeof(double);
     if (false && P->logM == 13) {  // measured: the specialised H kernel spills (r[16] + unrolled rounds) and is 3 % slower

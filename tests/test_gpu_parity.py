@@ -273,14 +273,16 @@ def _horner(coeffs, x, q):
     return acc
 
 
-def test_witness_map_beyond_one_tile_full_size():
-    """m = 10000 > 8192 constraints with headline-size primes: the natural multi-pass path (2^13
-    tiles).  Checked against the oracle's O(n^2) interpolation on one slot, and on other slots through
+@pytest.mark.parametrize("m", [1500, 3000, 8192, 10000])
+def test_witness_map_full_size_columns(m):
+    """Headline-size primes at column lengths the oracle cannot follow on every slot: M = 2048, 4096,
+    8192 (single-tile kernels at 128 / 256 / 512 threads, the last one the level-unrolled shape of
+    the benchmark) and m = 10000 > 8192 (the natural multi-pass path on 2^13 tiles).  Checked
+    against the oracle's O(n^2) interpolation on one slot, and on other slots through
     size-independent properties: P(j) = y_j on the domain and H*Z = A*B - C at random points."""
     dev = dev_for("toy44")
     prm = dev.prm
     ctx = H.oracle_ctx(prm)
-    m = 10000
     rng = np.random.RandomState(5)
     y = ctx.random_ring(91, m)
     got = host(dev.interpolate(dev.put(y)))

@@ -178,7 +178,8 @@ def main():
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s_m%d.json" % (prm.name, m))
             if os.path.exists(pmc):
-                k = json.load(open(pmc))["kernels"].get("rs::mac_kernel_v2<512>")
+                ks = [v for n, v in json.load(open(pmc))["kernels"].items() if n.startswith("rs::mac_kernel_v2")]
+                k = ks[0] if ks else None
                 if k:
                     traffic = int(k["hbm_bytes"] / k["launches_per_proof"])
             roofline = {"bound": "hbm", "kernel": "mac_kernel_v2", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -91,6 +91,21 @@ int rs_enc_mul_ring(rs_ctx *ctx, uint64_t *d_enc, const uint64_t *d_ring, size_t
 /* EncodingElem::operator+= on non-empty operands (seal_ring.tcc:489-506). */
 int rs_enc_add(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, const uint64_t *d_b, size_t count, rs_stream stream);
 
+/* ---- the two ends of the encoding scheme, either side of the prover ---- */
+/* EncodingElem::decode (ringsnark/seal/seal_ring.tcc:435-477; called by the verifiers at
+ * groth16.tcc:118-121, rinocchio.tcc:203-214): BGV decryption (c0 + c1*s, coefficient form, centred
+ * composition mod Q, reduction mod t = q_i) + BatchEncoder::decode.  d_sk: secret key [K][N_enc] in NTT
+ * form; d_enc [count][L][2][K][N_enc]; d_rings [count][L][N].  The noise-budget check of the
+ * reference (seal_ring.tcc:443-451) is a debugging aid and is not reproduced.  Synchronises. */
+int rs_enc_decode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size_t count, uint64_t *d_rings, rs_stream stream);
+/* EncodingElem::encode (ringsnark/seal/seal_ring.tcc:324-359; called by the generators at
+ * groth16.tcc:57-62, rinocchio.tcc:48-61): BatchEncoder::encode + symmetric BGV encryption
+ * c1 = a, c0 = -(a*s + t*e) + m.  Element k draws its randomness from the stream `seed + k`
+ * (splitmix64, ternary error: the CPU oracle's recipe -- SEAL's Blake2xb/CBD sampler is not
+ * restated, so ciphertext BYTES are not SEAL's; the scheme and every decryption are).  Synchronises. */
+int rs_enc_encode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_rings, size_t count, uint64_t seed, uint64_t *d_enc,
+                  rs_stream stream);
+
 /* Canonicalise integer sums of encoding elements in place (x mod Q_j): the epilogue of the
  * multi-GPU all-reduce of partial inner products; inputs < 2^63. */
 int rs_enc_reduce(rs_ctx *ctx, uint64_t *d_enc, size_t count, rs_stream stream);

@@ -1,0 +1,272 @@
+// encoding.hip -- SURVEY.md section 8(f) rows f2 / f3: the two ends of the encoding scheme that sit
+// either side of the prover.
+//
+//   rs_enc_decode   EncodingElem::decode  (ringsnark/seal/seal_ring.tcc:435-477): BGV decryption
+//                   (c0 + c1*s -> coefficient form -> centred mod Q -> mod t) followed by
+//                   BatchEncoder::decode (forward NTT mod t + slot gather).  What the verifier runs on
+//                   the proof elements (groth16.tcc:118-121, rinocchio.tcc:203-214).
+//   rs_enc_encode   EncodingElem::encode  (ringsnark/seal/seal_ring.tcc:324-359): BatchEncoder::encode
+//                   + symmetric BGV encryption.  What the generator runs on every CRS element.
+//
+// Randomness: SEAL's sampler (Blake2xb / SHAKE, centred binomial) is not restated;
+// the ciphertexts follow the CPU oracle's recipe (oracle/rs_oracle.c: splitmix64 stream, ternary
+// error), which is all the parity tests can pin.  Any valid BGV ciphertext exercises the prover.
+#include <algorithm>
+#include <cstring>
+
+#include "ntt_core.cuh"
+#include "rs_internal.hpp"
+
+namespace rs {
+
+// ---- decode ----------------------------------------------------------------------------------
+// v_j = iNTT_{Q_j}(c0 + c1 * s), canonical doubles.  grid (count * L, K)
+__global__ void __launch_bounds__(1024)
+decrypt_dot_kernel(const uint64_t *__restrict__ enc, const uint64_t *__restrict__ sk, double *__restrict__ V, int K, int logn,
+                   const NttTable *__restrict__ coeff_tabs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int n = 1 << logn;
+  const size_t el = blockIdx.x;  // (element, limb)
+  const int j = blockIdx.y;
+  const NttTable tab = coeff_tabs[j];
+  const Mod mod = tab.mod;
+  const uint64_t *c0 = enc + (el * 2 * K + j) * (size_t)n, *c1 = c0 + (size_t)K * n;
+  const uint64_t *sj = sk + (size_t)j * n;
+  for (int x = threadIdx.x; x < n; x += blockDim.x)
+    s[pidx(x)] = from_u64(c0[x]) + mulmod(from_u64(c1[x]), from_u64(sj[x]), mod);
+  __syncthreads();
+  lds_ntt_inv(s, logn, tab.d_itw, 1, mod, tab.inv_red_mask);
+  double *dst = V + (el * K + j) * (size_t)n;
+  for (int x = threadIdx.x; x < n; x += blockDim.x) dst[x] = canon(mulmod(reduce(s[pidx(x)], mod), tab.ninv, mod), mod);
+}
+
+// Constants of the CRT composition (SEAL Decryptor::bgv_decrypt composes to the centred
+// representative mod Q before reducing mod t): Garner mixed-radix digits, no big integers.
+struct CrtConsts {
+  int K;
+  Mod Qmod[RS_MAX_K];
+  double half[RS_MAX_K];                  // mixed-radix digits of floor(Q/2)
+  double prod_inv[RS_MAX_K];              // (prod_{i<k} Q_i)^-1 mod Q_k
+  double Qi_mod_Qk[RS_MAX_K][RS_MAX_K];   // [i][k] = Q_i mod Q_k
+};
+struct CrtLimb {
+  Mod tmod;
+  double Qk_mod_t[RS_MAX_K];
+  double Q_mod_t;
+};
+
+// centred CRT composition mod t, forward NTT mod t, slot gather.  grid (count * L)
+__global__ void __launch_bounds__(1024)
+crt_decode_kernel(const double *__restrict__ V, uint64_t *__restrict__ rings, int N, int L, int logn, CrtConsts cc,
+                  const CrtLimb *__restrict__ limbs, const uint32_t *__restrict__ index_map,
+                  const NttTable *__restrict__ plain_tabs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int n = 1 << logn, K = cc.K;
+  const size_t el = blockIdx.x;
+  const int limb = (int)(el % (size_t)L);
+  const CrtLimb cl = limbs[limb];
+  const NttTable tab = plain_tabs[limb];
+  const Mod tmod = cl.tmod;
+  const double *v = V + el * (size_t)K * n;
+  for (int x = threadIdx.x; x < n; x += blockDim.x) {
+    double d[RS_MAX_K];
+    d[0] = v[x];
+    for (int k = 1; k < K; k++) {  // value = d0 + Q0*(d1 + Q1*(d2 + ...))
+      const Mod mk = cc.Qmod[k];
+      double acc = 0.0;
+      for (int i = k - 1; i >= 0; i--) acc = reduce(mulmod(acc, cc.Qi_mod_Qk[i][k], mk) + reduce(d[i], mk), mk);
+      d[k] = canon(mulmod(reduce(v[(size_t)k * n + x] - acc, mk), cc.prod_inv[k], mk), mk);
+    }
+    bool upper = false;  // value > floor(Q/2)?
+    for (int k = K - 1; k >= 0; k--)
+      if (d[k] != cc.half[k]) {
+        upper = d[k] > cc.half[k];
+        break;
+      }
+    double r = 0.0;
+    for (int k = K - 1; k >= 0; k--) r = reduce(mulmod(r, cl.Qk_mod_t[k], tmod) + reduce(d[k], tmod), tmod);
+    if (upper) r -= cl.Q_mod_t;
+    s[pidx(x)] = reduce(r, tmod);
+  }
+  __syncthreads();
+  lds_ntt_fwd(s, logn, tab.d_tw, 1, tmod, tab.fwd_red_mask);  // BatchEncoder::decode
+  uint64_t *dst = rings + el * (size_t)N;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) dst[i] = to_u64(canon(s[pidx((int)index_map[i])], tmod));
+}
+
+// ---- encode ----------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix_at(uint64_t seed, uint64_t k) {  // k-th output (1-based) of the stream
+  uint64_t z = seed + k * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// One workgroup per (element, limb, prime j): c1 = a, c0 = -(a*s + t*e) + NTT(lift(BatchEncode(ring limb))).
+// Stream layout of oracle/rs_oracle.c rso_encrypt_symmetric: draws 1..n are the ternary error,
+// draw n + j*n + x + 1 is a_j[x].  grid (count * L, K); PER = n / blockDim <= 16
+__global__ void __launch_bounds__(1024)
+encode_kernel(const uint64_t *__restrict__ rings, const uint64_t *__restrict__ sk, uint64_t *__restrict__ enc, uint64_t seed0,
+              int N, int L, int K, int logn, const uint32_t *__restrict__ index_map, const NttTable *__restrict__ plain_tabs,
+              const NttTable *__restrict__ coeff_tabs, const uint64_t *__restrict__ qint, const uint64_t *__restrict__ Qint) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int n = 1 << logn;
+  const size_t el = blockIdx.x;
+  const size_t elem = el / (size_t)L;
+  const int limb = (int)(el % (size_t)L), j = blockIdx.y;
+  const NttTable pt = plain_tabs[limb], ct = coeff_tabs[j];
+  const Mod tmod = pt.mod, mod = ct.mod;
+  const uint64_t t = qint[limb], Q = Qint[j];
+  const uint64_t seed = (seed0 + elem) * 1315423911ull + (uint64_t)limb + 1;  // rso_enc_encode's per-limb stream
+  // BatchEncoder::encode: slot scatter + inverse NTT mod t
+  for (int p = threadIdx.x; p < n; p += blockDim.x) s[pidx(p)] = 0.0;
+  __syncthreads();
+  const uint64_t *src = rings + el * (size_t)N;
+  for (int x = threadIdx.x; x < N; x += blockDim.x) s[pidx((int)index_map[x])] = from_u64(src[x]);
+  __syncthreads();
+  lds_ntt_inv(s, logn, pt.d_itw, 1, tmod, pt.inv_red_mask);
+  // centred lift to Z_{Q_j} (in place; every thread touches only its own positions)
+  for (int p = threadIdx.x; p < n; p += blockDim.x) {
+    const double c = canon(mulmod(reduce(s[pidx(p)], tmod), pt.ninv, tmod), tmod);
+    s[pidx(p)] = reduce(center(c, tmod), mod);
+  }
+  __syncthreads();
+  lds_ntt_fwd(s, logn, ct.d_tw, 1, mod, ct.fwd_red_mask);
+  double P[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int p = threadIdx.x + k * blockDim.x;
+    if (p < n) P[k] = reduce(s[pidx(p)], mod);
+  }
+  __syncthreads();
+  // ternary error, NTT form
+  for (int p = threadIdx.x; p < n; p += blockDim.x) s[pidx(p)] = (double)((int)(splitmix_at(seed, (uint64_t)p + 1) % 3) - 1);
+  __syncthreads();
+  lds_ntt_fwd(s, logn, ct.d_tw, 1, mod, ct.fwd_red_mask);
+  const double tq = reduce(from_u64(t % Q), mod);
+  uint64_t *c0 = enc + (el * 2 * K + j) * (size_t)n, *c1 = c0 + (size_t)K * n;
+  const uint64_t *sj = sk + (size_t)j * n;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int p = threadIdx.x + k * blockDim.x;
+    if (p < n) {
+      const uint64_t a = splitmix_at(seed, (uint64_t)n + (uint64_t)j * n + (uint64_t)p + 1) % Q;
+      const double as = mulmod(from_u64(a), from_u64(sj[p]), mod);
+      const double te = mulmod(tq, reduce(s[pidx(p)], mod), mod);
+      c1[p] = a;
+      c0[p] = to_u64(canon(P[k] - as - te, mod));
+    }
+  }
+}
+
+static int enc_threads(int logn) { return (int)std::max(64, std::min(1024, (1 << logn) / 8)); }
+
+// small device copies of the tables (allocated per call: generator / verifier paths are not hot)
+struct TabCopies {
+  NttTable *d_plain = nullptr, *d_coeff = nullptr;
+  uint64_t *d_q = nullptr, *d_Q = nullptr;
+  explicit TabCopies(rs_ctx *ctx) {
+    RS_HIP(hipMalloc(&d_plain, sizeof(NttTable) * ctx->L));
+    RS_HIP(hipMemcpy(d_plain, ctx->plain, sizeof(NttTable) * ctx->L, hipMemcpyHostToDevice));
+    RS_HIP(hipMalloc(&d_coeff, sizeof(NttTable) * ctx->K));
+    RS_HIP(hipMemcpy(d_coeff, ctx->coeff, sizeof(NttTable) * ctx->K, hipMemcpyHostToDevice));
+    RS_HIP(hipMalloc(&d_q, sizeof(uint64_t) * ctx->L));
+    RS_HIP(hipMemcpy(d_q, ctx->q, sizeof(uint64_t) * ctx->L, hipMemcpyHostToDevice));
+    RS_HIP(hipMalloc(&d_Q, sizeof(uint64_t) * ctx->K));
+    RS_HIP(hipMemcpy(d_Q, ctx->Q, sizeof(uint64_t) * ctx->K, hipMemcpyHostToDevice));
+  }
+  ~TabCopies() {
+    (void)hipFree(d_plain);
+    (void)hipFree(d_coeff);
+    (void)hipFree(d_q);
+    (void)hipFree(d_Q);
+  }
+};
+
+}  // namespace rs
+
+using namespace rs;
+
+extern "C" {
+
+int rs_enc_decode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size_t count, uint64_t *d_rings, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_sk && d_enc && d_rings, "null argument");
+  if (count == 0) return RS_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const int L = ctx->L, K = ctx->K, n = ctx->N_enc;
+  hipStream_t st = S(stream);
+  // host constants of the CRT composition
+  CrtConsts cc;
+  memset(&cc, 0, sizeof(cc));
+  cc.K = K;
+  using namespace host;
+  {
+    uint64_t carry = 0;
+    for (int k = K - 1; k >= 0; k--) {  // digits of Q-1 are (Q_k - 1); halve from the top
+      const unsigned __int128 cur = (unsigned __int128)(ctx->Q[k] - 1) + (unsigned __int128)carry * ctx->Q[k];
+      cc.half[k] = (double)(uint64_t)(cur >> 1);
+      carry = (uint64_t)(cur & 1);
+    }
+  }
+  for (int k = 0; k < K; k++) {
+    const uint64_t Qk = ctx->Q[k];
+    cc.Qmod[k] = Mod{(double)Qk, 1.0 / (double)Qk};
+    uint64_t prod = 1 % Qk;
+    for (int i = 0; i < k; i++) prod = mulmod(prod, ctx->Q[i] % Qk, Qk);
+    cc.prod_inv[k] = k ? balanced(invmod(prod, Qk), Qk) : 1.0;
+    for (int i = 0; i < K; i++) cc.Qi_mod_Qk[i][k] = balanced(ctx->Q[i] % Qk, Qk);
+  }
+  std::vector<CrtLimb> hl(L);
+  for (int i = 0; i < L; i++) {
+    const uint64_t t = ctx->q[i];
+    hl[i].tmod = Mod{(double)t, 1.0 / (double)t};
+    uint64_t Qm = 1 % t;
+    for (int k = 0; k < K; k++) {
+      hl[i].Qk_mod_t[k] = balanced(ctx->Q[k] % t, t);
+      Qm = mulmod(Qm, ctx->Q[k] % t, t);
+    }
+    hl[i].Q_mod_t = balanced(Qm, t);
+  }
+  CrtLimb *d_limbs = nullptr;
+  RS_HIP(hipMalloc(&d_limbs, sizeof(CrtLimb) * L));
+  RS_HIP(hipMemcpyAsync(d_limbs, hl.data(), sizeof(CrtLimb) * L, hipMemcpyHostToDevice, st));
+  TabCopies tabs(ctx);
+  double *V = (double *)ws_get(ctx, 14, count * (size_t)L * K * n * sizeof(double));
+  const size_t lds = padded_len((size_t)n) * sizeof(double);
+  const int thr = enc_threads(ctx->logN_enc);
+  RS_HIP(hipFuncSetAttribute((const void *)decrypt_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RS_HIP(hipFuncSetAttribute((const void *)crt_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(decrypt_dot_kernel, dim3((unsigned)(count * L), K), dim3(thr), lds, st, d_enc, d_sk, V, K, ctx->logN_enc,
+                     tabs.d_coeff);
+  hipLaunchKernelGGL(crt_decode_kernel, dim3((unsigned)(count * L)), dim3(thr), lds, st, V, d_rings, ctx->N, L, ctx->logN_enc,
+                     cc, d_limbs, ctx->d_index_map, tabs.d_plain);
+  RS_HIP(hipGetLastError());
+  RS_HIP(hipStreamSynchronize(st));  // the table copies die with this call
+  (void)hipFree(d_limbs);
+  RS_API_END
+}
+
+int rs_enc_encode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_rings, size_t count, uint64_t seed, uint64_t *d_enc,
+                  rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && d_sk && d_rings && d_enc, "null argument");
+  if (count == 0) return RS_OK;
+  RS_REQUIRE(ctx->N_enc <= 16 * 1024, "encoding degree out of range");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  hipStream_t st = S(stream);
+  TabCopies tabs(ctx);
+  const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(double);
+  const int thr = std::max(enc_threads(ctx->logN_enc), ctx->N_enc / 16);
+  RS_HIP(hipFuncSetAttribute((const void *)encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(encode_kernel, dim3((unsigned)(count * ctx->L), ctx->K), dim3(thr), lds, st, d_rings, d_sk, d_enc, seed,
+                     ctx->N, ctx->L, ctx->K, ctx->logN_enc, ctx->d_index_map, tabs.d_plain, tabs.d_coeff, tabs.d_q, tabs.d_Q);
+  RS_HIP(hipGetLastError());
+  RS_HIP(hipStreamSynchronize(st));
+  RS_API_END
+}
+
+}  // extern "C"

@@ -177,6 +177,22 @@ class Device:
         _lib.check(self.lib.rs_enc_reduce(self.h, _ptr(enc), self._count(enc, self.enc_words), self.stream()))
         return enc
 
+    # ---- 8(f) f2 / f3
+    def enc_decode(self, sk, enc):
+        """EncodingElem::decode (seal_ring.tcc:435-477): sk [K][N_enc] NTT form -> ring elements."""
+        count = self._count(enc, self.enc_words)
+        out = self.ring_empty(count) if enc.dim() > 4 else self.ring_empty()
+        _lib.check(self.lib.rs_enc_decode(self.h, _ptr(sk), _ptr(enc), count, _ptr(out), self.stream()))
+        return out
+
+    def enc_encode(self, sk, rings, seed):
+        """EncodingElem::encode (seal_ring.tcc:324-359); element k uses the oracle's stream seed*65537 + k."""
+        count = self._count(rings, self.ring_words)
+        out = self.enc_empty(count) if rings.dim() > 2 else self.enc_empty()
+        _lib.check(self.lib.rs_enc_encode(self.h, _ptr(sk), _ptr(rings), count, C.c_uint64((seed * 65537) % 2**64), _ptr(out),
+                                          self.stream()))
+        return out
+
     # ---- a9
     def inner_product(self, encs, rings, kinds=None, want_used=True):
         """EncodingElem::inner_product.  Returns (out, used); used == 0 <=> EMPTY element."""

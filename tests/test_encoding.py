@@ -1,0 +1,79 @@
+"""EncodingElem::encode / ::decode on the device, and the end-to-end
+semantic check they make possible: a proof produced by the HIP prover under a REAL (encrypted)
+proving key satisfies the reference's verification equation (groth16.tcc:117-170)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from ringsnark_amd import params as P
+from ringsnark_amd import r1cs as R
+from tests import helpers as H
+from tests import snark_ref as S
+
+
+def test_oracle_generator_verifier_accept_and_reject():
+    """CPU only: the restated generator / verifier around the ORACLE prover (pins tests/snark_ref.py)."""
+    prm = P.preset("toy")
+    ctx = H.oracle_ctx(prm)
+    cs = R.chain_r1cs(6, prm.q)
+    asg = H.make_assignment(ctx, cs)
+    pk, vk = S.groth16_generator(ctx, cs, 5, ctx.enc_encode)
+    proof, empty = O.groth16_prove(ctx, H.oracle_cs(cs), pk, asg)
+    assert empty == [0, 0, 0]
+    A, B, C = (ctx.enc_decode(vk["sk"], proof[k]) for k in range(3))
+    assert S.groth16_verifier(ctx, cs, vk, asg[: cs.n_inputs], A, B, C)
+    bad = asg[: cs.n_inputs].copy()
+    bad[0, 0, 0] = (int(bad[0, 0, 0]) + 1) % prm.q[0]
+    assert not S.groth16_verifier(ctx, cs, vk, bad, A, B, C)
+    C2 = C.copy()
+    C2[1, 3] = (int(C2[1, 3]) + 1) % prm.q[1]
+    assert not S.groth16_verifier(ctx, cs, vk, asg[: cs.n_inputs], A, B, C2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["toy", "toy49", "C2"])
+def test_enc_encode_decode_match_oracle(name):
+    from ringsnark_amd.device import Device, to_host
+    prm = P.preset(name)
+    dev, ctx = Device(prm), H.oracle_ctx(prm)
+    sk = ctx.keygen(3)
+    rings = ctx.random_ring(41, 3)
+    rings[1] = 0
+    exp = ctx.enc_encode(sk, rings, 9)
+    dsk = dev.put(sk)
+    got = dev.enc_encode(dsk, dev.put(rings), 9)
+    assert (to_host(got) == exp).all()
+    # decode: fresh encodings, and products / sums of them (noise grows, centring matters)
+    dec = to_host(dev.enc_decode(dsk, got))
+    assert (dec == rings).all()
+    r2 = ctx.random_ring(42, 3)
+    ip, used = ctx.inner_product(exp, r2)
+    assert used == 3
+    d = to_host(dev.enc_decode(dsk, dev.put(ip)))
+    assert (d == ctx.enc_decode(sk, ip)).all()
+    want = ctx.ring_add(ctx.ring_mul(rings[0], r2[0]), ctx.ring_mul(rings[2], r2[2]))
+    assert (d == want).all()  # homomorphism: decode(<E(a), b>) = <a, b>
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,m", [("toy", 6), ("toy49", 12)])
+def test_device_proof_verifies_under_reference_equation(name, m):
+    """generator (CPU restatement, encryption on the DEVICE) -> device prover -> device decode ->
+    the reference's verification equation; then a tampered input must be rejected."""
+    from ringsnark_amd.device import Device, to_host
+    prm = P.preset(name)
+    dev, ctx = Device(prm), H.oracle_ctx(prm)
+    cs = R.chain_r1cs(m, prm.q)
+    asg = H.make_assignment(ctx, cs)
+
+    def encode_on_device(sk, rings, seed):
+        return to_host(dev.enc_encode(dev.put(sk), dev.put(rings), seed))
+
+    pk, vk = S.groth16_generator(ctx, cs, 21, encode_on_device)
+    got, empty = dev.groth16_prove(dev.r1cs(cs), {k: dev.put(v) for k, v in pk.items()}, dev.put(asg))
+    assert [int(e) for e in empty] == [0, 0, 0]
+    dec = to_host(dev.enc_decode(dev.put(vk["sk"]), got))
+    assert S.groth16_verifier(ctx, cs, vk, asg[: cs.n_inputs], dec[0], dec[1], dec[2])
+    bad = asg[: cs.n_inputs].copy()
+    bad[1, 0, 5] = (int(bad[1, 0, 5]) + 1) % prm.q[0]
+    assert not S.groth16_verifier(ctx, cs, vk, bad, dec[0], dec[1], dec[2])

@@ -106,6 +106,20 @@ int rs_enc_decode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size
 int rs_enc_encode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_rings, size_t count, uint64_t seed, uint64_t *d_enc,
                   rs_stream stream);
 
+/* ---- wire format of encoding elements (proofs, key vectors) ------------------
+ * The reference declares (de)serialisation of keys and proofs but does not implement it
+ * (zk_proof_systems/r1cs_ppzksnark.hpp:43-47,142-146; relations/variable.tcc:391-414 throws).
+ * Little endian: "RSNKENC1", u32 N, L, N_enc, K, u64 q[L], Q[K], u64 count, u8 empty[count], pad to
+ * 8 bytes, then count elements [L][2][K][N_enc] of canonical u64 residues (the ABI layout, so a
+ * SEAL-based verifier can adopt `Ciphertext::data()` limb by limb).  h_empty (may be NULL) marks
+ * EMPTY elements (seal_ring.tcc:412,432).  Deserialisation validates magic, dimensions, moduli,
+ * sizes and residue ranges; d_enc == NULL only returns the element count. */
+size_t rs_enc_wire_size(const rs_ctx *ctx, size_t count);
+int rs_enc_serialize(rs_ctx *ctx, const uint64_t *d_enc, const uint8_t *h_empty, size_t count, void *h_buf, size_t buf_bytes,
+                     rs_stream stream);
+int rs_enc_deserialize(rs_ctx *ctx, const void *h_buf, size_t buf_bytes, uint64_t *d_enc, uint8_t *h_empty, size_t capacity,
+                       size_t *h_count, rs_stream stream);
+
 /* Canonicalise integer sums of encoding elements in place (x mod Q_j): the epilogue of the
  * multi-GPU all-reduce of partial inner products; inputs < 2^63. */
 int rs_enc_reduce(rs_ctx *ctx, uint64_t *d_enc, size_t count, rs_stream stream);

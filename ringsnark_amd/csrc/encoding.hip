@@ -270,3 +270,102 @@ int rs_enc_encode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_rings, si
 }
 
 }  // extern "C"
+
+// ---- wire format -----------------------------------------------------------------
+// The reference declares serialisation of keys and proofs but never implements it
+// (r1cs_ppzksnark.hpp:43-47,142-146; variable.tcc:391-414 throws).  Format (little endian):
+//   u8[8]  magic "RSNKENC1"
+//   u32    N, L, N_enc, K
+//   u64    q[L], Q[K]
+//   u64    count                       number of encoding elements
+//   u8     empty[count]                1 = EMPTY element (seal_ring.tcc:412,432), payload all zero
+//   pad to a multiple of 8 bytes
+//   u64    payload[count][L][2][K][N_enc]   canonical residues, the layout of the ABI
+namespace rs {
+static const char kMagic[8] = {'R', 'S', 'N', 'K', 'E', 'N', 'C', '1'};
+static size_t wire_header_bytes(const rs_ctx *ctx, size_t count) {
+  const size_t raw = 8 + 16 + 8 * (size_t)(ctx->L + ctx->K) + 8 + count;
+  return (raw + 7) & ~(size_t)7;
+}
+}  // namespace rs
+
+extern "C" {
+
+size_t rs_enc_wire_size(const rs_ctx *ctx, size_t count) {
+  if (!ctx) return 0;
+  return wire_header_bytes(ctx, count) + count * ctx->enc_words() * sizeof(uint64_t);
+}
+
+int rs_enc_serialize(rs_ctx *ctx, const uint64_t *d_enc, const uint8_t *h_empty, size_t count, void *h_buf, size_t buf_bytes,
+                     rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && h_buf && (d_enc || count == 0), "null argument");
+  RS_REQUIRE(buf_bytes >= rs_enc_wire_size(ctx, count), "buffer too small (rs_enc_wire_size)");
+  uint8_t *p = (uint8_t *)h_buf;
+  const size_t hb = wire_header_bytes(ctx, count);
+  memset(p, 0, hb);
+  memcpy(p, kMagic, 8);
+  const uint32_t dims[4] = {(uint32_t)ctx->N, (uint32_t)ctx->L, (uint32_t)ctx->N_enc, (uint32_t)ctx->K};
+  memcpy(p + 8, dims, 16);
+  memcpy(p + 24, ctx->q, 8 * (size_t)ctx->L);
+  memcpy(p + 24 + 8 * (size_t)ctx->L, ctx->Q, 8 * (size_t)ctx->K);
+  const uint64_t c64 = count;
+  uint8_t *q = p + 24 + 8 * (size_t)(ctx->L + ctx->K);
+  memcpy(q, &c64, 8);
+  for (size_t i = 0; i < count; i++) q[8 + i] = h_empty ? (h_empty[i] ? 1 : 0) : 0;
+  if (count) {
+    RS_HIP(hipMemcpyAsync(p + hb, d_enc, count * ctx->enc_words() * sizeof(uint64_t), hipMemcpyDeviceToHost, S(stream)));
+    RS_HIP(hipStreamSynchronize(S(stream)));
+    if (h_empty)
+      for (size_t i = 0; i < count; i++)
+        if (h_empty[i]) memset(p + hb + i * ctx->enc_words() * sizeof(uint64_t), 0, ctx->enc_words() * sizeof(uint64_t));
+  }
+  RS_API_END
+}
+
+int rs_enc_deserialize(rs_ctx *ctx, const void *h_buf, size_t buf_bytes, uint64_t *d_enc, uint8_t *h_empty, size_t capacity,
+                       size_t *h_count, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && h_buf && h_count, "null argument");
+  const uint8_t *p = (const uint8_t *)h_buf;
+  const size_t fixed = 24 + 8 * (size_t)(ctx->L + ctx->K) + 8;
+  RS_REQUIRE(buf_bytes >= fixed, "truncated header");
+  RS_REQUIRE(memcmp(p, kMagic, 8) == 0, "bad magic: not a ringsnark_amd encoding stream");
+  uint32_t dims[4];
+  memcpy(dims, p + 8, 16);
+  RS_REQUIRE((int)dims[0] == ctx->N && (int)dims[1] == ctx->L && (int)dims[2] == ctx->N_enc && (int)dims[3] == ctx->K,
+             "stream was written for different ring / encoding dimensions");
+  RS_REQUIRE(memcmp(p + 24, ctx->q, 8 * (size_t)ctx->L) == 0 && memcmp(p + 24 + 8 * (size_t)ctx->L, ctx->Q, 8 * (size_t)ctx->K) == 0,
+             "stream was written for different moduli");
+  uint64_t c64;
+  memcpy(&c64, p + 24 + 8 * (size_t)(ctx->L + ctx->K), 8);
+  const size_t count = (size_t)c64;
+  *h_count = count;
+  RS_REQUIRE(buf_bytes >= rs_enc_wire_size(ctx, count), "truncated payload");
+  if (!d_enc) return RS_OK;  // size query
+  RS_REQUIRE(capacity >= count, "destination holds fewer elements than the stream");
+  const uint8_t *em = p + fixed;
+  const size_t hb = wire_header_bytes(ctx, count);
+  const uint64_t *payload = (const uint64_t *)(p + hb);
+  for (size_t i = 0; i < count; i++) {
+    if (h_empty) h_empty[i] = em[i];
+    RS_REQUIRE(em[i] <= 1, "corrupt empty flag");
+  }
+  // canonical-residue check on the host: a proof from the wire is untrusted input
+  const size_t n = (size_t)ctx->N_enc, per = ctx->enc_words();
+  for (size_t i = 0; i < count; i++)
+    for (int l = 0; l < ctx->L; l++)
+      for (int c = 0; c < 2; c++)
+        for (int j = 0; j < ctx->K; j++) {
+          const uint64_t *row = payload + i * per + (((size_t)l * 2 + c) * ctx->K + j) * n;
+          const uint64_t Qj = ctx->Q[j];
+          for (size_t x = 0; x < n; x++) RS_REQUIRE(row[x] < Qj, "residue out of range");
+        }
+  if (count) {
+    RS_HIP(hipMemcpyAsync(d_enc, payload, count * per * sizeof(uint64_t), hipMemcpyHostToDevice, S(stream)));
+    RS_HIP(hipStreamSynchronize(S(stream)));
+  }
+  RS_API_END
+}
+
+}  // extern "C"

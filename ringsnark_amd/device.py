@@ -177,6 +177,34 @@ class Device:
         _lib.check(self.lib.rs_enc_reduce(self.h, _ptr(enc), self._count(enc, self.enc_words), self.stream()))
         return enc
 
+    # ---- 8(f) f4
+    def enc_serialize(self, enc, empty=None):
+        """Encoding elements (a proof, a key vector) -> bytes in the wire format of ringsnark_amd.h."""
+        import numpy as np
+        count = self._count(enc, self.enc_words)
+        size = self.lib.rs_enc_wire_size(self.h, count)
+        buf = np.empty(size, dtype=np.uint8)
+        em = None
+        if empty is not None:
+            em = np.ascontiguousarray(empty, dtype=np.uint8)
+            assert em.size == count
+        _lib.check(self.lib.rs_enc_serialize(self.h, _ptr(enc), None if em is None else em.ctypes.data_as(_lib.u8p), count,
+                                             buf.ctypes.data_as(C.c_void_p), size, self.stream()))
+        return buf.tobytes()
+
+    def enc_deserialize(self, data):
+        """bytes -> (encodings [count][L][2][K][N_enc] on the device, empty flags).  Validates the stream."""
+        import numpy as np
+        buf = np.frombuffer(data, dtype=np.uint8)
+        cnt = C.c_size_t(0)
+        _lib.check(self.lib.rs_enc_deserialize(self.h, buf.ctypes.data_as(C.c_void_p), buf.size, None, None, 0, C.byref(cnt),
+                                               self.stream()))
+        out = self.enc_empty(cnt.value)
+        em = np.zeros(cnt.value, dtype=np.uint8)
+        _lib.check(self.lib.rs_enc_deserialize(self.h, buf.ctypes.data_as(C.c_void_p), buf.size, _ptr(out),
+                                               em.ctypes.data_as(_lib.u8p), cnt.value, C.byref(cnt), self.stream()))
+        return out, em
+
     # ---- 8(f) f2 / f3
     def enc_decode(self, sk, enc):
         """EncodingElem::decode (seal_ring.tcc:435-477): sk [K][N_enc] NTT form -> ring elements."""

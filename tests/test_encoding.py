@@ -77,3 +77,52 @@ def test_device_proof_verifies_under_reference_equation(name, m):
     bad = asg[: cs.n_inputs].copy()
     bad[1, 0, 5] = (int(bad[1, 0, 5]) + 1) % prm.q[0]
     assert not S.groth16_verifier(ctx, cs, vk, bad, dec[0], dec[1], dec[2])
+
+
+@pytest.mark.gpu
+def test_wire_format_roundtrip_and_validation():
+    """proofs / key vectors through the wire format of include/ringsnark_amd.h."""
+    import struct
+    from ringsnark_amd import _lib
+    from ringsnark_amd.device import Device, to_host
+    prm = P.preset("toy")
+    dev, ctx = Device(prm), H.oracle_ctx(prm)
+    enc = ctx.random_enc(5, 3)
+    data = dev.enc_serialize(dev.put(enc), empty=[0, 1, 0])
+    # header, field by field
+    assert data[:8] == b"RSNKENC1"
+    assert struct.unpack_from("<4I", data, 8) == (prm.N, prm.L, prm.N_enc, prm.K)
+    off = 24
+    assert list(struct.unpack_from("<%dQ" % prm.L, data, off)) == [int(x) for x in prm.q]
+    off += 8 * prm.L
+    assert list(struct.unpack_from("<%dQ" % prm.K, data, off)) == [int(x) for x in prm.Q]
+    off += 8 * prm.K
+    assert struct.unpack_from("<Q", data, off)[0] == 3 and data[off + 8: off + 11] == bytes([0, 1, 0])
+    hb = (off + 8 + 3 + 7) // 8 * 8
+    payload = np.frombuffer(data, dtype="<u8", offset=hb).reshape(enc.shape)
+    assert (payload[0] == enc[0]).all() and not payload[1].any() and (payload[2] == enc[2]).all()
+    back, empty = dev.enc_deserialize(data)
+    assert list(empty) == [0, 1, 0]
+    b = to_host(back)
+    assert (b[0] == enc[0]).all() and not b[1].any() and (b[2] == enc[2]).all()
+    # untrusted input: every corruption is refused with RS_ERR_INVALID
+    for mutate in ("magic", "dims", "modulus", "truncate", "residue", "flag"):
+        bad = bytearray(data)
+        if mutate == "magic":
+            bad[0] ^= 1
+        elif mutate == "dims":
+            struct.pack_into("<I", bad, 8, prm.N * 2)
+        elif mutate == "modulus":
+            struct.pack_into("<Q", bad, 24, int(prm.q[0]) + 2)
+        elif mutate == "truncate":
+            bad = bad[:-8]
+        elif mutate == "residue":
+            struct.pack_into("<Q", bad, hb, int(prm.Q[0]))
+        else:
+            bad[off + 8] = 7
+        with pytest.raises(_lib.RsError):
+            dev.enc_deserialize(bytes(bad))
+    # a different context refuses the stream
+    dev49 = Device(P.preset("toy49"))
+    with pytest.raises(_lib.RsError):
+        dev49.enc_deserialize(data)

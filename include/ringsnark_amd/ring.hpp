@@ -251,6 +251,34 @@ class EncodingElem {
   }
   friend bool operator==(const EncodingElem &a, const EncodingElem &b) { return a.w_ == b.w_; }
 
+  // EncodingElem::encode(sk, rs) (seal_ring.tcc:324-359) and ::decode(sk, e) (seal_ring.tcc:435-477).
+  // SecretKey here is the [K][N_enc] NTT-form key words; `seed` replaces SEAL's process-global PRNG.
+  using SecretKey = std::vector<uint64_t>;
+  static std::vector<EncodingElem> encode(const SecretKey &sk, const std::vector<RingElem> &rs, uint64_t seed = 1) {
+    const size_t ew = Context::enc_words(), rw = Context::ring_words();
+    std::vector<uint64_t> rings(rs.size() * rw);
+    for (size_t t = 0; t < rs.size(); t++) {
+      const RingElem rp = rs[t].to_poly();
+      std::memcpy(&rings[t * rw], rp.get_poly().data(), rw * 8);
+    }
+    DeviceWords dsk(sk.data(), sk.size()), dr(rings.data(), rings.size()), out(rs.size() * ew);
+    check(rs_enc_encode(Context::get_context(), dsk.get(), dr.get(), rs.size(), seed, out.get(), nullptr));
+    std::vector<uint64_t> all(rs.size() * ew);
+    out.download(all.data());
+    std::vector<EncodingElem> res;
+    res.reserve(rs.size());
+    for (size_t t = 0; t < rs.size(); t++) res.emplace_back(std::vector<uint64_t>(all.begin() + t * ew, all.begin() + (t + 1) * ew));
+    return res;
+  }
+  static RingElem decode(const SecretKey &sk, const EncodingElem &e) {
+    if (e.is_empty()) throw std::invalid_argument("cannot decode an empty encoding");
+    DeviceWords dsk(sk.data(), sk.size()), de(e.w_.data(), e.w_.size()), out(Context::ring_words());
+    check(rs_enc_decode(Context::get_context(), dsk.get(), de.get(), 1, out.get(), nullptr));
+    std::vector<uint64_t> w(Context::ring_words());
+    out.download(w.data());
+    return RingElem(std::move(w));
+  }
+
   // EncodingElem::inner_product (seal_ring.tcc:361-433) on host-resident vectors.  For resident
   // keys use ProvingKeyDevice below.
   template <class EncIt, class RingIt>

@@ -138,3 +138,61 @@ def groth16_verifier(ctx, cs, vk, primary, A, B, C):
     f_io = R.mul(f_io, R.inv(vk["gamma"]))
     rhs = R.add(R.add(R.mul(vk["alpha"], vk["beta"]), R.mul(vk["gamma"], f_io)), R.mul(vk["delta"], C))
     return bool((R.mul(A, B) == rhs).all())
+
+
+def rinocchio_generator(ctx, cs, seed, encode):
+    """rinocchio.tcc:5-72 (the key elements the prover reads).  Returns (pk, vk)."""
+    R = Ring(ctx)
+    rng = np.random.RandomState(seed)
+    s = R.random_exceptional(rng, cs.m)
+    At, Bt, Ct, Ht, Zt = instance_map_with_evaluation(R, cs, s)
+    sk = ctx.keygen(seed + 1)
+    alpha, r_v, r_w = (R.random_invertible(rng) for _ in range(3))
+    r_y = R.mul(r_v, r_w)
+    beta = R.random_invertible(rng)  # random_nonzero_element; invertible is a special case
+    s_pows = Ht[: cs.m + 1]
+    alpha_s_pows = [R.mul(x, alpha) for x in s_pows]
+    linchecks = []
+    for i in range(cs.n_aux):
+        idx = i + cs.n_inputs + 1
+        t = R.add(R.add(R.mul(r_v, At[idx]), R.mul(r_w, Bt[idx])), R.mul(r_y, Ct[idx]))
+        linchecks.append(R.mul(t, beta))
+    beta_Zt = R.mul(beta, Zt)
+    pk = {
+        "s_pows": encode(sk, np.stack(s_pows), seed + 10),
+        "alpha_s_pows": encode(sk, np.stack(alpha_s_pows), seed + 11),
+        "beta_prods": encode(sk, np.stack(linchecks), seed + 12),
+        "beta_rv_ts": encode(sk, np.stack([R.mul(beta_Zt, r_v)]), seed + 13)[0],
+        "beta_rw_ts": encode(sk, np.stack([R.mul(beta_Zt, r_w)]), seed + 14)[0],
+        "beta_ry_ts": encode(sk, np.stack([R.mul(beta_Zt, r_y)]), seed + 15)[0],
+    }
+    vk = {"s": s, "alpha": alpha, "beta": beta, "r_v": r_v, "r_w": r_w, "r_y": r_y, "sk": sk, "Zt": Zt}
+    return pk, vk
+
+
+def rinocchio_verifier(ctx, cs, vk, primary, decs):
+    """rinocchio.tcc:192-300 on the nine DECODED proof elements
+    (V_mid, V_mid', W_mid, W_mid', Y_mid, Y_mid', H, H', L_beta)."""
+    R = Ring(ctx)
+    V, Vp, W, Wp, Y, Yp, Hh, Hp, Lb = decs
+    L = R.mul(R.add(R.add(R.mul(V, vk["r_v"]), R.mul(W, vk["r_w"])), R.mul(Y, vk["r_y"])), vk["beta"])
+    padded = np.zeros((cs.n_vars,) + ctx.ring_shape(), dtype=np.uint64)
+    padded[: cs.n_inputs] = primary
+    ocs = H.oracle_cs(cs)
+    io_s = []
+    for which in range(3):
+        coeffs = np.empty((cs.m,) + ctx.ring_shape(), dtype=np.uint64)
+        for limb, q in enumerate(ctx.q):
+            ev = O.r1cs_evaluate(q, ocs, which, limb, np.ascontiguousarray(padded[:, limb, :]))
+            coeffs[:, limb, :] = O.interpolate(q, ev)
+        io_s.append(poly_eval_ring(R, coeffs, vk["s"]))
+    Pv = R.sub(R.mul(R.add(V, io_s[0]), R.add(W, io_s[1])), R.add(Y, io_s[2]))
+    checks = {
+        "V' = alpha V": (Vp == R.mul(V, vk["alpha"])).all(),
+        "W' = alpha W": (Wp == R.mul(W, vk["alpha"])).all(),
+        "Y' = alpha Y": (Yp == R.mul(Y, vk["alpha"])).all(),
+        "H' = alpha H": (Hp == R.mul(Hh, vk["alpha"])).all(),
+        "L_beta = L": (Lb == L).all(),
+        "P = H Z(s)": (Pv == R.mul(Hh, vk["Zt"])).all(),
+    }
+    return all(bool(v) for v in checks.values()), checks

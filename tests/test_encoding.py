@@ -30,6 +30,24 @@ def test_oracle_generator_verifier_accept_and_reject():
     assert not S.groth16_verifier(ctx, cs, vk, asg[: cs.n_inputs], A, B, C2)
 
 
+def test_oracle_rinocchio_generator_verifier_accept_and_reject():
+    """CPU only: Rinocchio's six verifier checks (rinocchio.tcc:192-300) around the ORACLE prover."""
+    prm = P.preset("toy")
+    ctx = H.oracle_ctx(prm)
+    cs = R.chain_r1cs(5, prm.q)
+    asg = H.make_assignment(ctx, cs)
+    pk, vk = S.rinocchio_generator(ctx, cs, 8, ctx.enc_encode)
+    proof, empty = O.rinocchio_prove(ctx, H.oracle_cs(cs), pk, asg)
+    assert empty == [0] * 9
+    decs = [ctx.enc_decode(vk["sk"], proof[k]) for k in range(9)]
+    ok, checks = S.rinocchio_verifier(ctx, cs, vk, asg[: cs.n_inputs], decs)
+    assert ok, checks
+    bad = asg[: cs.n_inputs].copy()
+    bad[0, 1, 2] = (int(bad[0, 1, 2]) + 1) % prm.q[1]
+    ok, checks = S.rinocchio_verifier(ctx, cs, vk, bad, decs)
+    assert not ok and not checks["P = H Z(s)"] and checks["L_beta = L"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["toy", "toy49", "C2"])
 def test_enc_encode_decode_match_oracle(name):
@@ -77,6 +95,23 @@ def test_device_proof_verifies_under_reference_equation(name, m):
     bad = asg[: cs.n_inputs].copy()
     bad[1, 0, 5] = (int(bad[1, 0, 5]) + 1) % prm.q[0]
     assert not S.groth16_verifier(ctx, cs, vk, bad, dec[0], dec[1], dec[2])
+
+
+@pytest.mark.gpu
+def test_device_rinocchio_proof_passes_reference_checks():
+    from ringsnark_amd.device import Device, to_host
+    prm = P.preset("toy49")
+    dev, ctx = Device(prm), H.oracle_ctx(prm)
+    cs = R.chain_r1cs(9, prm.q)
+    asg = H.make_assignment(ctx, cs)
+    pk, vk = S.rinocchio_generator(ctx, cs, 31, lambda sk, r, seed: to_host(dev.enc_encode(dev.put(sk), dev.put(r), seed)))
+    got, empty = dev.rinocchio_prove(dev.r1cs(cs), {k: dev.put(v) for k, v in pk.items()}, dev.put(asg))
+    assert [int(e) for e in empty] == [0] * 9
+    # the proof travels through the wire format on its way to the verifier
+    back, em = dev.enc_deserialize(dev.enc_serialize(got, empty=empty))
+    dec = to_host(dev.enc_decode(dev.put(vk["sk"]), back))
+    ok, checks = S.rinocchio_verifier(ctx, cs, vk, asg[: cs.n_inputs], [dec[k] for k in range(9)])
+    assert ok, checks
 
 
 @pytest.mark.gpu

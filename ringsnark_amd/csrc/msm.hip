@@ -89,10 +89,30 @@ plain_center_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t
     }
     const uint64_t *src = G.coeff[v] + ((size_t)t * L + limb) * (size_t)N;
     bool nz = false;
-    for (int x = threadIdx.x; x < N; x += blockDim.x) {
-      const uint64_t val = src[x];
-      nz |= (val != 0);
-      s[pidx((int)index_map[x])] = from_u64(val);
+    // loads in unrolled batches of 8 (a rolled loop waits for each coefficient and each map entry
+    // in turn; 16 at once do not fit beside the accumulators)
+    int tid = threadIdx.x;  // fresh copy per vector: keeps the 32 load addresses out of loop-invariant hoisting
+    asm volatile("" : "+v"(tid));
+#pragma unroll
+    for (int k0 = 0; k0 < EPT; k0 += 8) {
+      uint64_t val[8];
+      uint32_t pos[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int x = tid + (k0 + k) * blockDim.x;
+        if (x < N) {
+          val[k] = src[x];
+          pos[k] = index_map[x];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int x = tid + (k0 + k) * blockDim.x;
+        if (x < N) {
+          nz |= (val[k] != 0);
+          s[pidx((int)pos[k])] = from_u64(val[k]);
+        }
+      }
     }
     if (!__syncthreads_or(nz)) continue;  // is_zero term (this limb): contributes nothing
     if (threadIdx.x == 0 && G.nz[v]) atomicOr(&G.nz[v][t], 1u);
@@ -100,9 +120,11 @@ plain_center_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t
       lds_ntt_inv_wp<RS_PLAIN_MAXR, TileBlockFactory, LdsIO, 3>(s, TileBlockFactory{s}, LdsIO{s}, logn, logw, tab.d_itw, mod, tab.inv_red_mask);
     else
       lds_ntt_inv(s, logn, tab.d_itw, 1, mod, tab.inv_red_mask);
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int k = 0; k < EPT; k++) {
-      const int p = threadIdx.x + k * blockDim.x;
+      const int p = tid + k * blockDim.x;
       if (p < n) {
         const double c = canon(mulmod(reduce(s[pidx(p)], mod), tab.ninv, mod), mod);
         acc[k] += center(c, mod);

@@ -949,6 +949,46 @@ io_coeff_kernel(IoDesc io, const double *__restrict__ Lcols /* [ncols][L][M] */,
   reinterpret_cast<ulonglong2 *>(out + t * S)[pair] = o;
 }
 
+// Column-major interpolated `full` vector -> term-major io AND mid vectors in one pass:
+//   io[t]  = Lconst[t] + sum_k x_k (*) L_k[t]          (io shortcut, as io_coeff_kernel)
+//   mid[t] = full[t] - io[t] + const[limb][t]          (as mid_tm_kernel)
+// i.e. transpose_out + io_coeff + mid_tm fused: the column tile is transposed through LDS, the io
+// value is computed where it is needed, and both results are written once.  grid (S/32, M/32).
+__global__ void __launch_bounds__(256)
+io_mid_out_kernel(const double *__restrict__ cols, IoDesc io, const double *__restrict__ Lcols /* [ncols][L][M] */,
+                  const uint64_t *__restrict__ asg, const double *__restrict__ cst /* [L][M] or null */,
+                  uint64_t *__restrict__ io_out /* or null */, uint64_t *__restrict__ mid_out, size_t m, int N, int L,
+                  size_t M, const Mod *__restrict__ qmod) {
+  __shared__ double tile[32][33];
+  const size_t S = (size_t)L * N;
+  const size_t s0 = (size_t)blockIdx.x * 32, r0 = (size_t)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const size_t sl = s0 + k, r = r0 + tx;
+    tile[k][tx] = (sl < S && r < M) ? cols[sl * M + r] : 0.0;
+  }
+  __syncthreads();
+  const size_t sl = s0 + tx;
+  if (sl >= S) return;
+  const int limb = (int)(sl / (size_t)N);
+  const Mod mod = qmod[limb];
+  for (int k = ty; k < 32; k += 8) {
+    const size_t r = r0 + k;
+    if (r >= m) continue;
+    double a = 0.0;
+    for (int c = 0; c < io.count; c++) {
+      const double lv = center(Lcols[((size_t)io.column[c] * L + limb) * M + r], mod);
+      const int kk = io.k[c];
+      a += kk == 0 ? lv : mulmod(from_u64(asg[(size_t)(kk - 1) * S + sl]), lv, mod);
+      if ((c & 3) == 3) a = reduce(a, mod);
+    }
+    const double iov = canon(a, mod);
+    if (io_out) io_out[r * S + sl] = to_u64(iov);
+    const double cc = cst ? cst[(size_t)limb * M + r] : 0.0;
+    mid_out[r * S + sl] = to_u64(canon(tile[tx][k] - iov + cc, mod));
+  }
+}
+
 // term-major: full[t] <- full[t] - io[t] + const[limb][t]
 __global__ void __launch_bounds__(256)
 mid_tm_kernel(uint64_t *__restrict__ full, const uint64_t *__restrict__ io, const double *__restrict__ cst /* [L][M] or null */,
@@ -1617,6 +1657,13 @@ void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const ui
       if (outs[k]) hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(k), outs[k], m, S, M);
   } else {
     for (int w = 0; w < 3; w++) {
+      if (outs[3 + w]) {  // io (if wanted) and mid in one pass over the interpolated columns
+        IoDesc io{cs->d_io_k[w], cs->d_io_c[w], cs->io_count[w]};
+        const double *cst = cs->io_const_col[w] >= 0 ? cs->d_io_cols + (size_t)cs->io_const_col[w] * ctx->L * M : nullptr;
+        hipLaunchKernelGGL(io_mid_out_kernel, tgrid, dim3(256), 0, st, colv(3 + w), io, cs->d_io_cols, d_asg, cst, outs[w],
+                           outs[3 + w], m, ctx->N, ctx->L, M, ctx->d_qmod);
+        continue;
+      }
       uint64_t *io_dst = outs[w] ? outs[w] : evalbuf;  // evalbuf is free again: all evaluations are transposed
       if (need_io[w]) {
         IoDesc io{cs->d_io_k[w], cs->d_io_c[w], cs->io_count[w]};

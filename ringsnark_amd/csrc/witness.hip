@@ -847,6 +847,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
 #pragma unroll
     for (int j = 0; j < EPT; j++) r[j] = sb[pidx(ln + 64 * j)];  // own slice of T, for the second half
   }
+  __syncthreads();  // the cross-wave round below writes every block: all slices must be saved first
   double uu[EPT];
 #pragma unroll
   for (int half = 0; half < 2; half++) {
@@ -1062,6 +1063,53 @@ r1cs_eval_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restric
   reinterpret_cast<ulonglong2 *>(out + row * S)[pair] = o;
 }
 
+
+// linear_combination::evaluate straight into the column-major layout of the witness map
+// (r1cs_eval_kernel + transpose_in_kernel fused; rows >= m are the zero padding of the columns).
+// grid (S/32, M/32), 32 slots x 8 row groups per workgroup.
+__global__ void __launch_bounds__(256)
+r1cs_eval_cols_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const double *__restrict__ coeff,
+                      size_t nnz, const uint64_t *__restrict__ asg, double *__restrict__ cols, size_t m, int N, int L, size_t M,
+                      int mode, unsigned n_inputs, const Mod *__restrict__ qmod) {
+  __shared__ double tile[32][33];
+  const size_t S = (size_t)L * N;
+  const size_t s0 = (size_t)blockIdx.x * 32, r0 = (size_t)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t sl = s0 + tx;
+  if (sl < S) {
+    const int limb = (int)(sl / (size_t)N);
+    const Mod mod = qmod[limb];
+    for (int k = ty; k < 32; k += 8) {
+      const size_t row = r0 + k;
+      double a = 0.0;
+      if (row < m) {
+        int since = 0;
+        for (uint32_t e = row_ptr[row]; e < row_ptr[row + 1]; e++) {
+          const uint32_t c = col[e];
+          const double cf = coeff[(size_t)limb * nnz + e];
+          if (c == 0) {
+            a += cf;
+          } else {
+            const bool is_input = (c - 1) < n_inputs;
+            if ((mode == RS_EVAL_IO && !is_input) || (mode == RS_EVAL_MID && is_input)) continue;
+            a += mulmod(from_u64(asg[(size_t)(c - 1) * S + sl]), cf, mod);
+          }
+          if (++since == 4) {
+            since = 0;
+            a = reduce(a, mod);
+          }
+        }
+        a = canon(a, mod);
+      }
+      tile[k][tx] = a;
+    }
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const size_t slot = s0 + k, r = r0 + tx;
+    if (slot < S && r < M) cols[slot * M + r] = tile[tx][k];
+  }
+}
 
 // =============================================================================================
 // Multi-pass column transforms for M > 2^g_witness_lds_logM (a column no longer fits one LDS tile).
@@ -1615,10 +1663,10 @@ void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const ui
       r1cs_evaluate_run(ctx, cs, w, RS_EVAL_IO, d_asg, evalbuf, st);
       hipLaunchKernelGGL(transpose_in_kernel, tgrid, dim3(256), 0, st, evalbuf, colv(w), m, S, M);
     }
-    if (need_full[w]) {
-      r1cs_evaluate_run(ctx, cs, w, RS_EVAL_FULL, d_asg, evalbuf, st);
-      hipLaunchKernelGGL(transpose_in_kernel, tgrid, dim3(256), 0, st, evalbuf, colv(3 + w), m, S, M);
-    }
+    if (need_full[w])
+      hipLaunchKernelGGL(r1cs_eval_cols_kernel, tgrid, dim3(256), 0, st, cs->d_row_ptr[w], cs->d_col[w], cs->d_coeff[w],
+                         cs->nnz[w], d_asg, colv(3 + w), m, ctx->N, ctx->L, M, (int)RS_EVAL_FULL, (unsigned)cs->n_inputs,
+                         ctx->d_qmod);
   }
   RS_HIP(hipGetLastError());
   // batched interpolation over contiguous runs of needed vectors

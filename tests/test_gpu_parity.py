@@ -314,3 +314,27 @@ def test_witness_map_full_size_columns(m):
             lhs = _horner(Hh[:, limb, slot], x, q) * _horner(Z, x, q) % q
             rhs = (_horner(A[:, limb, slot] % q, x, q) * _horner(B[:, limb, slot] % q, x, q) - _horner(C[:, limb, slot] % q, x, q)) % q
             assert lhs == rhs
+
+
+@pytest.mark.parametrize("m", [1500, 3000, 8192, 9000])
+def test_witness_map_is_deterministic(m):
+    """Race detector for the LDS kernels: repeated runs on the same inputs must agree bit for bit
+    (a missing barrier shows up as run-to-run differences long before it fails a single comparison)."""
+    dev = dev_for("toy44")
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    cs = R.chain_r1cs(m, prm.q)
+    asg = dev.ring_empty(m + 2)
+    asg[:2] = dev.put(ctx.random_ring(93, 2))
+    dev.chain_assignment(asg, m)
+    dcs = dev.r1cs(cs)
+    ds = [dev.put(ctx.random_ring(94 + k)) for k in range(3)]
+    first = None
+    for _ in range(8):
+        w = dev.witness_map(dcs, asg, *ds)
+        cur = {k: host(w[k]).copy() for k in ("A_io", "A_mid", "B_mid", "C_mid", "H")}
+        if first is None:
+            first = cur
+        else:
+            for k in cur:
+                assert (cur[k] == first[k]).all(), k

@@ -954,39 +954,60 @@ io_coeff_kernel(IoDesc io, const double *__restrict__ Lcols /* [ncols][L][M] */,
 //   io[t]  = Lconst[t] + sum_k x_k (*) L_k[t]          (io shortcut, as io_coeff_kernel)
 //   mid[t] = full[t] - io[t] + const[limb][t]          (as mid_tm_kernel)
 // i.e. transpose_out + io_coeff + mid_tm fused: the column tile is transposed through LDS, the io
-// value is computed where it is needed, and both results are written once.  grid (S/32, M/32).
+// value is computed where it is needed, and both results are written once (16 bytes per lane).
+// grid (S/64, M/32).
 __global__ void __launch_bounds__(256)
 io_mid_out_kernel(const double *__restrict__ cols, IoDesc io, const double *__restrict__ Lcols /* [ncols][L][M] */,
                   const uint64_t *__restrict__ asg, const double *__restrict__ cst /* [L][M] or null */,
                   uint64_t *__restrict__ io_out /* or null */, uint64_t *__restrict__ mid_out, size_t m, int N, int L,
                   size_t M, const Mod *__restrict__ qmod) {
-  __shared__ double tile[32][33];
+  __shared__ double tile[64][33];  // [slot][row]
   const size_t S = (size_t)L * N;
-  const size_t s0 = (size_t)blockIdx.x * 32, r0 = (size_t)blockIdx.y * 32;
+  const size_t s0 = (size_t)blockIdx.x * 64, r0 = (size_t)blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int k = ty; k < 32; k += 8) {
+  for (int k = ty; k < 64; k += 8) {
     const size_t sl = s0 + k, r = r0 + tx;
     tile[k][tx] = (sl < S && r < M) ? cols[sl * M + r] : 0.0;
   }
   __syncthreads();
-  const size_t sl = s0 + tx;
+  const size_t sl = s0 + 2 * tx;  // this lane's slot pair (N is even: both slots in one limb)
   if (sl >= S) return;
+  const size_t pair = sl >> 1;
   const int limb = (int)(sl / (size_t)N);
   const Mod mod = qmod[limb];
   for (int k = ty; k < 32; k += 8) {
     const size_t r = r0 + k;
     if (r >= m) continue;
-    double a = 0.0;
+    double a0 = 0.0, a1 = 0.0;
     for (int c = 0; c < io.count; c++) {
       const double lv = center(Lcols[((size_t)io.column[c] * L + limb) * M + r], mod);
       const int kk = io.k[c];
-      a += kk == 0 ? lv : mulmod(from_u64(asg[(size_t)(kk - 1) * S + sl]), lv, mod);
-      if ((c & 3) == 3) a = reduce(a, mod);
+      if (kk == 0) {
+        a0 += lv;
+        a1 += lv;
+      } else {
+        const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(kk - 1) * S)[pair];
+        a0 += mulmod(from_u64(v.x), lv, mod);
+        a1 += mulmod(from_u64(v.y), lv, mod);
+      }
+      if ((c & 3) == 3) {
+        a0 = reduce(a0, mod);
+        a1 = reduce(a1, mod);
+      }
     }
-    const double iov = canon(a, mod);
-    if (io_out) io_out[r * S + sl] = to_u64(iov);
+    a0 = canon(a0, mod);
+    a1 = canon(a1, mod);
+    if (io_out) {
+      ulonglong2 o;
+      o.x = to_u64(a0);
+      o.y = to_u64(a1);
+      reinterpret_cast<ulonglong2 *>(io_out + r * S)[pair] = o;
+    }
     const double cc = cst ? cst[(size_t)limb * M + r] : 0.0;
-    mid_out[r * S + sl] = to_u64(canon(tile[tx][k] - iov + cc, mod));
+    ulonglong2 o;
+    o.x = to_u64(canon(tile[2 * tx][k] - a0 + cc, mod));
+    o.y = to_u64(canon(tile[2 * tx + 1][k] - a1 + cc, mod));
+    reinterpret_cast<ulonglong2 *>(mid_out + r * S)[pair] = o;
   }
 }
 
@@ -1066,48 +1087,55 @@ r1cs_eval_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restric
 
 // linear_combination::evaluate straight into the column-major layout of the witness map
 // (r1cs_eval_kernel + transpose_in_kernel fused; rows >= m are the zero padding of the columns).
-// grid (S/32, M/32), 32 slots x 8 row groups per workgroup.
+// grid (S/64, M/32): 64 slots x 32 rows per workgroup.
 __global__ void __launch_bounds__(256)
 r1cs_eval_cols_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const double *__restrict__ coeff,
                       size_t nnz, const uint64_t *__restrict__ asg, double *__restrict__ cols, size_t m, int N, int L, size_t M,
                       int mode, unsigned n_inputs, const Mod *__restrict__ qmod) {
-  __shared__ double tile[32][33];
+  __shared__ double tile[64][33];  // [slot][row]
   const size_t S = (size_t)L * N;
-  const size_t s0 = (size_t)blockIdx.x * 32, r0 = (size_t)blockIdx.y * 32;
+  const size_t s0 = (size_t)blockIdx.x * 64, r0 = (size_t)blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const size_t sl = s0 + tx;
+  const size_t sl = s0 + 2 * tx;  // slot pair of this lane, 16-byte loads of the assignment
   if (sl < S) {
+    const size_t pair = sl >> 1;
     const int limb = (int)(sl / (size_t)N);
     const Mod mod = qmod[limb];
     for (int k = ty; k < 32; k += 8) {
       const size_t row = r0 + k;
-      double a = 0.0;
+      double a0 = 0.0, a1 = 0.0;
       if (row < m) {
         int since = 0;
         for (uint32_t e = row_ptr[row]; e < row_ptr[row + 1]; e++) {
           const uint32_t c = col[e];
           const double cf = coeff[(size_t)limb * nnz + e];
           if (c == 0) {
-            a += cf;
+            a0 += cf;
+            a1 += cf;
           } else {
             const bool is_input = (c - 1) < n_inputs;
             if ((mode == RS_EVAL_IO && !is_input) || (mode == RS_EVAL_MID && is_input)) continue;
-            a += mulmod(from_u64(asg[(size_t)(c - 1) * S + sl]), cf, mod);
+            const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(c - 1) * S)[pair];
+            a0 += mulmod(from_u64(v.x), cf, mod);
+            a1 += mulmod(from_u64(v.y), cf, mod);
           }
           if (++since == 4) {
             since = 0;
-            a = reduce(a, mod);
+            a0 = reduce(a0, mod);
+            a1 = reduce(a1, mod);
           }
         }
-        a = canon(a, mod);
+        a0 = canon(a0, mod);
+        a1 = canon(a1, mod);
       }
-      tile[k][tx] = a;
+      tile[2 * tx][k] = a0;
+      tile[2 * tx + 1][k] = a1;
     }
   }
   __syncthreads();
-  for (int k = ty; k < 32; k += 8) {
+  for (int k = ty; k < 64; k += 8) {
     const size_t slot = s0 + k, r = r0 + tx;
-    if (slot < S && r < M) cols[slot * M + r] = tile[tx][k];
+    if (slot < S && r < M) cols[slot * M + r] = tile[k][tx];
   }
 }
 
@@ -1656,6 +1684,7 @@ void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const ui
   uint64_t *evalbuf = (uint64_t *)ws_get(ctx, 6, std::max<size_t>(m, 1) * S * sizeof(uint64_t));
   auto colv = [&](int k) { return colbuf + (size_t)k * vec; };
   const dim3 tgrid((unsigned)((S + 31) / 32), (unsigned)((M + 31) / 32));
+  const dim3 tgrid64((unsigned)((S + 63) / 64), (unsigned)((M + 31) / 32));
   const unsigned by = (unsigned)((S / 2 + 255) / 256);
   if (shortcut) build_io_cache(ctx, cs, P, cp, st);
   for (int w = 0; w < 3; w++) {
@@ -1664,7 +1693,7 @@ void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const ui
       hipLaunchKernelGGL(transpose_in_kernel, tgrid, dim3(256), 0, st, evalbuf, colv(w), m, S, M);
     }
     if (need_full[w])
-      hipLaunchKernelGGL(r1cs_eval_cols_kernel, tgrid, dim3(256), 0, st, cs->d_row_ptr[w], cs->d_col[w], cs->d_coeff[w],
+      hipLaunchKernelGGL(r1cs_eval_cols_kernel, tgrid64, dim3(256), 0, st, cs->d_row_ptr[w], cs->d_col[w], cs->d_coeff[w],
                          cs->nnz[w], d_asg, colv(3 + w), m, ctx->N, ctx->L, M, (int)RS_EVAL_FULL, (unsigned)cs->n_inputs,
                          ctx->d_qmod);
   }
@@ -1708,7 +1737,7 @@ void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const ui
       if (outs[3 + w]) {  // io (if wanted) and mid in one pass over the interpolated columns
         IoDesc io{cs->d_io_k[w], cs->d_io_c[w], cs->io_count[w]};
         const double *cst = cs->io_const_col[w] >= 0 ? cs->d_io_cols + (size_t)cs->io_const_col[w] * ctx->L * M : nullptr;
-        hipLaunchKernelGGL(io_mid_out_kernel, tgrid, dim3(256), 0, st, colv(3 + w), io, cs->d_io_cols, d_asg, cst, outs[w],
+        hipLaunchKernelGGL(io_mid_out_kernel, tgrid64, dim3(256), 0, st, colv(3 + w), io, cs->d_io_cols, d_asg, cst, outs[w],
                            outs[3 + w], m, ctx->N, ctx->L, M, ctx->d_qmod);
         continue;
       }

@@ -521,13 +521,13 @@ struct TreeMulOut {
 // half of the inverse is the SUM of the two M-point inverses -- two passes over an M-sized tile, so
 // the whole interpolation of a column runs in ONE launch at two workgroups per CU.
 template <int THREADS, int LOGT_CT = 0, bool NEWTON = false>
-__global__ void __launch_bounds__(THREADS, THREADS / 128)  // two workgroups per CU
+__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : THREADS / 128)  // two workgroups per CU (1024 threads: one, a 2^14 tile)
 tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t col0, unsigned S, unsigned slots_per_limb,
                     ColPlans plans) {
   const int logT = LOGT_CT ? LOGT_CT : logT_arg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
-  constexpr int LOGW = THREADS == 512 ? 3 : (THREADS == 256 ? 2 : (THREADS == 128 ? 1 : 0));
+  constexpr int LOGW = THREADS == 1024 ? 4 : (THREADS == 512 ? 3 : (THREADS == 256 ? 2 : (THREADS == 128 ? 1 : 0)));
   constexpr int EPT = 16;  // coefficients per lane: T / THREADS <= 16
   const int M = 1 << logM;
   // workgroup = one tile of T = 2^logT coefficients: levels 1..logT of the tree below position pos0
@@ -750,13 +750,13 @@ h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, do
 // between rounds.  Lane l of wave w owns positions off + l + 64 j; `u` is parked in the output
 // column (L2) while the second half runs.
 template <int THREADS, int LOGM_CT = 0>
-__global__ void __launch_bounds__(THREADS, THREADS / 128)
+__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : THREADS / 128)
 h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, double *__restrict__ H, int logM_arg, int m,
               unsigned slots_per_limb, ColPlans plans, const uint64_t *__restrict__ d1, const uint64_t *__restrict__ d2,
               const uint64_t *__restrict__ d3) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
-  constexpr int LOGW = THREADS == 512 ? 3 : (THREADS == 256 ? 2 : (THREADS == 128 ? 1 : 0));
+  constexpr int LOGW = THREADS == 1024 ? 4 : (THREADS == 512 ? 3 : (THREADS == 256 ? 2 : (THREADS == 128 ? 1 : 0)));
   constexpr int EPT = 16;
   const int logM = LOGM_CT ? LOGM_CT : logM_arg;
   const int M = 1 << logM;
@@ -1350,7 +1350,7 @@ static void launch_tree_tiles(double *cols, size_t ncols, size_t col0, int logM,
   const size_t T = (size_t)1 << logT;
   const size_t lds1 = padded_len(T) * sizeof(double);
   const unsigned grid = (unsigned)(ncols << (logM - logT));
-  const int thr = (int)std::max<size_t>(64, std::min<size_t>(512, T / 16));
+  const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, T / 16));  // 1024 only for a 2^14 tile (one workgroup per CU)
   RS_REQUIRE(T / thr <= 16 && logT >= 6, "tree tile out of range");
   RS_REQUIRE(!newton || logT == logM, "fused Newton conversion needs single-tile columns");
 #define RS_TREE_LAUNCH_K(KERN)                                                                                   \
@@ -1371,7 +1371,8 @@ static void launch_tree_tiles(double *cols, size_t ncols, size_t col0, int logM,
       RS_TREE_LAUNCH_K((tree_columns_kernel<512, 13, true>));
     else
       RS_TREE_LAUNCH_K((tree_columns_kernel<512, 13, false>));
-  } else if (thr == 512) RS_TREE_LAUNCH(512);
+  } else if (thr == 1024) RS_TREE_LAUNCH(1024);
+  else if (thr == 512) RS_TREE_LAUNCH(512);
   else if (thr == 256) RS_TREE_LAUNCH(256);
   else if (thr == 128) RS_TREE_LAUNCH(128);
   else RS_TREE_LAUNCH(64);
@@ -1512,9 +1513,17 @@ static size_t big_chunk_cols(const WitnessPlan *P) {
   return std::max<size_t>(1, ((size_t)6 << 30) / per_col);
 }
 
+// Columns handled by the M-tile kernels (fused Newton + tree, h_tile): 2^10 .. 2^13 at two workgroups
+// per CU, and 2^14 (a 136 KiB tile, one 1024-thread workgroup per CU) when the tile knob is at its
+// natural setting -- one launch instead of the multi-pass path.
+static bool single_tile_ok(int logM) {
+  if (g_witness_split != 2 || logM < 10) return false;
+  return logM <= g_witness_lds_logM || (logM == 14 && g_witness_lds_logM == 13);
+}
+
 static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, double *cols, size_t ncols, size_t S,
                           size_t slots_per_limb, hipStream_t st) {
-  if (P->logM <= g_witness_lds_logM && P->logM >= 10 && g_witness_split == 2) {
+  if (single_tile_ok(P->logM)) {
     // one launch, tile = M, two workgroups per CU: Newton conversion by the two rooted M-point
     // sub-transforms, then the product tree in place
     launch_tree_tiles(cols, ncols, 0, P->logM, P->logM, S, slots_per_limb, cp, st, true);
@@ -1556,7 +1565,7 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp,
 static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const double *A, const double *B, double *H,
                      size_t S, size_t N, const uint64_t *d1, const uint64_t *d2, const uint64_t *d3, hipStream_t st) {
   const size_t M = P->M;
-  if (P->logM <= g_witness_lds_logM && P->logM >= 10 && g_witness_split == 2) {
+  if (single_tile_ok(P->logM)) {
     const size_t lds1 = padded_len(M) * sizeof(double);
     const int thr = (int)(M / 16);
 #define RS_H_LAUNCH(KERN)                                                                                          \
@@ -1565,7 +1574,8 @@ static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, cons
     hipLaunchKernelGGL(KERN, dim3((unsigned)S), dim3(thr), lds1, st, A, B, H, P->logM, (int)P->m, (unsigned)N, cp, \
                        d1, d2, d3);                                                                                \
   } while (0)
-    if (thr == 512 && g_witness_tree_ct) RS_H_LAUNCH((h_tile_kernel<512, 13>));
+    if (thr == 1024) RS_H_LAUNCH((h_tile_kernel<1024, 0>));
+    else if (thr == 512 && g_witness_tree_ct) RS_H_LAUNCH((h_tile_kernel<512, 13>));
     else if (thr == 512) RS_H_LAUNCH((h_tile_kernel<512, 0>));
     else if (thr == 256) RS_H_LAUNCH((h_tile_kernel<256, 0>));
     else if (thr == 128) RS_H_LAUNCH((h_tile_kernel<128, 0>));

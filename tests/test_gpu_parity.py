@@ -273,11 +273,12 @@ def _horner(coeffs, x, q):
     return acc
 
 
-@pytest.mark.parametrize("m", [1500, 3000, 8192, 10000])
+@pytest.mark.parametrize("m", [1500, 3000, 8192, 10000, 20000])
 def test_witness_map_full_size_columns(m):
     """Headline-size primes at column lengths the oracle cannot follow on every slot: M = 2048, 4096,
-    8192 (single-tile kernels at 128 / 256 / 512 threads, the last one the level-unrolled shape of
-    the benchmark) and m = 10000 > 8192 (the natural multi-pass path on 2^13 tiles).  Checked
+    8192, 16384 (single-tile kernels at 128 / 256 / 512 / 1024 threads; 512 is the level-unrolled
+    shape of the benchmark, 1024 the one-workgroup-per-CU 2^14 tile) and m = 20000 (M = 2^15: the
+    natural multi-pass path on 2^13 tiles).  Checked
     against the oracle's O(n^2) interpolation on one slot, and on other slots through
     size-independent properties: P(j) = y_j on the domain and H*Z = A*B - C at random points."""
     dev = dev_for("toy44")
@@ -316,7 +317,7 @@ def test_witness_map_full_size_columns(m):
             assert lhs == rhs
 
 
-@pytest.mark.parametrize("m", [1500, 3000, 8192, 9000])
+@pytest.mark.parametrize("m", [1500, 3000, 8192, 9000, 17000])
 def test_witness_map_is_deterministic(m):
     """Race detector for the LDS kernels: repeated runs on the same inputs must agree bit for bit
     (a missing barrier shows up as run-to-run differences long before it fails a single comparison)."""

@@ -7,6 +7,9 @@ from ringsnark_amd.device import Device
 L_local = int(sys.argv[1]); logm = int(sys.argv[2]); tshare = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 prm = P.preset("C3"); prm = P.RingParams(prm.N, prm.q[:L_local], prm.N_enc, prm.Q)
 dev = Device(prm); m = 1 << logm
+if len(sys.argv) > 4:
+    from ringsnark_amd import _lib
+    _lib.check(_lib.load().rs_set_tuning(b"witness_lds_logM", int(sys.argv[4])))
 cs = R.chain_r1cs(m, prm.q); dcs = dev.r1cs(cs)
 asg = dev.ring_empty(m + 2); dev.fill_uniform(asg[:2], 0, 7); dev.chain_assignment(asg, m)
 mt = m // tshare

@@ -716,14 +716,18 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
         mac_launches++;
       }
     };
-    const bool v2 = g_mac_variant >= 2 && n_crs == 1 && n >= 2048 && n <= 8192;
-    if (v2) {  // streaming kernel: one accumulator set per launch
+    // streaming kernel, one accumulator set (CRS vector c, group g) per launch.  With two CRS
+    // vectors (Rinocchio's s_pows / alpha_s_pows) the plaintext transform is repeated per vector:
+    // measured faster than the generic kernel that shares it (g_mac_variant == 2: generic for n_crs == 2).
+    const bool v2 = g_mac_variant >= 2 && (n_crs == 1 || g_mac_variant != 2) && n >= 2048 && n <= 8192;
+    if (v2) {
+      for (int c = 0; c < n_crs; c++)
       for (int g = 0; g < n_groups; g++) {
         MacArgs2 a2;
         a2.C = Cptr(g);
         a2.terms = group_terms(g);
-        a2.crs = d_crs[0] + t0 * enc_words;
-        a2.partial = d_partial + (size_t)g * enc_words;
+        a2.crs = d_crs[c] + t0 * enc_words;
+        a2.partial = d_partial + (size_t)(c * n_groups + g) * enc_words;
         a2.part_stride = (size_t)n_sets * enc_words;
         a2.terms_per_chunk = base.terms_per_chunk;
         a2.n_chunks = base.n_chunks;

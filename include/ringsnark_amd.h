@@ -162,6 +162,17 @@ int rs_r1cs_evaluate(rs_ctx *ctx, const rs_r1cs *cs, int which /*0=a,1=b,2=c*/, 
                      const uint64_t *d_assignment /* [n_vars][L][N] */, uint64_t *d_out /* [m][L][N] */,
                      rs_stream stream);
 
+/* r1cs_to_qrp_instance_map_with_evaluation (reductions/r1cs_to_qrp/r1cs_to_qrp.tcc:76-116, with
+ * evaluate_all_lagrange_polynomials / compute_vanishing_polynomial, util/evaluation_domain.tcc:21-50):
+ * what generator and verifier compute from the constraint system and the secret point s
+ * (groth16.tcc:7-9,127-128; rinocchio.tcc:7-9,219-220).  d_s [L][N]; outputs d_At, d_Bt, d_Ct
+ * [n_vars+1][L][N] (A_k(s) per variable, k = 0 the constant one), d_Ht [m+1][L][N] (powers of s),
+ * d_Zt [L][N] (Z(s)).  Returns RS_ERR_NOT_INVERTIBLE with the reference's message when s hits the
+ * domain in some slot ("t cannot be one of the values in the domain").  Synchronises. */
+int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, uint64_t *d_At, uint64_t *d_Bt, uint64_t *d_Ct,
+                         uint64_t *d_Ht, uint64_t *d_Zt, rs_stream stream);
+
+
 /* ---- a10-a13: r1cs_to_qrp_witness_map (reductions/r1cs_to_qrp/r1cs_to_qrp.tcc:149-259) ----
  * Outputs in ring layout: A_io..C_mid [m][L][N], H [m+1][L][N]; h_Z [L][m+1] slot-constant
  * scalars (coefficients_for_Z).  d1,d2,d3: ring elements [L][N] or all NULL (zero).  Any output

@@ -73,6 +73,7 @@ SIGNATURES = {
     "rs_enc_wire_size": (C.c_size_t, [vp, C.c_size_t]),
     "rs_enc_serialize": (C.c_int, [vp, vp, u8p, C.c_size_t, vp, C.c_size_t, vp]),
     "rs_enc_deserialize": (C.c_int, [vp, vp, C.c_size_t, vp, u8p, C.c_size_t, C.POINTER(C.c_size_t), vp]),
+    "rs_instance_map_eval": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "rs_enc_decode": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp]),
     "rs_enc_encode": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint64, vp, vp]),
     "rs_inner_product": (C.c_int, [vp, vp, vp, u8p, C.c_size_t, vp, C.POINTER(C.c_size_t), vp]),

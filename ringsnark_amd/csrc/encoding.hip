@@ -369,3 +369,134 @@ int rs_enc_deserialize(rs_ctx *ctx, const void *h_buf, size_t buf_bytes, uint64_
 }
 
 }  // extern "C"
+
+// ---- r1cs_to_qrp_instance_map_with_evaluation --------------------------------------
+// ringsnark/reductions/r1cs_to_qrp/r1cs_to_qrp.tcc:76-116 with util/evaluation_domain.tcc:21-50.
+// What generator and verifier run before anything else (groth16.tcc:7-9, 127-128; rinocchio.tcc:7-9,
+// 219-220).  The reference spends O(m^2) ring multiplications on the Lagrange polynomials; here
+//     u_j(s) = Z(s) * (s - j)^-1 * c_j,   c_j = 1 / prod_{i != j} (j - i) = (-1)^(m-1-j) / (j! (m-1-j)!)
+// (slot-constant c_j), one batched ring inversion, and At / Bt / Ct = transpose(A/B/C) * u through
+// the same sparse kernel as row a14 on the transposed CSR.  Every value is a canonical residue of an
+// exact ring expression, hence bit-identical to the reference's order of operations.
+namespace rs {
+void r1cs_evaluate_run(rs_ctx *ctx, const rs_r1cs *cs, int which, int mode, const uint64_t *d_asg, uint64_t *d_out,
+                       hipStream_t st);
+
+// per slot: Ht[j] = s^j (j <= m), D[j] = s - j (j < m), Zt = prod_j (s - j)
+__global__ void __launch_bounds__(256)
+powers_kernel(const uint64_t *__restrict__ s, uint64_t *__restrict__ Ht, uint64_t *__restrict__ D, uint64_t *__restrict__ Zt,
+              size_t m, int N, int L, const Mod *__restrict__ qmod) {
+  const size_t S = (size_t)L * N, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S) return;
+  const Mod mod = qmod[i / (size_t)N];
+  const double sv = center(from_u64(s[i]), mod);
+  double pw = 1.0, z = 1.0;
+  for (size_t j = 0; j <= m; j++) {
+    Ht[j * S + i] = to_u64(canon(pw, mod));
+    if (j < m) {
+      const double d = reduce(sv - (double)j, mod);
+      D[j * S + i] = to_u64(canon(d, mod));
+      z = mulmod(z, d, mod);
+    }
+    pw = mulmod(pw, sv, mod);
+  }
+  Zt[i] = to_u64(canon(z, mod));
+}
+// u[j] = Zt * inv[j] * c[limb][j]   (in place over inv)
+__global__ void __launch_bounds__(256)
+lagrange_kernel(uint64_t *__restrict__ u, const uint64_t *__restrict__ Zt, const double *__restrict__ c, size_t m, int N, int L,
+                const Mod *__restrict__ qmod) {
+  const size_t S = (size_t)L * N, total = m * S, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t j = i / S, sl = i % S;
+    const int limb = (int)(sl / (size_t)N);
+    const Mod mod = qmod[limb];
+    const double v = mulmod(center(from_u64(Zt[sl]), mod), center(from_u64(u[i]), mod), mod);
+    u[i] = to_u64(canon(mulmod(v, c[(size_t)limb * m + j], mod), mod));
+  }
+}
+}  // namespace rs
+
+extern "C" {
+
+int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, uint64_t *d_At, uint64_t *d_Bt, uint64_t *d_Ct,
+                         uint64_t *d_Ht, uint64_t *d_Zt, rs_stream stream) {
+  RS_API_BEGIN
+  RS_REQUIRE(ctx && cs && d_s && d_At && d_Bt && d_Ct && d_Ht && d_Zt, "null argument");
+  const size_t m = cs->m, SW = ctx->ring_words();
+  const int L = ctx->L;
+  hipStream_t st = S(stream);
+  uint64_t *D = nullptr;
+  RS_HIP(hipMalloc(&D, m * SW * sizeof(uint64_t)));
+  struct Guard {
+    std::vector<void *> p;
+    ~Guard() {
+      for (void *x : p) (void)hipFree(x);
+    }
+  } guard;
+  guard.p.push_back(D);
+  hipLaunchKernelGGL(powers_kernel, dim3((unsigned)((SW + 255) / 256)), dim3(256), 0, st, d_s, d_Ht, D, d_Zt, m, ctx->N, L,
+                     ctx->d_qmod);
+  RS_HIP(hipGetLastError());
+  // "t cannot be one of the values in the domain" (evaluation_domain.tcc:24-26) == some s - j not invertible
+  const int rc = rs_ring_inv(ctx, D, D, m, stream);
+  if (rc == RS_ERR_NOT_INVERTIBLE) throw Error(RS_ERR_NOT_INVERTIBLE, "t cannot be one of the values in the domain");
+  RS_REQUIRE(rc == RS_OK, rs_last_error());
+  // slot-constant factors c_j = (-1)^(m-1-j) / (j! (m-1-j)!)
+  std::vector<double> hc((size_t)L * m);
+  for (int l = 0; l < L; l++) {
+    const uint64_t q = ctx->q[l];
+    RS_REQUIRE(q > m, "ring prime too small for the evaluation domain");
+    std::vector<uint64_t> fact(m);
+    fact[0] = 1;
+    for (size_t j = 1; j < m; j++) fact[j] = host::mulmod(fact[j - 1], (uint64_t)j % q, q);
+    for (size_t j = 0; j < m; j++) {
+      uint64_t v = host::invmod(host::mulmod(fact[j], fact[m - 1 - j], q), q);
+      if ((m - 1 - j) & 1) v = v ? q - v : 0;
+      hc[(size_t)l * m + j] = host::balanced(v, q);
+    }
+  }
+  double *d_c = nullptr;
+  RS_HIP(hipMalloc(&d_c, hc.size() * sizeof(double)));
+  guard.p.push_back(d_c);
+  RS_HIP(hipMemcpyAsync(d_c, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  const unsigned lb = (unsigned)std::min<size_t>((m * SW + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(lagrange_kernel, dim3(lb), dim3(256), 0, st, D, d_Zt, d_c, m, ctx->N, L, ctx->d_qmod);
+  RS_HIP(hipGetLastError());
+  RS_HIP(hipStreamSynchronize(st));  // hc
+  // transposed system: row k (variable k, 0 = the constant one) holds (constraint i + 1, coeff)
+  const size_t rows = cs->n_vars + 1;
+  std::vector<uint32_t> rp[3], col[3];
+  std::vector<uint64_t> cf[3];
+  const uint32_t *rpp[3], *colp[3];
+  const uint64_t *cfp[3];
+  size_t nnz[3];
+  for (int w = 0; w < 3; w++) {
+    const size_t z = cs->nnz[w];
+    nnz[w] = z;
+    rp[w].assign(rows + 1, 0);
+    for (size_t e = 0; e < z; e++) rp[w][cs->h_col[w][e] + 1]++;
+    for (size_t k = 0; k < rows; k++) rp[w][k + 1] += rp[w][k];
+    col[w].resize(std::max<size_t>(z, 1));
+    cf[w].resize(std::max<size_t>((size_t)L * z, 1));
+    std::vector<uint32_t> fill(rp[w].begin(), rp[w].end() - 1);
+    for (size_t i = 0; i < m; i++)
+      for (uint32_t e = cs->h_row_ptr[w][i]; e < cs->h_row_ptr[w][i + 1]; e++) {
+        const uint32_t dst = fill[cs->h_col[w][e]]++;
+        col[w][dst] = (uint32_t)(i + 1);
+        for (int l = 0; l < L; l++) cf[w][(size_t)l * z + dst] = cs->h_coeff[w][(size_t)l * z + e];
+      }
+    rpp[w] = rp[w].data();
+    colp[w] = col[w].data();
+    cfp[w] = cf[w].data();
+  }
+  rs_r1cs *tr = nullptr;
+  RS_REQUIRE(rs_r1cs_create(ctx, rows, m, 0, rpp, colp, cfp, nnz, &tr) == RS_OK, rs_last_error());
+  uint64_t *outs[3] = {d_At, d_Bt, d_Ct};
+  for (int w = 0; w < 3; w++) r1cs_evaluate_run(ctx, tr, w, RS_EVAL_FULL, D, outs[w], st);
+  RS_HIP(hipStreamSynchronize(st));
+  rs_r1cs_destroy(tr);
+  RS_API_END
+}
+
+}  // extern "C"

@@ -177,6 +177,17 @@ class Device:
         _lib.check(self.lib.rs_enc_reduce(self.h, _ptr(enc), self._count(enc, self.enc_words), self.stream()))
         return enc
 
+    # ---- 8(f) f2: instance map with evaluation
+    def instance_map_eval(self, dcs, s):
+        """r1cs_to_qrp_instance_map_with_evaluation (r1cs_to_qrp.tcc:76-116): returns At, Bt, Ct
+        [n_vars+1][L][N], Ht [m+1][L][N], Zt [L][N] for the point s [L][N]."""
+        n1 = dcs.cs.n_vars + 1
+        At, Bt, Ct = self.ring_empty(n1), self.ring_empty(n1), self.ring_empty(n1)
+        Ht, Zt = self.ring_empty(dcs.cs.m + 1), self.ring_empty()
+        _lib.check(self.lib.rs_instance_map_eval(self.h, dcs.h, _ptr(s), _ptr(At), _ptr(Bt), _ptr(Ct), _ptr(Ht), _ptr(Zt),
+                                                 self.stream()))
+        return At, Bt, Ct, Ht, Zt
+
     # ---- 8(f) f4
     def enc_serialize(self, enc, empty=None):
         """Encoding elements (a proof, a key vector) -> bytes in the wire format of ringsnark_amd.h."""

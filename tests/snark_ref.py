@@ -86,12 +86,13 @@ def instance_map_with_evaluation(R, cs, s):
     return out["a"], out["b"], out["c"], Ht, Zt
 
 
-def groth16_generator(ctx, cs, seed, encode):
-    """groth16.tcc:5-66.  `encode(sk, rings[count][L][N], seed) -> encodings`; returns (pk, vk)."""
+def groth16_generator(ctx, cs, seed, encode, imap=None):
+    """groth16.tcc:5-66.  `encode(sk, rings[count][L][N], seed) -> encodings`; `imap(s)` (optional)
+    replaces the CPU instance map with evaluation; returns (pk, vk)."""
     R = Ring(ctx)
     rng = np.random.RandomState(seed)
     s = R.random_exceptional(rng, cs.m)
-    At, Bt, Ct, Ht, Zt = instance_map_with_evaluation(R, cs, s)
+    At, Bt, Ct, Ht, Zt = imap(s) if imap else instance_map_with_evaluation(R, cs, s)
     sk = ctx.keygen(seed + 1)
     alpha, beta, gamma, delta = (R.random_invertible(rng) for _ in range(4))
     delta_inv = R.inv(delta)

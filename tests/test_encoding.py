@@ -76,8 +76,8 @@ def test_enc_encode_decode_match_oracle(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,m", [("toy", 6), ("toy49", 12)])
 def test_device_proof_verifies_under_reference_equation(name, m):
-    """generator (CPU restatement, encryption on the DEVICE) -> device prover -> device decode ->
-    the reference's verification equation; then a tampered input must be rejected."""
+    """generator (instance map with evaluation and encryption on the DEVICE) -> device prover ->
+    device decode -> the reference's verification equation; then a tampered input must be rejected."""
     from ringsnark_amd.device import Device, to_host
     prm = P.preset(name)
     dev, ctx = Device(prm), H.oracle_ctx(prm)
@@ -87,7 +87,10 @@ def test_device_proof_verifies_under_reference_equation(name, m):
     def encode_on_device(sk, rings, seed):
         return to_host(dev.enc_encode(dev.put(sk), dev.put(rings), seed))
 
-    pk, vk = S.groth16_generator(ctx, cs, 21, encode_on_device)
+    def imap_on_device(s):
+        return [to_host(x) for x in dev.instance_map_eval(dev.r1cs(cs), dev.put(s))]
+
+    pk, vk = S.groth16_generator(ctx, cs, 21, encode_on_device, imap_on_device)
     got, empty = dev.groth16_prove(dev.r1cs(cs), {k: dev.put(v) for k, v in pk.items()}, dev.put(asg))
     assert [int(e) for e in empty] == [0, 0, 0]
     dec = to_host(dev.enc_decode(dev.put(vk["sk"]), got))
@@ -161,3 +164,27 @@ def test_wire_format_roundtrip_and_validation():
     dev49 = Device(P.preset("toy49"))
     with pytest.raises(_lib.RsError):
         dev49.enc_deserialize(data)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,m,kind", [("toy", 6, "chain"), ("toy49", 11, "wide")])
+def test_instance_map_with_evaluation_matches_restatement(name, m, kind):
+    """At/Bt/Ct/Ht/Zt on the device against the O(m^2) restatement of
+    r1cs_to_qrp.tcc:76-116 (tests/snark_ref.py), bit for bit; a point inside the domain is refused."""
+    from ringsnark_amd import _lib
+    from ringsnark_amd.device import Device, to_host
+    prm = P.preset(name)
+    dev, ctx = Device(prm), H.oracle_ctx(prm)
+    cs = R.chain_r1cs(m, prm.q) if kind == "chain" else R.wide_r1cs(m, prm.q)
+    Rg = S.Ring(ctx)
+    s = Rg.random_exceptional(np.random.RandomState(4), m)
+    At, Bt, Ct, Ht, Zt = S.instance_map_with_evaluation(Rg, cs, s)
+    got = dev.instance_map_eval(dev.r1cs(cs), dev.put(s))
+    for g, e in zip(got[:4], (At, Bt, Ct, Ht)):
+        assert (to_host(g) == np.stack(e)).all()
+    assert (to_host(got[4]) == Zt).all()
+    bad = s.copy()
+    bad[1, 3] = m - 1  # s hits node m-1 in one slot
+    with pytest.raises(_lib.RsError) as ei:
+        dev.instance_map_eval(dev.r1cs(cs), dev.put(bad))
+    assert "t cannot be one of the values in the domain" in str(ei.value)

@@ -188,3 +188,25 @@ def test_instance_map_with_evaluation_matches_restatement(name, m, kind):
     with pytest.raises(_lib.RsError) as ei:
         dev.instance_map_eval(dev.r1cs(cs), dev.put(bad))
     assert "t cannot be one of the values in the domain" in str(ei.value)
+
+
+@pytest.mark.gpu
+def test_new_entry_points_reject_bad_arguments():
+    """Error behaviour of the 8(f) entry points: status codes, never a crash."""
+    import ctypes as C
+    from ringsnark_amd import _lib
+    from ringsnark_amd.device import Device, _ptr
+    dev = Device(P.preset("toy"))
+    lib = dev.lib
+    enc = dev.enc_empty(2)
+    buf = (C.c_uint8 * 16)()
+    assert lib.rs_enc_wire_size(None, 3) == 0
+    assert lib.rs_enc_serialize(dev.h, _ptr(enc), None, 2, buf, 16, None) == _lib.RS_ERR_INVALID
+    assert b"buffer too small" in lib.rs_last_error()
+    assert lib.rs_enc_decode(dev.h, None, _ptr(enc), 2, _ptr(dev.ring_empty(2)), None) == _lib.RS_ERR_INVALID
+    assert lib.rs_enc_encode(dev.h, None, None, 1, 0, None, None) == _lib.RS_ERR_INVALID
+    cnt = C.c_size_t(0)
+    assert lib.rs_enc_deserialize(dev.h, buf, 16, None, None, 0, C.byref(cnt), None) == _lib.RS_ERR_INVALID
+    assert lib.rs_instance_map_eval(dev.h, None, None, None, None, None, None, None, None) == _lib.RS_ERR_INVALID
+    # count == 0 is a no-op
+    assert lib.rs_enc_decode(dev.h, _ptr(enc), _ptr(enc), 0, _ptr(dev.ring_empty()), None) == _lib.RS_OK

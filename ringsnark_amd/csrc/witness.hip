@@ -599,7 +599,7 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
   wave_sync();
   school_levels_lds(sb, logb, logM, pos0 + off, P, wl);
   wave_sync();
-#pragma unroll
+#pragma unroll LOGT_CT ? 32 : 1
   for (int l = SCHOOL_LEVELS + 1; l <= (LOGT_CT ? LOGT_CT : 20); l++) {
     if (l > logT) break;
     const int n = 1 << l, h = n >> 1;

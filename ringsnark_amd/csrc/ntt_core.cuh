@@ -50,6 +50,16 @@ __host__ __device__ inline size_t padded_len(size_t n) { return n + (n >> PAD_SH
 __host__ __device__ __forceinline__ int pcomb(int pb, int poff) { return pb + poff; }
 __host__ __device__ __forceinline__ int pnext(int pi) { return pi + 1; }
 #endif
+// LDS address of a lane's j-th own position lane + 64*j, given p0 = pidx(lane): 64*j is a multiple
+// of the pad period, so the address is p0 plus a compile-time constant (it folds into the ds
+// instruction's immediate offset instead of costing three integer ops per access).
+__host__ __device__ __forceinline__ int own_pidx(int p0, int ln, int j) {
+#if RS_LDS_SWIZZLE
+  return pidx(ln + 64 * j);
+#else
+  return p0 + 64 * j + ((64 * j) >> PAD_SHIFT);
+#endif
+}
 // smallest block whose addresses are closed under pidx and translate with the block offset
 // (LdsBlockIO): wave-private transforms need n / W >= this
 constexpr int LDS_BLOCK_MIN = RS_LDS_SWIZZLE ? 256 : 128;

@@ -554,21 +554,23 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
       // hoisted over the transforms, spilled and reloaded one by one.
       int ln = lane;
       asm volatile("" : "+v"(ln));
+      int p0 = pidx(ln);
 #pragma unroll
       for (int j = 0; j < EPT; j++)
         if (j < per) {
           const int k = off + ln + 64 * j;
-          sb[pidx(ln + 64 * j)] = mulmod(c[k], P.invfact[k], mod);
+          sb[own_pidx(p0, ln, j)] = mulmod(c[k], P.invfact[k], mod);
         }
       __syncthreads();
       lds_ntt_fwd_wp<3, LdsIO, ColBlockFactory, 3>(s, lds, bf, logT, LOGW, P.tw, mod, P.fwd_mask2 >> 1, 2 + half);
       const double *eh = P.ehat + (size_t)half * M + off;
       ln = lane;
       asm volatile("" : "+v"(ln));
+      p0 = pidx(ln);
 #pragma unroll
       for (int j = 0; j < EPT; j++)
         if (j < per) {
-          const int pi = pidx(ln + 64 * j);
+          const int pi = own_pidx(p0, ln, j);
           sb[pi] = mulmod(reduce(sb[pi], mod), eh[ln + 64 * j], mod);
         }
       wave_sync();
@@ -576,19 +578,21 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
       if (half == 0) {
         ln = lane;
         asm volatile("" : "+v"(ln));
+        p0 = pidx(ln);
 #pragma unroll
         for (int j = 0; j < EPT; j++)
-          if (j < per) u[j] = sb[pidx(ln + 64 * j)];
+          if (j < per) u[j] = sb[own_pidx(p0, ln, j)];
         __syncthreads();  // every wave has saved its block before the tile is refilled
       }
     }
     // Newton coefficients k < m; the convolution tail is discarded
     int ln = lane;
     asm volatile("" : "+v"(ln));
+    const int p0 = pidx(ln);
 #pragma unroll
     for (int j = 0; j < EPT; j++)
       if (j < per) {
-        const int pi = pidx(ln + 64 * j);
+        const int pi = own_pidx(p0, ln, j);
         sb[pi] = (P.invfact[off + ln + 64 * j] != 0.0) ? reduce(u[j] + sb[pi], mod) : 0.0;
       }
   } else {
@@ -608,10 +612,11 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
     // spilled, and every use becomes a serialised scratch reload (s_waitcnt vmcnt(0))
     int ln = lane;
     asm volatile("" : "+v"(ln));
+    const int p0 = pidx(ln);
     double r[EPT];  // this lane's old coefficients; the F_left ones are added back at the end
 #pragma unroll
     for (int j = 0; j < EPT; j++)
-      if (j < per) r[j] = sb[pidx(ln + 64 * j)];
+      if (j < per) r[j] = sb[own_pidx(p0, ln, j)];
     const double *dh = P.dhat + (size_t)l * M + pos0 + off;
     if (priv) {
       // Nodes inside the wave's block, no workgroup barrier.  The first forward round reads
@@ -646,7 +651,7 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
 #pragma unroll
     for (int j = 0; j < EPT; j++)
       if (j < per) {
-        const int i = off + ln + 64 * j, pi = pidx(ln + 64 * j);
+        const int i = off + ln + 64 * j, pi = own_pidx(p0, ln, j);
         sb[pi] = reduce(sb[pi] + (((i & (n - 1)) < h) ? r[j] : 0.0), mod);
       }
     if (priv) wave_sync(); else __syncthreads();
@@ -773,29 +778,30 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
   const uint32_t fmask = P.fwd_mask2 >> 1, imask = P.inv_mask2;
   // `ln`: fresh copies of the lane index keep each phase's 16 tile addresses from being hoisted over
   // the transforms, spilled and reloaded one by one
-#define RS_FRESH_LANE() \
-  int ln = lane;        \
-  asm volatile("" : "+v"(ln))
+#define RS_FRESH_LANE()        \
+  int ln = lane;               \
+  asm volatile("" : "+v"(ln)); \
+  const int p0 __attribute__((unused)) = pidx(ln)
   double r[EPT];
 #pragma unroll
   for (int half = 0; half < 2; half++) {
     {
       RS_FRESH_LANE();
 #pragma unroll
-      for (int j = 0; j < EPT; j++) sb[pidx(ln + 64 * j)] = center(srcA[off + ln + 64 * j], mod);
+      for (int j = 0; j < EPT; j++) sb[own_pidx(p0, ln, j)] = center(srcA[off + ln + 64 * j], mod);
     }
     __syncthreads();
     lds_ntt_fwd_wp<3, LdsIO, ColBlockFactory, 3>(s, lds, bf, logM, LOGW, P.tw, mod, fmask, 2 + half);
     {
       RS_FRESH_LANE();
 #pragma unroll
-      for (int j = 0; j < EPT; j++) r[j] = reduce(sb[pidx(ln + 64 * j)], mod);
+      for (int j = 0; j < EPT; j++) r[j] = reduce(sb[own_pidx(p0, ln, j)], mod);
     }
     __syncthreads();  // every wave has its slice of the spectrum of A before the tile is refilled
     {
       RS_FRESH_LANE();
 #pragma unroll
-      for (int j = 0; j < EPT; j++) sb[pidx(ln + 64 * j)] = center(srcB[off + ln + 64 * j], mod);
+      for (int j = 0; j < EPT; j++) sb[own_pidx(p0, ln, j)] = center(srcB[off + ln + 64 * j], mod);
     }
     __syncthreads();
     lds_ntt_fwd_wp<3, LdsIO, ColBlockFactory, 3>(s, lds, bf, logM, LOGW, P.tw, mod, fmask, 2 + half);
@@ -803,7 +809,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
       RS_FRESH_LANE();
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
-        const int pi = pidx(ln + 64 * j);
+        const int pi = own_pidx(p0, ln, j);
         sb[pi] = mulmod(r[j], reduce(sb[pi], mod), mod);
       }
     }
@@ -812,7 +818,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
     if (half == 0) {
       RS_FRESH_LANE();
 #pragma unroll
-      for (int j = 0; j < EPT; j++) dst[off + ln + 64 * j] = reduce(sb[pidx(ln + 64 * j)], mod);  // park u
+      for (int j = 0; j < EPT; j++) dst[off + ln + 64 * j] = reduce(sb[own_pidx(p0, ln, j)], mod);  // park u
       __syncthreads();
     }
   }
@@ -821,13 +827,13 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
   {
     RS_FRESH_LANE();
 #pragma unroll
-    for (int j = 0; j < EPT; j++) r[j] = reduce(sb[pidx(ln + 64 * j)], mod);  // v
+    for (int j = 0; j < EPT; j++) r[j] = reduce(sb[own_pidx(p0, ln, j)], mod);  // v
   }
   __syncthreads();
   {
     RS_FRESH_LANE();
 #pragma unroll
-    for (int j = 0; j < EPT; j++) sb[pidx(ln + 64 * j)] = 0.0;
+    for (int j = 0; j < EPT; j++) sb[own_pidx(p0, ln, j)] = 0.0;
   }
   __syncthreads();
   {
@@ -845,7 +851,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
   {
     RS_FRESH_LANE();
 #pragma unroll
-    for (int j = 0; j < EPT; j++) r[j] = sb[pidx(ln + 64 * j)];  // own slice of T, for the second half
+    for (int j = 0; j < EPT; j++) r[j] = sb[own_pidx(p0, ln, j)];  // own slice of T, for the second half
   }
   __syncthreads();  // the cross-wave round below writes every block: all slices must be saved first
   double uu[EPT];
@@ -854,7 +860,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
     if (half == 1) {
       RS_FRESH_LANE();
 #pragma unroll
-      for (int j = 0; j < EPT; j++) sb[pidx(ln + 64 * j)] = r[j];
+      for (int j = 0; j < EPT; j++) sb[own_pidx(p0, ln, j)] = r[j];
       __syncthreads();
     }
     lds_ntt_fwd_wp<3, LdsIO, ColBlockFactory, 3>(s, lds, bf, logM, LOGW, P.tw, mod, fmask, 2 + half);
@@ -863,7 +869,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
       const double *sh = P.shat + (size_t)half * M + off;
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
-        const int pi = pidx(ln + 64 * j);
+        const int pi = own_pidx(p0, ln, j);
         sb[pi] = mulmod(reduce(sb[pi], mod), sh[ln + 64 * j], mod);
       }
     }
@@ -872,7 +878,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
     if (half == 0) {
       RS_FRESH_LANE();
 #pragma unroll
-      for (int j = 0; j < EPT; j++) uu[j] = sb[pidx(ln + 64 * j)];
+      for (int j = 0; j < EPT; j++) uu[j] = sb[own_pidx(p0, ln, j)];
       __syncthreads();
     }
   }
@@ -881,7 +887,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
     RS_FRESH_LANE();
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      const int pi = pidx(ln + 64 * j);
+      const int pi = own_pidx(p0, ln, j);
       sb[pi] = reduce(uu[j] + sb[pi], mod);
     }
   }

@@ -98,9 +98,17 @@ def main():
     from ringsnark_amd import dist as RD
     from ringsnark_amd.device import Device
 
+    # Developer rehearsal of the N > 1 path on a single-GPU box: RINGSNARK_BENCH_REHEARSAL=1 puts every
+    # rank on cuda:0 and uses gloo (the numbers mean nothing; the code path is the production one).
+    rehearsal = os.environ.get("RINGSNARK_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     prm = P.preset(args.preset)
     m = (1 << args.logm) * world
@@ -117,15 +125,17 @@ def main():
     dev.chain_assignment(asg, m)
     # Every rank allocates only the slice of the key it reads: its limbs, and (when limbs are shared)
     # a view positioned so that its term range [lo, hi) lands on real storage.
-    def key_vector(T, seed):
-        lo, hi = plan.term_range(T)
+    ranges = RD.groth16_key_ranges(plan, m, n_aux)
+
+    def key_vector(name, T, seed):
+        lo, hi = (0, T) if world == 1 else ranges[name]
         store = dev.fill_uniform(dev.enc_empty(max(hi - lo, 1)), 1, seed + 100 * plan.term_shard)
         return RD.TermWindow(store, lo, hi, T)
 
     pk = {
-        "s_pows": key_vector(m + 1, seed0 + 13),
-        "delta_ts": key_vector(m + 1, seed0 + 14),
-        "delta_mid": key_vector(n_aux, seed0 + 15),
+        "s_pows": key_vector("s_pows", m + 1, seed0 + 13),
+        "delta_ts": key_vector("delta_ts", m + 1, seed0 + 14),
+        "delta_mid": key_vector("delta_mid", n_aux, seed0 + 15),
         "alpha": dev.fill_uniform(dev.enc_empty(), 1, seed0 + 16),
         "beta": dev.fill_uniform(dev.enc_empty(), 1, seed0 + 17),
     }

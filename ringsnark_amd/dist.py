@@ -72,6 +72,14 @@ def groups_for(plan: ShardPlan):
     return term_groups[plan.limb_group]
 
 
+def groth16_key_ranges(plan: ShardPlan, m, n_aux):
+    """Term range [lo, hi) of every key vector that THIS rank reads in groth16_prove_sharded:
+    s_pows is used on its first m entries (A and B have m coefficients, groth16.tcc:89-101),
+    delta_ts on all m + 1 (H), delta_mid on n_aux.  A rank that stores only windows of the key
+    (bench.py) must allocate exactly these."""
+    return {"s_pows": plan.term_range(m), "delta_ts": plan.term_range(m + 1), "delta_mid": plan.term_range(n_aux)}
+
+
 def groth16_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_local, assignment_local, m, n_inputs, n_aux):
     """groth16::prover (zk_proof_systems/groth16/groth16.tcc:70-115) on this rank's shard.
 
@@ -79,14 +87,15 @@ def groth16_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_loc
     every rank."""
     w = backend.witness(cs_local, assignment_local, want=("A_io", "A_mid", "B_io", "B_mid", "H"))
     lead = plan.term_shard == 0  # exactly one shard per limb group adds alpha / beta
-    lo, hi = plan.term_range(m)
+    ranges = groth16_key_ranges(plan, m, n_aux)
+    lo, hi = ranges["s_pows"]
     ab = backend.msm([pk_local["s_pows"][lo:hi]],
                      [(w["A_io"][lo:hi], 0), (w["A_mid"][lo:hi], 0), (w["B_io"][lo:hi], 1), (w["B_mid"][lo:hi], 1)], 2,
                      addends=[pk_local["alpha"], pk_local["beta"]] if lead else None)
-    lo, hi = plan.term_range(m + 1)
+    lo, hi = ranges["delta_ts"]
     c = backend.msm([pk_local["delta_ts"][lo:hi]], [(w["H"][lo:hi], 0)], 1)
     if n_aux:
-        lo, hi = plan.term_range(n_aux)
+        lo, hi = ranges["delta_mid"]
         aux = assignment_local[n_inputs:]
         c2 = backend.msm([pk_local["delta_mid"][lo:hi]], [(aux[lo:hi], 0)], 1)
         c = backend.enc_add(c, c2)

@@ -165,3 +165,27 @@ def test_sharded_groth16_on_device_backend(tmp_path, q_override):
     out = str(tmp_path / "result.txt")
     mp.spawn(_gpu_worker, args=(2, _free_port(), 9, q_override, out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+def test_key_windows_cover_every_slice_the_sharded_prover_takes():
+    """bench.py allocates only a window of each key vector per rank; the windows must be exactly the
+    ranges groth16_prove_sharded reads (s_pows on m of its m+1 entries), for every plan shape."""
+    from ringsnark_amd import dist as RD
+    for world, L in ((1, 4), (2, 4), (4, 4), (8, 4), (4, 2), (8, 2), (3, 4), (6, 4)):
+        for m in (1, 2, 7, 1024, 8192 * world, 8192 * world + 1):
+            n_aux = m
+            covered = {k: [] for k in ("s_pows", "delta_ts", "delta_mid")}
+            for rank in range(world):
+                plan = RD.make_plan(world, rank, L)
+                rg = RD.groth16_key_ranges(plan, m, n_aux)
+                T = {"s_pows": m + 1, "delta_ts": m + 1, "delta_mid": n_aux}
+                for k, (lo, hi) in rg.items():
+                    w = RD.TermWindow(list(range(lo, hi)), lo, hi, T[k])
+                    assert w[lo:hi] == list(range(lo, hi))  # the slice the prover takes is inside the window
+                    if plan.limb_group == 0:
+                        covered[k].append((lo, hi))
+            # the term shards of one limb group tile [0, used) without gaps or overlaps
+            for k, used in (("s_pows", m), ("delta_ts", m + 1), ("delta_mid", n_aux)):
+                pieces = sorted(p for p in covered[k] if p[0] < p[1])
+                assert pieces[0][0] == 0 and pieces[-1][1] == used
+                assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))

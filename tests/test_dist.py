@@ -144,9 +144,10 @@ def _gpu_worker(rank, world, port, m, q_override, tmp):
         dev = Device(prm_local, 0)
         dcs = dev.r1cs(R.wide_r1cs(m, prm_local.q))
         pk_local = {}
+        ranges = RD.groth16_key_ranges(plan, m, cs_full.n_aux)
         for k, v in pk.items():
-            if v.ndim == 5:  # key vector: keep only this rank's limbs AND its term window
-                lo, hi = plan.term_range(v.shape[0])
+            if v.ndim == 5:  # key vector: keep only this rank's limbs AND the term window it reads
+                lo, hi = ranges[k]
                 pk_local[k] = RD.TermWindow(dev.put(np.ascontiguousarray(v[lo:hi][:, plan.limbs])), lo, hi, v.shape[0])
             else:
                 pk_local[k] = dev.put(np.ascontiguousarray(v[plan.limbs]))
@@ -160,10 +161,10 @@ def _gpu_worker(rank, world, port, m, q_override, tmp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q_override", [None, 1])
-def test_sharded_groth16_on_device_backend(tmp_path, q_override):
+@pytest.mark.parametrize("q_override,m", [(None, 9), (1, 9), (1, 8)])  # m even and odd: the windows of s_pows (m of m+1 entries)
+def test_sharded_groth16_on_device_backend(tmp_path, q_override, m):
     out = str(tmp_path / "result.txt")
-    mp.spawn(_gpu_worker, args=(2, _free_port(), 9, q_override, out), nprocs=2, join=True)
+    mp.spawn(_gpu_worker, args=(2, _free_port(), m, q_override, out), nprocs=2, join=True)
     assert open(out).read() == "ok"
 
 

@@ -282,15 +282,16 @@ mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff
       }
 }
 
-// mac_kernel_v2: the streaming form of the dominant kernel (one accumulator set, 1024 threads,
+// mac_kernel_v2: the streaming form of the dominant kernel (one accumulator set per launch,
 // 2048 <= N_enc <= 8192).  Differences from mac_kernel:
 //   * the twiddle table of Q_j lives in LDS next to the tile (68 + 64 KiB), so inside the term loop
 //     the ONLY vector-memory operations are the streamed operands;
-//   * ciphertext words of term t and the plaintext row of term t+1 are loaded into registers before
-//     the transform of term t starts, so HBM latency and transfer overlap the FP64 work;
-//   * the transform is the wave-private form (ntt_core.cuh): one cross-wave round, then each of the
-//     16 waves finishes its own 512-element block and multiplies exactly that block into its
-//     accumulators -- two workgroup barriers per term instead of seven.
+//   * the ciphertext words of term t are loaded into registers before the transform of term t
+//     starts (512-thread shape: also the plaintext row of term t+1), so HBM latency and transfer
+//     overlap the FP64 work -- provided nothing in the loop forces an early s_waitcnt vmcnt(0);
+//   * the transform is the wave-private form (ntt_core.cuh): the cross-wave stages, then each wave
+//     finishes its own block and multiplies exactly that block into its accumulators -- two or
+//     three workgroup barriers per term instead of seven.
 // radix of the wave-private rounds inside mac_kernel_v2: 3 keeps the kernel free of VGPR spills (a
 // scratch reload inside the term loop costs an s_waitcnt vmcnt(0), which drains the prefetched
 // ciphertext loads and serialises stream and transform)
@@ -306,9 +307,9 @@ struct MacArgs2 {
   int terms_per_chunk, n_chunks;
   int accumulate, acc_period, reduce_u;
 };
-// THREADS = 512: 8 waves, 256 VGPRs per lane -> the whole ciphertext of term t AND the plaintext
-// row of term t+1 are prefetched into registers, 8 coefficient pairs per lane, radix-16 private
-// rounds.  (A 1024-thread shape has half the registers per lane and spills.)
+// THREADS = 1024 (default at N_enc = 8192): 16 waves, 118 VGPRs, four waves per SIMD, the plaintext
+// row loaded where it is used.  THREADS = 512: 8 waves, ~240 VGPRs, the plaintext row of term t+1
+// prefetched as well.  Both use radix-8 private rounds (RS_MAC_MAXR) to stay free of scratch.
 // LOGN_CT != 0: transform length fixed at compile time (rounds specialised).  ABLATE (experiments,
 // tools/mac_ablate.py): 1 = skip the transform, 2 = skip the ciphertext loads, 4 = skip the C loads;
 // a compile-time parameter because a run-time branch around each load makes the compiler wait for

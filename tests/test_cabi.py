@@ -90,3 +90,25 @@ int main() {
         r = subprocess.run([gxx, "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"), f],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_adapters_run_against_the_library(tmp_path):
+    """tests/cpp/adapter_run.cpp: the RingElem / EncodingElem adapters, compiled with plain g++ and
+    linked against librs_hip.so, on the device: ring identities, the reference's error messages and
+    the encoding homomorphism through encode / *= / += / inner_product / decode."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "adapter_run")
+    libdir = os.path.join(ROOT, "ringsnark_amd")
+    r = subprocess.run([gxx, "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "adapter_run.cpp"), "-o", exe, "-L", libdir, "-lrs_hip",
+                        "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    prm = P.preset("toy")
+    args = [str(prm.N), str(prm.L)] + [str(x) for x in prm.q] + [str(prm.N_enc), str(prm.K)] + [str(x) for x in prm.Q]
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "adapter_run: OK" in r.stdout, r.stdout + r.stderr

@@ -29,7 +29,7 @@
 
 namespace rs {
 
-constexpr int SCHOOL_LEVELS = 3;  // tree levels with node size <= 8 use schoolbook products
+constexpr int SCHOOL_LEVELS = 4;  // tree levels with node size <= 8 use schoolbook products
 
 struct LimbPlan {
   uint64_t p = 0;

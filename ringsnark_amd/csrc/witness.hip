@@ -788,20 +788,20 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
     {
       RS_FRESH_LANE();
 #pragma unroll
-      for (int j = 0; j < EPT; j++) sb[own_pidx(p0, ln, j)] = center(srcA[off + ln + 64 * j], mod);
+      for (int j = 0; j < EPT; j++) sb[pidx(ln + 64 * j)] = center(srcA[off + ln + 64 * j], mod);
     }
     __syncthreads();
     lds_ntt_fwd_wp<3, LdsIO, ColBlockFactory, 3>(s, lds, bf, logM, LOGW, P.tw, mod, fmask, 2 + half);
     {
       RS_FRESH_LANE();
 #pragma unroll
-      for (int j = 0; j < EPT; j++) r[j] = reduce(sb[own_pidx(p0, ln, j)], mod);
+      for (int j = 0; j < EPT; j++) r[j] = reduce(sb[pidx(ln + 64 * j)], mod);
     }
     __syncthreads();  // every wave has its slice of the spectrum of A before the tile is refilled
     {
       RS_FRESH_LANE();
 #pragma unroll
-      for (int j = 0; j < EPT; j++) sb[own_pidx(p0, ln, j)] = center(srcB[off + ln + 64 * j], mod);
+      for (int j = 0; j < EPT; j++) sb[pidx(ln + 64 * j)] = center(srcB[off + ln + 64 * j], mod);
     }
     __syncthreads();
     lds_ntt_fwd_wp<3, LdsIO, ColBlockFactory, 3>(s, lds, bf, logM, LOGW, P.tw, mod, fmask, 2 + half);
@@ -809,7 +809,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
       RS_FRESH_LANE();
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
-        const int pi = own_pidx(p0, ln, j);
+        const int pi = pidx(ln + 64 * j);
         sb[pi] = mulmod(r[j], reduce(sb[pi], mod), mod);
       }
     }
@@ -818,7 +818,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
     if (half == 0) {
       RS_FRESH_LANE();
 #pragma unroll
-      for (int j = 0; j < EPT; j++) dst[off + ln + 64 * j] = reduce(sb[own_pidx(p0, ln, j)], mod);  // park u
+      for (int j = 0; j < EPT; j++) dst[off + ln + 64 * j] = reduce(sb[pidx(ln + 64 * j)], mod);  // park u
       __syncthreads();
     }
   }
@@ -827,13 +827,13 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
   {
     RS_FRESH_LANE();
 #pragma unroll
-    for (int j = 0; j < EPT; j++) r[j] = reduce(sb[own_pidx(p0, ln, j)], mod);  // v
+    for (int j = 0; j < EPT; j++) r[j] = reduce(sb[pidx(ln + 64 * j)], mod);  // v
   }
   __syncthreads();
   {
     RS_FRESH_LANE();
 #pragma unroll
-    for (int j = 0; j < EPT; j++) sb[own_pidx(p0, ln, j)] = 0.0;
+    for (int j = 0; j < EPT; j++) sb[pidx(ln + 64 * j)] = 0.0;
   }
   __syncthreads();
   {
@@ -851,7 +851,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
   {
     RS_FRESH_LANE();
 #pragma unroll
-    for (int j = 0; j < EPT; j++) r[j] = sb[own_pidx(p0, ln, j)];  // own slice of T, for the second half
+    for (int j = 0; j < EPT; j++) r[j] = sb[pidx(ln + 64 * j)];  // own slice of T, for the second half
   }
   __syncthreads();  // the cross-wave round below writes every block: all slices must be saved first
   double uu[EPT];
@@ -860,7 +860,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
     if (half == 1) {
       RS_FRESH_LANE();
 #pragma unroll
-      for (int j = 0; j < EPT; j++) sb[own_pidx(p0, ln, j)] = r[j];
+      for (int j = 0; j < EPT; j++) sb[pidx(ln + 64 * j)] = r[j];
       __syncthreads();
     }
     lds_ntt_fwd_wp<3, LdsIO, ColBlockFactory, 3>(s, lds, bf, logM, LOGW, P.tw, mod, fmask, 2 + half);
@@ -869,7 +869,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
       const double *sh = P.shat + (size_t)half * M + off;
 #pragma unroll
       for (int j = 0; j < EPT; j++) {
-        const int pi = own_pidx(p0, ln, j);
+        const int pi = pidx(ln + 64 * j);
         sb[pi] = mulmod(reduce(sb[pi], mod), sh[ln + 64 * j], mod);
       }
     }
@@ -878,7 +878,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
     if (half == 0) {
       RS_FRESH_LANE();
 #pragma unroll
-      for (int j = 0; j < EPT; j++) uu[j] = sb[own_pidx(p0, ln, j)];
+      for (int j = 0; j < EPT; j++) uu[j] = sb[pidx(ln + 64 * j)];
       __syncthreads();
     }
   }
@@ -887,7 +887,7 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
     RS_FRESH_LANE();
 #pragma unroll
     for (int j = 0; j < EPT; j++) {
-      const int pi = own_pidx(p0, ln, j);
+      const int pi = pidx(ln + 64 * j);
       sb[pi] = reduce(uu[j] + sb[pi], mod);
     }
   }

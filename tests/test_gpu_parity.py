@@ -339,3 +339,46 @@ def test_witness_map_is_deterministic(m):
         else:
             for k in cur:
                 assert (cur[k] == first[k]).all(), k
+
+
+def test_c4_shape_rinocchio_configuration():
+    """BASELINE.json configs[3] shape (C4: ring N = 16384 with six 48/49-bit primes, encodings
+    N_enc = 16384 with K = 8): transforms, the inner product (with its special terms) and a small
+    Rinocchio proof, bit-exact against the oracle.  N_enc = 16384 takes the generic MAC kernel and
+    the 136 KiB-tile transforms."""
+    from ringsnark_amd import _lib
+    dev = dev_for("C4")
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    rng = np.random.RandomState(2)
+    logn = prm.N_enc.bit_length() - 1
+    for modset, primes in ((_lib.RS_MOD_PLAIN, prm.q[-1:]), (_lib.RS_MOD_COEFF, prm.Q[-1:])):
+        idx = (prm.L if modset == _lib.RS_MOD_PLAIN else prm.K) - 1
+        p = primes[0]
+        a = (rng.randint(0, 2**62, size=(2, prm.N_enc), dtype=np.int64).astype(np.uint64)) % np.uint64(p)
+        d = dev.put(a)
+        dev.ntt(d, modset, idx)
+        t = O.NTT(logn, p)
+        assert (host(d)[1] == t.fwd(a[1])).all()
+        dev.ntt(d, modset, idx, inverse=True)
+        assert (host(d) == a).all()
+    T = 5
+    encs, rings = ctx.random_enc(31, T), ctx.random_ring(32, T)
+    kinds = np.zeros(T, dtype=np.uint8)
+    rings[2] = 0
+    kinds[4] = O.KIND_ONE
+    exp, used = ctx.inner_product(encs, rings, kinds)
+    got, gused = dev.inner_product(dev.put(encs), dev.put(rings), kinds)
+    assert gused == used and (host(got) == exp).all()
+    m = 3
+    cs = R.wide_r1cs(m, prm.q)
+    asg = H.make_assignment(ctx, cs)
+    pk = dict(s_pows=ctx.random_enc(81, m + 1), alpha_s_pows=ctx.random_enc(82, m + 1), beta_prods=ctx.random_enc(83, cs.n_aux),
+              beta_rv_ts=ctx.random_enc(84), beta_rw_ts=ctx.random_enc(85), beta_ry_ts=ctx.random_enc(86))
+    ds = [ctx.random_ring(90 + k) for k in range(3)]
+    exp, exp_empty = O.rinocchio_prove(ctx, H.oracle_cs(cs), pk, asg, *ds)
+    got, empty = dev.rinocchio_prove(dev.r1cs(cs), {k: dev.put(v) for k, v in pk.items()}, dev.put(asg), *[dev.put(d) for d in ds])
+    assert empty == exp_empty
+    g = host(got)
+    for k in range(9):
+        assert (g[k] == exp[k]).all(), k

@@ -397,4 +397,71 @@ __device__ __forceinline__ void lds_ntt_inv_wp(double *s, const InFactory make_i
   }
 }
 
+// Batched wave-private transforms: the tile holds 2^(logn - logsub) transforms of length 2^logsub,
+// each spanning 2^cw wave blocks (cw = logsub - (logn - logw) >= 1).  Only the cw top stages of
+// every transform cross waves; below them wave w finishes its block as the sub-transform rooted at
+// node 2^cw + (w mod 2^cw).  (The product tree's levels whose nodes are larger than a block.)
+template <int MAXR, class In, class OutFactory, int CROSSR = 3>
+__device__ __forceinline__ void lds_bntt_fwd_wp(double *s, const In first_in, const OutFactory make_out, int logn, int logw,
+                                                int logsub, const double *__restrict__ tw, const Mod mod, uint32_t red_mask) {
+  const LdsIO lds{s};
+  const int logb = logn - logw, cw = logsub - logb;
+  for (int st = 0; st < cw;) {
+    const int R = pick_radix(cw - st, CROSSR);
+    if (st == 0)
+      fwd_round_dispatch<CROSSR>(R, first_in, lds, logn, logsub, st, tw, 1, mod, red_mask);
+    else
+      fwd_round_dispatch<CROSSR>(R, lds, lds, logn, logsub, st, tw, 1, mod, red_mask);
+    __syncthreads();
+    st += R;
+  }
+  const int wave = threadIdx.x >> 6;
+  const int off = wave << logb;
+  const LdsBlockIO blk{s + pidx(off)};
+  const int root = (1 << cw) + (wave & ((1 << cw) - 1));
+  const uint32_t mask = red_mask >> cw;
+  const Lanes ln = wave_lanes();
+  int st = 0;
+  while (st < logb) {
+    const int R = pick_radix(logb - st, MAXR);
+    if (st + R >= logb)
+      fwd_round_dispatch<MAXR>(R, blk, make_out(off), logb, logb, st, tw, root, mod, mask, ln);
+    else
+      fwd_round_dispatch<MAXR>(R, blk, blk, logb, logb, st, tw, root, mod, mask, ln);
+    wave_sync();
+    st += R;
+  }
+}
+template <int MAXR, class InFactory, class Out, int CROSSR = 3>
+__device__ __forceinline__ void lds_bntt_inv_wp(double *s, const InFactory make_in, const Out last_out, int logn, int logw,
+                                                int logsub, const double *__restrict__ itw, const Mod mod, uint32_t red_mask) {
+  const LdsIO lds{s};
+  const int logb = logn - logw, cw = logsub - logb;
+  const int wave = threadIdx.x >> 6;
+  const int off = wave << logb;
+  const LdsBlockIO blk{s + pidx(off)};
+  const int root = (1 << cw) + (wave & ((1 << cw) - 1));
+  const Lanes ln = wave_lanes();
+  int st = 0;
+  while (st < logb) {
+    const int R = pick_radix(logb - st, MAXR);
+    if (st == 0)
+      inv_round_dispatch<MAXR>(R, make_in(off), blk, logb, logb, st, itw, root, mod, red_mask, ln);
+    else
+      inv_round_dispatch<MAXR>(R, blk, blk, logb, logb, st, itw, root, mod, red_mask, ln);
+    wave_sync();
+    st += R;
+  }
+  __syncthreads();
+  for (int st = 0; st < cw;) {
+    const int R = pick_radix(cw - st, CROSSR);
+    if (st + R >= cw)
+      inv_round_dispatch<CROSSR>(R, lds, last_out, logn, logsub, logb + st, itw, 1, mod, red_mask);
+    else
+      inv_round_dispatch<CROSSR>(R, lds, lds, logn, logsub, logb + st, itw, 1, mod, red_mask);
+    __syncthreads();
+    st += R;
+  }
+}
+
 }  // namespace rs

@@ -506,6 +506,13 @@ struct TreeMulOut {
   }
 };
 
+struct TreeMulFactory {  // per-block TreeMulOut (dh_tile: the level table at the tile's first coefficient)
+  double *s;
+  const double *dh_tile;
+  Mod mod;
+  __device__ __forceinline__ TreeMulOut operator()(int off) const { return TreeMulOut{s + pidx(off), dh_tile + off, mod}; }
+};
+
 // Newton -> monomial, one column per workgroup, tile = M doubles only (two workgroups per CU):
 // a level's F_left values wait in registers while the node regions are overwritten in place with
 // (F_right, 0), transformed, multiplied by the spectrum of D_left and transformed back.  Wave w
@@ -643,10 +650,12 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
         st += R;
       }
     } else {
-      // nodes span several waves: same fusion, workgroup-wide rounds (tile indices)
+      // nodes span 2^(l - logb) waves: only that many top stages cross waves (workgroup barriers); the
+      // rest of the forward transform, and the bottom of the inverse, stay inside the wave's block
       __syncthreads();
-      lds_ntt_fwd_io<3>(s, TreeRightIn{s, h}, TreeMulOut{s, dh - off, mod}, logT, l, P.tw, 1, mod, P.fmask[l]);
-      lds_bntt_inv<3>(s, logT, l, P.itw, mod, P.imask[l]);
+      lds_bntt_fwd_wp<3, TreeRightIn, TreeMulFactory, 3>(s, TreeRightIn{s, h}, TreeMulFactory{s, dh - off, mod}, logT, LOGW, l,
+                                                         P.tw, mod, P.fmask[l]);
+      lds_bntt_inv_wp<3, ColBlockFactory, LdsIO, 3>(s, ColBlockFactory{s}, LdsIO{s}, logT, LOGW, l, P.itw, mod, P.imask[l]);
     }
 #pragma unroll
     for (int j = 0; j < EPT; j++)

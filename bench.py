@@ -197,6 +197,26 @@ def main():
                         "launches": nlaunch, "avg_launch_ms": round(timings["msm_mac_ms"] / nlaunch, 3),
                         "algorithmic_bytes_per_launch": nbytes // nlaunch}
 
+    # the standalone transform (row a4), HBM bound by design: 16 bytes per coefficient per transform
+    ntt_roofline = None
+    if world == 1:
+        from ringsnark_amd import _lib
+        batch = 4096
+        polys = torch.empty((batch, prm.N_enc), dtype=torch.int64, device=dev.device).random_(0, int(prm.Q[0]))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            dev.ntt(polys, _lib.RS_MOD_COEFF, 0)
+        reps = 10
+        e0.record()  # the library launches on torch's current stream (device.py passes it down)
+        for _ in range(reps):
+            dev.ntt(polys, _lib.RS_MOD_COEFF, 0)
+        e1.record()
+        torch.cuda.synchronize()
+        gbs = batch * prm.N_enc * 16 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        ntt_roofline = {"bound": "hbm", "kernel": "forward NTT, %d transforms of %d points per launch" % (batch, prm.N_enc),
+                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        del polys
+
     if rank == 0:
         out = {
             "metric": "prover constraints/sec (ringGroth16, N=8192, 4 RNS primes)",
@@ -213,6 +233,8 @@ def main():
             out["phase_ms"] = {"witness_map": round(timings["witness_ms"], 3), "msm": round(timings["msm_ms"], 3)}
         if roofline:
             out["roofline"] = roofline
+        if ntt_roofline:
+            out["ntt_roofline"] = ntt_roofline
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prm, m)
         print(json.dumps(out), flush=True)

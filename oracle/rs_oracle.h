@@ -16,6 +16,13 @@
  *     functions below restate SEAL's published algorithms (cited inline) and are anchored on
  *     the reference's call sites (seal/seal_ring.tcc:324-548) and on homomorphic
  *     self-consistency (encode -> inner_product -> decode == ring inner product).
+ *   - SURVEY 8(f) f2 / f3 (EncodingElem::encode / ::decode, seal_ring.tcc:324-359, 435-477): the
+ *     BGV steps follow SEAL's Encryptor / Decryptor structure; the RANDOMNESS does not (splitmix64
+ *     stream, ternary error instead of Blake2xb / centred binomial) -- PARITY UNPINNED for the
+ *     ciphertext bytes, pinned for every decryption.
+ *   - rows a15 / a16 end to end: tests/snark_ref.py restates the generators and verifiers
+ *     (groth16.tcc:5-66,117-170; rinocchio.tcc:5-72,192-300); proofs of the oracle prover and of
+ *     the HIP prover satisfy the reference's verification equations under a real encrypted key.
  *
  * Layouts (all uint64_t, little endian, canonical residues):
  *   ring element      [L][N]            NTT-slot order         (seal/seal_ring.tcc:270)

@@ -382,3 +382,38 @@ def test_c4_shape_rinocchio_configuration():
     g = host(got)
     for k in range(9):
         assert (g[k] == exp[k]).all(), k
+
+
+def test_entry_points_are_reentrant_on_a_shared_context():
+    """SURVEY 8(b) threading: the reference calls inner_product from up to ten OpenMP sections
+    (rinocchio.tcc:106-163).  Four host threads hammer one context (ctypes drops the GIL inside
+    the library); every result must equal the sequential one."""
+    import threading
+    dev = dev_for("toy")
+    ctx = H.oracle_ctx(dev.prm)
+    T = 9
+    jobs = []
+    for k in range(4):
+        encs, rings = ctx.random_enc(200 + k, T), ctx.random_ring(300 + k, T)
+        a, b = ctx.random_ring(400 + k, 3), ctx.random_ring(500 + k, 3)
+        jobs.append((dev.put(encs), dev.put(rings), dev.put(a), dev.put(b), ctx.inner_product(encs, rings)[0], ctx.ring_mul(a, b)))
+    errors = []
+
+    def work(j):
+        try:
+            de, dr, da, db, exp_ip, exp_mul = jobs[j]
+            for _ in range(20):
+                got, _ = dev.inner_product(de, dr)
+                if not (host(got) == exp_ip).all():
+                    errors.append(("inner_product", j))
+                if not (host(dev.ring_mul(da, db)) == exp_mul).all():
+                    errors.append(("ring_mul", j))
+        except Exception as e:  # noqa: BLE001
+            errors.append((repr(e), j))
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]

@@ -610,6 +610,12 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
   wave_sync();
   school_levels_lds(sb, logb, logM, pos0 + off, P, wl);
   wave_sync();
+  // this lane's 16 coefficients travel from level to level in registers: a level's F_left values are
+  // exactly what its predecessor's recombination just wrote at the same positions
+  double r[EPT];
+#pragma unroll
+  for (int j = 0; j < EPT; j++)
+    if (j < per) r[j] = sb[pidx(lane + 64 * j)];
 #pragma unroll LOGT_CT ? 32 : 1
   for (int l = SCHOOL_LEVELS + 1; l <= (LOGT_CT ? LOGT_CT : 20); l++) {
     if (l > logT) break;
@@ -620,10 +626,6 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const int p0 = pidx(ln);
-    double r[EPT];  // this lane's old coefficients; the F_left ones are added back at the end
-#pragma unroll
-    for (int j = 0; j < EPT; j++)
-      if (j < per) r[j] = sb[own_pidx(p0, ln, j)];
     const double *dh = P.dhat + (size_t)l * M + pos0 + off;
     if (priv) {
       // Nodes inside the wave's block, no workgroup barrier.  The first forward round reads
@@ -661,13 +663,14 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
     for (int j = 0; j < EPT; j++)
       if (j < per) {
         const int i = off + ln + 64 * j, pi = own_pidx(p0, ln, j);
-        sb[pi] = reduce(sb[pi] + (((i & (n - 1)) < h) ? r[j] : 0.0), mod);
+        r[j] = reduce(sb[pi] + (((i & (n - 1)) < h) ? r[j] : 0.0), mod);
+        sb[pi] = r[j];
       }
     if (priv) wave_sync(); else __syncthreads();
   }
 #pragma unroll
   for (int j = 0; j < EPT; j++)
-    if (j < per) c[off + lane + 64 * j] = canon(sb[pidx(lane + 64 * j)], mod);
+    if (j < per) c[off + lane + 64 * j] = canon(r[j], mod);
 }
 
 

@@ -16,9 +16,13 @@
  *   vectors           [count][...]      element-major ("term-major")
  *
  * All functions return RS_OK (0) or an error code; rs_last_error() gives the message
- * (thread-local).  Entry points are re-entrant with respect to a shared rs_ctx as long as
- * concurrent calls use distinct streams (the reference calls inner_product from 10 OpenMP
- * sections, rinocchio.tcc:106-163).  stream is a hipStream_t passed as void* (NULL = default).
+ * (thread-local).  Entry points are re-entrant with respect to a shared rs_ctx (the reference
+ * calls inner_product from 10 OpenMP sections, rinocchio.tcc:106-163): enqueueing is serialised by a
+ * mutex, and the context's workspace buffers carry an event of their last use, which a call on
+ * ANOTHER stream waits for on the device -- callers need neither distinct streams nor host
+ * synchronisation between calls.  Calls that use workspace therefore do not overlap on the device.
+ * A call switches the calling thread's HIP device to the context's and restores it on return.
+ * stream is a hipStream_t passed as void* (NULL = default).
  */
 #ifndef RINGSNARK_AMD_H
 #define RINGSNARK_AMD_H
@@ -143,8 +147,13 @@ typedef struct rs_msm_vec {
   size_t T;                /* terms (<= crs_len) */
   int group;               /* output group index */
 } rs_msm_vec;
-int rs_msm(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs,
-           int n_vecs, int n_groups, uint64_t *d_out /* [n_crs][n_groups] enc elems */,
+/* crs_window: 0, or the number of elements actually stored per CRS vector -- logical element t
+ * is then read from index t % crs_window ("tiled" key: how a proving key larger than HBM, e.g. the
+ * 384 GiB key of the 2^16-constraint headline, is stood in for on one GPU; every term still streams
+ * a distinct-address 2 MiB element from HBM, windows are far larger than any cache).  Must be a
+ * multiple of the internal term tile: use a power of two. */
+int rs_msm(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, size_t crs_window,
+           const rs_msm_vec *vecs, int n_vecs, int n_groups, uint64_t *d_out /* [n_crs][n_groups] enc elems */,
            size_t *h_used /* [n_vecs] or NULL */, rs_stream stream);
 
 /* ---- a14: R1CS in CSR form + linear_combination::evaluate (relations/variable.tcc:246-254) -- */
@@ -167,8 +176,10 @@ int rs_r1cs_evaluate(rs_ctx *ctx, const rs_r1cs *cs, int which /*0=a,1=b,2=c*/, 
  * what generator and verifier compute from the constraint system and the secret point s
  * (groth16.tcc:7-9,127-128; rinocchio.tcc:7-9,219-220).  d_s [L][N]; outputs d_At, d_Bt, d_Ct
  * [n_vars+1][L][N] (A_k(s) per variable, k = 0 the constant one), d_Ht [m+1][L][N] (powers of s),
- * d_Zt [L][N] (Z(s)).  Returns RS_ERR_NOT_INVERTIBLE with the reference's message when s hits the
- * domain in some slot ("t cannot be one of the values in the domain").  Synchronises. */
+ * d_Zt [L][N] (Z(s)).  Division free, so s may coincide with a node in some slots (as in the
+ * reference's product loop); returns RS_ERR_NOT_INVERTIBLE with the reference's message ("t cannot be
+ * one of the values in the domain") only when s IS a domain element, i.e. equals RingT(j) in every
+ * slot of every limb (evaluation_domain.tcc:24-26).  Synchronises. */
 int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, uint64_t *d_At, uint64_t *d_Bt, uint64_t *d_Ct,
                          uint64_t *d_Ht, uint64_t *d_Zt, rs_stream stream);
 
@@ -182,6 +193,13 @@ int rs_witness_map(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_assignment,
                    const uint64_t *d_d2, const uint64_t *d_d3, uint64_t *d_A_io, uint64_t *d_B_io,
                    uint64_t *d_C_io, uint64_t *d_A_mid, uint64_t *d_B_mid, uint64_t *d_C_mid, uint64_t *d_H,
                    uint64_t *h_Z, rs_stream stream);
+/* The same map restricted to NTT slots [slot0, slot0 + nslots) of every limb (the witness map is
+ * slot-parallel: SURVEY.md 8(e), ranks sharing a limb split its slots).  Inputs in the full layout;
+ * outputs COMPACT: A_io..C_mid [m][L][nslots], H [m+1][L][nslots].  slot0 and nslots even. */
+int rs_witness_map_slots(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_assignment, const uint64_t *d_d1,
+                         const uint64_t *d_d2, const uint64_t *d_d3, int slot0, int nslots, uint64_t *d_A_io,
+                         uint64_t *d_B_io, uint64_t *d_C_io, uint64_t *d_A_mid, uint64_t *d_B_mid, uint64_t *d_C_mid,
+                         uint64_t *d_H, uint64_t *h_Z, rs_stream stream);
 /* util/polynomials.tcc:10-43 on the domain {0..n-1}: d_y, d_out [n][L][N] (may alias). */
 int rs_interpolate(rs_ctx *ctx, const uint64_t *d_y, uint64_t *d_out, size_t n, rs_stream stream);
 
@@ -194,6 +212,7 @@ typedef struct rs_groth16_pk {
   const uint64_t *d_delta_ts;  /* [m+1] */
   const uint64_t *d_delta_mid; /* [n_aux] */
   const uint64_t *d_alpha, *d_beta;
+  size_t window; /* 0 = vectors stored in full; else see crs_window of rs_msm */
 } rs_groth16_pk;
 int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, const uint64_t *d_assignment,
                      uint64_t *d_proof, int *h_empty /* [3] or NULL */, rs_stream stream);
@@ -205,6 +224,7 @@ typedef struct rs_rinocchio_pk {
   const uint64_t *d_s_pows, *d_alpha_s_pows; /* [m+1] */
   const uint64_t *d_beta_prods;              /* [n_aux] */
   const uint64_t *d_beta_rv_ts, *d_beta_rw_ts, *d_beta_ry_ts;
+  size_t window; /* 0 = vectors stored in full; else see crs_window of rs_msm */
 } rs_rinocchio_pk;
 int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk, const uint64_t *d_assignment,
                        const uint64_t *d_d1, const uint64_t *d_d2, const uint64_t *d_d3, uint64_t *d_proof,
@@ -218,8 +238,9 @@ typedef struct rs_timings {
 } rs_timings;
 int rs_last_timings(rs_ctx *ctx, rs_timings *out);
 int rs_set_profiling(rs_ctx *ctx, int enabled);
-/* process-wide tuning knobs for experiments ("ntt_variant": kernel shape of rs_ntt_*); results
- * are identical for every value. */
+/* process-wide kernel-shape knobs ("ntt_variant", "mac_variant", "witness_lds_logM", ...); results
+ * are identical for every accepted value.  (Knobs that alter results -- timing ablations -- exist
+ * only in the separate experiments build, `make -C ringsnark_amd/csrc experiments`.) */
 int rs_set_tuning(const char *key, int value);
 
 /* synthetic-workload helpers for the benchmark harness (device-side generators) */

@@ -379,7 +379,7 @@ inline proof prover(const proving_key_device &pk, const std::vector<RingElem> &p
   full.insert(full.end(), auxiliary_input.begin(), auxiliary_input.end());
   const std::vector<uint64_t> asg = flatten(full);
   DeviceWords dasg(asg.data(), asg.size()), dproof(3 * Context::enc_words());
-  rs_groth16_pk k{pk.s_pows_.get(), pk.delta_ts_.get(), pk.delta_mid_.get(), pk.alpha_.get(), pk.beta_.get()};
+  rs_groth16_pk k{pk.s_pows_.get(), pk.delta_ts_.get(), pk.delta_mid_.get(), pk.alpha_.get(), pk.beta_.get(), 0};
   int empty[3] = {0, 0, 0};
   check(rs_groth16_prove(Context::get_context(), pk.cs.get(), &k, dasg.get(), dproof.get(), empty, nullptr));
   std::vector<uint64_t> w(3 * Context::enc_words());

@@ -32,12 +32,13 @@ class MsmVec(C.Structure):
 
 
 class Groth16PK(C.Structure):
-    _fields_ = [("d_s_pows", vp), ("d_delta_ts", vp), ("d_delta_mid", vp), ("d_alpha", vp), ("d_beta", vp)]
+    _fields_ = [("d_s_pows", vp), ("d_delta_ts", vp), ("d_delta_mid", vp), ("d_alpha", vp), ("d_beta", vp),
+                ("window", C.c_size_t)]
 
 
 class RinocchioPK(C.Structure):
     _fields_ = [("d_s_pows", vp), ("d_alpha_s_pows", vp), ("d_beta_prods", vp), ("d_beta_rv_ts", vp),
-                ("d_beta_rw_ts", vp), ("d_beta_ry_ts", vp)]
+                ("d_beta_rw_ts", vp), ("d_beta_ry_ts", vp), ("window", C.c_size_t)]
 
 
 class Timings(C.Structure):
@@ -77,13 +78,14 @@ SIGNATURES = {
     "rs_enc_decode": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp]),
     "rs_enc_encode": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint64, vp, vp]),
     "rs_inner_product": (C.c_int, [vp, vp, vp, u8p, C.c_size_t, vp, C.POINTER(C.c_size_t), vp]),
-    "rs_msm": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_size_t, C.POINTER(MsmVec), C.c_int, C.c_int, vp,
+    "rs_msm": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_size_t, C.c_size_t, C.POINTER(MsmVec), C.c_int, C.c_int, vp,
                          C.POINTER(C.c_size_t), vp]),
     "rs_r1cs_create": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(u32p), C.POINTER(u32p),
                                  C.POINTER(u64p), C.POINTER(C.c_size_t), C.POINTER(vp)]),
     "rs_r1cs_destroy": (None, [vp]),
     "rs_r1cs_evaluate": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "rs_witness_map": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64p, vp]),
+    "rs_witness_map_slots": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, u64p, vp]),
     "rs_interpolate": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "rs_groth16_prove": (C.c_int, [vp, vp, C.POINTER(Groth16PK), vp, vp, C.POINTER(C.c_int), vp]),
     "rs_rinocchio_prove": (C.c_int, [vp, vp, C.POINTER(RinocchioPK), vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]),

@@ -14,7 +14,7 @@
 #include <algorithm>
 #include <cstring>
 
-#include "ntt_core.cuh"
+#include "ntt_core.hpp"
 #include "rs_internal.hpp"
 
 namespace rs {
@@ -193,10 +193,10 @@ using namespace rs;
 extern "C" {
 
 int rs_enc_decode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size_t count, uint64_t *d_rings, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_sk && d_enc && d_rings, "null argument");
   if (count == 0) return RS_OK;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  WsScope ws_scope(ctx, S(stream));
   const int L = ctx->L, K = ctx->K, n = ctx->N_enc;
   hipStream_t st = S(stream);
   // host constants of the CRT composition
@@ -252,11 +252,11 @@ int rs_enc_decode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size
 
 int rs_enc_encode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_rings, size_t count, uint64_t seed, uint64_t *d_enc,
                   rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_sk && d_rings && d_enc, "null argument");
   if (count == 0) return RS_OK;
   RS_REQUIRE(ctx->N_enc <= 16 * 1024, "encoding degree out of range");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  WsScope ws_scope(ctx, S(stream));
   hipStream_t st = S(stream);
   TabCopies tabs(ctx);
   const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(double);
@@ -298,7 +298,7 @@ size_t rs_enc_wire_size(const rs_ctx *ctx, size_t count) {
 
 int rs_enc_serialize(rs_ctx *ctx, const uint64_t *d_enc, const uint8_t *h_empty, size_t count, void *h_buf, size_t buf_bytes,
                      rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && h_buf && (d_enc || count == 0), "null argument");
   RS_REQUIRE(buf_bytes >= rs_enc_wire_size(ctx, count), "buffer too small (rs_enc_wire_size)");
   uint8_t *p = (uint8_t *)h_buf;
@@ -325,7 +325,7 @@ int rs_enc_serialize(rs_ctx *ctx, const uint64_t *d_enc, const uint8_t *h_empty,
 
 int rs_enc_deserialize(rs_ctx *ctx, const void *h_buf, size_t buf_bytes, uint64_t *d_enc, uint8_t *h_empty, size_t capacity,
                        size_t *h_count, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && h_buf && h_count, "null argument");
   const uint8_t *p = (const uint8_t *)h_buf;
   const size_t fixed = 24 + 8 * (size_t)(ctx->L + ctx->K) + 8;
@@ -339,18 +339,22 @@ int rs_enc_deserialize(rs_ctx *ctx, const void *h_buf, size_t buf_bytes, uint64_
              "stream was written for different moduli");
   uint64_t c64;
   memcpy(&c64, p + 24 + 8 * (size_t)(ctx->L + ctx->K), 8);
+  // The count is untrusted: bound it by what the buffer can hold BEFORE any size arithmetic (every
+  // element costs one flag byte + enc_bytes of payload), so that nothing below can wrap.
+  const size_t enc_bytes = ctx->enc_words() * sizeof(uint64_t);
+  RS_REQUIRE(c64 <= (uint64_t)((buf_bytes - fixed) / (1 + enc_bytes)), "truncated payload");
   const size_t count = (size_t)c64;
-  *h_count = count;
   RS_REQUIRE(buf_bytes >= rs_enc_wire_size(ctx, count), "truncated payload");
-  if (!d_enc) return RS_OK;  // size query
-  RS_REQUIRE(capacity >= count, "destination holds fewer elements than the stream");
   const uint8_t *em = p + fixed;
   const size_t hb = wire_header_bytes(ctx, count);
-  const uint64_t *payload = (const uint64_t *)(p + hb);
-  for (size_t i = 0; i < count; i++) {
-    if (h_empty) h_empty[i] = em[i];
-    RS_REQUIRE(em[i] <= 1, "corrupt empty flag");
+  for (size_t i = 0; i < count; i++) RS_REQUIRE(em[i] <= 1, "corrupt empty flag");
+  for (size_t i = fixed + count; i < hb; i++) RS_REQUIRE(p[i] == 0, "non-zero header padding");
+  if (!d_enc) {  // size query (header validated)
+    *h_count = count;
+    return RS_OK;
   }
+  RS_REQUIRE(capacity >= count, "destination holds fewer elements than the stream");
+  const uint64_t *payload = (const uint64_t *)(p + hb);
   // canonical-residue check on the host: a proof from the wire is untrusted input
   const size_t n = (size_t)ctx->N_enc, per = ctx->enc_words();
   for (size_t i = 0; i < count; i++)
@@ -359,12 +363,19 @@ int rs_enc_deserialize(rs_ctx *ctx, const void *h_buf, size_t buf_bytes, uint64_
         for (int j = 0; j < ctx->K; j++) {
           const uint64_t *row = payload + i * per + (((size_t)l * 2 + c) * ctx->K + j) * n;
           const uint64_t Qj = ctx->Q[j];
-          for (size_t x = 0; x < n; x++) RS_REQUIRE(row[x] < Qj, "residue out of range");
+          if (em[i]) {  // EMPTY element (seal_ring.tcc:412,432): the payload must be all zero
+            for (size_t x = 0; x < n; x++) RS_REQUIRE(row[x] == 0, "non-zero payload of an EMPTY element");
+          } else {
+            for (size_t x = 0; x < n; x++) RS_REQUIRE(row[x] < Qj, "residue out of range");
+          }
         }
   if (count) {
     RS_HIP(hipMemcpyAsync(d_enc, payload, count * per * sizeof(uint64_t), hipMemcpyHostToDevice, S(stream)));
     RS_HIP(hipStreamSynchronize(S(stream)));
   }
+  // outputs are written only after every check has passed
+  if (h_empty) memcpy(h_empty, em, count);
+  *h_count = count;
   RS_API_END
 }
 
@@ -382,38 +393,43 @@ namespace rs {
 void r1cs_evaluate_run(rs_ctx *ctx, const rs_r1cs *cs, int which, int mode, const uint64_t *d_asg, uint64_t *d_out,
                        hipStream_t st);
 
-// per slot: Ht[j] = s^j (j <= m), D[j] = s - j (j < m), Zt = prod_j (s - j)
+// Per slot, with d_j = s - j:  Ht[j] = s^j (j <= m),  Zt = prod_j d_j,  and the Lagrange values
+//     u_j = c_j * prod_{i != j} d_i = c_j * (prod_{i < j} d_i) * (prod_{i > j} d_i)
+// by a backward pass (suffix products parked in U) and a forward pass (running prefix): no
+// division, so a slot in which s happens to equal a domain element is handled exactly like the
+// reference's product loop (evaluation_domain.tcc:28-39).  hit[0] / hit[1] = min / max over slots of
+// the domain index the slot equals (0xFFFFFFFF: none): s IS a domain element -- the only case the
+// reference rejects (evaluation_domain.tcc:24-26) -- iff hit[0] == hit[1] != 0xFFFFFFFF.
 __global__ void __launch_bounds__(256)
-powers_kernel(const uint64_t *__restrict__ s, uint64_t *__restrict__ Ht, uint64_t *__restrict__ D, uint64_t *__restrict__ Zt,
-              size_t m, int N, int L, const Mod *__restrict__ qmod) {
+lagrange_kernel(const uint64_t *__restrict__ s, uint64_t *__restrict__ Ht, uint64_t *__restrict__ U, uint64_t *__restrict__ Zt,
+                const double *__restrict__ c /* [L][m] */, unsigned *__restrict__ hit, size_t m, int N, int L,
+                const Mod *__restrict__ qmod) {
   const size_t S = (size_t)L * N, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S) return;
-  const Mod mod = qmod[i / (size_t)N];
+  const int limb = (int)(i / (size_t)N);
+  const Mod mod = qmod[limb];
   const double sv = center(from_u64(s[i]), mod);
-  double pw = 1.0, z = 1.0;
+  unsigned my_hit = 0xFFFFFFFFu;
+  double suf = 1.0;
+  for (size_t j = m; j-- > 0;) {
+    U[j * S + i] = to_u64(canon(suf, mod));
+    const double d = reduce(sv - (double)j, mod);
+    if (canon(d, mod) == 0.0) my_hit = (unsigned)j;
+    suf = mulmod(suf, d, mod);
+  }
+  Zt[i] = to_u64(canon(suf, mod));
+  double pre = 1.0, pw = 1.0;
   for (size_t j = 0; j <= m; j++) {
     Ht[j * S + i] = to_u64(canon(pw, mod));
-    if (j < m) {
-      const double d = reduce(sv - (double)j, mod);
-      D[j * S + i] = to_u64(canon(d, mod));
-      z = mulmod(z, d, mod);
-    }
     pw = mulmod(pw, sv, mod);
+    if (j < m) {
+      const double v = mulmod(pre, center(from_u64(U[j * S + i]), mod), mod);
+      U[j * S + i] = to_u64(canon(mulmod(v, c[(size_t)limb * m + j], mod), mod));
+      pre = mulmod(pre, reduce(sv - (double)j, mod), mod);
+    }
   }
-  Zt[i] = to_u64(canon(z, mod));
-}
-// u[j] = Zt * inv[j] * c[limb][j]   (in place over inv)
-__global__ void __launch_bounds__(256)
-lagrange_kernel(uint64_t *__restrict__ u, const uint64_t *__restrict__ Zt, const double *__restrict__ c, size_t m, int N, int L,
-                const Mod *__restrict__ qmod) {
-  const size_t S = (size_t)L * N, total = m * S, stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const size_t j = i / S, sl = i % S;
-    const int limb = (int)(sl / (size_t)N);
-    const Mod mod = qmod[limb];
-    const double v = mulmod(center(from_u64(Zt[sl]), mod), center(from_u64(u[i]), mod), mod);
-    u[i] = to_u64(canon(mulmod(v, c[(size_t)limb * m + j], mod), mod));
-  }
+  atomicMin(&hit[0], my_hit);
+  atomicMax(&hit[1], my_hit);
 }
 }  // namespace rs
 
@@ -421,7 +437,7 @@ extern "C" {
 
 int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, uint64_t *d_At, uint64_t *d_Bt, uint64_t *d_Ct,
                          uint64_t *d_Ht, uint64_t *d_Zt, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && cs && d_s && d_At && d_Bt && d_Ct && d_Ht && d_Zt, "null argument");
   const size_t m = cs->m, SW = ctx->ring_words();
   const int L = ctx->L;
@@ -430,19 +446,14 @@ int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, ui
   RS_HIP(hipMalloc(&D, m * SW * sizeof(uint64_t)));
   struct Guard {
     std::vector<void *> p;
+    rs_r1cs *tr = nullptr;
     ~Guard() {
       for (void *x : p) (void)hipFree(x);
+      if (tr) rs_r1cs_destroy(tr);
     }
   } guard;
   guard.p.push_back(D);
-  hipLaunchKernelGGL(powers_kernel, dim3((unsigned)((SW + 255) / 256)), dim3(256), 0, st, d_s, d_Ht, D, d_Zt, m, ctx->N, L,
-                     ctx->d_qmod);
-  RS_HIP(hipGetLastError());
-  // "t cannot be one of the values in the domain" (evaluation_domain.tcc:24-26) == some s - j not invertible
-  const int rc = rs_ring_inv(ctx, D, D, m, stream);
-  if (rc == RS_ERR_NOT_INVERTIBLE) throw Error(RS_ERR_NOT_INVERTIBLE, "t cannot be one of the values in the domain");
-  RS_REQUIRE(rc == RS_OK, rs_last_error());
-  // slot-constant factors c_j = (-1)^(m-1-j) / (j! (m-1-j)!)
+  // slot-constant factors c_j = 1 / prod_{i != j} (j - i) = (-1)^(m-1-j) / (j! (m-1-j)!)
   std::vector<double> hc((size_t)L * m);
   for (int l = 0; l < L; l++) {
     const uint64_t q = ctx->q[l];
@@ -459,11 +470,22 @@ int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, ui
   double *d_c = nullptr;
   RS_HIP(hipMalloc(&d_c, hc.size() * sizeof(double)));
   guard.p.push_back(d_c);
+  unsigned *d_hit = nullptr;
+  RS_HIP(hipMalloc(&d_hit, 2 * sizeof(unsigned)));
+  guard.p.push_back(d_hit);
+  const unsigned hit0[2] = {0xFFFFFFFFu, 0u};
+  unsigned hit[2];
   RS_HIP(hipMemcpyAsync(d_c, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice, st));
-  const unsigned lb = (unsigned)std::min<size_t>((m * SW + 255) / 256, 256 * 16);
-  hipLaunchKernelGGL(lagrange_kernel, dim3(lb), dim3(256), 0, st, D, d_Zt, d_c, m, ctx->N, L, ctx->d_qmod);
+  RS_HIP(hipMemcpyAsync(d_hit, hit0, sizeof(hit0), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(lagrange_kernel, dim3((unsigned)((SW + 255) / 256)), dim3(256), 0, st, d_s, d_Ht, D, d_Zt, d_c, d_hit, m,
+                     ctx->N, L, ctx->d_qmod);
   RS_HIP(hipGetLastError());
-  RS_HIP(hipStreamSynchronize(st));  // hc
+  RS_HIP(hipMemcpyAsync(hit, d_hit, sizeof(hit), hipMemcpyDeviceToHost, st));
+  RS_HIP(hipStreamSynchronize(st));  // hc, hit
+  // evaluation_domain.tcc:24-26: rejected only when s equals a domain element AS A RING ELEMENT
+  // (every slot of every limb equal to the same j)
+  if (hit[0] == hit[1] && hit[0] != 0xFFFFFFFFu)
+    throw Error(RS_ERR_NOT_INVERTIBLE, "t cannot be one of the values in the domain");
   // transposed system: row k (variable k, 0 = the constant one) holds (constraint i + 1, coeff)
   const size_t rows = cs->n_vars + 1;
   std::vector<uint32_t> rp[3], col[3];
@@ -490,12 +512,10 @@ int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, ui
     colp[w] = col[w].data();
     cfp[w] = cf[w].data();
   }
-  rs_r1cs *tr = nullptr;
-  RS_REQUIRE(rs_r1cs_create(ctx, rows, m, 0, rpp, colp, cfp, nnz, &tr) == RS_OK, rs_last_error());
+  RS_REQUIRE(rs_r1cs_create(ctx, rows, m, 0, rpp, colp, cfp, nnz, &guard.tr) == RS_OK, rs_last_error());
   uint64_t *outs[3] = {d_At, d_Bt, d_Ct};
-  for (int w = 0; w < 3; w++) r1cs_evaluate_run(ctx, tr, w, RS_EVAL_FULL, D, outs[w], st);
+  for (int w = 0; w < 3; w++) r1cs_evaluate_run(ctx, guard.tr, w, RS_EVAL_FULL, D, outs[w], st);
   RS_HIP(hipStreamSynchronize(st));
-  rs_r1cs_destroy(tr);
   RS_API_END
 }
 

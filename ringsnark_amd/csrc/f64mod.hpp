@@ -18,7 +18,7 @@
 #include <cmath>
 #include <cstdint>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define RS_HD __host__ __device__ __forceinline__
 #else
 #define RS_HD inline

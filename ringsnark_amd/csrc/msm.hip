@@ -24,7 +24,7 @@
 #include <algorithm>
 #include <cstring>
 
-#include "ntt_core.cuh"
+#include "ntt_core.hpp"
 #include "rs_internal.hpp"
 
 namespace rs {
@@ -289,7 +289,7 @@ mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff
 //   * the ciphertext words of term t are loaded into registers before the transform of term t
 //     starts (512-thread shape: also the plaintext row of term t+1), so HBM latency and transfer
 //     overlap the FP64 work -- provided nothing in the loop forces an early s_waitcnt vmcnt(0);
-//   * the transform is the wave-private form (ntt_core.cuh): the cross-wave stages, then each wave
+//   * the transform is the wave-private form (ntt_core.hpp): the cross-wave stages, then each wave
 //     finishes its own block and multiplies exactly that block into its accumulators -- two or
 //     three workgroup barriers per term instead of seven.
 // radix of the wave-private rounds inside mac_kernel_v2: 3 keeps the kernel free of VGPR spills (a
@@ -554,12 +554,16 @@ static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, 
                        ctx->logN_enc, sc.d_coeff_tabs);                                                               \
     if (e1) RS_HIP(hipEventRecord(e1, st));                                                                           \
   } while (0)
+#ifdef RS_EXPERIMENTS  // timing-only ablations (wrong results): never part of the release library
     switch (g_mac_ablate) {
       case 1: RS_MAC_LAUNCH(1); break;
       case 2: RS_MAC_LAUNCH(2); break;
       case 6: RS_MAC_LAUNCH(6); break;
       default: RS_MAC_LAUNCH(0); break;
     }
+#else
+    RS_MAC_LAUNCH(0);
+#endif
 #undef RS_MAC_LAUNCH
     RS_HIP(hipGetLastError());
     return;
@@ -576,8 +580,11 @@ int g_mac_variant = 3;  // 3: streaming kernel, 1024-thread shape at N_enc = 819
 
 // Core grouped MSM.  addends: optional per-output (n_crs * n_groups) device pointers to encoding
 // elements added to the result (pk.alpha / pk.beta of groth16.tcc:95,103).
+// crs_window != 0: every CRS vector is stored as `crs_window` consecutive elements and logical
+// element t lives at index t % crs_window (tiled keys, see ringsnark_amd.h); tiles never straddle the wrap.
 void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
-             int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st) {
+             int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st,
+             size_t crs_window) {
   RS_REQUIRE(n_crs >= 1 && n_crs <= 2, "n_crs must be 1 or 2");
   RS_REQUIRE(n_groups >= 1 && n_groups <= MAX_GROUPS, "too many groups");
   RS_REQUIRE(n_crs * n_groups <= 12, "too many outputs");
@@ -633,6 +640,13 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
   // tiling: C workspace <= ~2 GiB
   const size_t c_bytes_per_term = (size_t)n_groups * L * n * sizeof(double);
   size_t tile_terms = std::max<size_t>(1, std::min<size_t>(Tmax, ((size_t)2 << 30) / c_bytes_per_term));
+  if (crs_window) {
+    size_t p2 = 1;
+    while (p2 * 2 <= tile_terms) p2 *= 2;
+    tile_terms = std::min(p2, crs_window);
+    RS_REQUIRE(crs_window % tile_terms == 0, "crs_window must be a multiple of the term tile (use a power of two)");
+  }
+  auto crs_at = [&](int c, size_t t0) { return d_crs[c] + (crs_window ? t0 % crs_window : t0) * enc_words; };
   int n_chunks = (int)std::min<size_t>(tile_terms, (size_t)std::max(1, (768 + L * K - 1) / (L * K)));
   if (Tmax == 0) n_chunks = 1;
   double *d_C = (double *)ws_get(ctx, 0, std::max<size_t>(256, tile_terms * c_bytes_per_term));
@@ -698,7 +712,7 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
         a.C[g] = Cptr(gs[g]);
         a.terms[g] = group_terms(gs[g]);
       }
-      for (int c = 0; c < NC; c++) a.crs[c] = d_crs[cs[c]] + t0 * enc_words;
+      for (int c = 0; c < NC; c++) a.crs[c] = crs_at(cs[c], t0);
       for (int c = 0; c < NC; c++)
         for (int g = 0; g < NG; g++) a.set_index[c * NG + g] = cs[c] * n_groups + gs[g];
       if (big)
@@ -727,7 +741,7 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
         MacArgs2 a2;
         a2.C = Cptr(g);
         a2.terms = group_terms(g);
-        a2.crs = d_crs[c] + t0 * enc_words;
+        a2.crs = crs_at(c, t0);
         a2.partial = d_partial + (size_t)(c * n_groups + g) * enc_words;
         a2.part_stride = (size_t)n_sets * enc_words;
         a2.terms_per_chunk = base.terms_per_chunk;
@@ -816,7 +830,7 @@ using namespace rs;
 extern "C" {
 
 int rs_batch_encode(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, size_t count, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_rings && d_plain, "null argument");
   if (count) {
     MsmScratch &sc = scratch_for(ctx);
@@ -829,35 +843,35 @@ int rs_batch_encode(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, siz
   RS_API_END
 }
 
-int rs_msm(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
-           int n_groups, uint64_t *d_out, size_t *h_used, rs_stream stream) {
-  RS_API_BEGIN
+int rs_msm(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, size_t crs_window, const rs_msm_vec *vecs,
+           int n_vecs, int n_groups, uint64_t *d_out, size_t *h_used, rs_stream stream) {
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_crs && vecs && d_out && n_vecs >= 1, "null argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  msm_run(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, nullptr, h_used, S(stream));
+  WsScope ws_scope(ctx, S(stream));
+  msm_run(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, nullptr, h_used, S(stream), crs_window);
   RS_API_END
 }
 
 int rs_inner_product(rs_ctx *ctx, const uint64_t *d_encs, const uint64_t *d_rings, const uint8_t *h_kinds, size_t T,
                      uint64_t *d_out, size_t *h_used, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_out && (T == 0 || (d_encs && d_rings)), "null argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  WsScope ws_scope(ctx, S(stream));
   rs_msm_vec v{d_rings, h_kinds, T, 0};
   const uint64_t *crs[1] = {d_encs};
-  msm_run(ctx, crs, 1, T, &v, 1, 1, d_out, nullptr, h_used, S(stream));
+  msm_run(ctx, crs, 1, T, &v, 1, 1, d_out, nullptr, h_used, S(stream), 0);
   RS_API_END
 }
 
 int rs_enc_mul_ring(rs_ctx *ctx, uint64_t *d_enc, const uint64_t *d_ring, size_t count, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_enc && d_ring, "null argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  WsScope ws_scope(ctx, S(stream));
   uint64_t *tmp = (uint64_t *)ws_get(ctx, 4, ctx->enc_words() * sizeof(uint64_t));
   for (size_t k = 0; k < count; k++) {
     rs_msm_vec v{d_ring + k * ctx->ring_words(), nullptr, 1, 0};
     const uint64_t *crs[1] = {d_enc + k * ctx->enc_words()};
-    msm_run(ctx, crs, 1, 1, &v, 1, 1, tmp, nullptr, nullptr, S(stream));
+    msm_run(ctx, crs, 1, 1, &v, 1, 1, tmp, nullptr, nullptr, S(stream), 0);
     RS_HIP(hipMemcpyAsync(d_enc + k * ctx->enc_words(), tmp, ctx->enc_words() * sizeof(uint64_t),
                           hipMemcpyDeviceToDevice, S(stream)));
   }
@@ -865,7 +879,7 @@ int rs_enc_mul_ring(rs_ctx *ctx, uint64_t *d_enc, const uint64_t *d_ring, size_t
 }
 
 int rs_enc_reduce(rs_ctx *ctx, uint64_t *d_enc, size_t count, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_enc, "null argument");
   const size_t words = count * ctx->enc_words();
   if (words) {
@@ -878,7 +892,7 @@ int rs_enc_reduce(rs_ctx *ctx, uint64_t *d_enc, size_t count, rs_stream stream) 
 }
 
 int rs_enc_add(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, const uint64_t *d_b, size_t count, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_dst && d_a && d_b, "null argument");
   enc_add_run(ctx, d_dst, d_a, d_b, count, S(stream));
   RS_API_END

@@ -1,4 +1,4 @@
-// ntt_core.cuh -- workgroup-cooperative radix-2^R number-theoretic transform over an LDS tile.
+// ntt_core.hpp -- workgroup-cooperative radix-2^R number-theoretic transform over an LDS tile.
 //
 // One workgroup owns one polynomial of n = 2^logn FP64-held residues (f64mod.hpp).  Stages are
 // processed in "rounds" of R <= MAXR stages: a thread pulls the 2^R elements of one radix-2^R

@@ -7,10 +7,12 @@
 
 namespace rs {
 void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
-             int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st);
+             int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st,
+             size_t crs_window);
 void enc_add_run(rs_ctx *ctx, uint64_t *dst, const uint64_t *x, const uint64_t *y, size_t count, hipStream_t st);
 void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const uint64_t *d1, const uint64_t *d2,
-                 const uint64_t *d3, uint64_t *const outs[7], uint64_t *h_Z, hipStream_t st);
+                 const uint64_t *d3, uint64_t *const outs[7], uint64_t *h_Z, hipStream_t st, int slot0 = 0, int nslots = -1,
+                 bool compact = false);
 void msm_scratch_release(rs_ctx *ctx);
 
 struct PhaseTimer {
@@ -89,10 +91,10 @@ extern "C" {
 
 int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, const uint64_t *d_assignment,
                      uint64_t *d_proof, int *h_empty, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && cs && pk && d_assignment && d_proof, "null argument");
   RS_REQUIRE(pk->d_s_pows && pk->d_delta_ts && pk->d_alpha && pk->d_beta, "incomplete proving key");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  WsScope ws_scope(ctx, S(stream));
   hipStream_t st = S(stream);
   const size_t m = cs->m, rw = ctx->ring_words(), ew = ctx->enc_words();
   const size_t n_aux = cs->n_vars - cs->n_inputs;
@@ -111,7 +113,7 @@ int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, co
     const uint64_t *crs[1] = {pk->d_s_pows};
     rs_msm_vec v[4] = {{A_io, nullptr, m, 0}, {A_mid, nullptr, m, 0}, {B_io, nullptr, m, 1}, {B_mid, nullptr, m, 1}};
     const uint64_t *add[2] = {pk->d_alpha, pk->d_beta};
-    msm_run(ctx, crs, 1, m + 1, v, 4, 2, d_proof, add, nullptr, st);
+    msm_run(ctx, crs, 1, m + 1, v, 4, 2, d_proof, add, nullptr, st, pk->window);
   }
   // C = <delta_ts, H> (+ <delta_mid, aux>)                                 (groth16.tcc:105-112)
   size_t used_h = 1, used_aux = 0;
@@ -119,13 +121,13 @@ int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, co
   if (n_aux) {
     const uint64_t *crs[1] = {pk->d_delta_mid};
     rs_msm_vec v{d_assignment + cs->n_inputs * rw, nullptr, n_aux, 0};
-    msm_run(ctx, crs, 1, n_aux, &v, 1, 1, C, nullptr, h_empty ? &used_aux : nullptr, st);
+    msm_run(ctx, crs, 1, n_aux, &v, 1, 1, C, nullptr, h_empty ? &used_aux : nullptr, st, pk->window);
   }
   {
     const uint64_t *crs[1] = {pk->d_delta_ts};
     rs_msm_vec v{H, nullptr, m + 1, 0};
     const uint64_t *add[1] = {n_aux ? C : nullptr};
-    msm_run(ctx, crs, 1, m + 1, &v, 1, 1, C, add, h_empty ? &used_h : nullptr, st);
+    msm_run(ctx, crs, 1, m + 1, &v, 1, 1, C, add, h_empty ? &used_h : nullptr, st, pk->window);
   }
   pt.mark(2);
   pt.finish();
@@ -139,11 +141,11 @@ int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, co
 int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk, const uint64_t *d_assignment,
                        const uint64_t *d_d1, const uint64_t *d_d2, const uint64_t *d_d3, uint64_t *d_proof, int *h_empty,
                        rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && cs && pk && d_assignment && d_proof, "null argument");
   RS_REQUIRE(pk->d_s_pows && pk->d_alpha_s_pows, "incomplete proving key");
   RS_REQUIRE((d_d1 && d_d2 && d_d3) || (!d_d1 && !d_d2 && !d_d3), "d1,d2,d3 must be all set or all null");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  WsScope ws_scope(ctx, S(stream));
   hipStream_t st = S(stream);
   const size_t m = cs->m, rw = ctx->ring_words(), ew = ctx->enc_words();
   const size_t n_aux = cs->n_vars - cs->n_inputs;
@@ -178,7 +180,7 @@ int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk
     const uint64_t *crs[2] = {pk->d_s_pows, pk->d_alpha_s_pows};
     rs_msm_vec v[5] = {{A_mid, nullptr, m, 0}, {B_mid, nullptr, m, 1}, {C_mid, nullptr, m, 2}, {H, nullptr, m + 1, 3},
                        {Zr, zkinds.data(), m + 1, 4}};
-    msm_run(ctx, crs, 2, m + 1, v, 5, 5, mo, nullptr, used, st);
+    msm_run(ctx, crs, 2, m + 1, v, 5, 5, mo, nullptr, used, st, pk->window);
   }
   auto slot = [&](int c, int g) { return mo + ((size_t)c * 5 + g) * ew; };
   int empty[9];
@@ -192,7 +194,7 @@ int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk
     rs_msm_vec v{d, nullptr, 1, 0};
     const uint64_t *crs[1] = {enc};
     const uint64_t *add[1] = {*dst_empty ? nullptr : dst};
-    msm_run(ctx, crs, 1, 1, &v, 1, 1, *dst_empty ? dst : tmp, add, nullptr, st);
+    msm_run(ctx, crs, 1, 1, &v, 1, 1, *dst_empty ? dst : tmp, add, nullptr, st, 0);
     if (!*dst_empty)
       RS_HIP(hipMemcpyAsync(dst, tmp, ew * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     *dst_empty = 0;
@@ -212,7 +214,7 @@ int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk
     size_t used_f = 0;
     const uint64_t *crs[1] = {pk->d_beta_prods};
     rs_msm_vec v{d_assignment + cs->n_inputs * rw, nullptr, n_aux, 0};
-    msm_run(ctx, crs, 1, n_aux, &v, 1, 1, F, nullptr, &used_f, st);
+    msm_run(ctx, crs, 1, n_aux, &v, 1, 1, F, nullptr, &used_f, st, pk->window);
     empty[8] = used_f == 0;
     if (zk) {
       add_scaled(F, &empty[8], pk->d_beta_rv_ts, d_d1);
@@ -228,9 +230,9 @@ int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk
 }
 
 int rs_fill_uniform(rs_ctx *ctx, uint64_t *d_dst, size_t count, int layout, uint64_t seed, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_dst && (layout == 0 || layout == 1), "bad argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  WsScope ws_scope(ctx, S(stream));
   uint64_t *mods = (uint64_t *)ws_get(ctx, 11, sizeof(uint64_t) * (RS_MAX_L + RS_MAX_K));
   RS_HIP(hipMemcpyAsync(mods, ctx->q, sizeof(uint64_t) * ctx->L, hipMemcpyHostToDevice, S(stream)));
   RS_HIP(hipMemcpyAsync(mods + RS_MAX_L, ctx->Q, sizeof(uint64_t) * ctx->K, hipMemcpyHostToDevice, S(stream)));
@@ -249,7 +251,7 @@ int rs_fill_uniform(rs_ctx *ctx, uint64_t *d_dst, size_t count, int layout, uint
 }
 
 int rs_chain_assignment(rs_ctx *ctx, uint64_t *d_assignment, size_t m, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_assignment, "null argument");
   const size_t S_ = ctx->ring_words();
   hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((S_ + 255) / 256)), dim3(256), 0, S(stream), d_assignment, m, ctx->N,

@@ -3,7 +3,7 @@
 #include <algorithm>
 #include <cstring>
 
-#include "ntt_core.cuh"
+#include "ntt_core.hpp"
 #include "rs_internal.hpp"
 
 namespace rs {
@@ -13,14 +13,44 @@ void set_last_error(const std::string &m) { g_last_error = m; }
 
 void *ws_get(rs_ctx *ctx, int slot, size_t bytes) {
   DeviceBuf &b = ctx->ws[slot];
+  if (b.used && b.last_stream != ctx->cur_stream) {
+    // the previous user ran on another stream: order this call's work after it (device side)
+    RS_HIP(hipStreamWaitEvent(ctx->cur_stream, b.last_use, 0));
+    b.last_stream = ctx->cur_stream;  // the wait is enqueued; later ws_get calls of this scope need not repeat it
+  }
   if (b.bytes < bytes) {
-    if (b.p) RS_HIP(hipFree(b.p));
+    if (b.p) {
+      if (b.used) RS_HIP(hipEventSynchronize(b.last_use));  // nothing may still read the old buffer
+      RS_HIP(hipStreamSynchronize(ctx->cur_stream));
+      RS_HIP(hipFree(b.p));
+    }
     b.p = nullptr;
     b.bytes = 0;
     RS_HIP(hipMalloc(&b.p, bytes));
     b.bytes = bytes;
   }
+  ctx->ws_touched |= 1u << slot;
   return b.p;
+}
+WsScope::~WsScope() {
+  for (int k = 0; k < 16; k++) {
+    if (!((ctx->ws_touched >> k) & 1u)) continue;
+    DeviceBuf &b = ctx->ws[k];
+    if (!b.last_use && hipEventCreateWithFlags(&b.last_use, hipEventDisableTiming) != hipSuccess) {
+      // cannot stamp: fall back to draining the stream so the buffer is certainly free
+      (void)hipStreamSynchronize(ctx->cur_stream);
+      b.used = false;
+      continue;
+    }
+    if (hipEventRecord(b.last_use, ctx->cur_stream) != hipSuccess) {
+      (void)hipStreamSynchronize(ctx->cur_stream);
+      b.used = false;
+      continue;
+    }
+    b.last_stream = ctx->cur_stream;
+    b.used = true;
+  }
+  ctx->ws_touched = 0;
 }
 
 // Stages before which every value must be brought back to |v| <= p/2 so that mulmod operands
@@ -171,7 +201,7 @@ __global__ void __launch_bounds__(THREADS) ntt_kernel(uint64_t *__restrict__ dat
   }
 }
 
-// Wave-private variant (ntt_core.cuh "wp"): one cross-wave round, then every wave finishes its own
+// Wave-private variant (ntt_core.hpp "wp"): one cross-wave round, then every wave finishes its own
 // contiguous block without workgroup barriers, and moves it between LDS and global memory itself
 // with fully coalesced 16-byte accesses.
 int g_ntt_repeat = 1;
@@ -510,7 +540,8 @@ int rs_ctx_create(int device, int N, int L, const uint64_t *q, int N_enc, int K,
   int ndev = 0;
   RS_HIP(hipGetDeviceCount(&ndev));
   if (ndev <= 0) throw Error(RS_ERR_HIP, "no HIP device: librs_hip has no CPU fallback");
-  RS_HIP(hipSetDevice(device));
+  RS_REQUIRE(device >= 0 && device < ndev, "device index out of range");
+  DeviceGuard device_guard(device);  // the caller's current device is restored on return
   for (int i = 0; i < L + K; i++) {
     const uint64_t p = i < L ? q[i] : Q[i - L];
     RS_REQUIRE(host::is_prime(p), "modulus is not prime");
@@ -565,6 +596,8 @@ void rs_witness_plans_destroy(rs_ctx *ctx);  // witness.hip
 
 void rs_ctx_destroy(rs_ctx *c) {
   if (!c) return;
+  int prev_device = -1;
+  (void)hipGetDevice(&prev_device);
   (void)hipSetDevice(c->device);
   rs_witness_plans_destroy(c);
   rs::msm_scratch_release(c);
@@ -573,40 +606,42 @@ void rs_ctx_destroy(rs_ctx *c) {
   if (c->d_qmod) (void)hipFree(c->d_qmod);
   if (c->d_Qmod) (void)hipFree(c->d_Qmod);
   if (c->d_index_map) (void)hipFree(c->d_index_map);
-  for (auto &b : c->ws)
+  for (auto &b : c->ws) {
+    if (b.last_use) (void)hipEventDestroy(b.last_use);
     if (b.p) (void)hipFree(b.p);
+  }
+  if (prev_device >= 0) (void)hipSetDevice(prev_device);
   delete c;
 }
 
 int rs_malloc(rs_ctx *ctx, size_t bytes, void **d_ptr) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_ptr, "null argument");
-  RS_HIP(hipSetDevice(ctx->device));
   RS_HIP(hipMalloc(d_ptr, bytes));
   RS_API_END
 }
 int rs_free(rs_ctx *ctx, void *d_ptr) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx, "null argument");
   if (d_ptr) RS_HIP(hipFree(d_ptr));
   RS_API_END
 }
 int rs_upload(rs_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx, "null argument");
   RS_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, S(stream)));
   RS_HIP(hipStreamSynchronize(S(stream)));
   RS_API_END
 }
 int rs_download(rs_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx, "null argument");
   RS_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, S(stream)));
   RS_HIP(hipStreamSynchronize(S(stream)));
   RS_API_END
 }
 int rs_sync(rs_ctx *ctx, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx, "null argument");
   RS_HIP(hipStreamSynchronize(S(stream)));
   RS_API_END
@@ -623,19 +658,19 @@ static const NttTable &pick_table(rs_ctx *ctx, int modset, int index) {
 }
 
 int rs_ntt_forward(rs_ctx *ctx, int modset, int index, uint64_t *d_data, size_t batch, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   launch_ntt(ctx, pick_table(ctx, modset, index), d_data, batch, false, S(stream));
   RS_API_END
 }
 int rs_ntt_inverse(rs_ctx *ctx, int modset, int index, uint64_t *d_data, size_t batch, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   launch_ntt(ctx, pick_table(ctx, modset, index), d_data, batch, true, S(stream));
   RS_API_END
 }
 
 #define RS_POINTWISE(NAME, OP, HAS_B)                                                                        \
   int NAME(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, const uint64_t *d_b, size_t count, rs_stream s) { \
-    RS_API_BEGIN                                                                                             \
+    RS_API_BEGIN_CTX(ctx)                                                                                    \
     RS_REQUIRE(ctx && d_dst && d_a && (d_b || !HAS_B), "null argument");                                     \
     launch_pointwise<OP>(ctx, d_dst, d_a, d_b, count, 0, S(s));                                              \
     RS_API_END                                                                                               \
@@ -645,30 +680,30 @@ RS_POINTWISE(rs_ring_sub, OP_SUB, true)
 RS_POINTWISE(rs_ring_mul, OP_MUL, true)
 
 int rs_ring_neg(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, size_t count, rs_stream s) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_dst && d_a, "null argument");
   launch_pointwise<OP_NEG>(ctx, d_dst, d_a, nullptr, count, 0, S(s));
   RS_API_END
 }
 int rs_ring_add_scalar(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, uint64_t scalar, size_t count, rs_stream s) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_dst && d_a, "null argument");
   launch_pointwise<OP_ADD_SCALAR>(ctx, d_dst, d_a, nullptr, count, scalar, S(s));
   RS_API_END
 }
 int rs_ring_mul_scalar(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, uint64_t scalar, size_t count, rs_stream s) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_dst && d_a, "null argument");
   launch_pointwise<OP_MUL_SCALAR>(ctx, d_dst, d_a, nullptr, count, scalar, S(s));
   RS_API_END
 }
 
 int rs_ring_inv(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, size_t count, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_dst && d_a, "null argument");
   const size_t words = count * ctx->ring_words();
   if (words) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    WsScope ws_scope(ctx, S(stream));
     char *ws = (char *)ws_get(ctx, 7, 256);
     unsigned *flags = (unsigned *)ws;
     uint64_t *qint = (uint64_t *)(ws + 64);
@@ -686,10 +721,10 @@ int rs_ring_inv(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, size_t count,
 }
 
 int rs_ring_is_zero(rs_ctx *ctx, const uint64_t *d_a, size_t count, uint8_t *h_flags, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_a && h_flags, "null argument");
   if (count) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    WsScope ws_scope(ctx, S(stream));
     unsigned *flags = (unsigned *)ws_get(ctx, 7, std::max<size_t>(256, count * 4));
     RS_HIP(hipMemsetAsync(flags, 0, count * 4, S(stream)));
     hipLaunchKernelGGL(ring_nonzero_kernel, dim3((unsigned)count), dim3(256), 0, S(stream), d_a, ctx->ring_words(), flags);
@@ -706,17 +741,20 @@ int rs_set_tuning(const char *key, int value) {
   RS_REQUIRE(key, "null argument");
   if (std::string(key) == "ntt_variant")
     g_ntt_variant = value;
+#ifdef RS_EXPERIMENTS  // these two CHANGE THE RESULTS (timing experiments, tools/): `make experiments` only
   else if (std::string(key) == "ntt_repeat")
     g_ntt_repeat = value;
-  else if (std::string(key) == "mac_variant")
-    g_mac_variant = value;
   else if (std::string(key) == "mac_ablate")
     g_mac_ablate = value;
-  else if (std::string(key) == "witness_split")
-    g_witness_split = value;
+#endif
+  else if (std::string(key) == "mac_variant")
+    g_mac_variant = value;
   else if (std::string(key) == "witness_tree_ct")
     g_witness_tree_ct = value;
-  else if (std::string(key) == "witness_lds_logM") {
+  else if (std::string(key) == "witness_col_budget_mib") {
+    RS_REQUIRE(value >= 1, "witness_col_budget_mib must be positive");
+    g_witness_col_budget_mib = value;
+  } else if (std::string(key) == "witness_lds_logM") {
     RS_REQUIRE(value >= 6 && value <= 13, "witness_lds_logM must be in [6, 13]");
     g_witness_lds_logM = value;
   }
@@ -726,13 +764,13 @@ int rs_set_tuning(const char *key, int value) {
 }
 
 int rs_set_profiling(rs_ctx *ctx, int enabled) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx, "null argument");
   ctx->profiling = enabled != 0;
   RS_API_END
 }
 int rs_last_timings(rs_ctx *ctx, rs_timings *out) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && out, "null argument");
   *out = ctx->timings;
   RS_API_END

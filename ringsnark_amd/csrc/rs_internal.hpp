@@ -34,6 +34,12 @@ void set_last_error(const std::string &m);
   } while (0)
 // wraps a C-ABI body
 #define RS_API_BEGIN try {
+// entry points that take a context: the calling thread's HIP device is switched to the context's
+// for the duration of the call (the current device is per host thread) and restored afterwards
+#define RS_API_BEGIN_CTX(ctx) \
+  try {                       \
+    RS_REQUIRE((ctx) != nullptr, "null context"); \
+    rs::DeviceGuard _rs_device_guard((ctx)->device);
 #define RS_API_END                                   \
   return RS_OK;                                      \
   }                                                  \
@@ -61,9 +67,16 @@ struct NttTable {
   uint32_t fwd_red_mask = 0, inv_red_mask = 0;  // stages before which values are re-reduced
 };
 
+// A cached workspace buffer of the context.  Workspaces are shared by every call on the context;
+// re-entrancy across streams is kept by an event per buffer: the event is recorded on the stream
+// of the last call that used the buffer (WsScope, below), and the next user on ANOTHER stream makes
+// its stream wait for it before touching the buffer.  Enqueueing is serialised by rs_ctx::mu.
 struct DeviceBuf {
   void *p = nullptr;
   size_t bytes = 0;
+  hipEvent_t last_use = nullptr;   // recorded at the end of the last call that touched the buffer
+  hipStream_t last_stream = nullptr;
+  bool used = false;               // last_use is valid
 };
 
 struct WitnessPlan;  // witness.hip
@@ -103,6 +116,8 @@ struct rs_ctx {
   std::map<size_t, rs::WitnessPlan *> plans;  // keyed by padded domain size M
   // workspace cache (grown on demand, per context; calls that need workspace serialise on mu)
   rs::DeviceBuf ws[16];
+  hipStream_t cur_stream = nullptr;  // stream of the call that holds mu (rs::WsScope)
+  uint32_t ws_touched = 0;           // workspace slots used by that call
   bool profiling = false;
   rs_timings timings{};
   size_t ring_words() const { return (size_t)L * N; }
@@ -112,6 +127,29 @@ struct rs_ctx {
 
 namespace rs {
 void *ws_get(rs_ctx *ctx, int slot, size_t bytes);
+// Holds the context lock for one API call on `st` and, on exit, stamps every workspace buffer the
+// call touched with an event on `st` (see DeviceBuf).  Every entry point that calls ws_get owns one.
+// Also pins the HIP current device of the calling thread to the context's device for the call.
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) RS_HIP(hipSetDevice(dev));
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+struct WsScope {
+  rs_ctx *ctx;
+  std::unique_lock<std::mutex> lk;
+  WsScope(rs_ctx *c, hipStream_t st) : ctx(c), lk(c->mu) {
+    ctx->cur_stream = st;
+    ctx->ws_touched = 0;
+  }
+  ~WsScope();
+};
 NttTable make_negacyclic_table(uint64_t p, int logn);
 void free_table(NttTable &t);
 uint32_t fwd_reduce_mask(uint64_t p, int logn);
@@ -121,8 +159,8 @@ inline hipStream_t S(rs_stream s) { return (hipStream_t)s; }
 // launch helpers implemented in the .hip files
 void msm_scratch_release(rs_ctx *ctx);  // msm.hip
 extern int g_mac_variant, g_mac_ablate;  // msm.hip tuning knobs
-extern int g_witness_split;               // witness.hip: split interpolation into two launches
 extern int g_witness_tree_ct;             // witness.hip: level-unrolled product-tree kernel
+extern int g_witness_col_budget_mib;       // witness.hip: column workspace of one chunk of the witness map
 extern int g_witness_lds_logM;           // witness.hip: largest column (log2) handled inside one LDS tile
 void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st);
 }  // namespace rs

@@ -18,13 +18,13 @@
 //        pointwise by Z there, transform back (deg H <= m-2 < M).  ZK patch terms
 //        (r1cs_to_qrp.tcc:230-235) are added coefficient-wise.
 //
-// All transforms run inside one workgroup's LDS tile (ntt_core.cuh); data are transposed once
+// All transforms run inside one workgroup's LDS tile (ntt_core.hpp); data are transposed once
 // from the boundary layout [term][limb][slot] to column-major [limb][slot][M] and back.
 // Requires q_i = 1 mod 4M (cyclic NTT of length 2M) and M <= 8192 in this round.
 #include <algorithm>
 #include <cstring>
 
-#include "ntt_core.cuh"
+#include "ntt_core.hpp"
 #include "rs_internal.hpp"
 
 namespace rs {
@@ -313,6 +313,25 @@ struct ColBlockFactory {
   __device__ __forceinline__ LdsBlockIO operator()(int off) const { return LdsBlockIO{s + pidx(off)}; }
 };
 
+// Which columns a launch works on, and where they live in the boundary layouts.  The witness map is
+// column-parallel (one column = one NTT slot of one ring limb), so a call may process any sub-range
+// of slots of any sub-range of limbs: column c of the chunk is slot `slot0 + c % ns` of limb
+// `limb0 + c / ns`.  Inputs (assignment, d1..d3) are always in the full layout [..][L][N]; outputs are
+// [t][L][out_N] with slot s stored at s - out_slot0 (out_N = N, out_slot0 = 0: the full layout;
+// out_N = ns, out_slot0 = slot0: the compact layout of a slot-sharded rank).
+// slot0, ns, out_slot0 are even (lanes move slot PAIRS with 16-byte accesses).
+struct ColMap {
+  int limb0, ns, slot0, N, L, out_N, out_slot0;
+  __device__ __forceinline__ void locate(size_t c, int &limb, int &slot) const {
+    limb = limb0 + (int)(c / (size_t)ns);
+    slot = slot0 + (int)(c % (size_t)ns);
+  }
+  __device__ __forceinline__ size_t in_index(int limb, int slot) const { return (size_t)limb * N + slot; }
+  __device__ __forceinline__ size_t out_index(int limb, int slot) const { return (size_t)limb * out_N + (slot - out_slot0); }
+  __host__ __device__ __forceinline__ size_t in_stride() const { return (size_t)L * N; }
+  __host__ __device__ __forceinline__ size_t out_stride() const { return (size_t)L * out_N; }
+};
+
 // [rows][S] u64 (term-major, S = L*N) -> [S][M] f64 (column-major), rows >= m zero-filled.
 __global__ void __launch_bounds__(256) transpose_in_kernel(const uint64_t *__restrict__ src, double *__restrict__ dst,
                                                            size_t m, size_t S, size_t M) {
@@ -329,20 +348,25 @@ __global__ void __launch_bounds__(256) transpose_in_kernel(const uint64_t *__res
     if (sl < S && r < M) dst[sl * M + r] = tile[tx][k];
   }
 }
-// [S][M] f64 canonical -> [rows][S] u64 for rows < m_out
+// [C][M] f64 canonical columns -> [rows][L][out_N] u64 for rows < m_out
 __global__ void __launch_bounds__(256) transpose_out_kernel(const double *__restrict__ src, uint64_t *__restrict__ dst,
-                                                            size_t m_out, size_t S, size_t M) {
+                                                            size_t m_out, size_t C, size_t M, ColMap cm) {
   __shared__ double tile[32][33];
   const size_t s0 = (size_t)blockIdx.x * 32, r0 = (size_t)blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int k = ty; k < 32; k += 8) {
-    const size_t sl = s0 + k, r = r0 + tx;
-    tile[k][tx] = (sl < S && r < M) ? src[sl * M + r] : 0.0;
+    const size_t c = s0 + k, r = r0 + tx;
+    tile[k][tx] = (c < C && r < M) ? src[c * M + r] : 0.0;
   }
   __syncthreads();
+  const size_t c = s0 + tx;
+  if (c >= C) return;
+  int limb, slot;
+  cm.locate(c, limb, slot);
+  const size_t o = cm.out_index(limb, slot), So = cm.out_stride();
   for (int k = ty; k < 32; k += 8) {
-    const size_t r = r0 + k, sl = s0 + tx;
-    if (r < m_out && sl < S) dst[r * S + sl] = to_u64(tile[tx][k]);
+    const size_t r = r0 + k;
+    if (r < m_out) dst[r * So + o] = to_u64(tile[tx][k]);
   }
 }
 
@@ -459,30 +483,6 @@ interp_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned 
   for (int j = threadIdx.x; j < M; j += blockDim.x) c[j] = canon(s[pidx(j)], mod);
 }
 
-
-// values at 0..m-1 -> Newton coefficients (first half of interp_columns_kernel), in place.
-template <int LOGM_CT = 0>  // != 0: column length fixed at compile time (rounds specialised)
-__global__ void __launch_bounds__(1024)
-newton_columns_kernel(double *__restrict__ cols, int logM_arg, unsigned S, unsigned slots_per_limb, ColPlans plans) {
-  const int logM = LOGM_CT ? LOGM_CT : logM_arg;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *s = reinterpret_cast<double *>(smem);
-  const int M = 1 << logM;
-  const size_t col = blockIdx.x;
-  const ColPlan &P = plans.l[(col % S) / slots_per_limb];
-  const Mod mod = P.mod;
-  double *c = cols + col * (size_t)M;
-  for (int j = threadIdx.x; j < M; j += blockDim.x) {
-    s[pidx(j)] = mulmod(c[j], P.invfact[j], mod);
-    s[pidx(M + j)] = 0.0;
-  }
-  __syncthreads();
-  lds_ntt_fwd<4>(s, logM + 1, P.tw, 1, mod, P.fwd_mask2);
-  for (int j = threadIdx.x; j < 2 * M; j += blockDim.x) s[pidx(j)] = mulmod(reduce(s[pidx(j)], mod), P.ehat[j], mod);
-  __syncthreads();
-  lds_ntt_inv<4>(s, logM + 1, P.itw, 1, mod, P.inv_mask2);
-  for (int j = threadIdx.x; j < M; j += blockDim.x) c[j] = (P.invfact[j] != 0.0) ? reduce(s[pidx(j)], mod) : 0.0;
-}
 
 // Source / sink functors of the product tree's wave-private levels (block-local indices).
 // First forward round of a level-l transform: element offset eoff inside the node is a left
@@ -684,7 +684,7 @@ template <int LOGM_CT = 0>
 __global__ void __launch_bounds__(1024)
 h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, double *__restrict__ H, int logM_arg, int m,
                  unsigned slots_per_limb, ColPlans plans, const uint64_t *__restrict__ d1,
-                 const uint64_t *__restrict__ d2, const uint64_t *__restrict__ d3) {
+                 const uint64_t *__restrict__ d2, const uint64_t *__restrict__ d3, ColMap cm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   const int logM = LOGM_CT ? LOGM_CT : logM_arg;
@@ -741,9 +741,12 @@ h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, do
   double e1 = 0.0, e2 = 0.0, e3 = 0.0, e12 = 0.0;
   const bool zk = d1 != nullptr;
   if (zk) {
-    e1 = center(from_u64(d1[col]), mod);
-    e2 = center(from_u64(d2[col]), mod);
-    e3 = center(from_u64(d3[col]), mod);
+    int dlimb, dslot;
+    cm.locate(col, dlimb, dslot);
+    const size_t di = cm.in_index(dlimb, dslot);
+    e1 = center(from_u64(d1[di]), mod);
+    e2 = center(from_u64(d2[di]), mod);
+    e3 = center(from_u64(d3[di]), mod);
     e12 = mulmod(e1, e2, mod);
   }
   double *dst = H + col * (size_t)M;
@@ -770,7 +773,7 @@ template <int THREADS, int LOGM_CT = 0>
 __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 4 : THREADS / 128)
 h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, double *__restrict__ H, int logM_arg, int m,
               unsigned slots_per_limb, ColPlans plans, const uint64_t *__restrict__ d1, const uint64_t *__restrict__ d2,
-              const uint64_t *__restrict__ d3) {
+              const uint64_t *__restrict__ d3, ColMap cm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   constexpr int LOGW = THREADS == 1024 ? 4 : (THREADS == 512 ? 3 : (THREADS == 256 ? 2 : (THREADS == 128 ? 1 : 0)));
@@ -907,9 +910,12 @@ h_tile_kernel(const double *__restrict__ A, const double *__restrict__ Bc, doubl
   double e1 = 0.0, e2 = 0.0, e3 = 0.0, e12 = 0.0;
   const bool zk = d1 != nullptr;
   if (zk) {
-    e1 = center(from_u64(d1[col]), mod);
-    e2 = center(from_u64(d2[col]), mod);
-    e3 = center(from_u64(d3[col]), mod);
+    int dlimb, dslot;
+    cm.locate(col, dlimb, dslot);
+    const size_t di = cm.in_index(dlimb, dslot);
+    e1 = center(from_u64(d1[di]), mod);
+    e2 = center(from_u64(d2[di]), mod);
+    e3 = center(from_u64(d3[di]), mod);
     e12 = mulmod(e1, e2, mod);
   }
   {
@@ -938,26 +944,28 @@ struct IoDesc {
   int count;
 };
 __global__ void __launch_bounds__(256)
-io_coeff_kernel(IoDesc io, const double *__restrict__ Lcols /* [ncols][L][M] */, const uint64_t *__restrict__ asg,
-                uint64_t *__restrict__ out, int N, int L, size_t M, const Mod *__restrict__ qmod) {
-  const size_t t = blockIdx.x, S = (size_t)L * N;
-  const size_t pair = (size_t)blockIdx.y * blockDim.x + threadIdx.x;
-  if (2 * pair >= S) return;
-  const int limb = (int)((2 * pair) / (size_t)N);
+io_coeff_kernel(IoDesc io, const double *__restrict__ Lcols /* [ncols][Ltot][M] */, const uint64_t *__restrict__ asg,
+                uint64_t *__restrict__ out, size_t C, size_t M, const Mod *__restrict__ qmod, ColMap cm) {
+  const size_t t = blockIdx.x;
+  const size_t c = 2 * ((size_t)blockIdx.y * blockDim.x + threadIdx.x);
+  if (c >= C) return;
+  int limb, slot;
+  cm.locate(c, limb, slot);
+  const size_t pair = cm.in_index(limb, slot) >> 1, Si = cm.in_stride();
   const Mod mod = qmod[limb];
   double a0 = 0.0, a1 = 0.0;
-  for (int c = 0; c < io.count; c++) {
-    const double lv = center(Lcols[((size_t)io.column[c] * L + limb) * M + t], mod);
-    const int k = io.k[c];
-    if (k == 0) {
+  for (int k = 0; k < io.count; k++) {
+    const double lv = center(Lcols[((size_t)io.column[k] * cm.L + limb) * M + t], mod);
+    const int v_ = io.k[k];
+    if (v_ == 0) {
       a0 += lv;
       a1 += lv;
     } else {
-      const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(k - 1) * S)[pair];
+      const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(v_ - 1) * Si)[pair];
       a0 += mulmod(from_u64(v.x), lv, mod);
       a1 += mulmod(from_u64(v.y), lv, mod);
     }
-    if ((c & 3) == 3) {
+    if ((k & 3) == 3) {
       a0 = reduce(a0, mod);
       a1 = reduce(a1, mod);
     }
@@ -965,50 +973,51 @@ io_coeff_kernel(IoDesc io, const double *__restrict__ Lcols /* [ncols][L][M] */,
   ulonglong2 o;
   o.x = to_u64(canon(a0, mod));
   o.y = to_u64(canon(a1, mod));
-  reinterpret_cast<ulonglong2 *>(out + t * S)[pair] = o;
+  reinterpret_cast<ulonglong2 *>(out + t * cm.out_stride())[cm.out_index(limb, slot) >> 1] = o;
 }
 
 // Column-major interpolated `full` vector -> term-major io AND mid vectors in one pass:
 //   io[t]  = Lconst[t] + sum_k x_k (*) L_k[t]          (io shortcut, as io_coeff_kernel)
-//   mid[t] = full[t] - io[t] + const[limb][t]          (as mid_tm_kernel)
-// i.e. transpose_out + io_coeff + mid_tm fused: the column tile is transposed through LDS, the io
-// value is computed where it is needed, and both results are written once (16 bytes per lane).
-// grid (S/64, M/32).
+//   mid[t] = full[t] - io[t] + const[limb][t]
+// i.e. transpose + io + mid fused: the column tile is transposed through LDS, the io value is
+// computed where it is needed, and both results are written once (16 bytes per lane).
+// grid (C/64, M/32).
 __global__ void __launch_bounds__(256)
-io_mid_out_kernel(const double *__restrict__ cols, IoDesc io, const double *__restrict__ Lcols /* [ncols][L][M] */,
-                  const uint64_t *__restrict__ asg, const double *__restrict__ cst /* [L][M] or null */,
-                  uint64_t *__restrict__ io_out /* or null */, uint64_t *__restrict__ mid_out, size_t m, int N, int L,
-                  size_t M, const Mod *__restrict__ qmod) {
-  __shared__ double tile[64][33];  // [slot][row]
-  const size_t S = (size_t)L * N;
+io_mid_out_kernel(const double *__restrict__ cols, IoDesc io, const double *__restrict__ Lcols /* [ncols][Ltot][M] */,
+                  const uint64_t *__restrict__ asg, const double *__restrict__ cst /* [Ltot][M] or null */,
+                  uint64_t *__restrict__ io_out /* or null */, uint64_t *__restrict__ mid_out, size_t m, size_t C,
+                  size_t M, const Mod *__restrict__ qmod, ColMap cm) {
+  __shared__ double tile[64][33];  // [column][row]
   const size_t s0 = (size_t)blockIdx.x * 64, r0 = (size_t)blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int k = ty; k < 64; k += 8) {
-    const size_t sl = s0 + k, r = r0 + tx;
-    tile[k][tx] = (sl < S && r < M) ? cols[sl * M + r] : 0.0;
+    const size_t c = s0 + k, r = r0 + tx;
+    tile[k][tx] = (c < C && r < M) ? cols[c * M + r] : 0.0;
   }
   __syncthreads();
-  const size_t sl = s0 + 2 * tx;  // this lane's slot pair (N is even: both slots in one limb)
-  if (sl >= S) return;
-  const size_t pair = sl >> 1;
-  const int limb = (int)(sl / (size_t)N);
+  const size_t c = s0 + 2 * tx;  // this lane's column pair (ns is even: both slots in one limb)
+  if (c >= C) return;
+  int limb, slot;
+  cm.locate(c, limb, slot);
+  const size_t pair = cm.in_index(limb, slot) >> 1, Si = cm.in_stride();
+  const size_t opair = cm.out_index(limb, slot) >> 1, So = cm.out_stride();
   const Mod mod = qmod[limb];
   for (int k = ty; k < 32; k += 8) {
     const size_t r = r0 + k;
     if (r >= m) continue;
     double a0 = 0.0, a1 = 0.0;
-    for (int c = 0; c < io.count; c++) {
-      const double lv = center(Lcols[((size_t)io.column[c] * L + limb) * M + r], mod);
-      const int kk = io.k[c];
+    for (int e = 0; e < io.count; e++) {
+      const double lv = center(Lcols[((size_t)io.column[e] * cm.L + limb) * M + r], mod);
+      const int kk = io.k[e];
       if (kk == 0) {
         a0 += lv;
         a1 += lv;
       } else {
-        const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(kk - 1) * S)[pair];
+        const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(kk - 1) * Si)[pair];
         a0 += mulmod(from_u64(v.x), lv, mod);
         a1 += mulmod(from_u64(v.y), lv, mod);
       }
-      if ((c & 3) == 3) {
+      if ((e & 3) == 3) {
         a0 = reduce(a0, mod);
         a1 = reduce(a1, mod);
       }
@@ -1019,46 +1028,28 @@ io_mid_out_kernel(const double *__restrict__ cols, IoDesc io, const double *__re
       ulonglong2 o;
       o.x = to_u64(a0);
       o.y = to_u64(a1);
-      reinterpret_cast<ulonglong2 *>(io_out + r * S)[pair] = o;
+      reinterpret_cast<ulonglong2 *>(io_out + r * So)[opair] = o;
     }
     const double cc = cst ? cst[(size_t)limb * M + r] : 0.0;
     ulonglong2 o;
     o.x = to_u64(canon(tile[2 * tx][k] - a0 + cc, mod));
     o.y = to_u64(canon(tile[2 * tx + 1][k] - a1 + cc, mod));
-    reinterpret_cast<ulonglong2 *>(mid_out + r * S)[pair] = o;
-  }
-}
-
-// term-major: full[t] <- full[t] - io[t] + const[limb][t]
-__global__ void __launch_bounds__(256)
-mid_tm_kernel(uint64_t *__restrict__ full, const uint64_t *__restrict__ io, const double *__restrict__ cst /* [L][M] or null */,
-              size_t m, int N, int L, size_t M, const Mod *__restrict__ qmod) {
-  const size_t S = (size_t)L * N, total = m * S / 2, stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const size_t t = (2 * i) / S;
-    const int limb = (int)(((2 * i) % S) / (size_t)N);
-    const Mod mod = qmod[limb];
-    const double c = cst ? cst[(size_t)limb * M + t] : 0.0;
-    const ulonglong2 f = reinterpret_cast<const ulonglong2 *>(full)[i], g = reinterpret_cast<const ulonglong2 *>(io)[i];
-    ulonglong2 o;
-    o.x = to_u64(canon(from_u64(f.x) - from_u64(g.x) + c, mod));
-    o.y = to_u64(canon(from_u64(f.y) - from_u64(g.y) + c, mod));
-    reinterpret_cast<ulonglong2 *>(full)[i] = o;
+    reinterpret_cast<ulonglong2 *>(mid_out + r * So)[opair] = o;
   }
 }
 
 // coefficients_for_X_mid = interp(full) - interp(io) + interp(constant part), in place over `full`.
 // (The reference evaluates index-0 terms in BOTH the io and the mid pass, r1cs_to_qrp.tcc:175-201.)
 __global__ void __launch_bounds__(256)
-mid_kernel(double *__restrict__ full, const double *__restrict__ io, const double *__restrict__ cst /* [L][M] or null */,
-           size_t M, size_t S, unsigned slots_per_limb, ColPlans plans) {
+mid_kernel(double *__restrict__ full, const double *__restrict__ io, const double *__restrict__ cst /* [Ltot][M] or null */,
+           size_t M, size_t S, unsigned slots_per_limb, ColPlans plans, int limb0) {
   const size_t total = S * M, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const size_t col = i / M, k = i % M;
-    const int limb = (int)(col / slots_per_limb);
+    const int limb = (int)(col / slots_per_limb);  // chunk-local: plans are shifted by limb0
     const Mod mod = plans.l[limb].mod;
     double v = full[i] - io[i];
-    if (cst) v += cst[(size_t)limb * M + k];
+    if (cst) v += cst[(size_t)(limb0 + limb) * M + k];
     full[i] = canon(v, mod);
   }
 }
@@ -1104,20 +1095,20 @@ r1cs_eval_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restric
 
 
 // linear_combination::evaluate straight into the column-major layout of the witness map
-// (r1cs_eval_kernel + transpose_in_kernel fused; rows >= m are the zero padding of the columns).
-// grid (S/64, M/32): 64 slots x 32 rows per workgroup.
+// (r1cs_eval_kernel + transpose fused; rows >= m are the zero padding of the columns).
+// grid (C/64, M/32): 64 columns x 32 rows per workgroup.
 __global__ void __launch_bounds__(256)
 r1cs_eval_cols_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const double *__restrict__ coeff,
-                      size_t nnz, const uint64_t *__restrict__ asg, double *__restrict__ cols, size_t m, int N, int L, size_t M,
-                      int mode, unsigned n_inputs, const Mod *__restrict__ qmod) {
-  __shared__ double tile[64][33];  // [slot][row]
-  const size_t S = (size_t)L * N;
+                      size_t nnz, const uint64_t *__restrict__ asg, double *__restrict__ cols, size_t m, size_t C, size_t M,
+                      int mode, unsigned n_inputs, const Mod *__restrict__ qmod, ColMap cm) {
+  __shared__ double tile[64][33];  // [column][row]
   const size_t s0 = (size_t)blockIdx.x * 64, r0 = (size_t)blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const size_t sl = s0 + 2 * tx;  // slot pair of this lane, 16-byte loads of the assignment
-  if (sl < S) {
-    const size_t pair = sl >> 1;
-    const int limb = (int)(sl / (size_t)N);
+  const size_t c = s0 + 2 * tx;  // column pair of this lane, 16-byte loads of the assignment
+  if (c < C) {
+    int limb, slot;
+    cm.locate(c, limb, slot);
+    const size_t pair = cm.in_index(limb, slot) >> 1, Si = cm.in_stride();
     const Mod mod = qmod[limb];
     for (int k = ty; k < 32; k += 8) {
       const size_t row = r0 + k;
@@ -1125,15 +1116,15 @@ r1cs_eval_cols_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__re
       if (row < m) {
         int since = 0;
         for (uint32_t e = row_ptr[row]; e < row_ptr[row + 1]; e++) {
-          const uint32_t c = col[e];
+          const uint32_t cv = col[e];
           const double cf = coeff[(size_t)limb * nnz + e];
-          if (c == 0) {
+          if (cv == 0) {
             a0 += cf;
             a1 += cf;
           } else {
-            const bool is_input = (c - 1) < n_inputs;
+            const bool is_input = (cv - 1) < n_inputs;
             if ((mode == RS_EVAL_IO && !is_input) || (mode == RS_EVAL_MID && is_input)) continue;
-            const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(c - 1) * S)[pair];
+            const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(cv - 1) * Si)[pair];
             a0 += mulmod(from_u64(v.x), cf, mod);
             a1 += mulmod(from_u64(v.y), cf, mod);
           }
@@ -1152,9 +1143,26 @@ r1cs_eval_cols_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__re
   }
   __syncthreads();
   for (int k = ty; k < 64; k += 8) {
-    const size_t slot = s0 + k, r = r0 + tx;
-    if (slot < S && r < M) cols[slot * M + r] = tile[k][tx];
+    const size_t cc = s0 + k, r = r0 + tx;
+    if (cc < C && r < M) cols[cc * M + r] = tile[k][tx];
   }
+}
+
+// H[m] when m == M (the column tile holds M rows only): d1*d2*Z[m] = d1*d2 (Z monic), zero without ZK
+__global__ void __launch_bounds__(256)
+h_top_kernel(uint64_t *__restrict__ top, const uint64_t *__restrict__ d1, const uint64_t *__restrict__ d2, size_t C,
+             const Mod *__restrict__ qmod, ColMap cm) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  int limb, slot;
+  cm.locate(c, limb, slot);
+  const Mod mod = qmod[limb];
+  uint64_t v = 0;
+  if (d1) {
+    const size_t di = cm.in_index(limb, slot);
+    v = to_u64(canon(mulmod(center(from_u64(d1[di]), mod), center(from_u64(d2[di]), mod), mod), mod));
+  }
+  top[cm.out_index(limb, slot)] = v;
 }
 
 // =============================================================================================
@@ -1163,7 +1171,7 @@ r1cs_eval_cols_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__re
 //     forward:  log2(n1) "cross" stages (gap >= Bn; twiddles depend on the block index only),
 //               then n1 independent length-Bn sub-transforms rooted at tree nodes n1 + b, in LDS;
 //     inverse:  the sub-transforms first, then the cross stages.
-// Both reuse the round functions of ntt_core.cuh (global-memory functors / `root`).
+// Both reuse the round functions of ntt_core.hpp (global-memory functors / `root`).
 // =============================================================================================
 struct TabPtrs {
   const double *t[RS_MAX_L];
@@ -1314,7 +1322,7 @@ sub_ntt_kernel(double *__restrict__ X, int logB, int log_n1, TabPtrs tabs, unsig
 __global__ void __launch_bounds__(256)
 h_patch_kernel(double *__restrict__ H, const double *__restrict__ A, const double *__restrict__ B, int logM, int m, size_t cols,
                size_t col0, unsigned S, unsigned slots_per_limb, ColPlans plans, const uint64_t *__restrict__ d1,
-               const uint64_t *__restrict__ d2, const uint64_t *__restrict__ d3) {
+               const uint64_t *__restrict__ d2, const uint64_t *__restrict__ d3, ColMap cm) {
   const size_t M = (size_t)1 << logM, total = cols * M, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const size_t col = i / M, k = i % M, gcol = (col0 + col) % S;
@@ -1322,20 +1330,24 @@ h_patch_kernel(double *__restrict__ H, const double *__restrict__ A, const doubl
     const Mod mod = P.mod;
     double h = ((long long)k <= (long long)m - 2) ? H[i] : 0.0;
     if (d1) {
-      const double e1 = center(from_u64(d1[gcol]), mod), e2 = center(from_u64(d2[gcol]), mod);
+      int dlimb, dslot;
+      cm.locate(gcol, dlimb, dslot);
+      const size_t di = cm.in_index(dlimb, dslot);
+      const double e1 = center(from_u64(d1[di]), mod), e2 = center(from_u64(d2[di]), mod);
       h += mulmod(e2, center(A[i], mod), mod) + mulmod(e1, center(B[i], mod), mod) + mulmod(mulmod(e1, e2, mod), P.ztab[k], mod);
-      if (k == 0) h -= center(from_u64(d3[gcol]), mod);
+      if (k == 0) h -= center(from_u64(d3[di]), mod);
     }
     H[i] = canon(h, mod);
   }
 }
 
-static ColPlans make_colplans(rs_ctx *ctx, const WitnessPlan *P) {
+// Column plans of limbs limb0, limb0+1, ...: entry k serves the k-th limb of a chunk
+static ColPlans make_colplans(rs_ctx *ctx, const WitnessPlan *P, int limb0 = 0) {
   ColPlans cp;
   memset(&cp, 0, sizeof(cp));
-  for (int i = 0; i < ctx->L; i++) {
+  for (int i = limb0; i < ctx->L; i++) {
     const LimbPlan &lp = P->limb[i];
-    ColPlan &c = cp.l[i];
+    ColPlan &c = cp.l[i - limb0];
     c.mod = lp.mod;
     c.tw = lp.d_tw;
     c.itw = lp.d_itw;
@@ -1359,7 +1371,6 @@ static int col_threads(size_t M) { return (int)std::max<size_t>(64, std::min<siz
 
 int g_witness_lds_logM = 13;  // columns up to 2^13 run entirely inside one LDS tile
 int g_witness_tree_ct = 1;    // 1: level-unrolled product-tree kernel for 2^13 tiles
-int g_witness_split = 2;      // M >= 1024 -- 2: fused Newton + tree kernel on an M tile; 1: Newton (2M tile) + tree launches; 0: one 2M-tile kernel
 
 // Newton -> monomial levels 1..logT on tiles of 2^logT coefficients of [ncols][M] columns; with
 // `newton` (logT == logM) the tiles hold values and the Newton conversion runs first, in the same launch
@@ -1448,7 +1459,7 @@ static void launch_sub(double *X, size_t ncols, size_t col0, int logtot, int log
 
 // multi-pass interpolation of `ncols` columns X[ncols][M] in place; W: workspace [ncols][2M]
 static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, double *X, double *W, size_t ncols, size_t col0,
-                       size_t S, size_t spl, hipStream_t st) {
+                       size_t S, size_t spl, int limb0, hipStream_t st) {
   const int logM = P->logM, logB = std::min(g_witness_lds_logM, logM);
   const size_t M = P->M;
   CrossArgs a{};
@@ -1465,7 +1476,7 @@ static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, do
   // values -> Newton coefficients: one cyclic convolution of length 2M
   a.logtot = a.logsub = logM + 1;
   launch_cross<false, CS_SCALE_PAD>(a, ncols, logB, cp, st);
-  for (int i = 0; i < ctx->L; i++) tp.t[i] = P->limb[i].d_ehat;
+  for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_ehat;
   launch_sub<2>(W, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * M) >> logB, S, spl, cp, st);
   launch_cross<true, CD_TAKE_LOW>(a, ncols, logB, cp, st);
   // product tree: levels <= logB inside LDS tiles
@@ -1476,7 +1487,7 @@ static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, do
     a.l = l;
     a.logsub = l;
     launch_cross<false, CS_FILL_RIGHT>(a, ncols, logB, cp, st);
-    for (int i = 0; i < ctx->L; i++) tp.t[i] = P->limb[i].d_dhat + (size_t)l * M;
+    for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_dhat + (size_t)l * M;
     launch_sub<2>(W, ncols, col0, logM, l, logB, &tp, M >> logB, S, spl, cp, st);
     if (l == logM)
       launch_cross<true, CD_COMBINE_CANON>(a, ncols, logB, cp, st);
@@ -1488,7 +1499,7 @@ static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, do
 // multi-pass H = quo(A*B, Z) (+ ZK patch) for `ncols` columns; W1, W2: workspaces [ncols][2M]
 static void big_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const double *A, const double *B, double *H,
                   double *W1, double *W2, size_t ncols, size_t col0, size_t S, size_t spl, const uint64_t *d1,
-                  const uint64_t *d2, const uint64_t *d3, hipStream_t st) {
+                  const uint64_t *d2, const uint64_t *d3, const ColMap &cm, int limb0, hipStream_t st) {
   const int logM = P->logM, logB = std::min(g_witness_lds_logM, logM);
   const size_t M = P->M;
   CrossArgs a{};
@@ -1515,13 +1526,13 @@ static void big_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const d
   a.W = W1;
   a.src = W2;
   launch_cross<false, CS_REV_TRUNC>(a, ncols, logB, cp, st);
-  for (int i = 0; i < ctx->L; i++) tp.t[i] = P->limb[i].d_shat;
+  for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_shat;
   launch_sub<2>(W1, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * M) >> logB, S, spl, cp, st);
   a.dst = H;
   launch_cross<true, CD_H_FINISH>(a, ncols, logB, cp, st);
   const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((ncols * M + 255) / 256, 256 * 16));
   hipLaunchKernelGGL(h_patch_kernel, dim3(blocks), dim3(256), 0, st, H, A, B, logM, (int)P->m, ncols, col0, (unsigned)S, (unsigned)spl, cp,
-                     d1, d2, d3);
+                     d1, d2, d3, cm);
   RS_HIP(hipGetLastError());
 }
 
@@ -1535,32 +1546,18 @@ static size_t big_chunk_cols(const WitnessPlan *P) {
 // per CU, and 2^14 (a 136 KiB tile, one 1024-thread workgroup per CU) when the tile knob is at its
 // natural setting -- one launch instead of the multi-pass path.
 static bool single_tile_ok(int logM) {
-  if (g_witness_split != 2 || logM < 10) return false;
+  if (logM < 10) return false;
   return logM <= g_witness_lds_logM || (logM == 14 && g_witness_lds_logM == 13);
 }
 
+// Interpolate `ncols` columns in place.  Column c belongs to chunk-local limb (c % S) / slots_per_limb
+// (several vectors of S columns are batched); cp is shifted so that entry 0 is limb0.
 static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, double *cols, size_t ncols, size_t S,
-                          size_t slots_per_limb, hipStream_t st) {
+                          size_t slots_per_limb, int limb0, hipStream_t st) {
   if (single_tile_ok(P->logM)) {
     // one launch, tile = M, two workgroups per CU: Newton conversion by the two rooted M-point
     // sub-transforms, then the product tree in place
     launch_tree_tiles(cols, ncols, 0, P->logM, P->logM, S, slots_per_limb, cp, st, true);
-    return;
-  }
-  if (P->logM <= g_witness_lds_logM && P->logM >= 10 && g_witness_split == 1) {
-    // two launches: the length-2M convolution in a 2M tile (one workgroup per CU), then the product tree
-    const size_t lds2 = padded_len(2 * P->M) * sizeof(double);
-    if (P->logM == 13) {
-      RS_HIP(hipFuncSetAttribute((const void *)newton_columns_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-      hipLaunchKernelGGL(newton_columns_kernel<13>, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds2, st, cols, P->logM,
-                         (unsigned)S, (unsigned)slots_per_limb, cp);
-    } else {
-      RS_HIP(hipFuncSetAttribute((const void *)newton_columns_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-      hipLaunchKernelGGL(newton_columns_kernel<0>, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds2, st, cols, P->logM,
-                         (unsigned)S, (unsigned)slots_per_limb, cp);
-    }
-    launch_tree_tiles(cols, ncols, 0, P->logM, P->logM, S, slots_per_limb, cp, st);
-    RS_HIP(hipGetLastError());
     return;
   }
   if (P->logM <= g_witness_lds_logM) {
@@ -1576,21 +1573,23 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp,
   double *W = (double *)ws_get(ctx, 12, chunk * 2 * P->M * sizeof(double));
   for (size_t c0 = 0; c0 < ncols; c0 += chunk) {
     const size_t nc = std::min(chunk, ncols - c0);
-    big_interp(ctx, P, cp, cols + c0 * P->M, W, nc, c0, S, slots_per_limb, st);
+    big_interp(ctx, P, cp, cols + c0 * P->M, W, nc, c0, S, slots_per_limb, limb0, st);
   }
 }
 
+// H for the S columns of a chunk (A, B, H: [S][M]); `spl` columns per limb, cm locates d1..d3
 static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const double *A, const double *B, double *H,
-                     size_t S, size_t N, const uint64_t *d1, const uint64_t *d2, const uint64_t *d3, hipStream_t st) {
+                     size_t S, size_t spl, const uint64_t *d1, const uint64_t *d2, const uint64_t *d3, const ColMap &cm,
+                     hipStream_t st) {
   const size_t M = P->M;
   if (single_tile_ok(P->logM)) {
     const size_t lds1 = padded_len(M) * sizeof(double);
     const int thr = (int)(M / 16);
-#define RS_H_LAUNCH(KERN)                                                                                          \
-  do {                                                                                                             \
-    RS_HIP(hipFuncSetAttribute((const void *)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));       \
-    hipLaunchKernelGGL(KERN, dim3((unsigned)S), dim3(thr), lds1, st, A, B, H, P->logM, (int)P->m, (unsigned)N, cp, \
-                       d1, d2, d3);                                                                                \
+#define RS_H_LAUNCH(KERN)                                                                                            \
+  do {                                                                                                               \
+    RS_HIP(hipFuncSetAttribute((const void *)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));         \
+    hipLaunchKernelGGL(KERN, dim3((unsigned)S), dim3(thr), lds1, st, A, B, H, P->logM, (int)P->m, (unsigned)spl, cp, \
+                       d1, d2, d3, cm);                                                                              \
   } while (0)
     if (thr == 1024) RS_H_LAUNCH((h_tile_kernel<1024, 0>));
     else if (thr == 512 && g_witness_tree_ct) RS_H_LAUNCH((h_tile_kernel<512, 13>));
@@ -1604,15 +1603,9 @@ static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, cons
   }
   if (P->logM <= g_witness_lds_logM) {
     const size_t lds = padded_len(2 * M) * sizeof(double);
-    if (false && P->logM == 13) {  // measured: the specialised H kernel spills (r[16] + unrolled rounds) and is 3 % slower
-      RS_HIP(hipFuncSetAttribute((const void *)h_columns_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(h_columns_kernel<13>, dim3((unsigned)S), dim3(col_threads(2 * M)), lds, st, A, B, H, P->logM, (int)P->m,
-                         (unsigned)N, cp, d1, d2, d3);
-    } else {
-      RS_HIP(hipFuncSetAttribute((const void *)h_columns_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(h_columns_kernel<0>, dim3((unsigned)S), dim3(col_threads(2 * M)), lds, st, A, B, H, P->logM, (int)P->m,
-                         (unsigned)N, cp, d1, d2, d3);
-    }
+    RS_HIP(hipFuncSetAttribute((const void *)h_columns_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(h_columns_kernel<0>, dim3((unsigned)S), dim3(col_threads(2 * M)), lds, st, A, B, H, P->logM, (int)P->m,
+                       (unsigned)spl, cp, d1, d2, d3, cm);
     RS_HIP(hipGetLastError());
     return;
   }
@@ -1621,7 +1614,7 @@ static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, cons
   double *W2 = (double *)ws_get(ctx, 13, chunk * 2 * M * sizeof(double));
   for (size_t c0 = 0; c0 < S; c0 += chunk) {
     const size_t nc = std::min(chunk, S - c0);
-    big_h(ctx, P, cp, A + c0 * M, B + c0 * M, H + c0 * M, W1, W2, nc, c0, S, N, d1, d2, d3, st);
+    big_h(ctx, P, cp, A + c0 * M, B + c0 * M, H + c0 * M, W1, W2, nc, c0, S, spl, d1, d2, d3, cm, cm.limb0, st);
   }
 }
 
@@ -1670,7 +1663,7 @@ static void build_io_cache(rs_ctx *ctx, const rs_r1cs *cs, const WitnessPlan *P,
   RS_HIP(hipMalloc(&mc->d_io_cols, std::max<size_t>(1, cols.size()) * sizeof(double)));
   if (ncols) {
     RS_HIP(hipMemcpy(mc->d_io_cols, cols.data(), cols.size() * sizeof(double), hipMemcpyHostToDevice));
-    launch_interp(ctx, P, cp, mc->d_io_cols, (size_t)ncols * L, L, 1, st);
+    launch_interp(ctx, P, cp, mc->d_io_cols, (size_t)ncols * L, L, 1, 0, st);
     RS_HIP(hipStreamSynchronize(st));
   }
   for (int w = 0; w < 3; w++) {
@@ -1689,16 +1682,15 @@ static void build_io_cache(rs_ctx *ctx, const rs_r1cs *cs, const WitnessPlan *P,
   mc->io_built = true;
 }
 
-// Witness map driver.  outs[k] (k = A_io,B_io,C_io,A_mid,B_mid,C_mid,H) may be null.
-void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const uint64_t *d1, const uint64_t *d2,
-                 const uint64_t *d3, uint64_t *const outs[7], uint64_t *h_Z, hipStream_t st) {
-  RS_REQUIRE((d1 && d2 && d3) || (!d1 && !d2 && !d3), "d1,d2,d3 must be all set or all null");
-  const size_t m = cs->m;
-  WitnessPlan *P = get_plan(ctx, m);
-  const ColPlans cp = make_colplans(ctx, P);
-  const size_t M = P->M, S = ctx->ring_words(), N = (size_t)ctx->N;
-  if (h_Z)
-    for (int i = 0; i < ctx->L; i++) memcpy(h_Z + (size_t)i * (m + 1), P->limb[i].Z.data(), sizeof(uint64_t) * (m + 1));
+int g_witness_col_budget_mib = 16 * 1024;  // column workspace of one chunk (tuning knob "witness_col_budget_mib")
+
+// One chunk of the witness map: limbs [limb0, limb0 + nl), slots [cm.slot0, cm.slot0 + cm.ns) of each.
+static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const uint64_t *d_asg, const uint64_t *d1,
+                          const uint64_t *d2, const uint64_t *d3, uint64_t *const outs[7], const ColMap &cm, int nl,
+                          const double *d_const, hipStream_t st) {
+  const size_t m = cs->m, M = P->M;
+  const size_t C = (size_t)nl * cm.ns;  // columns in this chunk
+  const ColPlans cp = make_colplans(ctx, P, cm.limb0);
   const bool needH = outs[6] != nullptr;
   const bool shortcut = cs->n_inputs <= IO_SHORTCUT_MAX_INPUTS;
   bool need_io[3], need_full[3];
@@ -1706,94 +1698,127 @@ void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const ui
     need_io[w] = outs[w] != nullptr || outs[3 + w] != nullptr;
     need_full[w] = outs[3 + w] != nullptr || (needH && w < 2);  // H needs A and B only
   }
-  // column-major workspace: slots 0..2 = io (fallback path only), 3..5 = full, 6 = H
-  const size_t vec = S * M;
-  double *colbuf = (double *)ws_get(ctx, 5, 7 * vec * sizeof(double));
-  uint64_t *evalbuf = (uint64_t *)ws_get(ctx, 6, std::max<size_t>(m, 1) * S * sizeof(uint64_t));
-  auto colv = [&](int k) { return colbuf + (size_t)k * vec; };
-  const dim3 tgrid((unsigned)((S + 31) / 32), (unsigned)((M + 31) / 32));
-  const dim3 tgrid64((unsigned)((S + 63) / 64), (unsigned)((M + 31) / 32));
-  const unsigned by = (unsigned)((S / 2 + 255) / 256);
-  if (shortcut) build_io_cache(ctx, cs, P, cp, st);
+  // column-major workspace, only the vectors this call needs: io (fallback path only), full, H
+  auto needed = [&](int k) { return k < 3 ? (need_io[k] && !shortcut) : (k < 6 ? need_full[k - 3] : needH); };
+  int slot_of[7], nvec = 0;
+  for (int k = 0; k < 7; k++) slot_of[k] = needed(k) ? nvec++ : -1;
+  const size_t vec = C * M;
+  double *colbuf = (double *)ws_get(ctx, 5, std::max<size_t>(1, (size_t)nvec * vec) * sizeof(double));
+  auto colv = [&](int k) { return colbuf + (size_t)slot_of[k] * vec; };
+  const dim3 tgrid((unsigned)((C + 31) / 32), (unsigned)((M + 31) / 32));
+  const dim3 tgrid64((unsigned)((C + 63) / 64), (unsigned)((M + 31) / 32));
   for (int w = 0; w < 3; w++) {
-    if (need_io[w] && !shortcut) {
-      r1cs_evaluate_run(ctx, cs, w, RS_EVAL_IO, d_asg, evalbuf, st);
-      hipLaunchKernelGGL(transpose_in_kernel, tgrid, dim3(256), 0, st, evalbuf, colv(w), m, S, M);
-    }
-    if (need_full[w])
+    if (needed(w))
       hipLaunchKernelGGL(r1cs_eval_cols_kernel, tgrid64, dim3(256), 0, st, cs->d_row_ptr[w], cs->d_col[w], cs->d_coeff[w],
-                         cs->nnz[w], d_asg, colv(3 + w), m, ctx->N, ctx->L, M, (int)RS_EVAL_FULL, (unsigned)cs->n_inputs,
-                         ctx->d_qmod);
+                         cs->nnz[w], d_asg, colv(w), m, C, M, (int)RS_EVAL_IO, (unsigned)cs->n_inputs, ctx->d_qmod, cm);
+    if (needed(3 + w))
+      hipLaunchKernelGGL(r1cs_eval_cols_kernel, tgrid64, dim3(256), 0, st, cs->d_row_ptr[w], cs->d_col[w], cs->d_coeff[w],
+                         cs->nnz[w], d_asg, colv(3 + w), m, C, M, (int)RS_EVAL_FULL, (unsigned)cs->n_inputs, ctx->d_qmod, cm);
   }
   RS_HIP(hipGetLastError());
-  // batched interpolation over contiguous runs of needed vectors
-  auto needed = [&](int k) { return k < 3 ? (need_io[k] && !shortcut) : need_full[k - 3]; };
-  for (int k = 0; k < 6; k++) {
-    if (!needed(k)) continue;
-    int e = k;
-    while (e + 1 < 6 && needed(e + 1)) e++;
-    launch_interp(ctx, P, cp, colv(k), (size_t)(e - k + 1) * S, S, N, st);
-    k = e;
+  // one batched interpolation: the needed io / full vectors are adjacent in the workspace
+  {
+    int n6 = 0;
+    for (int k = 0; k < 6; k++) n6 += needed(k);
+    if (n6) launch_interp(ctx, P, cp, colbuf, (size_t)n6 * C, C, (size_t)cm.ns, cm.limb0, st);
   }
-  if (needH) launch_h(ctx, P, cp, colv(3), colv(4), colv(6), S, N, d1, d2, d3, st);
+  if (needH) launch_h(ctx, P, cp, colv(3), colv(4), colv(6), C, (size_t)cm.ns, d1, d2, d3, cm, st);
   const unsigned eb = (unsigned)std::min<size_t>((vec + 255) / 256, 256 * 16);
   if (!shortcut) {
-    // fallback: interpolate the constant parts and combine in column-major form
-    double *d_const = nullptr;
-    bool any_const = false;
-    for (int w = 0; w < 3; w++) any_const = any_const || cs->has_const[w];
-    if (any_const) {
-      std::vector<double> hc((size_t)3 * ctx->L * M, 0.0);
-      for (int w = 0; w < 3; w++)
-        for (int i = 0; i < ctx->L; i++)
-          for (size_t r = 0; r < m; r++) hc[((size_t)w * ctx->L + i) * M + r] = (double)cs->h_const[w][(size_t)i * m + r];
-      d_const = (double *)ws_get(ctx, 4, hc.size() * sizeof(double));
-      RS_HIP(hipMemcpyAsync(d_const, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice, st));
-      RS_HIP(hipStreamSynchronize(st));  // hc goes out of scope
-      launch_interp(ctx, P, cp, d_const, (size_t)3 * ctx->L, (size_t)ctx->L, 1, st);
-    }
+    // fallback: X_mid = interp(full) - interp(io) + interp(constant part), combined in column-major form
     for (int w = 0; w < 3; w++) {
       if (!outs[3 + w]) continue;
       const double *cst = (d_const && cs->has_const[w]) ? d_const + (size_t)w * ctx->L * M : nullptr;
-      hipLaunchKernelGGL(mid_kernel, dim3(eb), dim3(256), 0, st, colv(3 + w), colv(w), cst, M, S, (unsigned)N, cp);
+      hipLaunchKernelGGL(mid_kernel, dim3(eb), dim3(256), 0, st, colv(3 + w), colv(w), cst, M, C, (unsigned)cm.ns, cp, cm.limb0);
     }
     RS_HIP(hipGetLastError());
     for (int k = 0; k < 6; k++)
-      if (outs[k]) hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(k), outs[k], m, S, M);
+      if (outs[k]) hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(k), outs[k], m, C, M, cm);
   } else {
     for (int w = 0; w < 3; w++) {
+      if (!need_io[w]) continue;
+      IoDesc io{cs->d_io_k[w], cs->d_io_c[w], cs->io_count[w]};
       if (outs[3 + w]) {  // io (if wanted) and mid in one pass over the interpolated columns
-        IoDesc io{cs->d_io_k[w], cs->d_io_c[w], cs->io_count[w]};
         const double *cst = cs->io_const_col[w] >= 0 ? cs->d_io_cols + (size_t)cs->io_const_col[w] * ctx->L * M : nullptr;
         hipLaunchKernelGGL(io_mid_out_kernel, tgrid64, dim3(256), 0, st, colv(3 + w), io, cs->d_io_cols, d_asg, cst, outs[w],
-                           outs[3 + w], m, ctx->N, ctx->L, M, ctx->d_qmod);
-        continue;
-      }
-      uint64_t *io_dst = outs[w] ? outs[w] : evalbuf;  // evalbuf is free again: all evaluations are transposed
-      if (need_io[w]) {
-        IoDesc io{cs->d_io_k[w], cs->d_io_c[w], cs->io_count[w]};
-        hipLaunchKernelGGL(io_coeff_kernel, dim3((unsigned)m, by), dim3(256), 0, st, io, cs->d_io_cols, d_asg, io_dst, ctx->N,
-                           ctx->L, M, ctx->d_qmod);
-      }
-      if (outs[3 + w]) {
-        hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(3 + w), outs[3 + w], m, S, M);
-        const double *cst = cs->io_const_col[w] >= 0 ? cs->d_io_cols + (size_t)cs->io_const_col[w] * ctx->L * M : nullptr;
-        const unsigned mb = (unsigned)std::min<size_t>((m * S / 2 + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(mid_tm_kernel, dim3(mb), dim3(256), 0, st, outs[3 + w], io_dst, cst, m, ctx->N, ctx->L, M, ctx->d_qmod);
+                           outs[3 + w], m, C, M, ctx->d_qmod, cm);
+      } else {  // io alone: no column work at all
+        const unsigned by = (unsigned)((C / 2 + 255) / 256);
+        hipLaunchKernelGGL(io_coeff_kernel, dim3((unsigned)m, by), dim3(256), 0, st, io, cs->d_io_cols, d_asg, outs[w], C, M,
+                           ctx->d_qmod, cm);
       }
     }
   }
   RS_HIP(hipGetLastError());
   if (needH) {
-    hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(6), outs[6], std::min(m + 1, M), S, M);
+    hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(6), outs[6], std::min(m + 1, M), C, M, cm);
+    if (m == M)  // row m does not exist in the M-row column tile
+      hipLaunchKernelGGL(h_top_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, outs[6] + m * cm.out_stride(), d1, d2, C,
+                         ctx->d_qmod, cm);
     RS_HIP(hipGetLastError());
-    if (m == M) {  // H[m] = d1*d2*Z[m] = d1*d2 (Z monic), zero without ZK
-      uint64_t *top = outs[6] + m * S;
-      if (d1)
-        RS_REQUIRE(rs_ring_mul(ctx, top, d1, d2, 1, (rs_stream)st) == RS_OK, rs_last_error());
-      else
-        RS_HIP(hipMemsetAsync(top, 0, S * sizeof(uint64_t), st));
+  }
+}
+
+// Witness map driver.  outs[k] (k = A_io,B_io,C_io,A_mid,B_mid,C_mid,H) may be null.  Slots
+// [slot0, slot0 + nslots) of every limb are processed; `compact` selects the output layout
+// [t][L][nslots] (a slot-sharded rank) instead of the full [t][L][N].  The columns are
+// worked through in chunks whose column-major workspace stays within g_witness_col_budget_mib
+// (at m = 2^16 and the headline ring that is one limb at a time: 3 x 4 GiB instead of 7 x 16 GiB).
+void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const uint64_t *d1, const uint64_t *d2,
+                 const uint64_t *d3, uint64_t *const outs[7], uint64_t *h_Z, hipStream_t st, int slot0 = 0, int nslots = -1,
+                 bool compact = false) {
+  RS_REQUIRE((d1 && d2 && d3) || (!d1 && !d2 && !d3), "d1,d2,d3 must be all set or all null");
+  if (nslots < 0) nslots = ctx->N - slot0;
+  RS_REQUIRE(slot0 >= 0 && nslots >= 2 && slot0 + nslots <= ctx->N && !(slot0 & 1) && !(nslots & 1),
+             "slot range must be even-aligned and inside the ring");
+  const size_t m = cs->m;
+  WitnessPlan *P = get_plan(ctx, m);
+  const size_t M = P->M;
+  const int L = ctx->L;
+  if (h_Z)
+    for (int i = 0; i < L; i++) memcpy(h_Z + (size_t)i * (m + 1), P->limb[i].Z.data(), sizeof(uint64_t) * (m + 1));
+  const bool shortcut = cs->n_inputs <= IO_SHORTCUT_MAX_INPUTS;
+  if (shortcut) build_io_cache(ctx, cs, P, make_colplans(ctx, P), st);
+  // fallback path: interpolated constant parts [3][L][M], once per call
+  double *d_const = nullptr;
+  if (!shortcut && (cs->has_const[0] || cs->has_const[1] || cs->has_const[2]) && (outs[3] || outs[4] || outs[5])) {
+    std::vector<double> hc((size_t)3 * L * M, 0.0);
+    for (int w = 0; w < 3; w++)
+      for (int i = 0; i < L; i++)
+        for (size_t r = 0; r < m; r++) hc[((size_t)w * L + i) * M + r] = (double)cs->h_const[w][(size_t)i * m + r];
+    d_const = (double *)ws_get(ctx, 4, hc.size() * sizeof(double));
+    RS_HIP(hipMemcpyAsync(d_const, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    RS_HIP(hipStreamSynchronize(st));  // hc goes out of scope
+    launch_interp(ctx, P, make_colplans(ctx, P), d_const, (size_t)3 * L, (size_t)L, 1, 0, st);
+  }
+  // chunking: as many whole limbs as fit the budget, else pieces of one limb (multiples of 64 slots)
+  int nvec = 0;
+  {
+    const bool needH = outs[6] != nullptr;
+    for (int w = 0; w < 3; w++) {
+      const bool need_io = outs[w] || outs[3 + w], need_full = outs[3 + w] || (needH && w < 2);
+      nvec += (need_io && !shortcut) + need_full;
     }
+    nvec += needH;
+  }
+  const size_t budget_cols =
+      std::max<size_t>(64, ((size_t)g_witness_col_budget_mib << 20) / (std::max(1, nvec) * M * sizeof(double)));
+  ColMap cm{0, nslots, slot0, ctx->N, L, compact ? nslots : ctx->N, compact ? slot0 : 0};
+  if ((size_t)nslots <= budget_cols) {
+    const int per = (int)std::max<size_t>(1, std::min<size_t>((size_t)L, budget_cols / (size_t)nslots));
+    for (int l0 = 0; l0 < L; l0 += per) {
+      cm.limb0 = l0;
+      witness_chunk(ctx, cs, P, d_asg, d1, d2, d3, outs, cm, std::min(per, L - l0), d_const, st);
+    }
+  } else {
+    const int piece = (int)std::max<size_t>(64, (budget_cols / 64) * 64);
+    for (int l0 = 0; l0 < L; l0++)
+      for (int s0 = 0; s0 < nslots; s0 += piece) {
+        cm.limb0 = l0;
+        cm.slot0 = slot0 + s0;
+        cm.ns = std::min(piece, nslots - s0);
+        witness_chunk(ctx, cs, P, d_asg, d1, d2, d3, outs, cm, 1, d_const, st);
+      }
   }
 }
 
@@ -1810,10 +1835,14 @@ void rs_witness_plans_destroy(rs_ctx *ctx) {
 
 int rs_r1cs_create(rs_ctx *ctx, size_t m, size_t n_vars, size_t n_inputs, const uint32_t *const h_row_ptr[3],
                    const uint32_t *const h_col[3], const uint64_t *const h_coeff[3], const size_t nnz[3], rs_r1cs **out) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && out && h_row_ptr && h_col && h_coeff && nnz, "null argument");
   RS_REQUIRE(m >= 1 && n_inputs <= n_vars, "bad R1CS shape");
-  rs_r1cs *cs = new rs_r1cs();
+  struct Holder {  // frees a partly built object when a check below throws
+    rs_r1cs *p;
+    ~Holder() { rs_r1cs_destroy(p); }
+  } holder{new rs_r1cs()};
+  rs_r1cs *cs = holder.p;
   cs->m = m;
   cs->n_vars = n_vars;
   cs->n_inputs = n_inputs;
@@ -1821,7 +1850,9 @@ int rs_r1cs_create(rs_ctx *ctx, size_t m, size_t n_vars, size_t n_inputs, const 
   for (int w = 0; w < 3; w++) {
     const size_t z = nnz[w];
     cs->nnz[w] = z;
+    RS_REQUIRE(h_row_ptr[w] && (h_col[w] || z == 0) && (h_coeff[w] || z == 0), "null matrix array");
     RS_REQUIRE(h_row_ptr[w][0] == 0 && h_row_ptr[w][m] == z, "row_ptr does not match nnz");
+    for (size_t r = 0; r < m; r++) RS_REQUIRE(h_row_ptr[w][r] <= h_row_ptr[w][r + 1], "row_ptr is not monotone");
     cs->h_row_ptr[w].assign(h_row_ptr[w], h_row_ptr[w] + m + 1);
     cs->h_col[w].assign(h_col[w], h_col[w] + z);
     cs->h_coeff[w].assign(h_coeff[w], h_coeff[w] + (size_t)ctx->L * z);
@@ -1847,6 +1878,7 @@ int rs_r1cs_create(rs_ctx *ctx, size_t m, size_t n_vars, size_t n_inputs, const 
     RS_HIP(hipMalloc(&cs->d_coeff[w], sizeof(double) * cf.size()));
     RS_HIP(hipMemcpy(cs->d_coeff[w], cf.data(), sizeof(double) * cf.size(), hipMemcpyHostToDevice));
   }
+  holder.p = nullptr;
   *out = cs;
   RS_API_END
 }
@@ -1866,7 +1898,7 @@ void rs_r1cs_destroy(rs_r1cs *cs) {
 
 int rs_r1cs_evaluate(rs_ctx *ctx, const rs_r1cs *cs, int which, int mode, const uint64_t *d_assignment, uint64_t *d_out,
                      rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && cs && d_assignment && d_out, "null argument");
   RS_REQUIRE(which >= 0 && which < 3 && mode >= 0 && mode <= 2, "bad selector");
   r1cs_evaluate_run(ctx, cs, which, mode, d_assignment, d_out, S(stream));
@@ -1877,26 +1909,39 @@ int rs_witness_map(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_assignment,
                    const uint64_t *d_d2, const uint64_t *d_d3, uint64_t *d_A_io, uint64_t *d_B_io, uint64_t *d_C_io,
                    uint64_t *d_A_mid, uint64_t *d_B_mid, uint64_t *d_C_mid, uint64_t *d_H, uint64_t *h_Z,
                    rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && cs && d_assignment, "null argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  WsScope ws_scope(ctx, S(stream));
   uint64_t *outs[7] = {d_A_io, d_B_io, d_C_io, d_A_mid, d_B_mid, d_C_mid, d_H};
   witness_run(ctx, cs, d_assignment, d_d1, d_d2, d_d3, outs, h_Z, S(stream));
   RS_API_END
 }
 
+int rs_witness_map_slots(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_assignment, const uint64_t *d_d1,
+                         const uint64_t *d_d2, const uint64_t *d_d3, int slot0, int nslots, uint64_t *d_A_io,
+                         uint64_t *d_B_io, uint64_t *d_C_io, uint64_t *d_A_mid, uint64_t *d_B_mid, uint64_t *d_C_mid,
+                         uint64_t *d_H, uint64_t *h_Z, rs_stream stream) {
+  RS_API_BEGIN_CTX(ctx)
+  RS_REQUIRE(ctx && cs && d_assignment, "null argument");
+  WsScope ws_scope(ctx, S(stream));
+  uint64_t *outs[7] = {d_A_io, d_B_io, d_C_io, d_A_mid, d_B_mid, d_C_mid, d_H};
+  witness_run(ctx, cs, d_assignment, d_d1, d_d2, d_d3, outs, h_Z, S(stream), slot0, nslots, true);
+  RS_API_END
+}
+
 int rs_interpolate(rs_ctx *ctx, const uint64_t *d_y, uint64_t *d_out, size_t n, rs_stream stream) {
-  RS_API_BEGIN
+  RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_y && d_out && n >= 1, "null argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  WsScope ws_scope(ctx, S(stream));
   WitnessPlan *P = get_plan(ctx, n);
   const ColPlans cp = make_colplans(ctx, P);
   const size_t M = P->M, S_ = ctx->ring_words();
   double *colbuf = (double *)ws_get(ctx, 5, S_ * M * sizeof(double));
   const dim3 tgrid((unsigned)((S_ + 31) / 32), (unsigned)((M + 31) / 32));
+  const ColMap cm{0, ctx->N, 0, ctx->N, ctx->L, ctx->N, 0};
   hipLaunchKernelGGL(transpose_in_kernel, tgrid, dim3(256), 0, S(stream), d_y, colbuf, n, S_, M);
-  launch_interp(ctx, P, cp, colbuf, S_, S_, (size_t)ctx->N, S(stream));
-  hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, S(stream), colbuf, d_out, n, S_, M);
+  launch_interp(ctx, P, cp, colbuf, S_, S_, (size_t)ctx->N, 0, S(stream));
+  hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, S(stream), colbuf, d_out, n, S_, M, cm);
   RS_HIP(hipGetLastError());
   RS_API_END
 }

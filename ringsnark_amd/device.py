@@ -247,10 +247,12 @@ class Device:
                                              C.byref(used) if want_used else None, self.stream()))
         return out, int(used.value)
 
-    def msm(self, crs_list, vecs, n_groups, want_used=False):
-        """vecs: list of (coeff tensor [T][L][N], kinds or None, group)."""
+    def msm(self, crs_list, vecs, n_groups, want_used=False, crs_len=None, window=0):
+        """vecs: list of (coeff tensor [T][L][N], kinds or None, group).  window != 0: the CRS tensors hold
+        `window` elements and logical element t is read from t % window (crs_len = logical length)."""
         n_crs = len(crs_list)
-        crs_len = self._count(crs_list[0], self.enc_words)
+        if crs_len is None:
+            crs_len = self._count(crs_list[0], self.enc_words)
         crs = (C.c_void_p * n_crs)(*[c.data_ptr() for c in crs_list])
         mv = (_lib.MsmVec * len(vecs))()
         keep = []
@@ -264,7 +266,7 @@ class Device:
                 mv[k].h_kinds = kk.ctypes.data_as(_lib.u8p)
         out = self.enc_empty(n_crs, n_groups)
         used = (C.c_size_t * len(vecs))()
-        _lib.check(self.lib.rs_msm(self.h, crs, n_crs, crs_len, mv, len(vecs), n_groups, _ptr(out),
+        _lib.check(self.lib.rs_msm(self.h, crs, n_crs, crs_len, window, mv, len(vecs), n_groups, _ptr(out),
                                    used if want_used else None, self.stream()))
         return out, [int(u) for u in used]
 
@@ -296,21 +298,40 @@ class Device:
         o["Z"] = Z
         return o
 
+    def witness_map_slots(self, dcs, assignment, slot0, nslots, d1=None, d2=None, d3=None,
+                          want=("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")):
+        """The witness map on slots [slot0, slot0+nslots) of every limb; outputs compact [t][L][nslots]."""
+        m = dcs.m
+        o = {}
+        mk = lambda rows: torch.empty((rows, self.L, nslots), dtype=torch.int64, device=self.device)
+        for k in ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid"):
+            o[k] = mk(m) if k in want else None
+        o["H"] = mk(m + 1) if "H" in want else None
+        Z = np.zeros((self.L, m + 1), dtype=np.uint64)
+        _lib.check(self.lib.rs_witness_map_slots(
+            self.h, dcs.h, _ptr(assignment), _ptr(d1), _ptr(d2), _ptr(d3), slot0, nslots, _ptr(o["A_io"]), _ptr(o["B_io"]),
+            _ptr(o["C_io"]), _ptr(o["A_mid"]), _ptr(o["B_mid"]), _ptr(o["C_mid"]), _ptr(o["H"]), Z.ctypes.data_as(_lib.u64p),
+            self.stream()))
+        o["Z"] = Z
+        return o
+
     # ---- a15 / a16
-    def groth16_prove(self, dcs, pk, assignment, want_empty=True):
-        """pk: dict s_pows, delta_ts, delta_mid, alpha, beta (CUDA tensors)."""
+    def groth16_prove(self, dcs, pk, assignment, want_empty=True, window=0):
+        """pk: dict s_pows, delta_ts, delta_mid, alpha, beta (CUDA tensors).  window != 0: the key vectors hold
+        `window` elements each, element t read from t % window (tiled synthetic key, ringsnark_amd.h)."""
         s = _lib.Groth16PK(pk["s_pows"].data_ptr(), pk["delta_ts"].data_ptr(),
                            pk["delta_mid"].data_ptr() if pk.get("delta_mid") is not None else None,
-                           pk["alpha"].data_ptr(), pk["beta"].data_ptr())
+                           pk["alpha"].data_ptr(), pk["beta"].data_ptr(), window)
         proof = self.enc_empty(3)
         empty = (C.c_int * 3)()
         _lib.check(self.lib.rs_groth16_prove(self.h, dcs.h, C.byref(s), _ptr(assignment), _ptr(proof),
                                              empty if want_empty else None, self.stream()))
         return proof, [int(e) for e in empty]
 
-    def rinocchio_prove(self, dcs, pk, assignment, d1=None, d2=None, d3=None):
+    def rinocchio_prove(self, dcs, pk, assignment, d1=None, d2=None, d3=None, window=0):
         g = lambda k: pk[k].data_ptr() if pk.get(k) is not None else None
-        s = _lib.RinocchioPK(g("s_pows"), g("alpha_s_pows"), g("beta_prods"), g("beta_rv_ts"), g("beta_rw_ts"), g("beta_ry_ts"))
+        s = _lib.RinocchioPK(g("s_pows"), g("alpha_s_pows"), g("beta_prods"), g("beta_rv_ts"), g("beta_rw_ts"), g("beta_ry_ts"),
+                             window)
         proof = self.enc_empty(9)
         empty = (C.c_int * 9)()
         _lib.check(self.lib.rs_rinocchio_prove(self.h, dcs.h, C.byref(s), _ptr(assignment), _ptr(d1), _ptr(d2), _ptr(d3),

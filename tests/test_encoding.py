@@ -144,7 +144,8 @@ def test_wire_format_roundtrip_and_validation():
     b = to_host(back)
     assert (b[0] == enc[0]).all() and not b[1].any() and (b[2] == enc[2]).all()
     # untrusted input: every corruption is refused with RS_ERR_INVALID
-    for mutate in ("magic", "dims", "modulus", "truncate", "residue", "flag"):
+    for mutate in ("magic", "dims", "modulus", "truncate", "residue", "flag", "count_wraps", "count_huge", "padding",
+                   "empty_payload"):
         bad = bytearray(data)
         if mutate == "magic":
             bad[0] ^= 1
@@ -156,10 +157,31 @@ def test_wire_format_roundtrip_and_validation():
             bad = bad[:-8]
         elif mutate == "residue":
             struct.pack_into("<Q", bad, hb, int(prm.Q[0]))
-        else:
+        elif mutate == "flag":
             bad[off + 8] = 7
+        elif mutate == "count_wraps":
+            # a count chosen so that header(count) + count * enc_bytes wraps around 2^64 to
+            # something <= len(buf): (1 + enc_bytes) is odd, hence invertible mod 2^64
+            step = 1 + prm.enc_words * 8
+            fixed = off + 8
+            cnt = (pow(step, -1, 1 << 64) * ((len(bad) - fixed - 64) % (1 << 64))) % (1 << 64)
+            assert cnt > 3 and (fixed + cnt * step) % (1 << 64) <= len(bad)
+            struct.pack_into("<Q", bad, off, cnt)
+        elif mutate == "count_huge":
+            struct.pack_into("<Q", bad, off, (1 << 64) - 1)
+        elif mutate == "padding":
+            bad[hb - 1] = 1  # header padding byte (3 flag bytes -> 5 bytes of padding)
+        else:  # the EMPTY element's payload must be zero
+            struct.pack_into("<Q", bad, hb + prm.enc_words * 8, 1)
         with pytest.raises(_lib.RsError):
             dev.enc_deserialize(bytes(bad))
+        # the size-query path must refuse a corrupt header as well (it used to return a garbage count)
+        if mutate in ("count_wraps", "count_huge", "flag", "padding", "truncate"):
+            import ctypes as C
+            buf = np.frombuffer(bytes(bad), dtype=np.uint8)
+            cnt_out = C.c_size_t(12345)
+            rc = dev.lib.rs_enc_deserialize(dev.h, buf.ctypes.data_as(C.c_void_p), buf.size, None, None, 0, C.byref(cnt_out), None)
+            assert rc != 0 and cnt_out.value == 12345, mutate
     # a different context refuses the stream
     dev49 = Device(P.preset("toy49"))
     with pytest.raises(_lib.RsError):
@@ -170,7 +192,7 @@ def test_wire_format_roundtrip_and_validation():
 @pytest.mark.parametrize("name,m,kind", [("toy", 6, "chain"), ("toy49", 11, "wide")])
 def test_instance_map_with_evaluation_matches_restatement(name, m, kind):
     """At/Bt/Ct/Ht/Zt on the device against the O(m^2) restatement of
-    r1cs_to_qrp.tcc:76-116 (tests/snark_ref.py), bit for bit; a point inside the domain is refused."""
+    r1cs_to_qrp.tcc:76-116 (tests/snark_ref.py), bit for bit; only a point that IS a domain element is refused."""
     from ringsnark_amd import _lib
     from ringsnark_amd.device import Device, to_host
     prm = P.preset(name)
@@ -183,8 +205,17 @@ def test_instance_map_with_evaluation_matches_restatement(name, m, kind):
     for g, e in zip(got[:4], (At, Bt, Ct, Ht)):
         assert (to_host(g) == np.stack(e)).all()
     assert (to_host(got[4]) == Zt).all()
-    bad = s.copy()
-    bad[1, 3] = m - 1  # s hits node m-1 in one slot
+    # s hitting a node in SOME slots is legal in the reference (evaluation_domain.tcc:24-39
+    # only rejects s == domain element as a ring element, and computes products without dividing)
+    hit = s.copy()
+    hit[1, 3] = m - 1
+    hit[0, 5] = 0
+    e = S.instance_map_with_evaluation(Rg, cs, hit)
+    got = dev.instance_map_eval(dev.r1cs(cs), dev.put(hit))
+    for g, x in zip(got[:4], e[:4]):
+        assert (to_host(g) == np.stack(x)).all()
+    assert (to_host(got[4]) == e[4]).all()
+    bad = np.full_like(s, m - 1)  # the ring element RingT(m-1): a domain element
     with pytest.raises(_lib.RsError) as ei:
         dev.instance_map_eval(dev.r1cs(cs), dev.put(bad))
     assert "t cannot be one of the values in the domain" in str(ei.value)

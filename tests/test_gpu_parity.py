@@ -417,3 +417,106 @@ def test_entry_points_are_reentrant_on_a_shared_context():
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_entry_points_on_distinct_streams_without_synchronising():
+    """calls that do NOT synchronise (want_used=False) issued from different streams share
+    the context's workspace; the per-buffer event must order them.  Every thread drives its own
+    torch stream and only synchronises at the very end."""
+    import threading
+
+    import torch
+    dev = dev_for("toy")
+    ctx = H.oracle_ctx(dev.prm)
+    T = 33
+    jobs = []
+    for k in range(4):
+        encs, rings = ctx.random_enc(700 + k, T), ctx.random_ring(800 + k, T)
+        jobs.append((dev.put(encs), dev.put(rings), ctx.inner_product(encs, rings)[0]))
+    torch.cuda.synchronize()
+    errors, results = [], [[] for _ in jobs]
+
+    def work(j):
+        try:
+            st = torch.cuda.Stream(device=dev.device)
+            with torch.cuda.stream(st):
+                for _ in range(25):
+                    results[j].append(dev.inner_product(jobs[j][0], jobs[j][1], want_used=False)[0])
+            st.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append((repr(e), j))
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    for j, outs in enumerate(results):
+        for r in outs:
+            assert (host(r) == jobs[j][2]).all(), j
+
+
+@pytest.mark.parametrize("name,m,kind,zk", [("toy", 40, "wide", True), ("toy", 64, "chain", False), ("toy", 100, "many_inputs", True),
+                                            ("toy44", 1500, "chain", True)])
+def test_witness_map_slot_ranges_and_chunks_equal_the_whole(name, m, kind, zk):
+    """the witness map is slot-parallel.  (a) rs_witness_map_slots on two halves of
+    the slots returns exactly the corresponding slices of the full map (compact layout, m == M case
+    included); (b) a tiny column budget (many chunks, pieces of one limb) changes nothing."""
+    dev = dev_for(name)
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    cs = {"wide": lambda: R.wide_r1cs(m, prm.q), "chain": lambda: R.chain_r1cs(m, prm.q),
+          "many_inputs": lambda: R.wide_r1cs(m, prm.q, n_inputs=70)}[kind]()
+    if name == "toy":
+        asg = dev.put(H.make_assignment(ctx, cs))
+    else:  # chain assignment on the device (the oracle's O(m^2) map is not needed here)
+        asg = dev.ring_empty(m + 2)
+        dev.fill_uniform(asg[:2], 0, 5)
+        dev.chain_assignment(asg, m)
+    ds = [dev.put(ctx.random_ring(60 + k)) for k in range(3)] if zk else [None] * 3
+    dcs = dev.r1cs(cs)
+    keys = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
+    full = {k: host(v) for k, v in dev.witness_map(dcs, asg, *ds).items() if k in keys}
+    half = prm.N // 2
+    for slot0, ns in ((0, half), (half, half), (prm.N // 4, 6)):
+        part = dev.witness_map_slots(dcs, asg, slot0, ns, *ds)
+        for k in keys:
+            assert (host(part[k]) == full[k][:, :, slot0:slot0 + ns]).all(), (k, slot0, ns)
+    _set_tuning(b"witness_col_budget_mib", 1)
+    try:
+        again = dev.witness_map(dcs, asg, *ds)
+        for k in keys:
+            assert (host(again[k]) == full[k]).all(), k
+        # a subset of outputs (the ringGroth16 set) through the chunked path
+        sub = dev.witness_map(dcs, asg, *ds, want=("A_io", "A_mid", "B_io", "B_mid", "H"))
+        for k in ("A_io", "A_mid", "B_io", "B_mid", "H"):
+            assert (host(sub[k]) == full[k]).all(), k
+    finally:
+        _set_tuning(b"witness_col_budget_mib", 16 * 1024)
+
+
+def test_msm_with_a_tiled_key_equals_the_explicit_key():
+    """crs_window (ringsnark_amd.h): logical element t is read from index t % window."""
+    import torch
+    dev = dev_for("toy")
+    ctx = H.oracle_ctx(dev.prm)
+    W, T = 8, 21
+    win = dev.put(ctx.random_enc(31, W))
+    explicit = torch.cat([win] * 3)[:T].contiguous()
+    v = dev.put(ctx.random_ring(32, T))
+    exp, _ = dev.msm([explicit], [(v, None, 0)], 1)
+    got, _ = dev.msm([win], [(v, None, 0)], 1, crs_len=T, window=W)
+    assert (host(got) == host(exp)).all()
+    # through the prover entry point
+    m = 19
+    cs = R.chain_r1cs(m, dev.prm.q)
+    asg = dev.put(H.make_assignment(ctx, cs))
+    pkw = dict(s_pows=dev.put(ctx.random_enc(41, W)), delta_ts=dev.put(ctx.random_enc(42, W)), delta_mid=dev.put(ctx.random_enc(43, W)),
+               alpha=dev.put(ctx.random_enc(44)), beta=dev.put(ctx.random_enc(45)))
+    tile = lambda t, n: torch.cat([t] * 4)[:n].contiguous()
+    pkx = dict(pkw, s_pows=tile(pkw["s_pows"], m + 1), delta_ts=tile(pkw["delta_ts"], m + 1), delta_mid=tile(pkw["delta_mid"], m))
+    dcs = dev.r1cs(cs)
+    got, _ = dev.groth16_prove(dcs, pkw, asg, window=W)
+    exp, _ = dev.groth16_prove(dcs, pkx, asg)
+    assert (host(got) == host(exp)).all()

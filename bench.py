@@ -1,23 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- ringGroth16 prover throughput on MI355X (BASELINE.json metric).
+"""bench.py -- ringGroth16 prover throughput on MI355X (BASELINE.json metric, headline configuration).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one groth16::prover call (witness map + all encoding inner products) on a synthetic
-chain R1CS (x_i * x_{i+1} = x_{i+2}) with the proving key (synthetic CRS: uniform
-residues, legitimate because prover cost is data independent) and the assignment already resident
-in HBM.  Workload: headline ring shape C3 (N=8192, L=4 ring primes, N_enc=8192, K=4) with
-m = 2^13 constraints PER GPU (48 GiB of proving key per GPU).  For N > 1 ONE proof of m = 2^13 * N
-constraints is sharded over limbs, then over constraint ranges (ringsnark_amd/dist.py), so the
-per-GPU share of the encoding inner products is constant: weak scaling; N = 8 is the BASELINE.json
-headline configuration (2^16 constraints, N = 8192, 4 RNS primes).
+One step = one groth16::prover call (zk_proof_systems/groth16/groth16.tcc:70-115: the witness map and
+all encoding inner products) of the HEADLINE statement: m = 2^16 constraints on the ring N = 8192,
+L = 4 primes (preset C3), encodings N_enc = 8192, K = 4; synthetic chain R1CS x_i * x_{i+1} = x_{i+2}
+(n_aux = m), proving key and assignment resident in HBM when the clock starts.
 
-Prints ONE JSON line on rank 0.
+The 2^16-constraint key is 384 GiB and cannot be resident on one 288 GiB GPU, so the key is a TILED
+SYNTHETIC CRS: every key vector is stored as a window of 2^logw uniformly random elements (2 MiB each)
+and term t reads element t mod 2^logw (include/ringsnark_amd.h, crs_window).  Every term still streams a
+2 MiB element from HBM at an address 32 GiB away from its previous use (windows are >= 100x larger than
+the 256 MiB Infinity Cache), and prover cost is data independent, so the timing is that of the full key.
+The witness map is the real m = 2^16 one.
+
+For N > 1 the SAME statement is proven by N ranks (strong scaling): limbs first, then the ranks sharing
+a limb split its NTT slots for the witness map and its terms for the inner products
+(ringsnark_amd/dist.py).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -26,57 +30,232 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from ringsnark_amd import params as P  # noqa: E402
 from ringsnark_amd import r1cs as R  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_PEAK_T = 39.3     # vector FP64 FMA issue peak, T lane-ops/s: 256 CUs x 64 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md)
+# kernels bounded by FP64 issue (LDS-resident transforms); everything else is bounded by HBM
+FP64_KERNELS = ("tree_columns_kernel", "h_tile_kernel", "h_columns_kernel", "interp_columns_kernel", "sub_ntt_kernel",
+                "plain_center_kernel")
 
 
-def cpu_baseline(prm, m, budget_terms=64, m_s=96, slots_s=256):
-    """The CPU oracle (a scalar port of the reference's algorithm, 1 thread) timed on a bounded
-    sample of the same workload: `budget_terms` inner-product terms at full ring shape, and the
-    reference's O(m^2) witness map at m_s constraints on slots_s slots of limb 0, scaled by
-    (m/m_s)^2 * (N*L/slots_s) (its cost is exactly quadratic in m and linear in slots)."""
-    import numpy as np
+def rocprof_name(name):
+    """Profile-record name -> the kernel name rocprofv3 prints (prefix match on `rs::<name>`)."""
+    return "rs::" + name.split("<")[0]
 
+
+def kernel_roofline(k, pmc):
+    """Roofline object of one per-kernel record from rs_profile_read (live HIP events on the launch stream)."""
+    sec = k["total_ms"] * 1e-3
+    fp64 = any(k["name"].startswith(p) for p in FP64_KERNELS)
+    out = {"kernel": k["name"], "launches": k["launches"], "avg_launch_ms": round(k["total_ms"] / max(1, k["launches"]), 4)}
+    if fp64:
+        ach = k["fp64_ops"] / sec / 1e12
+        out.update({"bound": "fp64-issue", "achieved": round(ach, 2), "peak": FP64_PEAK_T, "unit": "T lane-op/s",
+                    "frac": round(ach / FP64_PEAK_T, 4), "fp64_ops_per_launch": int(k["fp64_ops"] / max(1, k["launches"])),
+                    "hbm_frac": round(k["alg_bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4)})
+    else:
+        ach = k["alg_bytes"] / sec / 1e9
+        out.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)})
+    out["algorithmic_bytes_per_launch"] = int(k["alg_bytes"] / max(1, k["launches"]))
+    # HBM traffic from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE; tools/pmc_summary.py), same configuration,
+    # keyed by the exact kernel family; null when the committed file does not hold this kernel
+    traffic = None
+    if pmc:
+        fam = [v for n, v in pmc.get("kernels", {}).items() if n.startswith(rocprof_name(k["name"])) and
+               (("<" not in k["name"]) or k["name"].split("<")[1].rstrip(">") in n)]
+        if fam:
+            traffic = int(sum(v["hbm_bytes"] for v in fam) / max(1, sum(v["launches_per_proof"] for v in fam)))
+    out["traffic"] = traffic
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# post-run check (untimed): the proof that was timed against the CPU oracle
+# ---------------------------------------------------------------------------------------------------
+def check_columns(prm, cs, asg_cols, w_cols, cols, rng):
+    """Property checks of the device witness map on single (limb, slot) columns, at random points r:
+         A_io(r) + A_mid(r) = sum_j a_j L_j(r)   (the interpolant of the constraint evaluations; same for B)
+         A_io(r)            = sum_j a^io_j L_j(r) (primary inputs only, r1cs_to_qrp.tcc:189-208)
+         A(r) B(r) - C(r)   = H(r) Z(r)           (r1cs_to_qrp.tcc:242-253; the assignment satisfies the system)
+       with L_j(r) = Z(r) / ((r - j) w_j), w_j = (-1)^(m-1-j) j! (m-1-j)!  -- O(m) integer arithmetic per point."""
+    m = cs.m
+    for (limb, slot) in cols:
+        q = int(prm.q[limb])
+        x = [int(v) for v in asg_cols[(limb, slot)]]  # assignment of this column, n_vars entries
+        fact = [1] * m
+        for j in range(1, m):
+            fact[j] = fact[j - 1] * j % q
+
+        def evals(name, mode):
+            rp, col, cf = cs.mats[name]
+            out = [0] * m
+            for i in range(m):
+                acc = 0
+                for e in range(int(rp[i]), int(rp[i + 1])):
+                    c = int(col[e])
+                    if c == 0:
+                        acc += int(cf[limb, e])
+                    elif mode == "full" or (c - 1) < cs.n_inputs:
+                        acc += int(cf[limb, e]) * x[c - 1]
+                out[i] = acc % q
+            return out
+
+        ya, yb, yc = evals("a", "full"), evals("b", "full"), evals("c", "full")
+        ya_io = evals("a", "io")
+        for _ in range(2):
+            r = int(rng.randint(m, 2**31)) * 65537 % q
+            if r < m:
+                r += m
+            # prefix / suffix products of (r - j): Z(r) and every prod_{i != j}(r - i) without inversions
+            pre = [1] * (m + 1)
+            for j in range(m):
+                pre[j + 1] = pre[j] * (r - j) % q
+            suf = [1] * (m + 1)
+            for j in range(m - 1, -1, -1):
+                suf[j] = suf[j + 1] * (r - j) % q
+            Zr = pre[m]
+            inv_w = [pow(fact[j] * fact[m - 1 - j] % q, q - 2, q) for j in range(m)]
+
+            def lagr(y):
+                acc = 0
+                for j in range(m):
+                    t = y[j] * pre[j] % q * suf[j + 1] % q * inv_w[j]
+                    acc += -t if (m - 1 - j) & 1 else t
+                return acc % q
+
+            def horner(coeffs):
+                acc = 0
+                for c in reversed(coeffs):
+                    acc = (acc * r + int(c)) % q
+                return acc
+
+            g = w_cols[(limb, slot)]
+            A, B = (horner(g["A_io"]) + horner(g["A_mid"])) % q, (horner(g["B_io"]) + horner(g["B_mid"])) % q
+            if A != lagr(ya) or B != lagr(yb):
+                return "interpolant mismatch at limb %d slot %d" % (limb, slot)
+            if horner(g["A_io"]) != lagr(ya_io):
+                return "io interpolant mismatch at limb %d slot %d" % (limb, slot)
+            if (A * B - lagr(yc)) % q != horner(g["H"]) * Zr % q:
+                return "H(r) Z(r) != A(r) B(r) - C(r) at limb %d slot %d" % (limb, slot)
+    return None
+
+
+def post_run_check(dev, prm, cs, dcs, asg, pk, proof, m, W, seed=5):
+    """(1) >= 4 witness-map columns by the identities above; (2) two full (limb, component, prime) slabs of the
+    proof -- one of A, one of C -- recomputed by the CPU oracle from the device's coefficient vectors and the
+    key window.  Returns (ok, info)."""
+    from ringsnark_amd.device import to_host
+    from tests import helpers as H
+
+    t_start = time.perf_counter()
+    octx = H.oracle_ctx(prm)
+    rng = np.random.RandomState(seed)
+    slabs = [("A", int(rng.randint(prm.L)), int(rng.randint(2)), int(rng.randint(prm.K))),
+             ("C", int(rng.randint(prm.L)), int(rng.randint(2)), int(rng.randint(prm.K)))]
+    # what the check needs from the key and the proof, before the key is released
+    key = {}
+    for elem, l, c, j in slabs:
+        names = ("s_pows", "alpha") if elem == "A" else ("delta_ts", "delta_mid")
+        for nme in names:
+            t = pk[nme]
+            key[(nme, l, c, j)] = to_host(t[..., l, c, j, :].contiguous()).reshape(-1, prm.N_enc)
+    proof_h = {(e, l, c, j): to_host(proof[{"A": 0, "B": 1, "C": 2}[e], l, c, j].contiguous()) for e, l, c, j in slabs}
+    for k in list(pk.keys()):
+        del pk[k]
+    torch.cuda.empty_cache()
+    # the prover's own witness map, re-run through the same chunking (deterministic: identical vectors)
+    w = dev.witness_map(dcs, asg, want=("A_io", "A_mid", "B_io", "B_mid", "H"))
+    torch.cuda.synchronize()
+    cols = [(int(rng.randint(prm.L)), int(rng.randint(prm.N))) for _ in range(4)] + [(0, 0), (prm.L - 1, prm.N - 1)]
+    asg_cols = {c: to_host(asg[:, c[0], c[1]].contiguous()) for c in cols}
+    w_cols = {c: {k: to_host(w[k][:, c[0], c[1]].contiguous()) for k in ("A_io", "A_mid", "B_io", "B_mid", "H")} for c in cols}
+    err = check_columns(prm, cs, asg_cols, w_cols, cols, rng)
+    if err:
+        return False, {"error": err}
+    t_cols = time.perf_counter() - t_start
+
+    def slab_sum(acc, key_slab, vec, limb, j, T):
+        step = 4096
+        for t0 in range(0, T, step):
+            rows = to_host(vec[t0:min(T, t0 + step), limb, :].contiguous())
+            octx.inner_product_slab(limb, j, key_slab, rows, acc, t0=t0, window=key_slab.shape[0], threads=0)
+
+    for elem, l, c, j in slabs:
+        acc = np.zeros(prm.N_enc, dtype=np.uint64)
+        if elem == "A":  # groth16.tcc:89-95
+            slab_sum(acc, key[("s_pows", l, c, j)], w["A_io"], l, j, m)
+            slab_sum(acc, key[("s_pows", l, c, j)], w["A_mid"], l, j, m)
+            acc = (acc + key[("alpha", l, c, j)][0]) % np.uint64(prm.Q[j])
+        else:  # groth16.tcc:105-112
+            slab_sum(acc, key[("delta_ts", l, c, j)], w["H"], l, j, m + 1)
+            slab_sum(acc, key[("delta_mid", l, c, j)], asg[cs.n_inputs:], l, j, cs.n_aux)
+        if not (acc == proof_h[(elem, l, c, j)]).all():
+            return False, {"error": "proof element %s slab (limb %d, component %d, prime %d) differs from the CPU oracle" % (elem, l, c, j)}
+    return True, {"columns": len(cols), "points_per_column": 2,
+                  "slabs": ["%s[limb %d][comp %d][prime %d]" % s for s in slabs],
+                  "seconds": round(time.perf_counter() - t_start, 1), "columns_seconds": round(t_cols, 1)}
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (a port of the reference's algorithm) on a bounded sample
+# ---------------------------------------------------------------------------------------------------
+def cpu_baseline(prm, m, n_aux):
+    """oracle/rs_oracle.c timed on this box's host cores: 1 thread (what groth16::prover uses -- no OpenMP in
+    groth16.tcc:70-115) and all cores (OpenMP over terms / slots).  MSM: inner-product terms at
+    full ring shape.  Witness map: the reference's O(m^2) algorithm measured at a small m_s on a few slots and
+    scaled by (m/m_s)^2 x (N L / slots): its cost is exactly quadratic in m and linear in slots."""
     from oracle import oracle as O
     from tests import helpers as H
 
     ctx = H.oracle_ctx(prm)
-    encs, rings = ctx.random_enc(1, budget_terms), ctx.random_ring(2, budget_terms)
-    t0 = time.perf_counter()
-    ctx.inner_product(encs, rings)
-    t_term = (time.perf_counter() - t0) / budget_terms
-    cs = R.chain_r1cs(m_s, prm.q[:1])
-    q = prm.q[0]
-    rng = np.random.RandomState(3)
-    asg = np.zeros((m_s + 2, slots_s), dtype=np.uint64)
-    asg[0] = rng.randint(1, 2**31, slots_s)
-    asg[1] = rng.randint(1, 2**31, slots_s)
-    for i in range(m_s):
-        asg[i + 2] = (asg[i].astype(object) * asg[i + 1].astype(object) % q).astype(np.uint64)
-    t0 = time.perf_counter()
-    O.witness_map(q, H.oracle_cs(cs), 0, asg)
-    t_w = (time.perf_counter() - t0) * (m / m_s) ** 2 * (prm.N * prm.L / slots_s)
-    terms = 4 * m + (m + 1) + m  # groth16.tcc:89-112 with n_aux = m
-    total = t_w + terms * t_term
+    nthr = O.max_threads()
+    terms_total = 4 * m + (m + 1) + n_aux  # groth16.tcc:89-112
+    win = 16
+    encs = ctx.random_enc(1, win)
+
+    def msm_rate(threads, T):
+        rings = ctx.random_ring(2, T)
+        t0 = time.perf_counter()
+        if threads == 1:
+            ctx.inner_product(np.ascontiguousarray(np.concatenate([encs] * ((T + win - 1) // win))[:T]), rings)
+        else:
+            ctx.inner_product(encs, rings, threads=threads, window=win)
+        return (time.perf_counter() - t0) / T  # seconds per term
+
+    def witness_time(threads, m_s, slots):
+        cs = R.chain_r1cs(m_s, prm.q[:1])
+        q = prm.q[0]
+        rng = np.random.RandomState(3)
+        asg = np.zeros((m_s + 2, slots), dtype=np.uint64)
+        asg[0] = rng.randint(1, 2**31, slots)
+        asg[1] = rng.randint(1, 2**31, slots)
+        for i in range(m_s):
+            asg[i + 2] = (asg[i].astype(object) * asg[i + 1].astype(object) % q).astype(np.uint64)
+        t0 = time.perf_counter()
+        O.witness_map(q, H.oracle_cs(cs), 0, asg, threads=threads)
+        return (time.perf_counter() - t0) * (m / m_s) ** 2 * (prm.N * prm.L / slots)
+
+    t1_term = msm_rate(1, 48)
+    tN_term = msm_rate(0, max(64, 8 * nthr))
+    w1 = witness_time(1, 128, 256)
+    wN = witness_time(0, 128, max(256, 32 * nthr))
+    one = m / (w1 + terms_total * t1_term)
+    allc = m / (wN + terms_total * tN_term)
     return {
-        "value": m / total, "unit": "constraints/s", "cores": 1, "kind": "port",
-        "sample": "oracle/rs_oracle.c, 1 thread: inner_product on %d terms at full shape (%.1f ms/term x %d terms) + "
-                  "O(m^2) witness map measured at m=%d on %d slots and extrapolated x(m/%d)^2 x(N*L/%d) (%.0f s)"
-                  % (budget_terms, t_term * 1e3, terms, m_s, slots_s, m_s, slots_s, t_w),
+        "value": allc, "unit": "constraints/s", "cores": nthr, "kind": "port",
+        "sample": "oracle/rs_oracle.c (-O3 -fopenmp): inner_product on %d terms (1 thread) / %d terms (%d threads) at full "
+                  "ring shape, scaled to the %d terms of one proof; the reference's O(m^2) witness map at m=128 on 256 / %d slots, "
+                  "scaled x(m/128)^2 x(N L/slots)" % (48, max(64, 8 * nthr), nthr, terms_total, max(256, 32 * nthr)),
+        "one_thread": {"value": one, "cores": 1, "msm_s_per_proof": terms_total * t1_term, "witness_s_per_proof": w1},
+        "all_cores": {"value": allc, "cores": nthr, "msm_s_per_proof": terms_total * tN_term, "witness_s_per_proof": wN},
+        "msm_only": {"one_thread": m / (terms_total * t1_term), "all_cores": m / (terms_total * tN_term), "unit": "constraints/s"},
+        "witness_only": {"one_thread": m / w1, "all_cores": m / wN, "unit": "constraints/s", "note": "extrapolated from m=128"},
     }
-
-
-def mac_algorithmic_bytes(prm, m, n_aux):
-    """Algorithmic bytes of the three mac_kernel launches of one proof (DESIGN.md "Roofline"):
-    every ciphertext word once, every centred plaintext row once, every accumulator set once."""
-    enc = prm.enc_words * 8
-    crow = prm.L * prm.N_enc * 8
-    launches = [(m, 2), (m + 1, 1)] + ([(n_aux, 1)] if n_aux else [])
-    return sum(T * (enc + ng * crow) + ng * enc for T, ng in launches), len(launches)
 
 
 def main():
@@ -85,8 +264,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--preset", default="C3")
-    ap.add_argument("--logm", type=int, default=13, help="log2 of the constraints per GPU")
+    ap.add_argument("--logm", type=int, default=16, help="log2 of the constraints of the statement (all GPUs together)")
+    ap.add_argument("--logw", type=int, default=14, help="log2 of the key window (stored elements per key vector) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,7 +292,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     prm = P.preset(args.preset)
-    m = (1 << args.logm) * world
+    m = 1 << args.logm
     plan = RD.make_plan(world, rank, prm.L)
     prm_local = P.RingParams(prm.N, [prm.q[i] for i in plan.limbs], prm.N_enc, prm.Q, name=prm.name)
     dev = Device(prm_local, local_rank)
@@ -123,14 +304,16 @@ def main():
     asg = dev.ring_empty(m + 2)
     dev.fill_uniform(asg[:2], 0, seed0 + 7)
     dev.chain_assignment(asg, m)
-    # Every rank allocates only the slice of the key it reads: its limbs, and (when limbs are shared)
-    # a view positioned so that its term range [lo, hi) lands on real storage.
+    # Key: every rank stores, per key vector, a window of at most 2^logw elements of its limbs; a rank whose
+    # term range is shorter than the window stores exactly its range (TiledKey maps a logical term to storage).
     ranges = RD.groth16_key_ranges(plan, m, n_aux)
+    W = 1 << args.logw
 
     def key_vector(name, T, seed):
         lo, hi = (0, T) if world == 1 else ranges[name]
-        store = dev.fill_uniform(dev.enc_empty(max(hi - lo, 1)), 1, seed + 100 * plan.term_shard)
-        return RD.TermWindow(store, lo, hi, T)
+        stored = min(max(hi - lo, 1), W)
+        store = dev.fill_uniform(dev.enc_empty(stored), 1, seed + 100 * plan.term_shard)
+        return RD.TiledKey(store, lo, hi, T)
 
     pk = {
         "s_pows": key_vector("s_pows", m + 1, seed0 + 13),
@@ -139,15 +322,20 @@ def main():
         "alpha": dev.fill_uniform(dev.enc_empty(), 1, seed0 + 16),
         "beta": dev.fill_uniform(dev.enc_empty(), 1, seed0 + 17),
     }
+    stored_gib = sum(v.store.numel() * 8 for v in pk.values() if isinstance(v, RD.TiledKey)) / 2**30
+    tiled = any(isinstance(v, RD.TiledKey) and v.window for v in pk.values())
     term_group = RD.groups_for(plan) if world > 1 else None
     backend = RD.DeviceBackend(dev)
-
-    pk1 = {k: (v.store if isinstance(v, RD.TermWindow) else v) for k, v in pk.items()}
+    pk1 = {k: (v.store if isinstance(v, RD.TiledKey) else v) for k, v in pk.items()}
+    window1 = W if (world == 1 and tiled) else 0
+    proof = [None]
 
     def step():
         if world == 1:
-            return dev.groth16_prove(dcs, pk1, asg, want_empty=False)[0]
-        return RD.groth16_prove_sharded(backend, plan, term_group, dcs, pk, asg, m, cs.n_inputs, n_aux)
+            proof[0] = dev.groth16_prove(dcs, pk1, asg, want_empty=False, window=window1)[0]
+        else:
+            proof[0] = RD.groth16_prove_sharded(backend, plan, term_group, dcs, pk, asg, m, cs.n_inputs, n_aux)
+        return proof[0]
 
     def fence():
         torch.cuda.synchronize()
@@ -170,76 +358,91 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = m * args.steps / elapsed
 
-    # dominant kernel (mac_kernel) timed live with HIP events on the launch stream
-    roofline = None
-    timings = None
+    # ---- per-kernel device time of one more (untimed) step: HIP events on the launch stream inside the library
+    roofline = mac_roofline = timings = kernels = None
     if world == 1:
+        pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_%s_m%d.json" % (prm.name, m))
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
         dev.set_profiling(True)
+        dev.profile_read()
         step()
         torch.cuda.synchronize()
         timings = dev.last_timings()
+        stats = dev.profile_read()
         dev.set_profiling(False)
-        nbytes, nl = mac_algorithmic_bytes(prm, m, n_aux)
-        if timings["msm_mac_ms"] > 0:
-            achieved = nbytes / (timings["msm_mac_ms"] * 1e-3) / 1e9
-            nlaunch = max(1, timings["msm_mac_launches"])
-            # HBM traffic of the same kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB units;
-            # tools/pmc_summary.py), collected offline with rocprofv3 --pmc on this exact configuration
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s_m%d.json" % (prm.name, m))
-            if os.path.exists(pmc):
-                ks = [v for n, v in json.load(open(pmc))["kernels"].items() if n.startswith("rs::mac_kernel_v2")]
-                k = ks[0] if ks else None
-                if k:
-                    traffic = int(k["hbm_bytes"] / k["launches_per_proof"])
-            roofline = {"bound": "hbm", "kernel": "mac_kernel_v2", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "launches": nlaunch, "avg_launch_ms": round(timings["msm_mac_ms"] / nlaunch, 3),
-                        "algorithmic_bytes_per_launch": nbytes // nlaunch}
+        tot = sum(k["total_ms"] for k in stats) or 1.0
+        kernels = [{"name": k["name"], "ms": round(k["total_ms"], 2), "share": round(k["total_ms"] / tot, 4),
+                    "launches": k["launches"]} for k in stats[:10]]
+        if stats:
+            roofline = kernel_roofline(stats[0], pmc)  # the dominant kernel by time
+        mac = [k for k in stats if k["name"].startswith("mac_kernel")]
+        if mac:
+            mac_roofline = kernel_roofline(mac[0], pmc)
 
-    # the standalone transform (row a4), HBM bound by design: 16 bytes per coefficient per transform
+    # ---- the standalone transform (row a4), HBM bound by design: 16 bytes per coefficient per transform, on 1 GiB
     ntt_roofline = None
     if world == 1:
         from ringsnark_amd import _lib
-        batch = 4096
+        batch = (1 << 30) // (prm.N_enc * 8)
         polys = torch.empty((batch, prm.N_enc), dtype=torch.int64, device=dev.device).random_(0, int(prm.Q[0]))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
+        for _ in range(2):
             dev.ntt(polys, _lib.RS_MOD_COEFF, 0)
-        reps = 10
+        reps = 5
         e0.record()  # the library launches on torch's current stream (device.py passes it down)
         for _ in range(reps):
             dev.ntt(polys, _lib.RS_MOD_COEFF, 0)
         e1.record()
         torch.cuda.synchronize()
         gbs = batch * prm.N_enc * 16 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        ntt_roofline = {"bound": "hbm", "kernel": "forward NTT, %d transforms of %d points per launch" % (batch, prm.N_enc),
+        ntt_roofline = {"bound": "hbm", "kernel": "forward NTT, %d transforms of %d points per launch (1 GiB in place)" % (batch, prm.N_enc),
                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
         del polys
 
+    # ---- untimed post-run check of the timed proof against the CPU oracle
+    check = None
+    if world == 1 and not args.no_check:
+        pk.clear()  # the check releases the key (pk1 holds the last references) before it re-runs the witness map
+        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk1, proof[0], m, window1 or pk1["s_pows"].shape[0])
+        check = dict(info, ok=ok)
+
     if rank == 0:
+        key_gib = (3 * m + 2) * prm.enc_words * 8 / 2**30
         out = {
             "metric": "prover constraints/sec (ringGroth16, N=8192, 4 RNS primes)",
             "value": round(value, 1), "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "ringGroth16 prover, synthetic chain R1CS m=%d constraints (2^%d per GPU, n_aux=m), ring N=%d L=%d, "
-                                   "encodings N_enc=%d K=%d, synthetic CRS %.1f GiB resident in HBM (%.1f GiB per GPU)"
-                                   % (m, args.logm, prm.N, prm.L, prm.N_enc, prm.K, (3 * m + 2) * prm.enc_words * 8 / 2**30,
-                                      (3 * m + 2) * prm.enc_words * 8 / 2**30 / world),
-                       "preset": prm.name, "constraints": m, "parallelism": "limbs%d x terms%d" % (plan.limb_groups, plan.term_shards)},
+            "config": {"workload": "ringGroth16 prover (groth16.tcc:70-115), synthetic chain R1CS m=%d constraints (n_aux=m), ring N=%d L=%d, "
+                                   "encodings N_enc=%d K=%d; %s; real m=%d witness map"
+                                   % (m, prm.N, prm.L, prm.N_enc, prm.K,
+                                      ("tiled synthetic CRS: %.0f GiB key stood in for by a resident window of 2^%d elements per key vector "
+                                       "(%.0f GiB in HBM), term index wrapped" % (key_gib, args.logw, stored_gib)) if tiled else
+                                      ("synthetic CRS %.0f GiB, %.0f GiB resident per GPU" % (key_gib, stored_gib)), m),
+                       "preset": prm.name, "constraints": m, "key_window": (W if tiled else None),
+                       "parallelism": "limbs%d x shards%d" % (plan.limb_groups, plan.term_shards)},
         }
         if timings:
             out["phase_ms"] = {"witness_map": round(timings["witness_ms"], 3), "msm": round(timings["msm_ms"], 3)}
+        if kernels:
+            out["kernels"] = kernels
         if roofline:
             out["roofline"] = roofline
+        if mac_roofline:
+            out["mac_roofline"] = mac_roofline
         if ntt_roofline:
             out["ntt_roofline"] = ntt_roofline
+        if check is not None:
+            out["check"] = check
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(prm, m)
+            out["cpu_baseline"] = cpu_baseline(prm, m, n_aux)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if check is not None and not check["ok"]:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

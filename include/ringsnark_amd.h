@@ -233,11 +233,21 @@ int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk
 /* ---- measurement hooks (bench.py): per-phase device time of the last prover call, in ms ---- */
 typedef struct rs_timings {
   float evaluate_ms, witness_ms, msm_ms, total_ms;
-  float msm_mac_ms;      /* time inside the dominant MAC kernel */
-  int msm_mac_launches;  /* number of launches of that kernel */
 } rs_timings;
 int rs_last_timings(rs_ctx *ctx, rs_timings *out);
 int rs_set_profiling(rs_ctx *ctx, int enabled);
+/* Per-kernel device time of everything launched on the context since profiling was enabled (or
+ * since the last read): HIP events on the launch stream around every launch, summed per kernel,
+ * sorted by time.  alg_bytes / fp64_ops: the ALGORITHMIC HBM bytes and FP64 instructions (per lane)
+ * of those launches as DESIGN.md section 3 defines them -- the numerators of the rooflines.
+ * Returns the number of distinct kernels in *n_out (may exceed capacity); clears the record. */
+typedef struct rs_kernel_stat {
+  char name[48];
+  int launches;
+  float total_ms;
+  double alg_bytes, fp64_ops;
+} rs_kernel_stat;
+int rs_profile_read(rs_ctx *ctx, rs_kernel_stat *out, int capacity, int *n_out);
 /* process-wide kernel-shape knobs ("ntt_variant", "mac_variant", "witness_lds_logM", ...); results
  * are identical for every accepted value.  (Knobs that alter results -- timing ablations -- exist
  * only in the separate experiments build, `make -C ringsnark_amd/csrc experiments`.) */

@@ -110,6 +110,12 @@ def lib():
         L.rso_vanishing.argtypes = [C.c_uint64, C.c_size_t, u64p]
         L.rso_r1cs_evaluate.argtypes = [C.c_uint64, C.c_size_t, C.POINTER(R1CS), C.c_int, C.c_int, u64p, u64p]
         L.rso_witness_map.argtypes = [C.c_uint64, C.c_size_t, C.POINTER(R1CS), C.c_int] + [u64p] * 12
+        L.rso_witness_map_mt.argtypes = [C.c_uint64, C.c_size_t, C.POINTER(R1CS), C.c_int] + [u64p] * 12 + [C.c_int]
+        L.rso_max_threads.restype = C.c_int
+        L.rso_inner_product_mt.restype = C.c_size_t
+        L.rso_inner_product_mt.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p, C.POINTER(C.c_uint8), C.c_size_t, u64p, C.c_int]
+        L.rso_inner_product_slab.argtypes = [C.c_void_p, C.c_int, C.c_int, u64p, C.c_size_t, C.c_size_t, C.c_size_t, u64p,
+                                             C.c_size_t, u64p, C.c_int]
         L.rso_groth16_prove.argtypes = [C.c_void_p, C.POINTER(R1CS), C.POINTER(Groth16PK), u64p, u64p, C.POINTER(C.c_int)]
         L.rso_rinocchio_prove.argtypes = [C.c_void_p, C.POINTER(R1CS), C.POINTER(RinocchioPK)] + [u64p] * 5 + [C.POINTER(C.c_int)]
         L.rso_fill_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, u64p]
@@ -283,19 +289,33 @@ class Ctx:
         lib().rso_enc_add(self.h, p64(a), p64(np.ascontiguousarray(b)))
         return a
 
-    def inner_product(self, encs, rings, kinds=None):
+    def inner_product(self, encs, rings, kinds=None, threads=1, window=0):
+        """EncodingElem::inner_product; threads != 1: terms spread over OpenMP threads (0 = all cores);
+        window != 0 (threads != 1 only): encs holds `window` elements, term t uses encs[t % window]."""
         encs, rings = np.ascontiguousarray(encs), np.ascontiguousarray(rings)
         T = rings.shape[0]
-        assert encs.shape[0] == T
+        assert encs.shape[0] == (window or T) and (threads != 1 or not window)
         out = np.zeros(self.enc_shape(), dtype=np.uint64)
         kp = None
         if kinds is not None:
             kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
             kp = kinds.ctypes.data_as(u8p)
-        used = lib().rso_inner_product(self.h, p64(encs), p64(rings), kp, T, p64(out))
+        if threads == 1:
+            used = lib().rso_inner_product(self.h, p64(encs), p64(rings), kp, T, p64(out))
+        else:
+            used = lib().rso_inner_product_mt(self.h, p64(encs), window, p64(rings), kp, T, p64(out), threads)
         return out, int(used)
 
-    # ---- BGV (fixtures / homomorphism checks)
+    def inner_product_slab(self, limb, j, ct_slabs, rows, acc, t0=0, window=None, threads=0):
+        """acc[N_enc] += sum_t ct_slabs[(t0+t) % window] * NTT_Qj(lift(encode(rows[t]))): one (limb, component,
+        prime) slab of an inner product.  ct_slabs [W][N_enc] (that slab of every stored key element), rows [T][N]."""
+        ct_slabs, rows = np.ascontiguousarray(ct_slabs, dtype=np.uint64), np.ascontiguousarray(rows, dtype=np.uint64)
+        assert ct_slabs.shape[1] == self.N_enc and rows.shape[1] == self.N and acc.shape == (self.N_enc,)
+        W = ct_slabs.shape[0] if window is None else window
+        assert W <= ct_slabs.shape[0]
+        lib().rso_inner_product_slab(self.h, limb, j, p64(ct_slabs), self.N_enc, W, t0, p64(rows), rows.shape[0], p64(acc), threads)
+        return acc
+
     def keygen(self, seed):
         sk = np.empty((self.K, self.N_enc), dtype=np.uint64)
         lib().rso_keygen(self.h, seed, p64(sk))
@@ -407,19 +427,26 @@ def r1cs_evaluate(q, cs, which, limb, assignment):
     return out
 
 
-def witness_map(q, cs, limb, assignment, d1=None, d2=None, d3=None):
-    """One limb; assignment [n_vars][S].  Returns dict of A_io..C_mid [m][S], Z [m+1], H [m+1][S]."""
+def max_threads():
+    return int(lib().rso_max_threads())
+
+
+def witness_map(q, cs, limb, assignment, d1=None, d2=None, d3=None, threads=1):
+    """One limb; assignment [n_vars][S].  Returns dict of A_io..C_mid [m][S], Z [m+1], H [m+1][S].
+    threads != 1: the S slots are spread over OpenMP threads (0 = all cores)."""
     assignment = np.ascontiguousarray(assignment, dtype=np.uint64)
     S, m = assignment.shape[1], cs.m
     o = {k: np.empty((m, S), dtype=np.uint64) for k in ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid")}
     o["Z"] = np.empty(m + 1, dtype=np.uint64)
     o["H"] = np.empty((m + 1, S), dtype=np.uint64)
     ds = [None if d is None else np.ascontiguousarray(d, dtype=np.uint64) for d in (d1, d2, d3)]
-    lib().rso_witness_map(
-        q, S, cs.ref(), limb, p64(assignment), p64(ds[0]), p64(ds[1]), p64(ds[2]),
-        p64(o["A_io"]), p64(o["B_io"]), p64(o["C_io"]), p64(o["A_mid"]), p64(o["B_mid"]), p64(o["C_mid"]),
-        p64(o["Z"]), p64(o["H"]),
-    )
+    args = [q, S, cs.ref(), limb, p64(assignment), p64(ds[0]), p64(ds[1]), p64(ds[2]),
+            p64(o["A_io"]), p64(o["B_io"]), p64(o["C_io"]), p64(o["A_mid"]), p64(o["B_mid"]), p64(o["C_mid"]),
+            p64(o["Z"]), p64(o["H"])]
+    if threads == 1:
+        lib().rso_witness_map(*args)
+    else:
+        lib().rso_witness_map_mt(*args, threads)
     return o
 
 

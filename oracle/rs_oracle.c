@@ -384,6 +384,142 @@ size_t rso_inner_product(const rso_ctx *c, const uint64_t *encs, const uint64_t 
   return used;
 }
 
+/* ---- multi-core forms used by bench.py (all-core cpu_baseline, post-run check) and by the
+ * configuration-scale golden vectors.  Same arithmetic as above, OpenMP over terms -- the
+ * parallelisation SURVEY.md 8(d) prescribes for the CPU baseline ("all host cores with OpenMP over
+ * terms"); the reference itself runs inner_product serially (seal_ring.tcc:415-431). ---- */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+static int pick_threads(int threads) {
+#ifdef _OPENMP
+  return threads > 0 ? threads : omp_get_max_threads();
+#else
+  (void)threads;
+  return 1;
+#endif
+}
+int rso_max_threads(void) { return pick_threads(0); }
+
+/* inner_product with the terms spread over `threads` threads (per-thread partial sums, added at the
+ * end: modular addition is associative, the result is the same canonical element).  window != 0:
+ * only `window` encodings are stored and term t uses encs[t % window] (timing samples). */
+size_t rso_inner_product_mt(const rso_ctx *c, const uint64_t *encs, size_t window, const uint64_t *rings,
+                            const uint8_t *kinds, size_t T, uint64_t *out, int threads) {
+  const size_t ew = rso_enc_words(c), rw = rso_ring_words(c);
+  const int nt = pick_threads(threads);
+  uint64_t *part = (uint64_t *)calloc((size_t)nt * ew, sizeof(uint64_t));
+  size_t *used = (size_t *)calloc((size_t)nt, sizeof(size_t));
+#pragma omp parallel num_threads(nt)
+  {
+#ifdef _OPENMP
+    const int id = omp_get_thread_num();
+#else
+    const int id = 0;
+#endif
+    uint64_t *tmp = (uint64_t *)malloc(sizeof(uint64_t) * ew), *acc = part + (size_t)id * ew;
+#pragma omp for schedule(static)
+    for (long long t = 0; t < (long long)T; t++) {
+      const int kind = kinds ? kinds[t] : RSO_KIND_POLY;
+      const uint64_t *b = rings + (size_t)t * rw;
+      if (kind == RSO_KIND_POLY && rso_ring_is_zero(c, b)) continue;
+      memcpy(tmp, encs + (window ? (size_t)t % window : (size_t)t) * ew, sizeof(uint64_t) * ew);
+      if (kind != RSO_KIND_ONE) rso_enc_mul_ring(c, tmp, b);
+      rso_enc_add(c, acc, tmp);
+      used[id]++;
+    }
+    free(tmp);
+  }
+  size_t total = 0;
+  memset(out, 0, sizeof(uint64_t) * ew);
+  for (int k = 0; k < nt; k++) {
+    rso_enc_add(c, out, part + (size_t)k * ew);
+    total += used[k];
+  }
+  free(part);
+  free(used);
+  return total;
+}
+
+/* One (limb, component, prime j) slab of an inner product, accumulated into acc[N_enc]:
+ *     acc += sum_{t < T} ct[(t0 + t) % window] * NTT_{Q_j}(lift(iNTT_{q_limb}(scatter(rows[t]))))
+ * ct: the slab (limb, component, j) of each STORED key element, ct_stride words apart; window =
+ * number of stored elements (tiled key; pass window >= t0 + T for an ordinary key); rows: the limb's
+ * N values of each coefficient [T][N].  What the device proof's slab must equal, term range by term
+ * range (bench.py post-run check). */
+void rso_inner_product_slab(const rso_ctx *c, int limb, int j, const uint64_t *ct, size_t ct_stride,
+                            size_t window, size_t t0, const uint64_t *rows, size_t T, uint64_t *acc,
+                            int threads) {
+  const size_t n = (size_t)c->N_enc;
+  const int nt = pick_threads(threads);
+  const uint64_t Q = c->Q[j], t_mod = c->q[limb];
+  uint64_t *part = (uint64_t *)calloc((size_t)nt * n, sizeof(uint64_t));
+#pragma omp parallel num_threads(nt)
+  {
+#ifdef _OPENMP
+    const int id = omp_get_thread_num();
+#else
+    const int id = 0;
+#endif
+    uint64_t *P = (uint64_t *)malloc(sizeof(uint64_t) * n), *a = part + (size_t)id * n;
+#pragma omp for schedule(static)
+    for (long long t = 0; t < (long long)T; t++) {
+      const uint64_t *row = rows + (size_t)t * c->N;
+      int nz = 0;
+      for (int x = 0; x < c->N && !nz; x++) nz = row[x] != 0;
+      if (!nz) continue; /* zero plaintext: contributes nothing */
+      rso_batch_encode(c, limb, row, P);
+      for (size_t x = 0; x < n; x++) P[x] = lift_centered(P[x], t_mod, Q);
+      rso_ntt_fwd(c->coeff[j], P);
+      const uint64_t *cw = ct + (((size_t)t0 + (size_t)t) % window) * ct_stride;
+      for (size_t x = 0; x < n; x++) a[x] = addmod(a[x], rso_mulmod(cw[x], P[x], Q), Q);
+    }
+    free(P);
+  }
+  for (int k = 0; k < nt; k++)
+    for (size_t x = 0; x < n; x++) acc[x] = addmod(acc[x], part[(size_t)k * n + x], Q);
+  free(part);
+}
+
+/* rso_witness_map with the S independent slots spread over threads (each thread runs the
+ * reference's O(m^2) map on its own block of slots).  Layouts as rso_witness_map. */
+void rso_witness_map_mt(uint64_t q, size_t S, const rso_r1cs *cs, int limb, const uint64_t *assignment,
+                        const uint64_t *d1, const uint64_t *d2, const uint64_t *d3, uint64_t *A_io,
+                        uint64_t *B_io, uint64_t *C_io, uint64_t *A_mid, uint64_t *B_mid,
+                        uint64_t *C_mid, uint64_t *Z, uint64_t *H, int threads) {
+  const int nt = pick_threads(threads);
+  const size_t m = cs->m, nv = cs->n_vars;
+#pragma omp parallel for schedule(static) num_threads(nt)
+  for (int k = 0; k < nt; k++) {
+    const size_t lo = S * (size_t)k / (size_t)nt, hi = S * (size_t)(k + 1) / (size_t)nt, w = hi - lo;
+    if (!w) continue;
+    uint64_t *asg = (uint64_t *)malloc(sizeof(uint64_t) * nv * w);
+    uint64_t *dd[3] = {NULL, NULL, NULL};
+    const uint64_t *ds[3] = {d1, d2, d3};
+    for (size_t v = 0; v < nv; v++) memcpy(asg + v * w, assignment + v * S + lo, sizeof(uint64_t) * w);
+    for (int e = 0; e < 3; e++)
+      if (ds[e]) {
+        dd[e] = (uint64_t *)malloc(sizeof(uint64_t) * w);
+        memcpy(dd[e], ds[e] + lo, sizeof(uint64_t) * w);
+      }
+    uint64_t *o[7];
+    for (int e = 0; e < 7; e++) o[e] = (uint64_t *)malloc(sizeof(uint64_t) * (m + 1) * w);
+    uint64_t *Zl = (uint64_t *)malloc(sizeof(uint64_t) * (m + 1));
+    rso_witness_map(q, w, cs, limb, asg, dd[0], dd[1], dd[2], o[0], o[1], o[2], o[3], o[4], o[5], Zl, o[6]);
+    uint64_t *dst[7] = {A_io, B_io, C_io, A_mid, B_mid, C_mid, H};
+    for (int e = 0; e < 7; e++) {
+      const size_t rows = e == 6 ? m + 1 : m;
+      if (dst[e])
+        for (size_t r = 0; r < rows; r++) memcpy(dst[e] + r * S + lo, o[e] + r * w, sizeof(uint64_t) * w);
+      free(o[e]);
+    }
+    if (k == 0 && Z) memcpy(Z, Zl, sizeof(uint64_t) * (m + 1));
+    free(Zl);
+    free(asg);
+    for (int e = 0; e < 3; e++) free(dd[e]);
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * PRNG + BGV symmetric encryption.  NOT SEAL's sampler (Blake2xb / centred binomial): the
  * prover never inspects ciphertext randomness, so any valid BGV ciphertext exercises the path

@@ -106,6 +106,15 @@ void rso_enc_add(const rso_ctx *c, uint64_t *enc, const uint64_t *other);
 size_t rso_inner_product(const rso_ctx *c, const uint64_t *encs, const uint64_t *rings,
                          const uint8_t *kinds, size_t T, uint64_t *out);
 
+/* ---- multi-core forms (bench.py cpu_baseline / post-run check; golden vectors at configuration
+ * scale).  threads <= 0: all cores OpenMP reports. ---- */
+int rso_max_threads(void);
+size_t rso_inner_product_mt(const rso_ctx *c, const uint64_t *encs, size_t window, const uint64_t *rings,
+                            const uint8_t *kinds, size_t T, uint64_t *out, int threads);
+void rso_inner_product_slab(const rso_ctx *c, int limb, int j, const uint64_t *ct, size_t ct_stride,
+                            size_t window, size_t t0, const uint64_t *rows, size_t T, uint64_t *acc,
+                            int threads);
+
 /* ---- BGV symmetric encryption restated (for CRS fixtures / homomorphism checks only) ---- */
 void rso_keygen(const rso_ctx *c, uint64_t seed, uint64_t *sk /* [K][N_enc] NTT form */);
 void rso_encrypt_symmetric(const rso_ctx *c, int limb, const uint64_t *sk, const uint64_t *plain,
@@ -159,6 +168,11 @@ void rso_witness_map(uint64_t q, size_t S, const rso_r1cs *cs, int limb, const u
                      const uint64_t *d1, const uint64_t *d2, const uint64_t *d3, uint64_t *A_io,
                      uint64_t *B_io, uint64_t *C_io, uint64_t *A_mid, uint64_t *B_mid,
                      uint64_t *C_mid, uint64_t *Z, uint64_t *H);
+
+void rso_witness_map_mt(uint64_t q, size_t S, const rso_r1cs *cs, int limb, const uint64_t *assignment,
+                        const uint64_t *d1, const uint64_t *d2, const uint64_t *d3, uint64_t *A_io,
+                        uint64_t *B_io, uint64_t *C_io, uint64_t *A_mid, uint64_t *B_mid,
+                        uint64_t *C_mid, uint64_t *Z, uint64_t *H, int threads);
 
 /* ---- provers (zk_proof_systems/groth16/groth16.tcc:70-115, rinocchio/rinocchio.tcc:75-190).
  * All vectors in ring layout [count][L][N] / encoding layout [count][L][2][K][N_enc].

@@ -42,8 +42,12 @@ class RinocchioPK(C.Structure):
 
 
 class Timings(C.Structure):
-    _fields_ = [("evaluate_ms", C.c_float), ("witness_ms", C.c_float), ("msm_ms", C.c_float), ("total_ms", C.c_float),
-                ("msm_mac_ms", C.c_float), ("msm_mac_launches", C.c_int)]
+    _fields_ = [("evaluate_ms", C.c_float), ("witness_ms", C.c_float), ("msm_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int), ("total_ms", C.c_float), ("alg_bytes", C.c_double),
+                ("fp64_ops", C.c_double)]
 
 
 # name -> (restype, argtypes); every function of include/ringsnark_amd.h
@@ -91,6 +95,7 @@ SIGNATURES = {
     "rs_rinocchio_prove": (C.c_int, [vp, vp, C.POINTER(RinocchioPK), vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]),
     "rs_last_timings": (C.c_int, [vp, C.POINTER(Timings)]),
     "rs_set_profiling": (C.c_int, [vp, C.c_int]),
+    "rs_profile_read": (C.c_int, [vp, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int)]),
     "rs_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "rs_fill_uniform": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_uint64, vp]),
     "rs_chain_assignment": (C.c_int, [vp, vp, C.c_size_t, vp]),

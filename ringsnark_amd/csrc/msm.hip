@@ -519,28 +519,24 @@ void msm_scratch_release(rs_ctx *ctx) {
 }
 
 template <int NG, int NC, int PAIRS>
-static void launch_mac(rs_ctx *ctx, const MacArgs &a, const MsmScratch &sc, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+static void launch_mac(rs_ctx *ctx, const MacArgs &a, const MsmScratch &sc, hipStream_t st) {
   const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(double);
   const int rows = a.n_chunks * ctx->L;
   const unsigned blocks = (unsigned)(((rows + 7) / 8) * 8 * ctx->K);
   RS_HIP(hipFuncSetAttribute((const void *)mac_kernel<NG, NC, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (e0) RS_HIP(hipEventRecord(e0, st));
   hipLaunchKernelGGL((mac_kernel<NG, NC, PAIRS>), dim3(blocks), dim3(tile_threads(ctx->logN_enc)), lds, st, a, ctx->L,
                      ctx->K, ctx->logN_enc, sc.d_coeff_tabs);
-  if (e1) RS_HIP(hipEventRecord(e1, st));
   RS_HIP(hipGetLastError());
 }
 
 extern int g_mac_variant, g_mac_ablate;
-static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, hipStream_t st) {
   const size_t lds = (padded_len((size_t)ctx->N_enc) + (size_t)ctx->N_enc) * sizeof(double);
   const int rows = a.n_chunks * ctx->L;
   const unsigned blocks = (unsigned)(((rows + 7) / 8) * 8 * ctx->K);
   if (g_mac_variant == 3 && ctx->logN_enc == 13) {  // 16 waves of 128 VGPRs (4 waves per SIMD), plaintext row not prefetched
     RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<1024, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (e0) RS_HIP(hipEventRecord(e0, st));
     hipLaunchKernelGGL((mac_kernel_v2<1024, 13>), dim3(blocks), dim3(1024), lds, st, a, ctx->L, ctx->K, ctx->logN_enc, sc.d_coeff_tabs);
-    if (e1) RS_HIP(hipEventRecord(e1, st));
     RS_HIP(hipGetLastError());
     return;
   }
@@ -549,10 +545,8 @@ static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, 
   do {                                                                                                                \
     RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<512, 13, AB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                (int)lds));                                                                           \
-    if (e0) RS_HIP(hipEventRecord(e0, st));                                                                           \
     hipLaunchKernelGGL((mac_kernel_v2<512, 13, AB>), dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K,             \
                        ctx->logN_enc, sc.d_coeff_tabs);                                                               \
-    if (e1) RS_HIP(hipEventRecord(e1, st));                                                                           \
   } while (0)
 #ifdef RS_EXPERIMENTS  // timing-only ablations (wrong results): never part of the release library
     switch (g_mac_ablate) {
@@ -569,9 +563,7 @@ static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, 
     return;
   }
   RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (e0) RS_HIP(hipEventRecord(e0, st));
   hipLaunchKernelGGL(mac_kernel_v2<512>, dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K, ctx->logN_enc, sc.d_coeff_tabs);
-  if (e1) RS_HIP(hipEventRecord(e1, st));
   RS_HIP(hipGetLastError());
 }
 
@@ -664,18 +656,20 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
   else
     RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  float mac_ms = 0;
-  int mac_launches = 0;
-  if (ctx->profiling) {
-    RS_HIP(hipEventCreate(&e0));
-    RS_HIP(hipEventCreate(&e1));
-  }
+  // rooflines: per (term, limb) a plaintext row costs one inverse transform of
+  // length n, the batching scatter and the centred lift; per (term, limb, prime) the MAC reads two
+  // ciphertext polynomials and one plaintext row, runs one forward transform and 2n multiply-adds
+  const double nd = (double)n, logn_d = (double)ctx->logN_enc;
   if (Tmax == 0) RS_HIP(hipMemsetAsync(d_partial, 0, (size_t)n_chunks * n_sets * enc_words * sizeof(uint64_t), st));
 
   int tile_idx = 0;
   for (size_t t0 = 0; t0 < Tmax; t0 += tile_terms, tile_idx++) {
     const size_t tt = std::min(tile_terms, Tmax - t0);
+    double rows_in = 0;  // coefficient rows (term, limb) read by this tile
+    for (int v = 0; v < n_vecs; v++) rows_in += (double)(vecs[v].T > t0 ? std::min(tt, vecs[v].T - t0) : 0) * L;
+    {
+    ProfScope prof_plain(ctx, st, "plain_center_kernel", rows_in * (double)ctx->N * 8.0 + (double)tt * L * n_groups * nd * 8.0,
+                         rows_in * (ntt_fp64(nd, logn_d) + 14.0 * nd));
     if (plain13)
       hipLaunchKernelGGL((plain_center_kernel<16, 13>), dim3((unsigned)tt, L, n_groups), dim3(plain_thr), lds, st, pa, d_C,
                          (unsigned long long)t0, (unsigned long long)tile_terms, ctx->N, L, ctx->logN_enc,
@@ -688,6 +682,7 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
       hipLaunchKernelGGL(plain_center_kernel<8>, dim3((unsigned)tt, L, n_groups), dim3(thr), lds, st, pa, d_C,
                          (unsigned long long)t0, (unsigned long long)tile_terms, ctx->N, L, ctx->logN_enc,
                          ctx->d_index_map, sc.d_plain_tabs);
+    }
     RS_HIP(hipGetLastError());
     MacArgs base;
     memset(&base, 0, sizeof(base));
@@ -715,21 +710,19 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
       for (int c = 0; c < NC; c++) a.crs[c] = crs_at(cs[c], t0);
       for (int c = 0; c < NC; c++)
         for (int g = 0; g < NG; g++) a.set_index[c * NG + g] = cs[c] * n_groups + gs[g];
+      double units = 0;  // (term, limb, prime) transforms
+      for (int g = 0; g < NG; g++) units += (double)a.terms[g] * L * K;
+      ProfScope prof(ctx, st, "mac_kernel",
+                     (double)tt * NC * (double)enc_words * 8.0 + units * nd * 8.0 / K + (double)NG * NC * (double)enc_words * 8.0,
+                     units * (ntt_fp64(nd, logn_d) + NC * 15.0 * nd));
       if (big)
-        launch_mac<1, 1, 8>(ctx, a, sc, st, e0, e1);
+        launch_mac<1, 1, 8>(ctx, a, sc, st);
       else if (NG == 2 && NC == 1)
-        launch_mac<2, 1, 4>(ctx, a, sc, st, e0, e1);
+        launch_mac<2, 1, 4>(ctx, a, sc, st);
       else if (NG == 1 && NC == 2)
-        launch_mac<1, 2, 4>(ctx, a, sc, st, e0, e1);
+        launch_mac<1, 2, 4>(ctx, a, sc, st);
       else
-        launch_mac<1, 1, 4>(ctx, a, sc, st, e0, e1);
-      if (e0) {
-        RS_HIP(hipEventSynchronize(e1));
-        float ms = 0;
-        RS_HIP(hipEventElapsedTime(&ms, e0, e1));
-        mac_ms += ms;
-        mac_launches++;
-      }
+        launch_mac<1, 1, 4>(ctx, a, sc, st);
     };
     // streaming kernel, one accumulator set (CRS vector c, group g) per launch.  With two CRS
     // vectors (Rinocchio's s_pows / alpha_s_pows) the plaintext transform is repeated per vector:
@@ -749,14 +742,12 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
         a2.accumulate = base.accumulate;
         a2.acc_period = base.acc_period;
         a2.reduce_u = base.reduce_u;
-        launch_mac_v2(ctx, a2, sc, st, e0, e1);
-        if (e0) {
-          RS_HIP(hipEventSynchronize(e1));
-          float ms = 0;
-          RS_HIP(hipEventElapsedTime(&ms, e0, e1));
-          mac_ms += ms;
-          mac_launches++;
-        }
+        // every ciphertext word of the group's terms once, every plaintext row once (shared by the K
+        // prime workgroups through L2), the accumulator set written once
+        const double terms = (double)a2.terms;
+        ProfScope prof(ctx, st, "mac_kernel_v2", terms * ((double)enc_words * 8.0 + (double)L * nd * 8.0) + (double)enc_words * 8.0,
+                       terms * L * K * (ntt_fp64(nd, logn_d) + 15.0 * nd));
+        launch_mac_v2(ctx, a2, sc, st);
       }
     } else if (big) {  // one (crs, group) pair per launch
       for (int c = 0; c < n_crs; c++)
@@ -805,12 +796,6 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
       h_used[v] = cnt;
       off += vecs[v].T;
     }
-  }
-  if (ctx->profiling) {
-    RS_HIP(hipEventDestroy(e0));
-    RS_HIP(hipEventDestroy(e1));
-    ctx->timings.msm_mac_ms += mac_ms;
-    ctx->timings.msm_mac_launches += mac_launches;
   }
 }
 

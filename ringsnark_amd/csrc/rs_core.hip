@@ -32,6 +32,26 @@ void *ws_get(rs_ctx *ctx, int slot, size_t bytes) {
   ctx->ws_touched |= 1u << slot;
   return b.p;
 }
+static hipEvent_t prof_event(rs_ctx *ctx) {
+  if (!ctx->prof_pool.empty()) {
+    hipEvent_t e = ctx->prof_pool.back();
+    ctx->prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  RS_HIP(hipEventCreate(&e));
+  return e;
+}
+ProfScope::ProfScope(rs_ctx *c, hipStream_t s, const char *name, double alg_bytes, double fp64_ops) : ctx(c), st(s) {
+  if (!ctx->profiling) return;
+  ProfRec r{name, prof_event(ctx), prof_event(ctx), alg_bytes, fp64_ops};
+  RS_HIP(hipEventRecord(r.e0, st));
+  ctx->prof.push_back(r);
+  idx = (int)ctx->prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (idx >= 0) (void)hipEventRecord(ctx->prof[idx].e1, st);
+}
 WsScope::~WsScope() {
   for (int k = 0; k < 16; k++) {
     if (!((ctx->ws_touched >> k) & 1u)) continue;
@@ -606,6 +626,11 @@ void rs_ctx_destroy(rs_ctx *c) {
   if (c->d_qmod) (void)hipFree(c->d_qmod);
   if (c->d_Qmod) (void)hipFree(c->d_Qmod);
   if (c->d_index_map) (void)hipFree(c->d_index_map);
+  for (auto &r : c->prof) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  for (auto e : c->prof_pool) (void)hipEventDestroy(e);
   for (auto &b : c->ws) {
     if (b.last_use) (void)hipEventDestroy(b.last_use);
     if (b.p) (void)hipFree(b.p);
@@ -767,6 +792,37 @@ int rs_set_profiling(rs_ctx *ctx, int enabled) {
   RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx, "null argument");
   ctx->profiling = enabled != 0;
+  RS_API_END
+}
+int rs_profile_read(rs_ctx *ctx, rs_kernel_stat *out, int capacity, int *n_out) {
+  RS_API_BEGIN_CTX(ctx)
+  RS_REQUIRE(ctx && n_out && (out || capacity == 0), "null argument");
+  std::unique_lock<std::mutex> lk(ctx->mu);
+  std::vector<rs_kernel_stat> agg;
+  for (auto &r : ctx->prof) {
+    RS_HIP(hipEventSynchronize(r.e1));
+    float ms = 0;
+    RS_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+    ctx->prof_pool.push_back(r.e0);
+    ctx->prof_pool.push_back(r.e1);
+    size_t k = 0;
+    for (; k < agg.size(); k++)
+      if (strncmp(agg[k].name, r.name, sizeof(agg[k].name)) == 0) break;
+    if (k == agg.size()) {
+      rs_kernel_stat z;
+      memset(&z, 0, sizeof(z));
+      strncpy(z.name, r.name, sizeof(z.name) - 1);
+      agg.push_back(z);
+    }
+    agg[k].launches++;
+    agg[k].total_ms += ms;
+    agg[k].alg_bytes += r.bytes;
+    agg[k].fp64_ops += r.fp64;
+  }
+  ctx->prof.clear();
+  std::sort(agg.begin(), agg.end(), [](const rs_kernel_stat &a, const rs_kernel_stat &b) { return a.total_ms > b.total_ms; });
+  *n_out = (int)agg.size();
+  for (int k = 0; k < capacity && k < (int)agg.size(); k++) out[k] = agg[k];
   RS_API_END
 }
 int rs_last_timings(rs_ctx *ctx, rs_timings *out) {

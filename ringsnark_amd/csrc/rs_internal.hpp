@@ -79,6 +79,14 @@ struct DeviceBuf {
   bool used = false;               // last_use is valid
 };
 
+// One timed launch (rs_set_profiling): events on the launch stream around the kernel, plus the
+// launch's ALGORITHMIC bytes and FP64 instruction count (per lane) as DESIGN.md defines them.
+struct ProfRec {
+  const char *name;
+  hipEvent_t e0, e1;
+  double bytes, fp64;
+};
+
 struct WitnessPlan;  // witness.hip
 struct R1cs;         // r1cs in CSR on device
 
@@ -120,6 +128,8 @@ struct rs_ctx {
   uint32_t ws_touched = 0;           // workspace slots used by that call
   bool profiling = false;
   rs_timings timings{};
+  std::vector<rs::ProfRec> prof;        // launches recorded since the last rs_profile_read
+  std::vector<hipEvent_t> prof_pool;    // recycled events
   size_t ring_words() const { return (size_t)L * N; }
   size_t ct_words() const { return (size_t)2 * K * N_enc; }
   size_t enc_words() const { return (size_t)L * 2 * K * N_enc; }
@@ -141,6 +151,17 @@ struct DeviceGuard {
     if (prev >= 0) (void)hipSetDevice(prev);
   }
 };
+// Times ONE kernel launch when profiling is on (no-op otherwise):  { ProfScope p(...); launch; }
+struct ProfScope {
+  rs_ctx *ctx;
+  hipStream_t st;
+  int idx = -1;
+  ProfScope(rs_ctx *c, hipStream_t s, const char *name, double alg_bytes, double fp64_ops);
+  ~ProfScope();
+};
+// FP64 instruction counts used for the rooflines: a lazy butterfly is 8 instructions (6 mulmod +
+// add + sub), a pointwise modular multiply 7 (mulmod + a reduce/canon step), per lane.
+inline double ntt_fp64(double n, double logn) { return 8.0 * (n / 2.0) * logn; }
 struct WsScope {
   rs_ctx *ctx;
   std::unique_lock<std::mutex> lk;

@@ -1374,9 +1374,22 @@ int g_witness_tree_ct = 1;    // 1: level-unrolled product-tree kernel for 2^13 
 
 // Newton -> monomial levels 1..logT on tiles of 2^logT coefficients of [ncols][M] columns; with
 // `newton` (logT == logM) the tiles hold values and the Newton conversion runs first, in the same launch
-static void launch_tree_tiles(double *cols, size_t ncols, size_t col0, int logM, int logT, size_t S, size_t slots_per_limb,
-                              const ColPlans &cp, hipStream_t st, bool newton = false) {
+// FP64 instructions (per lane) of the product tree on one tile of T = 2^logT coefficients: levels
+// 1..4 by schoolbook (120 modular multiplies + as many additions per 16 coefficients), every level
+// above by a forward and an inverse batched transform plus the spectrum product and the recombination
+static double tree_fp64(double T, int logT) {
+  double f = T / 16.0 * (120.0 * 7.0 + 4.0 * 16.0 * 3.0);
+  for (int l = SCHOOL_LEVELS + 1; l <= logT; l++) f += 2.0 * ntt_fp64(T, l) + 10.0 * T;
+  return f;
+}
+static void launch_tree_tiles(rs_ctx *ctx, double *cols, size_t ncols, size_t col0, int logM, int logT, size_t S,
+                              size_t slots_per_limb, const ColPlans &cp, hipStream_t st, bool newton = false) {
   const size_t T = (size_t)1 << logT;
+  const double tiles = (double)(ncols << (logM - logT));
+  // Newton conversion (single-tile columns): two passes of forward + inverse M-point transforms and two pointwise products
+  const double newton_fp64 = newton ? 4.0 * ntt_fp64((double)T, logT) + 31.0 * (double)T : 0.0;
+  ProfScope prof(ctx, st, newton ? "tree_columns_kernel<NEWTON>" : "tree_columns_kernel", tiles * (double)T * 16.0,
+                 tiles * (tree_fp64((double)T, logT) + newton_fp64));
   const size_t lds1 = padded_len(T) * sizeof(double);
   const unsigned grid = (unsigned)(ncols << (logM - logT));
   const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, T / 16));  // 1024 only for a 2^14 tile (one workgroup per CU)
@@ -1423,8 +1436,16 @@ static void launch_cross_pass(int R, const dim3 &grid, const CrossArgs &a, const
 // Cross stages of the length-2^logsub transforms in W[ncols][2^logtot]: forward stages
 // [0, logsub-logB) (the first pass reads through source MODE from a.src), or inverse stages
 // [logB, logsub) (the last pass writes through sink MODE to a.dst).
+// algorithmic 8-byte words per column of a cross pass that reads through source / writes through sink MODE
 template <bool INV, int MODE>
-static void launch_cross(CrossArgs a, size_t ncols, int logB, const ColPlans &cp, hipStream_t st) {
+static double cross_words(const CrossArgs &a, bool special) {
+  const double n = (double)((size_t)1 << a.logtot), M = (double)((size_t)1 << a.logM);
+  if (!special || MODE == 0) return 2.0 * n;
+  if (!INV) return n + (MODE == CS_FILL_RIGHT ? M / 2.0 : M);                  // source words + workspace written
+  return n + (MODE == CD_COMBINE || MODE == CD_COMBINE_CANON ? 1.5 * M : M);  // workspace read + sink traffic
+}
+template <bool INV, int MODE>
+static void launch_cross(rs_ctx *ctx, CrossArgs a, size_t ncols, int logB, const ColPlans &cp, hipStream_t st) {
   const int ncross = a.logsub - logB;
   const size_t groups = ((size_t)1 << a.logtot);
   int done = 0;
@@ -1434,6 +1455,8 @@ static void launch_cross(CrossArgs a, size_t ncols, int logB, const ColPlans &cp
     const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>((groups >> R) / 256, 1024));
     const dim3 grid(gx, (unsigned)ncols);
     const bool special = INV ? (done + R >= ncross) : (done == 0);
+    ProfScope prof(ctx, st, "cross_kernel", (double)ncols * 8.0 * cross_words<INV, MODE>(a, special),
+                   (double)ncols * ntt_fp64((double)groups, R));
     if (special)
       launch_cross_pass<INV, MODE>(R, grid, a, cp, st);
     else
@@ -1444,10 +1467,14 @@ static void launch_cross(CrossArgs a, size_t ncols, int logB, const ColPlans &cp
 }
 
 template <int MODE>
-static void launch_sub(double *X, size_t ncols, size_t col0, int logtot, int logsub, int logB, const TabPtrs *tabs,
+static void launch_sub(rs_ctx *ctx, double *X, size_t ncols, size_t col0, int logtot, int logsub, int logB, const TabPtrs *tabs,
                        size_t tab_period, size_t S, size_t spl, const ColPlans &cp, hipStream_t st) {
   const size_t lds = padded_len((size_t)1 << logB) * sizeof(double);
   const size_t bpc = (size_t)1 << (logtot - logB);
+  static const char *const names[4] = {"sub_ntt_kernel<0>", "sub_ntt_kernel<1>", "sub_ntt_kernel<2>", "sub_ntt_kernel<3>"};
+  const double Bn = (double)((size_t)1 << logB), blocks = (double)(ncols * bpc);
+  ProfScope prof(ctx, st, names[MODE], blocks * Bn * (MODE == 3 ? 24.0 : 16.0),
+                 blocks * ((MODE >= 2 ? 2.0 : 1.0) * ntt_fp64(Bn, logB) + (MODE >= 2 ? 7.0 * Bn : 0.0)));
   static TabPtrs none{};
   const TabPtrs &tp = tabs ? *tabs : none;
   RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1475,24 +1502,24 @@ static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, do
   TabPtrs tp{};
   // values -> Newton coefficients: one cyclic convolution of length 2M
   a.logtot = a.logsub = logM + 1;
-  launch_cross<false, CS_SCALE_PAD>(a, ncols, logB, cp, st);
+  launch_cross<false, CS_SCALE_PAD>(ctx, a, ncols, logB, cp, st);
   for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_ehat;
-  launch_sub<2>(W, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * M) >> logB, S, spl, cp, st);
-  launch_cross<true, CD_TAKE_LOW>(a, ncols, logB, cp, st);
+  launch_sub<2>(ctx, W, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * M) >> logB, S, spl, cp, st);
+  launch_cross<true, CD_TAKE_LOW>(ctx, a, ncols, logB, cp, st);
   // product tree: levels <= logB inside LDS tiles
-  launch_tree_tiles(X, ncols, col0, logM, logB, S, spl, cp, st);
+  launch_tree_tiles(ctx, X, ncols, col0, logM, logB, S, spl, cp, st);
   // levels above: F_node = F_left + D_left * F_right with multi-pass transforms of length 2^l
   a.logtot = logM;
   for (int l = logB + 1; l <= logM; l++) {
     a.l = l;
     a.logsub = l;
-    launch_cross<false, CS_FILL_RIGHT>(a, ncols, logB, cp, st);
+    launch_cross<false, CS_FILL_RIGHT>(ctx, a, ncols, logB, cp, st);
     for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_dhat + (size_t)l * M;
-    launch_sub<2>(W, ncols, col0, logM, l, logB, &tp, M >> logB, S, spl, cp, st);
+    launch_sub<2>(ctx, W, ncols, col0, logM, l, logB, &tp, M >> logB, S, spl, cp, st);
     if (l == logM)
-      launch_cross<true, CD_COMBINE_CANON>(a, ncols, logB, cp, st);
+      launch_cross<true, CD_COMBINE_CANON>(ctx, a, ncols, logB, cp, st);
     else
-      launch_cross<true, CD_COMBINE>(a, ncols, logB, cp, st);
+      launch_cross<true, CD_COMBINE>(ctx, a, ncols, logB, cp, st);
   }
 }
 
@@ -1514,23 +1541,24 @@ static void big_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const d
   // W1 = spectrum of A; W2 = A * B (spectrum product inside the sub-transform kernel of B)
   a.W = W1;
   a.src = A;
-  launch_cross<false, CS_PAD_CENTER>(a, ncols, logB, cp, st);
-  launch_sub<0>(W1, ncols, col0, logM + 1, logM + 1, logB, nullptr, 1, S, spl, cp, st);
+  launch_cross<false, CS_PAD_CENTER>(ctx, a, ncols, logB, cp, st);
+  launch_sub<0>(ctx, W1, ncols, col0, logM + 1, logM + 1, logB, nullptr, 1, S, spl, cp, st);
   a.W = W2;
   a.src = B;
-  launch_cross<false, CS_PAD_CENTER>(a, ncols, logB, cp, st);
+  launch_cross<false, CS_PAD_CENTER>(ctx, a, ncols, logB, cp, st);
   tp.t[0] = W1;
-  launch_sub<3>(W2, ncols, col0, logM + 1, logM + 1, logB, &tp, 1, S, spl, cp, st);
-  launch_cross<true, CD_PLAIN>(a, ncols, logB, cp, st);
+  launch_sub<3>(ctx, W2, ncols, col0, logM + 1, logM + 1, logB, &tp, 1, S, spl, cp, st);
+  launch_cross<true, CD_PLAIN>(ctx, a, ncols, logB, cp, st);
   // U = rev(P) * rev(Z)^-1 mod x^(m-1)
   a.W = W1;
   a.src = W2;
-  launch_cross<false, CS_REV_TRUNC>(a, ncols, logB, cp, st);
+  launch_cross<false, CS_REV_TRUNC>(ctx, a, ncols, logB, cp, st);
   for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_shat;
-  launch_sub<2>(W1, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * M) >> logB, S, spl, cp, st);
+  launch_sub<2>(ctx, W1, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * M) >> logB, S, spl, cp, st);
   a.dst = H;
-  launch_cross<true, CD_H_FINISH>(a, ncols, logB, cp, st);
+  launch_cross<true, CD_H_FINISH>(ctx, a, ncols, logB, cp, st);
   const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((ncols * M + 255) / 256, 256 * 16));
+  ProfScope prof(ctx, st, "h_patch_kernel", (double)ncols * (double)M * (d1 ? 32.0 : 16.0), d1 ? 24.0 * (double)ncols * (double)M : 0.0);
   hipLaunchKernelGGL(h_patch_kernel, dim3(blocks), dim3(256), 0, st, H, A, B, logM, (int)P->m, ncols, col0, (unsigned)S, (unsigned)spl, cp,
                      d1, d2, d3, cm);
   RS_HIP(hipGetLastError());
@@ -1557,13 +1585,15 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp,
   if (single_tile_ok(P->logM)) {
     // one launch, tile = M, two workgroups per CU: Newton conversion by the two rooted M-point
     // sub-transforms, then the product tree in place
-    launch_tree_tiles(cols, ncols, 0, P->logM, P->logM, S, slots_per_limb, cp, st, true);
+    launch_tree_tiles(ctx, cols, ncols, 0, P->logM, P->logM, S, slots_per_limb, cp, st, true);
     return;
   }
   if (P->logM <= g_witness_lds_logM) {
     // the 2M convolution tile, or the product tree's tile + scratch when M is below the LDS block size
     const size_t lds = std::max(padded_len(2 * P->M), padded_len(tree_scratch_offset((int)P->M) + P->M)) * sizeof(double);
     RS_HIP(hipFuncSetAttribute((const void *)interp_columns_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope prof(ctx, st, "interp_columns_kernel", (double)ncols * (double)P->M * 16.0,
+                   (double)ncols * (2.0 * ntt_fp64(2.0 * (double)P->M, P->logM + 1) + 21.0 * (double)P->M + tree_fp64((double)P->M, P->logM)));
     hipLaunchKernelGGL(interp_columns_kernel, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds, st, cols, P->logM,
                        (unsigned)S, (unsigned)slots_per_limb, cp);
     RS_HIP(hipGetLastError());
@@ -1585,6 +1615,9 @@ static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, cons
   if (single_tile_ok(P->logM)) {
     const size_t lds1 = padded_len(M) * sizeof(double);
     const int thr = (int)(M / 16);
+    // ten M-point transforms, four pointwise products, the ZK patch
+    ProfScope prof(ctx, st, "h_tile_kernel", (double)S * (double)M * 24.0,
+                   (double)S * (10.0 * ntt_fp64((double)M, P->logM) + (d1 ? 52.0 : 28.0) * (double)M));
 #define RS_H_LAUNCH(KERN)                                                                                            \
   do {                                                                                                               \
     RS_HIP(hipFuncSetAttribute((const void *)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));         \
@@ -1604,6 +1637,8 @@ static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, cons
   if (P->logM <= g_witness_lds_logM) {
     const size_t lds = padded_len(2 * M) * sizeof(double);
     RS_HIP(hipFuncSetAttribute((const void *)h_columns_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope prof(ctx, st, "h_columns_kernel", (double)S * (double)M * 24.0,
+                   (double)S * (5.0 * ntt_fp64(2.0 * (double)M, P->logM + 1) + (d1 ? 52.0 : 28.0) * (double)M));
     hipLaunchKernelGGL(h_columns_kernel<0>, dim3((unsigned)S), dim3(col_threads(2 * M)), lds, st, A, B, H, P->logM, (int)P->m,
                        (unsigned)spl, cp, d1, d2, d3, cm);
     RS_HIP(hipGetLastError());
@@ -1707,14 +1742,15 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
   auto colv = [&](int k) { return colbuf + (size_t)slot_of[k] * vec; };
   const dim3 tgrid((unsigned)((C + 31) / 32), (unsigned)((M + 31) / 32));
   const dim3 tgrid64((unsigned)((C + 63) / 64), (unsigned)((M + 31) / 32));
-  for (int w = 0; w < 3; w++) {
-    if (needed(w))
+  for (int w = 0; w < 3; w++)
+    for (int full = 0; full < 2; full++) {
+      if (!needed(3 * full + w)) continue;
+      // per (row, slot): 8 bytes of assignment per non-zero + 8 bytes of column written
+      ProfScope prof(ctx, st, "r1cs_eval_cols_kernel", (double)C * 8.0 * ((double)cs->nnz[w] + (double)M), 7.0 * (double)C * (double)cs->nnz[w]);
       hipLaunchKernelGGL(r1cs_eval_cols_kernel, tgrid64, dim3(256), 0, st, cs->d_row_ptr[w], cs->d_col[w], cs->d_coeff[w],
-                         cs->nnz[w], d_asg, colv(w), m, C, M, (int)RS_EVAL_IO, (unsigned)cs->n_inputs, ctx->d_qmod, cm);
-    if (needed(3 + w))
-      hipLaunchKernelGGL(r1cs_eval_cols_kernel, tgrid64, dim3(256), 0, st, cs->d_row_ptr[w], cs->d_col[w], cs->d_coeff[w],
-                         cs->nnz[w], d_asg, colv(3 + w), m, C, M, (int)RS_EVAL_FULL, (unsigned)cs->n_inputs, ctx->d_qmod, cm);
-  }
+                         cs->nnz[w], d_asg, colv(3 * full + w), m, C, M, full ? (int)RS_EVAL_FULL : (int)RS_EVAL_IO,
+                         (unsigned)cs->n_inputs, ctx->d_qmod, cm);
+    }
   RS_HIP(hipGetLastError());
   // one batched interpolation: the needed io / full vectors are adjacent in the workspace
   {
@@ -1729,21 +1765,29 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
     for (int w = 0; w < 3; w++) {
       if (!outs[3 + w]) continue;
       const double *cst = (d_const && cs->has_const[w]) ? d_const + (size_t)w * ctx->L * M : nullptr;
+      ProfScope prof(ctx, st, "mid_kernel", (double)vec * 24.0, 3.0 * (double)vec);
       hipLaunchKernelGGL(mid_kernel, dim3(eb), dim3(256), 0, st, colv(3 + w), colv(w), cst, M, C, (unsigned)cm.ns, cp, cm.limb0);
     }
     RS_HIP(hipGetLastError());
     for (int k = 0; k < 6; k++)
-      if (outs[k]) hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(k), outs[k], m, C, M, cm);
+      if (outs[k]) {
+        ProfScope prof(ctx, st, "transpose_out_kernel", (double)C * (double)m * 16.0, 0.0);
+        hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(k), outs[k], m, C, M, cm);
+      }
   } else {
     for (int w = 0; w < 3; w++) {
       if (!need_io[w]) continue;
       IoDesc io{cs->d_io_k[w], cs->d_io_c[w], cs->io_count[w]};
       if (outs[3 + w]) {  // io (if wanted) and mid in one pass over the interpolated columns
         const double *cst = cs->io_const_col[w] >= 0 ? cs->d_io_cols + (size_t)cs->io_const_col[w] * ctx->L * M : nullptr;
+        // 8 bytes of column read, 8 or 16 written, the primary inputs re-read per row (L2 resident)
+        ProfScope prof(ctx, st, "io_mid_out_kernel", (double)C * (double)m * (outs[w] ? 24.0 : 16.0),
+                       (double)C * (double)m * (7.0 * io.count + 4.0));
         hipLaunchKernelGGL(io_mid_out_kernel, tgrid64, dim3(256), 0, st, colv(3 + w), io, cs->d_io_cols, d_asg, cst, outs[w],
                            outs[3 + w], m, C, M, ctx->d_qmod, cm);
       } else {  // io alone: no column work at all
         const unsigned by = (unsigned)((C / 2 + 255) / 256);
+        ProfScope prof(ctx, st, "io_coeff_kernel", (double)C * (double)m * 8.0, (double)C * (double)m * 7.0 * io.count);
         hipLaunchKernelGGL(io_coeff_kernel, dim3((unsigned)m, by), dim3(256), 0, st, io, cs->d_io_cols, d_asg, outs[w], C, M,
                            ctx->d_qmod, cm);
       }
@@ -1751,7 +1795,10 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
   }
   RS_HIP(hipGetLastError());
   if (needH) {
-    hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(6), outs[6], std::min(m + 1, M), C, M, cm);
+    {
+      ProfScope prof(ctx, st, "transpose_out_kernel", (double)C * (double)m * 16.0, 0.0);
+      hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(6), outs[6], std::min(m + 1, M), C, M, cm);
+    }
     if (m == M)  // row m does not exist in the M-row column tile
       hipLaunchKernelGGL(h_top_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, outs[6] + m * cm.out_stride(), d1, d2, C,
                          ctx->d_qmod, cm);

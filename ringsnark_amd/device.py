@@ -347,6 +347,15 @@ class Device:
         _lib.check(self.lib.rs_last_timings(self.h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in _lib.Timings._fields_}
 
+    def profile_read(self):
+        """[{name, launches, total_ms, alg_bytes, fp64_ops}] per kernel since profiling was switched on, by time."""
+        cap = 64
+        arr = (_lib.KernelStat * cap)()
+        n = C.c_int(0)
+        _lib.check(self.lib.rs_profile_read(self.h, arr, cap, C.byref(n)))
+        return [{"name": arr[k].name.decode(), "launches": arr[k].launches, "total_ms": arr[k].total_ms,
+                 "alg_bytes": arr[k].alg_bytes, "fp64_ops": arr[k].fp64_ops} for k in range(min(cap, n.value))]
+
     def fill_uniform(self, t, layout, seed):
         words = self.ring_words if layout == 0 else self.enc_words
         _lib.check(self.lib.rs_fill_uniform(self.h, _ptr(t), self._count(t, words), layout, seed, self.stream()))

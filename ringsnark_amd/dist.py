@@ -1,27 +1,34 @@
-"""Multi-GPU ringGroth16 prover: one process per GPU, torch.distributed (RCCL over xGMI).
+"""Multi-GPU provers: one process per GPU, torch.distributed (RCCL over xGMI).
 
 Sharding:
   * RNS limbs first.  A ring limb i is an independent problem end to end -- its own N witness-map
     columns over F_{q_i} and its own BGV encoding context (ciphertexts [2][K][N_enc] with plain
-    modulus q_i) -- so a rank simply builds its context over a SUBSET of the ring primes and holds
-    the matching slice [:, limbs] of the CRS and of the assignment.  No exchange is needed until
-    the proof is assembled.
-  * Constraints (MSM terms) second, when there are more ranks than limbs: the ranks sharing a limb
-    split the term range; their partial encoding sums are combined by ONE all-reduce(SUM) of
-    3 * L_local encoding elements (residues < 2^50, so the integer sum of <= 2^13 partials cannot
-    overflow int64) followed by a reduction mod Q_j.  The witness map of a shared limb is
-    replicated inside the pair (it is column-parallel, not term-parallel).
-  * The proof {A, B, C} is assembled by an all-gather over the limb axis.
+    modulus q_i) -- so a rank builds its context over a SUBSET of the ring primes and holds the
+    matching slice [:, limbs] of the key and of the assignment.  No exchange until the proof is
+    assembled.
+  * When there are more ranks than limbs, the G_t ranks sharing a limb set ("limb group") split
+      - the WITNESS MAP by NTT slots (it is column parallel: rank s takes slots [s N/G_t, (s+1) N/G_t)
+        of every limb it owns, rs_witness_map_slots), then ONE pairwise exchange (point-to-point
+        sends over xGMI, issued as one batch) turns the slot-sharded coefficient vectors into
+        term-sharded ones: rank s receives, from every peer, the rows of ITS term range;
+      - the INNER PRODUCTS by terms (constraints): each rank multiplies its term range of the key,
+        and the partial encoding sums are combined by ONE all-reduce(SUM) (residues < 2^50, so integer
+        sums of <= 2^13 partials cannot overflow int64) followed by a reduction mod Q_j.
+  * The proof is assembled by an all-gather over the limb axis.
 
-`backend` abstracts the arithmetic (Device in production; the CPU tests drive the same code over
+`backend` abstracts the arithmetic (DeviceBackend in production; the CPU tests drive the same code over
 gloo with an oracle-backed stand-in to check the sharding and the collectives).
 """
 import math
+from collections import namedtuple
 from dataclasses import dataclass
 from typing import List
 
+import numpy as np
 import torch
 import torch.distributed as dist
+
+RS_KIND_POLY, RS_KIND_ONE = 0, 2
 
 
 @dataclass
@@ -30,28 +37,64 @@ class ShardPlan:
     rank: int
     L: int
     limb_groups: int  # G_l
-    term_shards: int  # G_t
+    term_shards: int  # G_t: ranks per limb group (they split slots for the witness map, terms for the MSM)
     limbs: List[int]  # ring limbs owned by this rank
     term_shard: int
     limb_group: int
 
-    def term_range(self, T):
+    def term_range(self, T, shard=None):
+        s = self.term_shard if shard is None else shard
         per = (T + self.term_shards - 1) // self.term_shards
-        lo = min(T, self.term_shard * per)
+        lo = min(T, s * per)
         return lo, min(T, lo + per)
 
+    def slot_range(self, N, shard=None):
+        """(slot0, nslots) of the witness-map share of a shard: contiguous, even-aligned blocks."""
+        s = self.term_shard if shard is None else shard
+        per = -(-N // self.term_shards)
+        per += per & 1
+        lo = min(N, s * per)
+        return lo, min(N, lo + per) - lo
 
-class TermWindow:
-    """A key vector of logical length T of which this rank stores only terms [lo, hi)."""
+    def group_ranks(self):
+        """Global ranks of this rank's limb group, by shard index."""
+        return [self.limb_group + self.limb_groups * s for s in range(self.term_shards)]
+
+
+# A slice of a key vector handed to backend.msm: `tensor` holds the stored elements, `length` logical terms are
+# read, logical term t from tensor[t % window] when window != 0 (tiled key, include/ringsnark_amd.h crs_window).
+KeySlice = namedtuple("KeySlice", "tensor length window")
+
+
+class TiledKey:
+    """A key vector of logical length T of which this rank reads terms [lo, hi) only.  `store` holds either
+    exactly those hi - lo elements, or fewer ("window"): then logical term t lives at store[(t - lo) % len(store)]
+    (tiled synthetic key for statements whose key exceeds HBM)."""
 
     def __init__(self, store, lo, hi, T):
         self.store, self.lo, self.hi, self.T = store, lo, hi, T
+        n = len(store)
+        assert n >= 1 and (n >= hi - lo or n & (n - 1) == 0), "a window must be a power of two"
+        self.window = n if n < hi - lo else 0
 
     def __getitem__(self, sl):
         assert isinstance(sl, slice) and sl.step is None
         a, b = sl.start or 0, self.T if sl.stop is None else sl.stop
         assert self.lo <= a <= b <= self.hi, "term range outside this rank's window"
-        return self.store[a - self.lo:b - self.lo]
+        if self.window:
+            assert a == self.lo, "a tiled key is read from the start of the rank's range"
+            return KeySlice(self.store, b - a, self.window)
+        return KeySlice(self.store[a - self.lo:b - self.lo], b - a, 0)
+
+
+TermWindow = TiledKey  # older name
+
+
+def key_slice(v, a, b):
+    """v: TiledKey or a plain tensor holding the whole vector."""
+    if isinstance(v, TiledKey):
+        return v[a:b]
+    return KeySlice(v[a:b], b - a, 0)
 
 
 def make_plan(world, rank, L) -> ShardPlan:
@@ -63,13 +106,15 @@ def make_plan(world, rank, L) -> ShardPlan:
 
 
 def groups_for(plan: ShardPlan):
-    """Process groups: ranks sharing a limb group (term all-reduce).  Every rank must call this
-    (dist.new_group is collective)."""
-    term_groups = []
+    """Process group of this rank's limb group (the ranks that exchange witness rows and all-reduce partial
+    sums).  Every rank must call this (dist.new_group is collective)."""
+    mine = None
     for lg in range(plan.limb_groups):
         ranks = [lg + plan.limb_groups * s for s in range(plan.term_shards)]
-        term_groups.append(dist.new_group(ranks) if plan.term_shards > 1 else None)
-    return term_groups[plan.limb_group]
+        g = dist.new_group(ranks) if plan.term_shards > 1 else None
+        if lg == plan.limb_group:
+            mine = g
+    return mine
 
 
 def groth16_key_ranges(plan: ShardPlan, m, n_aux):
@@ -80,39 +125,179 @@ def groth16_key_ranges(plan: ShardPlan, m, n_aux):
     return {"s_pows": plan.term_range(m), "delta_ts": plan.term_range(m + 1), "delta_mid": plan.term_range(n_aux)}
 
 
+def rinocchio_key_ranges(plan: ShardPlan, m, n_aux):
+    """rinocchio.tcc:106-163: s_pows / alpha_s_pows on m + 1 entries (h and z; the *_mid vectors use the first
+    m of them), beta_prods on n_aux."""
+    return {"s_pows": plan.term_range(m + 1), "alpha_s_pows": plan.term_range(m + 1), "beta_prods": plan.term_range(n_aux)}
+
+
+# ---------------------------------------------------------------------------------------------------
+# slot-sharded witness map -> term-sharded coefficient vectors
+# ---------------------------------------------------------------------------------------------------
+def _p2p(ops_send, ops_recv, group):
+    """One batch of point-to-point transfers inside `group`: (tensor, global peer rank) lists.  RCCL runs the
+    batch as one grouped all-to-all over the direct xGMI links; gloo (CPU tests, single-GPU rehearsals) moves
+    host tensors, so device tensors are staged through the host there."""
+    if not ops_send and not ops_recv:
+        return
+    stage = dist.get_backend(group) == "gloo" and any(t.is_cuda for t, _ in ops_send + ops_recv)
+    if stage:
+        send_h = [(t.cpu(), p) for t, p in ops_send]
+        recv_h = [(torch.empty(t.shape, dtype=t.dtype), p) for t, p in ops_recv]
+    else:
+        send_h, recv_h = ops_send, ops_recv
+    ops = [dist.P2POp(dist.isend, t.contiguous(), p, group) for t, p in send_h] + [dist.P2POp(dist.irecv, t, p, group) for t, p in recv_h]
+    for r in dist.batch_isend_irecv(ops):
+        r.wait()
+    if stage:
+        for (dst, _), (src, _) in zip(ops_recv, recv_h):
+            dst.copy_(src)
+
+
+def sharded_witness(backend, plan: ShardPlan, group, cs_local, assignment_local, want, ranges, ds=(None, None, None)):
+    """The witness map of this rank's limbs, returned TERM-sharded: {k: rows [lo_k, hi_k) of vector k, all N
+    slots}, plus "Z" (host array [L_local][m+1]).  ranges[k] = function shard -> (lo, hi) of vector k.
+    With one rank per limb group this is the plain witness map; otherwise every rank maps its slot range
+    (rs_witness_map_slots) and one batch of point-to-point transfers re-shards slots -> terms."""
+    if plan.term_shards == 1:
+        w = backend.witness(cs_local, assignment_local, want, ds)
+        out = {k: w[k][ranges[k](0)[0]:ranges[k](0)[1]] for k in want}
+        out["Z"] = w["Z"]
+        return out
+    N = backend.N
+    s0, ns = plan.slot_range(N)
+    wc = backend.witness_slots(cs_local, assignment_local, s0, ns, want, ds)  # compact [rows][L][ns]
+    peers = plan.group_ranks()
+    me = plan.term_shard
+    out, sends, recvs, pending = {"Z": wc["Z"]}, [], [], []
+    for k in want:
+        lo, hi = ranges[k](me)
+        full = torch.empty((hi - lo,) + tuple(wc[k].shape[1:-1]) + (N,), dtype=wc[k].dtype, device=wc[k].device)
+        full[..., s0:s0 + ns] = wc[k][lo:hi]
+        out[k] = full
+        for s, peer in enumerate(peers):
+            if s == me:
+                continue
+            plo, phi = ranges[k](s)
+            if phi > plo and ns > 0:
+                sends.append((wc[k][plo:phi], peer))
+            ps0, pns = plan.slot_range(N, s)
+            if hi > lo and pns > 0:
+                buf = torch.empty((hi - lo,) + tuple(wc[k].shape[1:-1]) + (pns,), dtype=wc[k].dtype, device=wc[k].device)
+                recvs.append((buf, peer))
+                pending.append((full, ps0, pns, buf))
+    _p2p(sends, recvs, group)
+    for full, ps0, pns, buf in pending:
+        full[..., ps0:ps0 + pns] = buf
+    return out
+
+
+def _gather_limbs(plan: ShardPlan, piece, n_elems):
+    """all-gather over every rank, keep one copy per limb (shard 0 of each limb group holds the reduced sums)."""
+    if plan.world == 1:
+        return piece
+    pieces = [torch.empty_like(piece) for _ in range(plan.world)]
+    dist.all_gather(pieces, piece)
+    full = torch.empty((n_elems, plan.L) + tuple(piece.shape[2:]), dtype=piece.dtype, device=piece.device)
+    for lg in range(plan.limb_groups):
+        limbs = [i for i in range(plan.L) if i % plan.limb_groups == lg]
+        full[:, limbs] = pieces[lg]  # rank lg is shard 0 of limb group lg
+    return full
+
+
 def groth16_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_local, assignment_local, m, n_inputs, n_aux):
     """groth16::prover (zk_proof_systems/groth16/groth16.tcc:70-115) on this rank's shard.
 
     *_local hold only this rank's limbs.  Returns the full proof [3][L][2][K][N_enc] (int64) on
     every rank."""
-    w = backend.witness(cs_local, assignment_local, want=("A_io", "A_mid", "B_io", "B_mid", "H"))
+    rng_ab = lambda s: plan.term_range(m, s)
+    rng_h = lambda s: plan.term_range(m + 1, s)
+    w = sharded_witness(backend, plan, term_group, cs_local, assignment_local, ("A_io", "A_mid", "B_io", "B_mid", "H"),
+                        {"A_io": rng_ab, "A_mid": rng_ab, "B_io": rng_ab, "B_mid": rng_ab, "H": rng_h})
     lead = plan.term_shard == 0  # exactly one shard per limb group adds alpha / beta
     ranges = groth16_key_ranges(plan, m, n_aux)
     lo, hi = ranges["s_pows"]
-    ab = backend.msm([pk_local["s_pows"][lo:hi]],
-                     [(w["A_io"][lo:hi], 0), (w["A_mid"][lo:hi], 0), (w["B_io"][lo:hi], 1), (w["B_mid"][lo:hi], 1)], 2,
-                     addends=[pk_local["alpha"], pk_local["beta"]] if lead else None)
+    ab, _ = backend.msm([key_slice(pk_local["s_pows"], lo, hi)], [(w["A_io"], None, 0), (w["A_mid"], None, 0), (w["B_io"], None, 1), (w["B_mid"], None, 1)], 2,
+                        addends=[pk_local["alpha"], pk_local["beta"]] if lead else None)
     lo, hi = ranges["delta_ts"]
-    c = backend.msm([pk_local["delta_ts"][lo:hi]], [(w["H"][lo:hi], 0)], 1)
+    c, _ = backend.msm([key_slice(pk_local["delta_ts"], lo, hi)], [(w["H"], None, 0)], 1)
+    ab, c = ab[0], c[0]
     if n_aux:
         lo, hi = ranges["delta_mid"]
         aux = assignment_local[n_inputs:]
-        c2 = backend.msm([pk_local["delta_mid"][lo:hi]], [(aux[lo:hi], 0)], 1)
-        c = backend.enc_add(c, c2)
+        c2, _ = backend.msm([key_slice(pk_local["delta_mid"], lo, hi)], [(aux[lo:hi], None, 0)], 1)
+        c = backend.enc_add(c, c2[0])
     piece = torch.cat([ab.reshape((2,) + tuple(ab.shape[-4:])), c.reshape((1,) + tuple(c.shape[-4:]))], dim=0).contiguous()
     if plan.term_shards > 1:
         dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=term_group)
         piece = backend.enc_reduce(piece)
-    if plan.world == 1:
-        return piece
-    # all-gather over every rank, then keep one copy per limb (shard 0 of each limb group)
-    pieces = [torch.empty_like(piece) for _ in range(plan.world)]
-    dist.all_gather(pieces, piece)
-    full = torch.empty((3, plan.L) + tuple(piece.shape[2:]), dtype=piece.dtype, device=piece.device)
-    for lg in range(plan.limb_groups):
-        limbs = [i for i in range(plan.L) if i % plan.limb_groups == lg]
-        full[:, limbs] = pieces[lg]  # rank lg is term shard 0 of limb group lg
-    return full
+    return _gather_limbs(plan, piece, 3)
+
+
+def rinocchio_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_local, assignment_local, m, n_inputs, n_aux,
+                            d1=None, d2=None, d3=None):
+    """rinocchio::prover (zk_proof_systems/rinocchio/rinocchio.tcc:75-190) on this rank's shard: the ten inner
+    products of :106-163 over this rank's term range in one grouped pass over both key vectors, F over its range
+    of beta_prods (:176-185), one all-reduce of the eleven partial sums, then the ZK shifts (:167-174, 181-183) on
+    the reduced sums.  d1,d2,d3: ring elements [L_local][N] or all None.  Returns (proof [9][L][2][K][N_enc],
+    empty[9]) on every rank."""
+    zk = d1 is not None
+    assert (d1 is None) == (d2 is None) == (d3 is None)
+    rng_mid = lambda s: (plan.term_range(m + 1, s)[0], min(plan.term_range(m + 1, s)[1], m))
+    rng_h = lambda s: plan.term_range(m + 1, s)
+    w = sharded_witness(backend, plan, term_group, cs_local, assignment_local, ("A_mid", "B_mid", "C_mid", "H"),
+                        {"A_mid": rng_mid, "B_mid": rng_mid, "C_mid": rng_mid, "H": rng_h}, (d1, d2, d3))
+    ranges = rinocchio_key_ranges(plan, m, n_aux)
+    lo, hi = ranges["s_pows"]
+    # coefficients_for_Z as ring elements (slot constant); its monic leading coefficient is the RingElem
+    # Scalar 1 (evaluation_domain.tcc:55-58), which passes the ciphertext through (seal_ring.tcc:525-527)
+    zrows = backend.broadcast_scalars(w["Z"][:, lo:hi])
+    zkinds = np.full(hi - lo, RS_KIND_POLY, dtype=np.uint8)
+    if hi == m + 1 and hi > lo:
+        zkinds[-1] = RS_KIND_ONE
+    mo, used = backend.msm([key_slice(pk_local["s_pows"], lo, hi), key_slice(pk_local["alpha_s_pows"], lo, hi)],
+                           [(w["A_mid"], None, 0), (w["B_mid"], None, 1), (w["C_mid"], None, 2), (w["H"], None, 3), (zrows, zkinds, 4)], 5,
+                           want_used=True)
+    enc_shape = tuple(mo.shape[-4:])
+    used_f = 0
+    if n_aux:
+        flo, fhi = ranges["beta_prods"]
+        f, uf = backend.msm([key_slice(pk_local["beta_prods"], flo, fhi)], [(assignment_local[n_inputs:][flo:fhi], None, 0)], 1, want_used=True)
+        f, used_f = f.reshape((1,) + enc_shape), uf[0]
+    else:
+        f = torch.zeros((1,) + enc_shape, dtype=mo.dtype, device=mo.device)
+    piece = torch.cat([mo.reshape((10,) + enc_shape), f], dim=0).contiguous()
+    counts = torch.tensor(list(used) + [used_f], dtype=torch.int64)
+    if plan.term_shards > 1:
+        dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=term_group)
+        piece = backend.enc_reduce(piece)
+        cnt = counts.to(piece.device) if dist.get_backend(term_group) != "gloo" else counts
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=term_group)
+        counts = cnt.cpu()
+    counts = [int(x) for x in counts]
+    slot = lambda c, g: piece[c * 5 + g]
+    elems, empty = [], []
+    for k in range(4):  # A, A', B, B', C, C', D, D'
+        for c in range(2):
+            elems.append(slot(c, k))
+            empty.append(counts[k] == 0)
+    elems.append(piece[10])
+    empty.append(counts[5] == 0)
+
+    def add_scaled(idx, enc, d):  # elems[idx] += d * enc   (RingT * EncT then +=, rinocchio.tcc:168-173, 181-183)
+        t = backend.enc_mul_ring(enc, d)
+        elems[idx] = t if empty[idx] else backend.enc_add(elems[idx], t)
+        empty[idx] = False
+
+    if zk:
+        for k, d in enumerate((d1, d2, d3)):
+            add_scaled(2 * k, slot(0, 4), d)
+            add_scaled(2 * k + 1, slot(1, 4), d)
+        if n_aux:
+            for d, name in ((d1, "beta_rv_ts"), (d2, "beta_rw_ts"), (d3, "beta_ry_ts")):
+                add_scaled(8, pk_local[name], d)
+    out = torch.stack([e.reshape(enc_shape) for e in elems]).contiguous()
+    return _gather_limbs(plan, out, 9), [int(e) for e in empty]
 
 
 class DeviceBackend:
@@ -120,19 +305,34 @@ class DeviceBackend:
 
     def __init__(self, dev):
         self.dev = dev
+        self.N = dev.N
 
-    def witness(self, dcs, assignment, want):
-        return self.dev.witness_map(dcs, assignment, want=want)
+    def witness(self, dcs, assignment, want, ds=(None, None, None)):
+        return self.dev.witness_map(dcs, assignment, *ds, want=want)
 
-    def msm(self, crs_list, vecs, n_groups, addends=None):
-        out, _ = self.dev.msm(crs_list, [(v.contiguous(), None, g) for v, g in vecs], n_groups)
-        out = out[0]
+    def witness_slots(self, dcs, assignment, slot0, nslots, want, ds=(None, None, None)):
+        return self.dev.witness_map_slots(dcs, assignment, slot0, nslots, *ds, want=want)
+
+    def msm(self, crs_list, vecs, n_groups, addends=None, want_used=False):
+        """crs_list: KeySlice per key vector (same length / window).  Returns ([n_crs][n_groups] encodings, used)."""
+        ks = crs_list[0]
+        assert all(k.length == ks.length and k.window == ks.window for k in crs_list)
+        out, used = self.dev.msm([k.tensor for k in crs_list], [(v.contiguous(), kinds, g) for v, kinds, g in vecs], n_groups,
+                                 want_used=want_used, crs_len=ks.length, window=ks.window)
         if addends is not None:
-            out = torch.stack([self.dev.enc_add(out[g], addends[g]) for g in range(n_groups)])
-        return out
+            out = torch.stack([torch.stack([self.dev.enc_add(out[c][g], addends[g]) for g in range(n_groups)]) for c in range(len(crs_list))])
+        return out, used
 
     def enc_add(self, a, b):
         return self.dev.enc_add(a.contiguous(), b.contiguous())
 
+    def enc_mul_ring(self, enc, ring):
+        return self.dev.enc_mul_ring(enc.contiguous(), ring.contiguous())
+
     def enc_reduce(self, piece):
         return self.dev.enc_reduce(piece)
+
+    def broadcast_scalars(self, z):
+        """[L][rows] host residues -> ring elements [rows][L][N] with the value in every slot."""
+        t = self.dev.put(np.ascontiguousarray(z.T))  # [rows][L]
+        return t.unsqueeze(-1).expand(t.shape[0], t.shape[1], self.N).contiguous()

@@ -22,6 +22,7 @@ from tests import helpers as H
 class OracleBackend:
     def __init__(self, ctx):
         self.ctx = ctx
+        self.N = ctx.N
 
     @staticmethod
     def _np(t):
@@ -31,41 +32,67 @@ class OracleBackend:
     def _t(a):
         return torch.from_numpy(np.ascontiguousarray(a).view(np.int64))
 
-    def witness(self, cs, assignment, want):
+    def witness_slots(self, cs, assignment, slot0, nslots, want, ds=(None, None, None)):
+        """The oracle's O(m^2) map on the slot range only (every slot is an independent problem)."""
         asg = self._np(assignment)
-        out = {k: np.zeros((cs.m + (1 if k == "H" else 0), self.ctx.L, self.ctx.N), dtype=np.uint64) for k in want}
+        out = {k: np.zeros((cs.m + (1 if k == "H" else 0), self.ctx.L, nslots), dtype=np.uint64) for k in want}
+        Z = np.zeros((self.ctx.L, cs.m + 1), dtype=np.uint64)
         ocs = H.oracle_cs(cs)
+        sl = slice(slot0, slot0 + nslots)
         for limb in range(self.ctx.L):
-            w = O.witness_map(self.ctx.q[limb], ocs, limb, np.ascontiguousarray(asg[:, limb, :]))
+            dl = [None if d is None else np.ascontiguousarray(self._np(d)[limb, sl]) for d in ds]
+            w = O.witness_map(self.ctx.q[limb], ocs, limb, np.ascontiguousarray(asg[:, limb, sl]), *dl)
             for k in want:
                 out[k][:, limb, :] = w[k]
-        return {k: self._t(v) for k, v in out.items()}
+            Z[limb] = w["Z"]
+        res = {k: self._t(v) for k, v in out.items()}
+        res["Z"] = Z
+        return res
 
-    def msm(self, crs_list, vecs, n_groups, addends=None):
-        crs = self._np(crs_list[0])
-        outs = []
-        for g in range(n_groups):
-            acc = np.zeros(self.ctx.enc_shape(), dtype=np.uint64)
-            for v, gg in vecs:
-                if gg != g or v.shape[0] == 0:
-                    continue
-                ip, used = self.ctx.inner_product(crs, self._np(v))
-                if used:
-                    acc = self.ctx.enc_add(acc, ip)
-            if addends is not None:
-                acc = self.ctx.enc_add(acc, self._np(addends[g]))
-            outs.append(acc)
-        return self._t(np.stack(outs))
+    def witness(self, cs, assignment, want, ds=(None, None, None)):
+        return self.witness_slots(cs, assignment, 0, self.ctx.N, want, ds)
+
+    def msm(self, crs_list, vecs, n_groups, addends=None, want_used=False):
+        outs, used = [], [0] * len(vecs)
+        for ci, ks in enumerate(crs_list):
+            crs = self._np(ks.tensor)
+            if ks.window:  # tiled key: logical term t is stored element t % window
+                crs = np.concatenate([crs] * (-(-ks.length // ks.window)))[:ks.length]
+            row = []
+            for g in range(n_groups):
+                acc = np.zeros(self.ctx.enc_shape(), dtype=np.uint64)
+                for vi, (v, kinds, gg) in enumerate(vecs):
+                    if gg != g or v.shape[0] == 0:
+                        continue
+                    ip, u = self.ctx.inner_product(crs[:v.shape[0]], self._np(v), kinds)
+                    if ci == 0:
+                        used[vi] = u
+                    if u:
+                        acc = self.ctx.enc_add(acc, ip)
+                if addends is not None:
+                    acc = self.ctx.enc_add(acc, self._np(addends[g]))
+                row.append(acc)
+            outs.append(np.stack(row))
+        return self._t(np.stack(outs)), used
 
     def enc_add(self, a, b):
-        return self._t(np.stack([self.ctx.enc_add(x, y) for x, y in zip(self._np(a).reshape((-1,) + self.ctx.enc_shape()),
-                                                                          self._np(b).reshape((-1,) + self.ctx.enc_shape()))]))
+        sh = a.shape
+        r = np.stack([self.ctx.enc_add(x, y) for x, y in zip(self._np(a).reshape((-1,) + self.ctx.enc_shape()),
+                                                             self._np(b).reshape((-1,) + self.ctx.enc_shape()))])
+        return self._t(r.reshape(sh))
+
+    def enc_mul_ring(self, enc, ring):
+        return self._t(self.ctx.enc_mul_ring(self._np(enc).reshape(self.ctx.enc_shape()).copy(), self._np(ring)))
 
     def enc_reduce(self, piece):
         a = self._np(piece).copy()
         for j, Q in enumerate(self.ctx.Q):
             a[..., j, :] %= np.uint64(Q)
         return self._t(a)
+
+    def broadcast_scalars(self, z):
+        z = np.ascontiguousarray(z.T)  # [rows][L]
+        return self._t(np.repeat(z[:, :, None], self.ctx.N, axis=2))
 
 
 def _free_port():
@@ -76,7 +103,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, preset, m, q_override, tmp):
+def _rinocchio_key(ctx, m, n_aux, zk):
+    return dict(s_pows=ctx.random_enc(81, m + 1), alpha_s_pows=ctx.random_enc(82, m + 1), beta_prods=ctx.random_enc(83, n_aux),
+                beta_rv_ts=ctx.random_enc(84), beta_rw_ts=ctx.random_enc(85), beta_ry_ts=ctx.random_enc(86))
+
+
+def _worker(rank, world, port, preset, m, q_override, tmp, prover="groth16", zk=False):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
         prm = P.preset(preset)
@@ -85,8 +117,12 @@ def _worker(rank, world, port, preset, m, q_override, tmp):
         ctx_full = H.oracle_ctx(prm)
         cs_full = R.wide_r1cs(m, prm.q)
         asg = H.make_assignment(ctx_full, cs_full)
-        pk = dict(s_pows=ctx_full.random_enc(71, m + 1), delta_ts=ctx_full.random_enc(72, m + 1),
-                  delta_mid=ctx_full.random_enc(73, cs_full.n_aux), alpha=ctx_full.random_enc(74), beta=ctx_full.random_enc(75))
+        if prover == "groth16":
+            pk = dict(s_pows=ctx_full.random_enc(71, m + 1), delta_ts=ctx_full.random_enc(72, m + 1),
+                      delta_mid=ctx_full.random_enc(73, cs_full.n_aux), alpha=ctx_full.random_enc(74), beta=ctx_full.random_enc(75))
+        else:
+            pk = _rinocchio_key(ctx_full, m, cs_full.n_aux, zk)
+        ds = [ctx_full.random_ring(60 + k) for k in range(3)] if zk else [None] * 3
         plan = RD.make_plan(world, rank, prm.L)
         tg = RD.groups_for(plan)
         prm_local = P.RingParams(prm.N, [prm.q[i] for i in plan.limbs], prm.N_enc, prm.Q)
@@ -95,26 +131,54 @@ def _worker(rank, world, port, preset, m, q_override, tmp):
         t = OracleBackend._t
         pk_local = {k: t(v[:, plan.limbs] if v.ndim == 5 else v[plan.limbs]) for k, v in pk.items()}
         asg_local = t(asg[:, plan.limbs])
-        got = RD.groth16_prove_sharded(backend, plan, tg, cs_local, pk_local, asg_local, m, cs_full.n_inputs, cs_full.n_aux)
+        if prover == "groth16":
+            got = RD.groth16_prove_sharded(backend, plan, tg, cs_local, pk_local, asg_local, m, cs_full.n_inputs, cs_full.n_aux)
+            exp, exp_empty, got_empty = O.groth16_prove(ctx_full, H.oracle_cs(cs_full), pk, asg)[0], None, None
+        else:
+            dl = [None if d is None else t(d[plan.limbs]) for d in ds]
+            got, got_empty = RD.rinocchio_prove_sharded(backend, plan, tg, cs_local, pk_local, asg_local, m, cs_full.n_inputs,
+                                                        cs_full.n_aux, *dl)
+            exp, exp_empty = O.rinocchio_prove(ctx_full, H.oracle_cs(cs_full), pk, asg, *ds)
         if rank == 0:
-            exp, _ = O.groth16_prove(ctx_full, H.oracle_cs(cs_full), pk, asg)
-            ok = bool((OracleBackend._np(got) == exp).all())
+            ok = bool((OracleBackend._np(got) == exp).all()) and got_empty == exp_empty
             open(tmp, "w").write("ok" if ok else "mismatch")
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("q_override,desc", [(None, "limb split: 2 limbs over 2 ranks"), (1, "term split: 1 limb, all-reduce of partial sums")])
+@pytest.mark.parametrize("q_override,desc", [(None, "limb split: 2 limbs over 2 ranks"),
+                                             (1, "one limb on 2 ranks: slot-sharded witness map, row exchange, term-sharded MSM, all-reduce")])
 def test_sharded_groth16_equals_single_process(tmp_path, q_override, desc):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(2, _free_port(), "toy", 7, q_override, out), nprocs=2, join=True)
     assert open(out).read() == "ok", desc
 
 
+@pytest.mark.parametrize("q_override,zk", [(None, False), (1, True), (1, False)])
+def test_sharded_rinocchio_equals_single_process(tmp_path, q_override, zk):
+    """rinocchio.tcc:75-190 sharded (BASELINE.json configs[3]): limb split, and slots / terms split inside a limb."""
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(2, _free_port(), "toy", 6, q_override, out, "rinocchio", zk), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_sharded_groth16_three_ranks_uneven_ranges(tmp_path):
+    """3 ranks on one limb: uneven slot blocks (N = 32 -> 12, 12, 8) and term ranges."""
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(3, _free_port(), "toy", 8, 1, out), nprocs=3, join=True)
+    assert open(out).read() == "ok"
+
+
 def test_shard_plans():
     for world, L, exp in [(1, 4, (1, 1)), (2, 4, (2, 1)), (4, 4, (4, 1)), (8, 4, (4, 2)), (8, 6, (2, 4)), (3, 4, (1, 3))]:
         plans = [RD.make_plan(world, r, L) for r in range(world)]
         assert (plans[0].limb_groups, plans[0].term_shards) == exp
+        # the slot blocks of a limb group tile [0, N), even aligned
+        for N in (32, 8192, 6):
+            blocks = [plans[0].slot_range(N, s) for s in range(plans[0].term_shards)]
+            assert blocks[0][0] == 0 and sum(b[1] for b in blocks) == N
+            assert all(b[0] % 2 == 0 and b[1] % 2 == 0 for b in blocks)
+            assert all(x[0] + x[1] == y[0] for x, y in zip(blocks, blocks[1:]) if y[1])
         # every (limb, term) cell is covered exactly once
         T = 37
         cover = np.zeros((L, T), dtype=int)
@@ -125,7 +189,7 @@ def test_shard_plans():
         assert (cover == 1).all()
 
 
-def _gpu_worker(rank, world, port, m, q_override, tmp):
+def _gpu_worker(rank, world, port, m, q_override, tmp, prover="groth16", zk=False):
     """Both ranks drive the REAL device backend on cuda:0 (gloo transports the collectives)."""
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
@@ -136,26 +200,37 @@ def _gpu_worker(rank, world, port, m, q_override, tmp):
         ctx_full = H.oracle_ctx(prm)
         cs_full = R.wide_r1cs(m, prm.q)
         asg = H.make_assignment(ctx_full, cs_full)
-        pk = dict(s_pows=ctx_full.random_enc(71, m + 1), delta_ts=ctx_full.random_enc(72, m + 1),
-                  delta_mid=ctx_full.random_enc(73, cs_full.n_aux), alpha=ctx_full.random_enc(74), beta=ctx_full.random_enc(75))
+        if prover == "groth16":
+            pk = dict(s_pows=ctx_full.random_enc(71, m + 1), delta_ts=ctx_full.random_enc(72, m + 1),
+                      delta_mid=ctx_full.random_enc(73, cs_full.n_aux), alpha=ctx_full.random_enc(74), beta=ctx_full.random_enc(75))
+        else:
+            pk = _rinocchio_key(ctx_full, m, cs_full.n_aux, zk)
+        ds = [ctx_full.random_ring(60 + k) for k in range(3)] if zk else [None] * 3
         plan = RD.make_plan(world, rank, prm.L)
         tg = RD.groups_for(plan)
         prm_local = P.RingParams(prm.N, [prm.q[i] for i in plan.limbs], prm.N_enc, prm.Q)
         dev = Device(prm_local, 0)
         dcs = dev.r1cs(R.wide_r1cs(m, prm_local.q))
         pk_local = {}
-        ranges = RD.groth16_key_ranges(plan, m, cs_full.n_aux)
+        ranges = (RD.groth16_key_ranges if prover == "groth16" else RD.rinocchio_key_ranges)(plan, m, cs_full.n_aux)
         for k, v in pk.items():
             if v.ndim == 5:  # key vector: keep only this rank's limbs AND the term window it reads
                 lo, hi = ranges[k]
-                pk_local[k] = RD.TermWindow(dev.put(np.ascontiguousarray(v[lo:hi][:, plan.limbs])), lo, hi, v.shape[0])
+                pk_local[k] = RD.TiledKey(dev.put(np.ascontiguousarray(v[lo:max(hi, lo + 1)][:, plan.limbs])), lo, hi, v.shape[0])
             else:
                 pk_local[k] = dev.put(np.ascontiguousarray(v[plan.limbs]))
-        got = RD.groth16_prove_sharded(RD.DeviceBackend(dev), plan, tg, dcs, pk_local, dev.put(np.ascontiguousarray(asg[:, plan.limbs])),
-                                       m, cs_full.n_inputs, cs_full.n_aux)
+        dasg = dev.put(np.ascontiguousarray(asg[:, plan.limbs]))
+        if prover == "groth16":
+            got = RD.groth16_prove_sharded(RD.DeviceBackend(dev), plan, tg, dcs, pk_local, dasg, m, cs_full.n_inputs, cs_full.n_aux)
+            exp, exp_empty, got_empty = O.groth16_prove(ctx_full, H.oracle_cs(cs_full), pk, asg)[0], None, None
+        else:
+            dl = [None if d is None else dev.put(np.ascontiguousarray(d[plan.limbs])) for d in ds]
+            got, got_empty = RD.rinocchio_prove_sharded(RD.DeviceBackend(dev), plan, tg, dcs, pk_local, dasg, m, cs_full.n_inputs,
+                                                        cs_full.n_aux, *dl)
+            exp, exp_empty = O.rinocchio_prove(ctx_full, H.oracle_cs(cs_full), pk, asg, *ds)
         if rank == 0:
-            exp, _ = O.groth16_prove(ctx_full, H.oracle_cs(cs_full), pk, asg)
-            open(tmp, "w").write("ok" if bool((to_host(got) == exp).all()) else "mismatch")
+            ok = bool((to_host(got) == exp).all()) and got_empty == exp_empty
+            open(tmp, "w").write("ok" if ok else "mismatch")
     finally:
         dist.destroy_process_group()
 
@@ -165,6 +240,16 @@ def _gpu_worker(rank, world, port, m, q_override, tmp):
 def test_sharded_groth16_on_device_backend(tmp_path, q_override, m):
     out = str(tmp_path / "result.txt")
     mp.spawn(_gpu_worker, args=(2, _free_port(), m, q_override, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q_override,m,zk", [(None, 7, True), (1, 8, True), (1, 9, False)])
+def test_sharded_rinocchio_on_device_backend(tmp_path, q_override, m, zk):
+    """The sharded Rinocchio prover (limb split; slot-sharded witness map + row exchange + term-sharded MSM) with
+    both ranks on the real device backend, against the single-process oracle."""
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_gpu_worker, args=(2, _free_port(), m, q_override, out, "rinocchio", zk), nprocs=2, join=True)
     assert open(out).read() == "ok"
 
 
@@ -181,8 +266,8 @@ def test_key_windows_cover_every_slice_the_sharded_prover_takes():
                 rg = RD.groth16_key_ranges(plan, m, n_aux)
                 T = {"s_pows": m + 1, "delta_ts": m + 1, "delta_mid": n_aux}
                 for k, (lo, hi) in rg.items():
-                    w = RD.TermWindow(list(range(lo, hi)), lo, hi, T[k])
-                    assert w[lo:hi] == list(range(lo, hi))  # the slice the prover takes is inside the window
+                    w = RD.TiledKey(list(range(lo, max(hi, lo + 1))), lo, hi, T[k])
+                    assert list(w[lo:hi].tensor) == list(range(lo, hi))  # the slice the prover takes is inside the window
                     if plan.limb_group == 0:
                         covered[k].append((lo, hi))
             # the term shards of one limb group tile [0, used) without gaps or overlaps

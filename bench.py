@@ -74,131 +74,9 @@ def kernel_roofline(k, pmc):
     return out
 
 
-# ---------------------------------------------------------------------------------------------------
-# post-run check (untimed): the proof that was timed against the CPU oracle
-# ---------------------------------------------------------------------------------------------------
-def check_columns(prm, cs, asg_cols, w_cols, cols, rng):
-    """Property checks of the device witness map on single (limb, slot) columns, at random points r:
-         A_io(r) + A_mid(r) = sum_j a_j L_j(r)   (the interpolant of the constraint evaluations; same for B)
-         A_io(r)            = sum_j a^io_j L_j(r) (primary inputs only, r1cs_to_qrp.tcc:189-208)
-         A(r) B(r) - C(r)   = H(r) Z(r)           (r1cs_to_qrp.tcc:242-253; the assignment satisfies the system)
-       with L_j(r) = Z(r) / ((r - j) w_j), w_j = (-1)^(m-1-j) j! (m-1-j)!  -- O(m) integer arithmetic per point."""
-    m = cs.m
-    for (limb, slot) in cols:
-        q = int(prm.q[limb])
-        x = [int(v) for v in asg_cols[(limb, slot)]]  # assignment of this column, n_vars entries
-        fact = [1] * m
-        for j in range(1, m):
-            fact[j] = fact[j - 1] * j % q
-
-        def evals(name, mode):
-            rp, col, cf = cs.mats[name]
-            out = [0] * m
-            for i in range(m):
-                acc = 0
-                for e in range(int(rp[i]), int(rp[i + 1])):
-                    c = int(col[e])
-                    if c == 0:
-                        acc += int(cf[limb, e])
-                    elif mode == "full" or (c - 1) < cs.n_inputs:
-                        acc += int(cf[limb, e]) * x[c - 1]
-                out[i] = acc % q
-            return out
-
-        ya, yb, yc = evals("a", "full"), evals("b", "full"), evals("c", "full")
-        ya_io = evals("a", "io")
-        for _ in range(2):
-            r = int(rng.randint(m, 2**31)) * 65537 % q
-            if r < m:
-                r += m
-            # prefix / suffix products of (r - j): Z(r) and every prod_{i != j}(r - i) without inversions
-            pre = [1] * (m + 1)
-            for j in range(m):
-                pre[j + 1] = pre[j] * (r - j) % q
-            suf = [1] * (m + 1)
-            for j in range(m - 1, -1, -1):
-                suf[j] = suf[j + 1] * (r - j) % q
-            Zr = pre[m]
-            inv_w = [pow(fact[j] * fact[m - 1 - j] % q, q - 2, q) for j in range(m)]
-
-            def lagr(y):
-                acc = 0
-                for j in range(m):
-                    t = y[j] * pre[j] % q * suf[j + 1] % q * inv_w[j]
-                    acc += -t if (m - 1 - j) & 1 else t
-                return acc % q
-
-            def horner(coeffs):
-                acc = 0
-                for c in reversed(coeffs):
-                    acc = (acc * r + int(c)) % q
-                return acc
-
-            g = w_cols[(limb, slot)]
-            A, B = (horner(g["A_io"]) + horner(g["A_mid"])) % q, (horner(g["B_io"]) + horner(g["B_mid"])) % q
-            if A != lagr(ya) or B != lagr(yb):
-                return "interpolant mismatch at limb %d slot %d" % (limb, slot)
-            if horner(g["A_io"]) != lagr(ya_io):
-                return "io interpolant mismatch at limb %d slot %d" % (limb, slot)
-            if (A * B - lagr(yc)) % q != horner(g["H"]) * Zr % q:
-                return "H(r) Z(r) != A(r) B(r) - C(r) at limb %d slot %d" % (limb, slot)
-    return None
-
-
-def post_run_check(dev, prm, cs, dcs, asg, pk, proof, m, W, seed=5):
-    """(1) >= 4 witness-map columns by the identities above; (2) two full (limb, component, prime) slabs of the
-    proof -- one of A, one of C -- recomputed by the CPU oracle from the device's coefficient vectors and the
-    key window.  Returns (ok, info)."""
-    from ringsnark_amd.device import to_host
-    from tests import helpers as H
-
-    t_start = time.perf_counter()
-    octx = H.oracle_ctx(prm)
-    rng = np.random.RandomState(seed)
-    slabs = [("A", int(rng.randint(prm.L)), int(rng.randint(2)), int(rng.randint(prm.K))),
-             ("C", int(rng.randint(prm.L)), int(rng.randint(2)), int(rng.randint(prm.K)))]
-    # what the check needs from the key and the proof, before the key is released
-    key = {}
-    for elem, l, c, j in slabs:
-        names = ("s_pows", "alpha") if elem == "A" else ("delta_ts", "delta_mid")
-        for nme in names:
-            t = pk[nme]
-            key[(nme, l, c, j)] = to_host(t[..., l, c, j, :].contiguous()).reshape(-1, prm.N_enc)
-    proof_h = {(e, l, c, j): to_host(proof[{"A": 0, "B": 1, "C": 2}[e], l, c, j].contiguous()) for e, l, c, j in slabs}
-    for k in list(pk.keys()):
-        del pk[k]
-    torch.cuda.empty_cache()
-    # the prover's own witness map, re-run through the same chunking (deterministic: identical vectors)
-    w = dev.witness_map(dcs, asg, want=("A_io", "A_mid", "B_io", "B_mid", "H"))
-    torch.cuda.synchronize()
-    cols = [(int(rng.randint(prm.L)), int(rng.randint(prm.N))) for _ in range(4)] + [(0, 0), (prm.L - 1, prm.N - 1)]
-    asg_cols = {c: to_host(asg[:, c[0], c[1]].contiguous()) for c in cols}
-    w_cols = {c: {k: to_host(w[k][:, c[0], c[1]].contiguous()) for k in ("A_io", "A_mid", "B_io", "B_mid", "H")} for c in cols}
-    err = check_columns(prm, cs, asg_cols, w_cols, cols, rng)
-    if err:
-        return False, {"error": err}
-    t_cols = time.perf_counter() - t_start
-
-    def slab_sum(acc, key_slab, vec, limb, j, T):
-        step = 4096
-        for t0 in range(0, T, step):
-            rows = to_host(vec[t0:min(T, t0 + step), limb, :].contiguous())
-            octx.inner_product_slab(limb, j, key_slab, rows, acc, t0=t0, window=key_slab.shape[0], threads=0)
-
-    for elem, l, c, j in slabs:
-        acc = np.zeros(prm.N_enc, dtype=np.uint64)
-        if elem == "A":  # groth16.tcc:89-95
-            slab_sum(acc, key[("s_pows", l, c, j)], w["A_io"], l, j, m)
-            slab_sum(acc, key[("s_pows", l, c, j)], w["A_mid"], l, j, m)
-            acc = (acc + key[("alpha", l, c, j)][0]) % np.uint64(prm.Q[j])
-        else:  # groth16.tcc:105-112
-            slab_sum(acc, key[("delta_ts", l, c, j)], w["H"], l, j, m + 1)
-            slab_sum(acc, key[("delta_mid", l, c, j)], asg[cs.n_inputs:], l, j, cs.n_aux)
-        if not (acc == proof_h[(elem, l, c, j)]).all():
-            return False, {"error": "proof element %s slab (limb %d, component %d, prime %d) differs from the CPU oracle" % (elem, l, c, j)}
-    return True, {"columns": len(cols), "points_per_column": 2,
-                  "slabs": ["%s[limb %d][comp %d][prime %d]" % s for s in slabs],
-                  "seconds": round(time.perf_counter() - t_start, 1), "columns_seconds": round(t_cols, 1)}
+# post-run check (untimed): tests/proof_check.py -- witness-map identities on sampled columns and full proof
+# slabs recomputed by the CPU oracle
+from tests.proof_check import groth16_check as post_run_check  # noqa: E402
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -774,6 +774,8 @@ int rs_set_tuning(const char *key, int value) {
 #endif
   else if (std::string(key) == "mac_variant")
     g_mac_variant = value;
+  else if (std::string(key) == "witness_sub_ct")
+    g_witness_sub_ct = value;
   else if (std::string(key) == "witness_tree_ct")
     g_witness_tree_ct = value;
   else if (std::string(key) == "witness_col_budget_mib") {

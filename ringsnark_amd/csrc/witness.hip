@@ -1318,6 +1318,72 @@ sub_ntt_kernel(double *__restrict__ X, int logB, int log_n1, TabPtrs tabs, unsig
   for (int i = threadIdx.x; i < Bn; i += blockDim.x) x[i] = s[pidx(i)];
 }
 
+// Last forward round of a fused sub-transform: spectrum times a table that is itself a lazily reduced
+// spectrum (MODE 3: the other workspace).
+struct SubMulLazyOut {
+  double *sb;
+  const double *dh;
+  Mod mod;
+  __device__ __forceinline__ int pbase(int base) const { return pidx(base); }
+  __device__ __forceinline__ void store(int base, int pb, int eoff, int poff, double v) const {
+    sb[pcomb(pb, poff)] = mulmod(reduce(v, mod), reduce(dh[base + eoff], mod), mod);
+  }
+};
+struct SubMulLazyFactory {
+  double *s;
+  const double *dh_tile;
+  Mod mod;
+  __device__ __forceinline__ SubMulLazyOut operator()(int off) const { return SubMulLazyOut{s + pidx(off), dh_tile + off, mod}; }
+};
+
+#ifndef RS_SUB_MAXR
+#define RS_SUB_MAXR 4  // radix of the wave-private rounds of sub_ntt_ct_kernel
+#endif
+// sub_ntt_kernel for the production tile (Bn = 2^LOGB, compile time; 512 threads, two workgroups per CU):
+//   * the cross-wave round of the forward transform reads the block straight from global memory and the
+//     cross-wave round of the inverse writes it straight back (no staging pass, no extra barriers);
+//   * the table product rides the last forward round's store (no separate pointwise pass);
+//   * forward-only blocks (MODE 0) are stored by the wave that finished them.
+// Same arithmetic and operation order per coefficient as sub_ntt_kernel: results are identical.
+template <int MODE, int LOGB>
+__global__ void __launch_bounds__(512, 4)
+sub_ntt_ct_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab_period, unsigned blocks_per_col, size_t col0,
+                  unsigned S, unsigned slots_per_limb, ColPlans plans) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  constexpr int LOGW = 3, Bn = 1 << LOGB;
+  const size_t blk = blockIdx.x;
+  const size_t col = blk / blocks_per_col;
+  const int limb = (int)(((col0 + col) % S) / slots_per_limb);
+  const ColPlan &P = plans.l[limb];
+  const Mod mod = P.mod;
+  const int root = (1 << log_n1) + (int)(blk & ((1u << log_n1) - 1));
+  const int logn = LOGB + log_n1;
+  double *x = X + blk * (size_t)Bn;
+  const GlobalF64IO gio{x};
+  const ColBlockFactory bf{s};
+  const uint32_t fmask = P.fmask[logn] >> log_n1, imask = P.imask[logn];
+  if (MODE == 0) {
+    lds_ntt_fwd_wp<RS_SUB_MAXR, GlobalF64IO, ColBlockFactory, 3>(s, gio, bf, LOGB, LOGW, P.tw, mod, fmask, root);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int BS = Bn >> LOGW;
+    const int off = wave * BS;
+    const double *sb = s + pidx(off);
+    const int p0 = pidx(lane);
+#pragma unroll
+    for (int j = 0; j < BS / 64; j++) x[off + lane + 64 * j] = sb[own_pidx(p0, lane, j)];
+    return;
+  }
+  if (MODE == 2) {
+    const double *tab = tabs.t[limb] + (size_t)(blk % tab_period) * Bn;
+    lds_ntt_fwd_wp<RS_SUB_MAXR, GlobalF64IO, TreeMulFactory, 3>(s, gio, TreeMulFactory{s, tab, mod}, LOGB, LOGW, P.tw, mod, fmask, root);
+  } else {
+    const double *tab = tabs.t[0] + blk * (size_t)Bn;
+    lds_ntt_fwd_wp<RS_SUB_MAXR, GlobalF64IO, SubMulLazyFactory, 3>(s, gio, SubMulLazyFactory{s, tab, mod}, LOGB, LOGW, P.tw, mod, fmask, root);
+  }
+  lds_ntt_inv_wp<RS_SUB_MAXR, ColBlockFactory, GlobalF64IO, 3>(s, bf, gio, LOGB, LOGW, P.itw, mod, imask, root);
+}
+
 // ZK patch of the multi-pass H: H += d2*A + d1*B + d1*d2*Z, H[0] -= d3; then canonical form.
 __global__ void __launch_bounds__(256)
 h_patch_kernel(double *__restrict__ H, const double *__restrict__ A, const double *__restrict__ B, int logM, int m, size_t cols,
@@ -1371,6 +1437,7 @@ static int col_threads(size_t M) { return (int)std::max<size_t>(64, std::min<siz
 
 int g_witness_lds_logM = 13;  // columns up to 2^13 run entirely inside one LDS tile
 int g_witness_tree_ct = 1;    // 1: level-unrolled product-tree kernel for 2^13 tiles
+int g_witness_sub_ct = 1;     // 1: compile-time-length sub-transform kernel for 2^13 blocks of the multi-pass path
 
 // Newton -> monomial levels 1..logT on tiles of 2^logT coefficients of [ncols][M] columns; with
 // `newton` (logT == logM) the tiles hold values and the Newton conversion runs first, in the same launch
@@ -1477,6 +1544,13 @@ static void launch_sub(rs_ctx *ctx, double *X, size_t ncols, size_t col0, int lo
                  blocks * ((MODE >= 2 ? 2.0 : 1.0) * ntt_fp64(Bn, logB) + (MODE >= 2 ? 7.0 * Bn : 0.0)));
   static TabPtrs none{};
   const TabPtrs &tp = tabs ? *tabs : none;
+  if (logB == 13 && MODE != 1 && g_witness_sub_ct) {
+    RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_ct_kernel<MODE, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((sub_ntt_ct_kernel<MODE, 13>), dim3((unsigned)(ncols * bpc)), dim3(512), lds, st, X, logsub - logB, tp,
+                       (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp);
+    RS_HIP(hipGetLastError());
+    return;
+  }
   RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, ((size_t)1 << logB) / 16));
   hipLaunchKernelGGL(sub_ntt_kernel<MODE>, dim3((unsigned)(ncols * bpc)), dim3(thr), lds, st, X, logB, logsub - logB, tp,

@@ -1,0 +1,195 @@
+"""Checks of a device proof at sizes where the oracle's O(m^2) witness map cannot be run in full
+(test infrastructure; used by the -m gpu tests at configuration scale and by bench.py's untimed post-run check).
+
+Two parts, both against the CPU oracle / exact integer arithmetic:
+  1. the device witness map on sampled (limb, slot) columns, through polynomial identities at random points
+     (O(m) integer operations per column and point);
+  2. full (limb, component, prime) slabs of proof elements, recomputed by the oracle (OpenMP over terms) from the
+     device's coefficient vectors and the proving key.
+"""
+import time
+
+import numpy as np
+
+
+def _column_identities(q, m, cs, limb, x, g, ds, rng, points=2, rinocchio=False):
+    """One column.  x: assignment [n_vars]; g: dict of device coefficient vectors of this column; ds = (d1, d2, d3)
+    slot values (0 without ZK).  Identities, at random r with L_j(r) = prod_{i != j}(r - i) / w_j,
+    w_j = (-1)^(m-1-j) j! (m-1-j)!:
+         X_io(r) + X_mid(r) = sum_j (x_j + const_j) L_j(r)   the reference counts index-0 terms in both passes
+                                                              (r1cs_to_qrp.tcc:175-201)
+         X_io(r)            = sum_j x^io_j L_j(r)
+         H(r) Z(r)          = A(r) B(r) - C(r) + Z(r) (d2 A(r) + d1 B(r) - d3 + d1 d2 Z(r))   (r1cs_to_qrp.tcc:230-253)
+    with A, B, C the interpolants of the full evaluations (the assignment satisfies the system)."""
+    fact = [1] * m
+    for j in range(1, m):
+        fact[j] = fact[j - 1] * j % q
+    inv_w = [pow(fact[j] * fact[m - 1 - j] % q, q - 2, q) for j in range(m)]
+
+    def evals(name, mode):
+        rp, col, cf = cs.mats[name]
+        out = [0] * m
+        for i in range(m):
+            acc = 0
+            for e in range(int(rp[i]), int(rp[i + 1])):
+                c = int(col[e])
+                if c == 0:
+                    if mode != "vars":
+                        acc += int(cf[limb, e])
+                elif mode == "const":
+                    continue
+                elif mode in ("full", "vars") or (c - 1) < cs.n_inputs:
+                    acc += int(cf[limb, e]) * x[c - 1]
+            out[i] = acc % q
+        return out
+
+    y = {n: evals(n, "full") for n in "abc"}
+    y_io = {n: evals(n, "io") for n in "abc"}
+    y_const = {n: evals(n, "const") for n in "abc"}
+    d1, d2, d3 = ds
+    for _ in range(points):
+        r = (int(rng.randint(m, 2**31)) * 65537 + 12345) % q
+        if r < m:
+            r += m
+        pre = [1] * (m + 1)
+        for j in range(m):
+            pre[j + 1] = pre[j] * (r - j) % q
+        suf = [1] * (m + 1)
+        for j in range(m - 1, -1, -1):
+            suf[j] = suf[j + 1] * (r - j) % q
+        Zr = pre[m]
+
+        def lagr(yv):
+            acc = 0
+            for j in range(m):
+                t = yv[j] * pre[j] % q * suf[j + 1] % q * inv_w[j]
+                acc += -t if (m - 1 - j) & 1 else t
+            return acc % q
+
+        def horner(coeffs):
+            acc = 0
+            for c in reversed(coeffs):
+                acc = (acc * r + int(c)) % q
+            return acc
+
+        full = {n: lagr(y[n]) for n in "abc"}
+        for n, N_ in (("a", "A"), ("b", "B"), ("c", "C")):
+            io_r = lagr(y_io[n])
+            if N_ + "_io" in g and horner(g[N_ + "_io"]) != io_r:
+                return "%s_io interpolant mismatch" % N_
+            if N_ + "_mid" in g and horner(g[N_ + "_mid"]) != (full[n] + lagr(y_const[n]) - io_r) % q:
+                return "%s_mid interpolant mismatch" % N_
+        if "H" in g:
+            A, B, C = full["a"], full["b"], full["c"]
+            rhs = (A * B - C + Zr * (d2 * A + d1 * B - d3 + d1 * d2 * Zr)) % q
+            if horner(g["H"]) * Zr % q != rhs:
+                return "H(r) Z(r) identity fails"
+    return None
+
+
+def check_columns(prm, cs, asg, w, cols, rng, ds=(None, None, None)):
+    """asg: device assignment [n_vars][L][N]; w: dict of device coefficient vectors [rows][L][N]."""
+    from ringsnark_amd.device import to_host
+    for (limb, slot) in cols:
+        x = [int(v) for v in to_host(asg[:, limb, slot].contiguous())]
+        g = {k: to_host(v[:, limb, slot].contiguous()) for k, v in w.items() if k != "Z" and v is not None}
+        dv = tuple(0 if d is None else int(to_host(d[limb, slot].contiguous().reshape(1))[0]) for d in ds)
+        err = _column_identities(int(prm.q[limb]), cs.m, cs, limb, x, g, dv, rng)
+        if err:
+            return "%s at limb %d slot %d" % (err, limb, slot)
+    return None
+
+
+def slab_inner_product(octx, acc, key_slab, vec, limb, j, T, kinds=None, step=4096):
+    """acc += the (limb, ., j) slab of <key, vec[:T]> by the CPU oracle; key_slab [W][N_enc] (W < T: tiled key)."""
+    from ringsnark_amd.device import to_host
+    assert kinds is None
+    for t0 in range(0, T, step):
+        rows = to_host(vec[t0:min(T, t0 + step), limb, :].contiguous())
+        octx.inner_product_slab(limb, j, key_slab, rows, acc, t0=t0, window=key_slab.shape[0], threads=0)
+
+
+def key_slab(t, l, c, j, n_enc):
+    from ringsnark_amd.device import to_host
+    return to_host(t[..., l, c, j, :].contiguous()).reshape(-1, n_enc)
+
+
+def groth16_check(dev, prm, cs, dcs, asg, pk, proof, m, W=None, seed=5, n_cols=4):
+    """ringGroth16 proof (groth16.tcc:70-115) computed by the device for (cs, asg, pk): (1) witness-map identities
+    on n_cols random columns + the two corner columns; (2) two full (limb, component, prime) slabs -- one of A, one
+    of C -- against the CPU oracle.  pk: dict of device tensors; its entries are RELEASED (the caller must hold no
+    other reference when memory is tight).  Returns (ok, info)."""
+    import torch
+
+    from ringsnark_amd.device import to_host
+    from tests import helpers as H
+
+    t_start = time.perf_counter()
+    octx = H.oracle_ctx(prm)
+    rng = np.random.RandomState(seed)
+    slabs = [("A", int(rng.randint(prm.L)), int(rng.randint(2)), int(rng.randint(prm.K))),
+             ("C", int(rng.randint(prm.L)), int(rng.randint(2)), int(rng.randint(prm.K)))]
+    key = {}
+    for elem, l, c, j in slabs:
+        for nme in (("s_pows", "alpha") if elem == "A" else ("delta_ts", "delta_mid")):
+            key[(nme, l, c, j)] = key_slab(pk[nme], l, c, j, prm.N_enc)
+    proof_h = {(e, l, c, j): to_host(proof[{"A": 0, "B": 1, "C": 2}[e], l, c, j].contiguous()) for e, l, c, j in slabs}
+    for k in list(pk.keys()):
+        del pk[k]
+    torch.cuda.empty_cache()
+    # the prover's own witness map, re-run through the same chunking (deterministic: identical vectors)
+    w = dev.witness_map(dcs, asg, want=("A_io", "A_mid", "B_io", "B_mid", "H"))
+    torch.cuda.synchronize()
+    cols = [(int(rng.randint(prm.L)), int(rng.randint(prm.N))) for _ in range(n_cols)] + [(0, 0), (prm.L - 1, prm.N - 1)]
+    err = check_columns(prm, cs, asg, {k: w[k] for k in ("A_io", "A_mid", "B_io", "B_mid", "H")}, cols, rng)
+    if err:
+        return False, {"error": err}
+    t_cols = time.perf_counter() - t_start
+    for elem, l, c, j in slabs:
+        acc = np.zeros(prm.N_enc, dtype=np.uint64)
+        if elem == "A":  # groth16.tcc:89-95
+            slab_inner_product(octx, acc, key[("s_pows", l, c, j)], w["A_io"], l, j, m)
+            slab_inner_product(octx, acc, key[("s_pows", l, c, j)], w["A_mid"], l, j, m)
+            acc = (acc + key[("alpha", l, c, j)][0]) % np.uint64(prm.Q[j])
+        else:  # groth16.tcc:105-112
+            slab_inner_product(octx, acc, key[("delta_ts", l, c, j)], w["H"], l, j, m + 1)
+            slab_inner_product(octx, acc, key[("delta_mid", l, c, j)], asg[cs.n_inputs:], l, j, cs.n_aux)
+        if not (acc == proof_h[(elem, l, c, j)]).all():
+            return False, {"error": "proof element %s slab (limb %d, component %d, prime %d) differs from the CPU oracle" % (elem, l, c, j)}
+    return True, {"columns": len(cols), "points_per_column": 2,
+                  "slabs": ["%s[limb %d][comp %d][prime %d]" % s for s in slabs],
+                  "seconds": round(time.perf_counter() - t_start, 1), "columns_seconds": round(t_cols, 1)}
+
+
+def rinocchio_check(dev, prm, cs, dcs, asg, pk, proof, m, ds=(None, None, None), seed=6, n_cols=3):
+    """Rinocchio proof {A,A',B,B',C,C',D,D',F} (rinocchio.tcc:75-190): witness-map identities on sampled columns
+    (with the ZK patch when ds are given) and, without ZK shifts on them, the slabs D' = <alpha_s_pows, H> and
+    F = <beta_prods, aux> (non-ZK) or B = <s_pows, B_mid> against the CPU oracle."""
+    import torch
+
+    from ringsnark_amd.device import to_host
+    from tests import helpers as H
+
+    octx = H.oracle_ctx(prm)
+    rng = np.random.RandomState(seed)
+    zk = ds[0] is not None
+    w = dev.witness_map(dcs, asg, *ds, want=("A_mid", "B_mid", "C_mid", "H"))
+    torch.cuda.synchronize()
+    cols = [(int(rng.randint(prm.L)), int(rng.randint(prm.N))) for _ in range(n_cols)] + [(prm.L - 1, prm.N - 1)]
+    err = check_columns(prm, cs, asg, {k: w[k] for k in ("A_mid", "B_mid", "C_mid", "H")}, cols, rng, ds)
+    if err:
+        return False, {"error": err}
+    # D' (index 7) carries no ZK shift (rinocchio.tcc:167-174 shifts A..C' only); F (index 8) only without ZK
+    checks = [(7, "alpha_s_pows", "H", m + 1)]
+    if not zk and cs.n_aux:
+        checks.append((8, "beta_prods", "aux", cs.n_aux))
+    done = []
+    for idx, kname, vname, T in checks:
+        l, c, j = int(rng.randint(prm.L)), int(rng.randint(2)), int(rng.randint(prm.K))
+        acc = np.zeros(prm.N_enc, dtype=np.uint64)
+        vec = asg[cs.n_inputs:] if vname == "aux" else w[vname]
+        slab_inner_product(octx, acc, key_slab(pk[kname], l, c, j, prm.N_enc), vec, l, j, T)
+        if not (acc == to_host(proof[idx, l, c, j].contiguous())).all():
+            return False, {"error": "proof element %d slab (limb %d, component %d, prime %d) differs from the CPU oracle" % (idx, l, c, j)}
+        done.append("elem%d[limb %d][comp %d][prime %d]" % (idx, l, c, j))
+    return True, {"columns": len(cols), "slabs": done}

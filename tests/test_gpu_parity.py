@@ -520,3 +520,46 @@ def test_msm_with_a_tiled_key_equals_the_explicit_key():
     got, _ = dev.groth16_prove(dcs, pkw, asg, window=W)
     exp, _ = dev.groth16_prove(dcs, pkx, asg)
     assert (host(got) == host(exp)).all()
+
+
+@pytest.mark.parametrize("m,zk", [(20000, True), (40000, False)])
+def test_multipass_tuned_sub_transform_kernel_equals_generic(m, zk):
+    """M >= 2^15: the multi-pass path runs its 2^13-point sub-transforms through sub_ntt_ct_kernel (direct global
+    I/O, table product fused into the last forward round); it must reproduce the generic kernel bit for bit."""
+    dev = dev_for("toy44")
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    cs = R.chain_r1cs(m, prm.q)
+    asg = dev.ring_empty(m + 2)
+    dev.fill_uniform(asg[:2], 0, 9)
+    dev.chain_assignment(asg, m)
+    ds = [dev.put(ctx.random_ring(60 + k)) for k in range(3)] if zk else [None] * 3
+    dcs = dev.r1cs(cs)
+    keys = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
+    tuned = {k: host(v) for k, v in dev.witness_map(dcs, asg, *ds).items() if k in keys}
+    _set_tuning(b"witness_sub_ct", 0)
+    try:
+        generic = {k: host(v) for k, v in dev.witness_map(dcs, asg, *ds).items() if k in keys}
+    finally:
+        _set_tuning(b"witness_sub_ct", 1)
+    for k in keys:
+        assert (tuned[k] == generic[k]).all(), k
+
+
+def test_multipass_production_tile_matches_oracle_on_a_few_slots():
+    """The multi-pass path at its production tile (2^13) against the oracle's O(m^2) map: m = 16400 (M = 2^15), four
+    slots per limb (rs_witness_map_slots), oracle spread over the host cores."""
+    dev = dev_for("toy44")
+    prm = dev.prm
+    m, slot0, ns = 16400, 10, 4
+    cs = R.chain_r1cs(m, prm.q)
+    asg = dev.ring_empty(m + 2)
+    dev.fill_uniform(asg[:2], 0, 11)
+    dev.chain_assignment(asg, m)
+    w = dev.witness_map_slots(dev.r1cs(cs), asg, slot0, ns, want=("A_io", "A_mid", "B_mid", "H"))
+    a = host(asg)
+    ocs = H.oracle_cs(cs)
+    for limb in range(prm.L):
+        exp = O.witness_map(prm.q[limb], ocs, limb, np.ascontiguousarray(a[:, limb, slot0:slot0 + ns]), threads=0)
+        for k in ("A_io", "A_mid", "B_mid", "H"):
+            assert (host(w[k])[:, limb, :] == exp[k]).all(), (k, limb)

@@ -16,7 +16,7 @@
  *   vectors           [count][...]      element-major ("term-major")
  *
  * All functions return RS_OK (0) or an error code; rs_last_error() gives the message
- * (thread-local).  Entry points are re-entrant with respect to a shared rs_ctx (the reference
+ * (thread-local).  Entry points are re-entrant with respect to a shared context (the reference
  * calls inner_product from 10 OpenMP sections, rinocchio.tcc:106-163): enqueueing is serialised by a
  * mutex, and the context's workspace buffers carry an event of their last use, which a call on
  * ANOTHER stream waits for on the device -- callers need neither distinct streams nor host

@@ -14,11 +14,17 @@
 #ifndef RINGSNARK_AMD_RING_HPP
 #define RINGSNARK_AMD_RING_HPP
 
+#include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <functional>
+#include <iostream>
 #include <memory>
+#include <ostream>
+#include <random>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -53,6 +59,13 @@ class Context {
     if (!ctx()) throw std::invalid_argument("context not set");
     return params();
   }
+  // Host PRNG behind RingElem::random_* and EncodingElem::keygen / encode (the reference draws from SEAL's
+  // process-global generator, seal_ring.hpp:27,92-95).  Seeded from std::random_device unless seed_prng is called.
+  static std::mt19937_64 &prng() {
+    static std::mt19937_64 g{std::random_device{}()};
+    return g;
+  }
+  static void seed_prng(uint64_t seed) { prng().seed(seed); }
   static size_t ring_words() { return (size_t)get_params().L * get_params().N; }
   static size_t enc_words() { return (size_t)get_params().L * 2 * get_params().K * get_params().N_enc; }
 
@@ -80,6 +93,15 @@ class DeviceWords {
   DeviceWords(const DeviceWords &) = delete;
   DeviceWords &operator=(const DeviceWords &) = delete;
   DeviceWords(DeviceWords &&o) noexcept : p_(o.p_), words_(o.words_) { o.p_ = nullptr; }
+  DeviceWords &operator=(DeviceWords &&o) noexcept {
+    if (this != &o) {
+      if (p_) rs_free(Context::get_context(), p_);
+      p_ = o.p_;
+      words_ = o.words_;
+      o.p_ = nullptr;
+    }
+    return *this;
+  }
   ~DeviceWords() {
     if (p_) rs_free(Context::get_context(), p_);
   }
@@ -102,6 +124,53 @@ class RingElem {
   }
   static RingElem one() { return RingElem(1); }
   static RingElem zero() { return RingElem(0); }
+
+  // seal_ring.hpp:72-88: a Scalar uniform below the first ring prime and above the domain size, so that its
+  // differences with the nodes 0..m-1 are units.  Domain: anything with a member `m` (evaluation_domain<RingT>).
+  template <class Domain>
+  static RingElem random_exceptional_element(const std::shared_ptr<Domain> &domain) {
+    const uint64_t q1 = Context::get_params().q[0];
+    const uint64_t lo = domain ? (uint64_t)domain->m : 0;
+    if (lo + 1 >= q1) throw std::invalid_argument("not enough exceptional elements");
+    std::uniform_int_distribution<uint64_t> d(domain ? lo + 1 : 0, q1 - 1);
+    return RingElem(d(Context::prng()));
+  }
+  static RingElem random_exceptional_element(std::nullptr_t = nullptr) {  // no domain: any scalar below q_1
+    struct NoDomain {
+      size_t m = 0;
+    };
+    return random_exceptional_element(std::shared_ptr<NoDomain>());
+  }
+  // seal_ring.hpp:90-101: uniform residues in every slot of every limb
+  static RingElem random_element() {
+    const Params &p = Context::get_params();
+    std::vector<uint64_t> w(Context::ring_words());
+    for (int i = 0; i < p.L; i++) {
+      std::uniform_int_distribution<uint64_t> d(0, p.q[i] - 1);
+      for (int x = 0; x < p.N; x++) w[(size_t)i * p.N + x] = d(Context::prng());
+    }
+    return RingElem(std::move(w));
+  }
+  static RingElem random_invertible_element() {  // seal_ring.hpp:103-109
+    RingElem res;
+    do {
+      res = random_element();
+    } while (!res.is_invertible());
+    return res;
+  }
+  static RingElem random_nonzero_element() {  // seal_ring.hpp:111-117
+    RingElem res;
+    do {
+      res = random_element();
+    } while (res.is_zero());
+    return res;
+  }
+  size_t hash() const {  // seal_ring.hpp:170, used by std::hash below
+    if (!is_poly_) return std::hash<uint64_t>()(scalar_);
+    size_t h = 0xcbf29ce484222325ull;
+    for (uint64_t v : poly_) h = (h ^ (size_t)v) * 0x100000001b3ull;
+    return h;
+  }
 
   bool is_poly() const { return is_poly_; }
   bool is_scalar() const { return !is_poly_; }
@@ -213,6 +282,17 @@ inline RingElem operator+(RingElem a, const RingElem &b) { return a += b; }
 inline RingElem operator-(RingElem a, const RingElem &b) { return a -= b; }
 inline RingElem operator*(RingElem a, const RingElem &b) { return a *= b; }
 inline RingElem operator/(RingElem a, const RingElem &b) { return a /= b; }
+// seal_ring.tcc:279-303: a scalar prints as its value, a polynomial limb by limb
+inline std::ostream &operator<<(std::ostream &out, const RingElem &e) {
+  if (e.is_scalar()) return out << e.get_scalar();
+  const Params &p = Context::get_params();
+  for (int i = 0; i < p.L; i++) {
+    out << (i ? "; [" : "[");
+    for (int x = 0; x < p.N; x++) out << (x ? " " : "") << e.get_poly()[(size_t)i * p.N + x];
+    out << "]";
+  }
+  return out;
+}
 
 class EncodingElem {
  public:
@@ -254,7 +334,36 @@ class EncodingElem {
   // EncodingElem::encode(sk, rs) (seal_ring.tcc:324-359) and ::decode(sk, e) (seal_ring.tcc:435-477).
   // SecretKey here is the [K][N_enc] NTT-form key words; `seed` replaces SEAL's process-global PRNG.
   using SecretKey = std::vector<uint64_t>;
-  static std::vector<EncodingElem> encode(const SecretKey &sk, const std::vector<RingElem> &rs, uint64_t seed = 1) {
+  using PublicKey = std::nullptr_t;  // seal_ring.hpp:230-231: affine combinations need no public key material
+  // seal_ring.hpp:254-264: one secret key per encoding context.  All L contexts here share N_enc and the data
+  // primes Q_j, so ONE ternary secret in NTT form [K][N_enc] serves them all (as rs_enc_encode / rs_enc_decode
+  // expect); the ternary coefficients come from Context::prng(), the transform runs on the device.
+  static std::tuple<PublicKey, SecretKey> keygen() {
+    const Params &p = Context::get_params();
+    std::vector<int> tern(p.N_enc);
+    std::uniform_int_distribution<int> d(-1, 1);
+    for (auto &t : tern) t = d(Context::prng());
+    SecretKey sk((size_t)p.K * p.N_enc);
+    for (int j = 0; j < p.K; j++)
+      for (int x = 0; x < p.N_enc; x++) sk[(size_t)j * p.N_enc + x] = tern[x] < 0 ? p.Q[j] - 1 : (uint64_t)tern[x];
+    DeviceWords d_sk(sk.data(), sk.size());
+    for (int j = 0; j < p.K; j++)
+      check(rs_ntt_forward(Context::get_context(), RS_MOD_COEFF, j, d_sk.get() + (size_t)j * p.N_enc, 1, nullptr));
+    check(rs_sync(Context::get_context(), nullptr));
+    d_sk.download(sk.data());
+    return {nullptr, sk};
+  }
+  static size_t size_in_bits_pk(const PublicKey &) { return 0; }  // seal_ring.hpp:348
+  static size_t size_in_bits_sk(const SecretKey &) {              // seal_ring.hpp:350-361: per context, per data prime
+    const Params &p = Context::get_params();
+    size_t s = 0;
+    for (uint64_t Qj : p.Q) s += (size_t)p.L * (64 - __builtin_clzll(Qj)) * (size_t)p.N_enc;
+    return s;
+  }
+  static std::vector<EncodingElem> encode(const SecretKey &sk, const std::vector<RingElem> &rs) {
+    return encode(sk, rs, Context::prng()());
+  }
+  static std::vector<EncodingElem> encode(const SecretKey &sk, const std::vector<RingElem> &rs, uint64_t seed) {
     const size_t ew = Context::enc_words(), rw = Context::ring_words();
     std::vector<uint64_t> rings(rs.size() * rw);
     for (size_t t = 0; t < rs.size(); t++) {
@@ -339,7 +448,10 @@ class DeviceR1cs {
 inline std::vector<uint64_t> flatten(const std::vector<EncodingElem> &v) {
   std::vector<uint64_t> out;
   out.reserve(v.size() * Context::enc_words());
-  for (const auto &e : v) out.insert(out.end(), e.words().begin(), e.words().end());
+  for (const auto &e : v) {
+    if (e.is_empty()) throw std::invalid_argument("empty encoding in a key vector");
+    out.insert(out.end(), e.words().begin(), e.words().end());
+  }
   return out;
 }
 inline std::vector<uint64_t> flatten(const std::vector<RingElem> &v) {
@@ -352,29 +464,87 @@ inline std::vector<uint64_t> flatten(const std::vector<RingElem> &v) {
   return out;
 }
 
+// CSR export of the reference's r1cs_constraint_system<RingElem>
+// (relations/constraint_satisfaction_problems/r1cs/r1cs.hpp:118-123; linear_combination::terms of
+// linear_term{index, coeff}, relations/variable.hpp).  Duck-typed, so this header needs none of the
+// reference's: CS has constraints[i].{a,b,c}.terms, primary_input_size, auxiliary_input_size.
+// Coefficients must be slot-constant ring elements (Scalars, or polynomials equal in every slot of a limb) --
+// what gadgetlib produces; anything else is refused.
+template <class CS>
+R1csCsr export_csr(const CS &cs) {
+  const Params &p = Context::get_params();
+  R1csCsr out;
+  out.m = cs.constraints.size();
+  out.n_inputs = cs.primary_input_size;
+  out.n_vars = cs.primary_input_size + cs.auxiliary_input_size;
+  std::vector<std::vector<uint64_t>> per_limb[3];
+  for (int w = 0; w < 3; w++) {
+    out.row_ptr[w].assign(1, 0);
+    per_limb[w].assign(p.L, {});
+  }
+  auto add = [&](int w, const auto &lc) {
+    for (const auto &t : lc.terms) {
+      if ((size_t)t.index > out.n_vars) throw std::invalid_argument("variable index out of range");
+      out.col[w].push_back((uint32_t)t.index);
+      const RingElem &c = t.coeff;
+      for (int i = 0; i < p.L; i++) {
+        uint64_t v;
+        if (c.is_scalar()) {
+          v = c.get_scalar() % p.q[i];
+        } else {
+          v = c.get_poly()[(size_t)i * p.N];
+          for (int x = 1; x < p.N; x++)
+            if (c.get_poly()[(size_t)i * p.N + x] != v) throw std::invalid_argument("R1CS coefficient is not slot constant");
+        }
+        per_limb[w][i].push_back(v);
+      }
+    }
+    out.row_ptr[w].push_back((uint32_t)out.col[w].size());
+  };
+  for (const auto &c : cs.constraints) {
+    add(0, c.a);
+    add(1, c.b);
+    add(2, c.c);
+  }
+  for (int w = 0; w < 3; w++)
+    for (int i = 0; i < p.L; i++) out.coeff[w].insert(out.coeff[w].end(), per_limb[w][i].begin(), per_limb[w][i].end());
+  return out;
+}
+
+inline EncodingElem take_element(const std::vector<uint64_t> &w, size_t i) {
+  const size_t ew = Context::enc_words();
+  return EncodingElem(std::vector<uint64_t>(w.begin() + i * ew, w.begin() + (i + 1) * ew));
+}
+inline DeviceWords upload_words(const std::vector<uint64_t> &w) { return DeviceWords(w.data(), w.size()); }
+
 namespace groth16 {
-// proving_key (zk_proof_systems/groth16/groth16.hpp:14-48) uploaded once, kept in HBM.
+// proving_key (zk_proof_systems/groth16/groth16.hpp:9-48) uploaded once, kept in HBM.
 struct proving_key_device {
   proving_key_device(const R1csCsr &cs_, const std::vector<EncodingElem> &s_pows, const std::vector<EncodingElem> &delta_ts,
                      const std::vector<EncodingElem> &delta_mid, const EncodingElem &alpha, const EncodingElem &beta)
       : cs(cs_),
-        s_pows_(up(flatten(s_pows))),
-        delta_ts_(up(flatten(delta_ts))),
-        delta_mid_(up(flatten(delta_mid))),
-        alpha_(up(alpha.words())),
-        beta_(up(beta.words())) {}
+        s_pows_(upload_words(flatten(s_pows))),
+        delta_ts_(upload_words(flatten(delta_ts))),
+        delta_mid_(upload_words(flatten(delta_mid))),
+        alpha_(upload_words(alpha.words())),
+        beta_(upload_words(beta.words())) {}
+  // from the reference's groth16::proving_key<RingElem, EncodingElem> (any type with these members)
+  template <class PK>
+  static proving_key_device from(const PK &pk) {
+    return proving_key_device(export_csr(pk.constraint_system), pk.s_pows, pk.delta_ts, pk.delta_mid, pk.alpha, pk.beta);
+  }
   DeviceR1cs cs;
   DeviceWords s_pows_, delta_ts_, delta_mid_, alpha_, beta_;
-
- private:
-  static DeviceWords up(const std::vector<uint64_t> &w) { return DeviceWords(w.data(), w.size()); }
 };
-struct proof {
+struct proof {  // groth16.hpp:107-117
   EncodingElem A, B, C;
+  size_t size_in_bits() const { return A.size_in_bits() + B.size_in_bits() + C.size_in_bits(); }
 };
-// groth16::prover (groth16.tcc:70-115)
+// groth16::prover (groth16.tcc:70-115) on a device-resident key
 inline proof prover(const proving_key_device &pk, const std::vector<RingElem> &primary_input,
                     const std::vector<RingElem> &auxiliary_input) {
+  if (primary_input.size() != pk.cs.n_inputs || primary_input.size() + auxiliary_input.size() != pk.cs.n_vars)
+    throw std::invalid_argument("assignment does not match the constraint system");
   std::vector<RingElem> full(primary_input);
   full.insert(full.end(), auxiliary_input.begin(), auxiliary_input.end());
   const std::vector<uint64_t> asg = flatten(full);
@@ -387,11 +557,99 @@ inline proof prover(const proving_key_device &pk, const std::vector<RingElem> &p
   proof p;
   EncodingElem *dst[3] = {&p.A, &p.B, &p.C};
   for (int i = 0; i < 3; i++)
-    if (!empty[i])
-      *dst[i] = EncodingElem(std::vector<uint64_t>(w.begin() + i * Context::enc_words(), w.begin() + (i + 1) * Context::enc_words()));
+    if (!empty[i]) *dst[i] = take_element(w, i);
   return p;
+}
+// ... and with the reference's own signature: prover(pk, primary_input, auxiliary_input) on its proving_key type
+// (uploads the key for this call; keep a proving_key_device for repeated proofs)
+template <class PK, class = decltype(std::declval<const PK &>().constraint_system)>
+proof prover(const PK &pk, const std::vector<RingElem> &primary_input, const std::vector<RingElem> &auxiliary_input) {
+  return prover(proving_key_device::from(pk), primary_input, auxiliary_input);
 }
 }  // namespace groth16
 
+namespace rinocchio {
+// proving_key (zk_proof_systems/rinocchio/rinocchio.hpp:9-60) on the device
+struct proving_key_device {
+  proving_key_device(const R1csCsr &cs_, const std::vector<EncodingElem> &s_pows, const std::vector<EncodingElem> &alpha_s_pows,
+                     const std::vector<EncodingElem> &beta_prods, const EncodingElem &beta_rv_ts, const EncodingElem &beta_rw_ts,
+                     const EncodingElem &beta_ry_ts)
+      : cs(cs_),
+        s_pows_(upload_words(flatten(s_pows))),
+        alpha_s_pows_(upload_words(flatten(alpha_s_pows))),
+        beta_prods_(upload_words(flatten(beta_prods))),
+        beta_rv_ts_(upload_words(beta_rv_ts.words())),
+        beta_rw_ts_(upload_words(beta_rw_ts.words())),
+        beta_ry_ts_(upload_words(beta_ry_ts.words())) {}
+  template <class PK>
+  static proving_key_device from(const PK &pk) {
+    return proving_key_device(export_csr(pk.constraint_system), pk.s_pows, pk.alpha_s_pows, pk.beta_prods, pk.beta_rv_ts,
+                              pk.beta_rw_ts, pk.beta_ry_ts);
+  }
+  DeviceR1cs cs;
+  DeviceWords s_pows_, alpha_s_pows_, beta_prods_, beta_rv_ts_, beta_rw_ts_, beta_ry_ts_;
+};
+struct proof {  // rinocchio.hpp:110-147: {A, A', B, B', C, C', D, D', F}
+  EncodingElem A, A_prime, B, B_prime, C, C_prime, D, D_prime, F;
+  size_t size_in_bits() const {
+    return A.size_in_bits() + A_prime.size_in_bits() + B.size_in_bits() + B_prime.size_in_bits() + C.size_in_bits() +
+           C_prime.size_in_bits() + D.size_in_bits() + D_prime.size_in_bits() + F.size_in_bits();
+  }
+};
+// rinocchio::prover (rinocchio.tcc:75-190).  d1, d2, d3: the blinding elements; the overload without them samples
+// them as the reference does (:81-90: random invertible elements when there are auxiliary inputs, else zero).
+inline proof prover(const proving_key_device &pk, const std::vector<RingElem> &primary_input,
+                    const std::vector<RingElem> &auxiliary_input, const RingElem *d1, const RingElem *d2, const RingElem *d3) {
+  if (primary_input.size() != pk.cs.n_inputs || primary_input.size() + auxiliary_input.size() != pk.cs.n_vars)
+    throw std::invalid_argument("assignment does not match the constraint system");
+  std::vector<RingElem> full(primary_input);
+  full.insert(full.end(), auxiliary_input.begin(), auxiliary_input.end());
+  const std::vector<uint64_t> asg = flatten(full);
+  DeviceWords dasg(asg.data(), asg.size()), dproof(9 * Context::enc_words());
+  DeviceWords dd[3];
+  const uint64_t *dp[3] = {nullptr, nullptr, nullptr};
+  if (d1) {
+    const RingElem *ds[3] = {d1, d2, d3};
+    for (int k = 0; k < 3; k++) {
+      const RingElem t = ds[k]->to_poly();
+      dd[k] = upload_words(t.get_poly());
+      dp[k] = dd[k].get();
+    }
+  }
+  rs_rinocchio_pk k{pk.s_pows_.get(), pk.alpha_s_pows_.get(), pk.beta_prods_.get(), pk.beta_rv_ts_.get(),
+                    pk.beta_rw_ts_.get(), pk.beta_ry_ts_.get(), 0};
+  int empty[9] = {0};
+  check(rs_rinocchio_prove(Context::get_context(), pk.cs.get(), &k, dasg.get(), dp[0], dp[1], dp[2], dproof.get(), empty, nullptr));
+  std::vector<uint64_t> w(9 * Context::enc_words());
+  dproof.download(w.data());
+  proof p;
+  EncodingElem *dst[9] = {&p.A, &p.A_prime, &p.B, &p.B_prime, &p.C, &p.C_prime, &p.D, &p.D_prime, &p.F};
+  for (int i = 0; i < 9; i++)
+    if (!empty[i]) *dst[i] = take_element(w, i);
+  return p;
+}
+inline proof prover(const proving_key_device &pk, const std::vector<RingElem> &primary_input,
+                    const std::vector<RingElem> &auxiliary_input) {
+  if (auxiliary_input.empty()) {
+    std::cout << "[Prover] using non-zero-knowledge SNARK, since no auxiliary inputs are defined" << std::endl;  // rinocchio.tcc:82-87
+    return prover(pk, primary_input, auxiliary_input, nullptr, nullptr, nullptr);
+  }
+  const RingElem d1 = RingElem::random_invertible_element(), d2 = RingElem::random_invertible_element(),
+                 d3 = RingElem::random_invertible_element();
+  return prover(pk, primary_input, auxiliary_input, &d1, &d2, &d3);
+}
+template <class PK, class = decltype(std::declval<const PK &>().constraint_system)>
+proof prover(const PK &pk, const std::vector<RingElem> &primary_input, const std::vector<RingElem> &auxiliary_input) {
+  return prover(proving_key_device::from(pk), primary_input, auxiliary_input);
+}
+}  // namespace rinocchio
+
 }  // namespace ringsnark::amd
+
+namespace std {
+template <>
+struct hash<ringsnark::amd::RingElem> {  // seal_ring.hpp:412-419
+  size_t operator()(const ringsnark::amd::RingElem &r) const { return r.hash(); }
+};
+}  // namespace std
 #endif

@@ -112,3 +112,74 @@ def test_cpp_adapters_run_against_the_library(tmp_path):
     args = [str(prm.N), str(prm.L)] + [str(x) for x in prm.q] + [str(prm.N_enc), str(prm.K)] + [str(x) for x in prm.Q]
     r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "adapter_run: OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_reference_templates_compile_on_the_adapters():
+    """north_star: "keeping the RingElem/EncodingElem operator surface so gadgetlib/relations are untouched".
+    The reference's own gadgetlib/, relations/ and zk_proof_systems/r1cs_ppzksnark.hpp (the <RingT, EncT> contract,
+    :173-188) must compile, as they lie under /root/reference, with RingT = ringsnark::amd::RingElem and
+    EncT = ringsnark::amd::EncodingElem: oracle/ref_adapter_prove.cpp instantiates protoboard, pb_variable_array,
+    r1cs_constraint_system (add_constraint, is_satisfied, linear_combination::evaluate), proving_key<R, E> and the
+    adapters' provers on them.  (The same file is built into oracle/_ref/ and RUN on the GPU by
+    test_reference_gadgetlib_drives_the_device_provers.)"""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None or not os.path.isdir("/root/reference/ringsnark"):
+        pytest.skip("needs g++ and /root/reference (build container only)")
+    r = subprocess.run([gxx, "-std=c++17", "-fsyntax-only", "-Wall", "-I", "/root/reference", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "oracle", "ref_adapter_prove.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_reference_gadgetlib_drives_the_device_provers(tmp_path):
+    """oracle/_ref/ref_adapter_prove (built in the container from the reference's headers + the C++ adapters + librs_hip.so):
+    a circuit assembled with the reference's protoboard, checked by the reference's is_satisfied() on device ring
+    arithmetic, proven by ringsnark::amd::groth16::prover and rinocchio::prover FROM C++.  The proofs must equal what
+    the ctypes host obtains from the same key and assignment, and the ringGroth16 one must equal the CPU oracle's."""
+    import subprocess
+
+    import numpy as np
+    from oracle import oracle as O
+    from ringsnark_amd import r1cs as R
+    from ringsnark_amd.device import Device, to_host
+    from tests import helpers as H
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_adapter_prove")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_adapter_prove not built (needs /root/reference at build time)")
+    prm = P.preset("toy")
+    m = 6
+    args = [str(prm.N), str(prm.L)] + [str(x) for x in prm.q] + [str(prm.N_enc), str(prm.K)] + [str(x) for x in prm.Q] + [str(m), str(tmp_path)]
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ref_adapter_prove: OK" in r.stdout, r.stdout + r.stderr
+    rd = lambda name, shape=None: (lambda a: a if shape is None else a.reshape(shape))(np.fromfile(str(tmp_path / name), dtype=np.uint64))
+    mm, n_vars, n_inputs = [int(v) for v in open(str(tmp_path / "meta.txt")).read().split()[:3]]
+    assert (mm, n_vars, n_inputs) == (m, m + 2, 2)
+    mats = {}
+    for w, name in enumerate("abc"):
+        col = rd("col%d.bin" % w).astype(np.uint32)
+        mats[name] = (rd("row_ptr%d.bin" % w).astype(np.uint32), col, rd("coeff%d.bin" % w, (prm.L, col.shape[0])))
+    # the CSR export holds what the reference's gadgetlib produced: a-rows have 3 terms (x_i, 3 x_{i+1}, the constant 2)
+    assert mats["a"][1].shape[0] == 3 * m and (mats["a"][1] == 0).sum() == m
+    cs = R.R1CS(m, n_vars, n_inputs, mats)
+    dev = Device(prm)
+    ctx = H.oracle_ctx(prm)
+    asg = rd("assignment.bin", (n_vars,) + ctx.ring_shape())
+    enc = lambda name, n=None: rd(name, ctx.enc_shape() if n is None else ctx.enc_shape(n))
+    gpk = dict(s_pows=enc("g_s_pows.bin", m + 1), delta_ts=enc("g_delta_ts.bin", m + 1), delta_mid=enc("g_delta_mid.bin", m),
+               alpha=enc("g_alpha.bin"), beta=enc("g_beta.bin"))
+    dcs = dev.r1cs(cs)
+    got, _ = dev.groth16_prove(dcs, {k: dev.put(v) for k, v in gpk.items()}, dev.put(asg))
+    cpp = enc("g_proof.bin", 3)
+    assert (to_host(got) == cpp).all(), "C++ adapter prover and ctypes host disagree"
+    exp, _ = O.groth16_prove(ctx, H.oracle_cs(cs), gpk, asg)
+    assert (cpp == exp).all(), "C++ adapter prover differs from the CPU oracle"
+    rpk = dict(s_pows=enc("r_s_pows.bin", m + 1), alpha_s_pows=enc("r_alpha_s_pows.bin", m + 1), beta_prods=enc("r_beta_prods.bin", m),
+               beta_rv_ts=enc("r_beta_rv_ts.bin"), beta_rw_ts=enc("r_beta_rw_ts.bin"), beta_ry_ts=enc("r_beta_ry_ts.bin"))
+    ds = rd("r_d.bin", ctx.ring_shape(3))
+    got, _ = dev.rinocchio_prove(dcs, {k: dev.put(v) for k, v in rpk.items()}, dev.put(asg), *[dev.put(d) for d in ds])
+    cppr = enc("r_proof.bin", 9)
+    assert (to_host(got) == cppr).all()
+    expr, _ = O.rinocchio_prove(ctx, H.oracle_cs(cs), rpk, asg, *ds)
+    assert (cppr == expr).all()

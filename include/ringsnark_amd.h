@@ -203,6 +203,22 @@ int rs_witness_map_slots(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_assig
 /* util/polynomials.tcc:10-43 on the domain {0..n-1}: d_y, d_out [n][L][N] (may alias). */
 int rs_interpolate(rs_ctx *ctx, const uint64_t *d_y, uint64_t *d_out, size_t n, rs_stream stream);
 
+/* ---- a11: multiply / add / divide of polynomials with ring-element coefficients
+ * (util/polynomials.tcc:62-81, Boost.Math polynomial in the reference).  Vectors [n][L][N], coefficient k in row k;
+ * slot-wise polynomial arithmetic over the fields F_{q_i}, schoolbook as in the reference.  Operands and results are
+ * normalised the way Boost's polynomial is: *h_len (may be NULL) = length after stripping trailing coefficients equal
+ * to RingT(0); rows at or beyond *h_len of the output are zero.  Synchronise.
+ *   multiply: d_out [na+nb-1]     add: d_out [max(na,nb)]
+ *   divide:   d_quot [nn-nd+1] (untouched if nn < nd: the quotient is the zero polynomial, *h_len = 0); the
+ *             divisor's leading coefficient must be a unit, else RS_ERR_NOT_INVERTIBLE ("element is not invertible
+ *             in ring", what RingElem::operator/ throws inside Boost's division). */
+int rs_poly_multiply(rs_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, size_t *h_len,
+                     rs_stream stream);
+int rs_poly_add(rs_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, size_t *h_len,
+                rs_stream stream);
+int rs_poly_divide(rs_ctx *ctx, const uint64_t *d_num, size_t nn, const uint64_t *d_den, size_t nd, uint64_t *d_quot, size_t *h_len,
+                   rs_stream stream);
+
 /* ---- a15 / a16: provers -------------------------------------------------------------------
  * groth16::prover (zk_proof_systems/groth16/groth16.tcc:70-115).  pk vectors are device
  * resident; proof = {A,B,C} [3] encoding elements; h_empty[k] = 1 if the reference would leave

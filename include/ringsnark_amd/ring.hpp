@@ -14,6 +14,7 @@
 #ifndef RINGSNARK_AMD_RING_HPP
 #define RINGSNARK_AMD_RING_HPP
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
@@ -509,6 +510,48 @@ R1csCsr export_csr(const CS &cs) {
   for (int w = 0; w < 3; w++)
     for (int i = 0; i < p.L; i++) out.coeff[w].insert(out.coeff[w].end(), per_limb[w][i].begin(), per_limb[w][i].end());
   return out;
+}
+
+// util/polynomials.hpp:17-41 on device-resident data: multiply / add / divide (Boost schoolbook product, sum and long
+// division in the reference, polynomials.tcc:62-81) and interpolate on the domain {0..n-1}
+// (polynomials.tcc:10-43 with util/evaluation_domain.tcc:8-13).  Results are normalised like Boost's polynomial.
+namespace detail {
+using PolyFn = int (*)(rs_ctx *, const uint64_t *, size_t, const uint64_t *, size_t, uint64_t *, size_t *, rs_stream);
+inline std::vector<RingElem> poly_binary(PolyFn fn, const std::vector<RingElem> &x, const std::vector<RingElem> &y, size_t rows) {
+  const size_t rw = Context::ring_words();
+  const std::vector<uint64_t> hx = flatten(x), hy = flatten(y);
+  DeviceWords dx(hx.data(), hx.size()), dy(hy.data(), hy.size()), out(std::max<size_t>(rows, 1) * rw);
+  size_t len = 0;
+  check(fn(Context::get_context(), dx.get(), x.size(), dy.get(), y.size(), out.get(), &len, nullptr));
+  std::vector<uint64_t> w(std::max<size_t>(rows, 1) * rw);
+  out.download(w.data());
+  std::vector<RingElem> res;
+  for (size_t k = 0; k < len; k++) res.emplace_back(std::vector<uint64_t>(w.begin() + k * rw, w.begin() + (k + 1) * rw));
+  return res;
+}
+}  // namespace detail
+inline std::vector<RingElem> multiply(const std::vector<RingElem> &x, const std::vector<RingElem> &y) {
+  return detail::poly_binary(rs_poly_multiply, x, y, x.empty() || y.empty() ? 0 : x.size() + y.size() - 1);
+}
+inline std::vector<RingElem> add(const std::vector<RingElem> &x, const std::vector<RingElem> &y) {
+  return detail::poly_binary(rs_poly_add, x, y, std::max(x.size(), y.size()));
+}
+inline std::vector<RingElem> divide(const std::vector<RingElem> &numerator, const std::vector<RingElem> &denominator) {
+  return detail::poly_binary(rs_poly_divide, numerator, denominator,
+                             numerator.size() >= denominator.size() ? numerator.size() - denominator.size() + 1 : 0);
+}
+// interpolate(x, y) for the reference's domain x_j = j
+inline std::vector<RingElem> interpolate_on_domain(const std::vector<RingElem> &y) {
+  const size_t rw = Context::ring_words(), n = y.size();
+  const std::vector<uint64_t> hy = flatten(y);
+  DeviceWords dy(hy.data(), hy.size());
+  check(rs_interpolate(Context::get_context(), dy.get(), dy.get(), n, nullptr));
+  check(rs_sync(Context::get_context(), nullptr));
+  std::vector<uint64_t> w(n * rw);
+  dy.download(w.data());
+  std::vector<RingElem> res;
+  for (size_t k = 0; k < n; k++) res.emplace_back(std::vector<uint64_t>(w.begin() + k * rw, w.begin() + (k + 1) * rw));
+  return res;
 }
 
 inline EncodingElem take_element(const std::vector<uint64_t> &w, size_t i) {

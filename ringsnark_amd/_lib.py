@@ -91,6 +91,9 @@ SIGNATURES = {
     "rs_witness_map": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64p, vp]),
     "rs_witness_map_slots": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, u64p, vp]),
     "rs_interpolate": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "rs_poly_multiply": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.POINTER(C.c_size_t), vp]),
+    "rs_poly_add": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.POINTER(C.c_size_t), vp]),
+    "rs_poly_divide": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.POINTER(C.c_size_t), vp]),
     "rs_groth16_prove": (C.c_int, [vp, vp, C.POINTER(Groth16PK), vp, vp, C.POINTER(C.c_int), vp]),
     "rs_rinocchio_prove": (C.c_int, [vp, vp, C.POINTER(RinocchioPK), vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]),
     "rs_last_timings": (C.c_int, [vp, C.POINTER(Timings)]),

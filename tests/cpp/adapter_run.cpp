@@ -102,6 +102,44 @@ int main(int argc, char **argv) {
   EXPECT(EncodingElem::inner_product(es.begin(), es.end(), zeros.begin(), zeros.end()).is_empty());  // seal_ring.tcc:412,432
   EXPECT((EncodingElem() += es[0]) == es[0]);
 
+  // the rest of the <RingT, EncT> concept
+  {
+    Context::seed_prng(99);
+    const RingElem u = RingElem::random_invertible_element(), nz = RingElem::random_nonzero_element();
+    EXPECT(u.is_invertible() && !nz.is_zero() && u.is_poly());
+    struct Dom {
+      size_t m = 40;
+    };
+    const RingElem s = RingElem::random_exceptional_element(std::make_shared<Dom>());
+    EXPECT(s.is_scalar() && s.get_scalar() > 40 && s.get_scalar() < p.q[0]);
+    EXPECT(RingElem::random_exceptional_element().is_scalar());
+    EXPECT(std::hash<RingElem>()(u) == std::hash<RingElem>()(RingElem(u)) && std::hash<RingElem>()(RingElem(7)) == std::hash<uint64_t>()(7));
+    auto [pk_enc, sk2] = EncodingElem::keygen();
+    (void)pk_enc;
+    EXPECT(sk2.size() == (size_t)p.K * p.N_enc && EncodingElem::size_in_bits_pk(nullptr) == 0 && EncodingElem::size_in_bits_sk(sk2) > 0);
+    const std::vector<EncodingElem> e2 = EncodingElem::encode(sk2, {u, nz});
+    EXPECT(EncodingElem::decode(sk2, e2[0]) == u && EncodingElem::decode(sk2, e2[1]) == nz);
+    EXPECT(EncodingElem::decode(sk2, e2[0] * nz + e2[1]) == u * nz + nz);
+    // util/polynomials.hpp helpers: divide(multiply(q, x), x) == q (util/division_test.cpp:28-49, n = 12)
+    std::vector<RingElem> xs, qs;
+    for (uint64_t i = 0; i < 12; i++) {
+      xs.push_back(RingElem(2 * i + 1));
+      qs.push_back(RingElem(i + 1));
+    }
+    const std::vector<RingElem> prod = multiply(qs, xs), back = divide(prod, xs);
+    EXPECT(prod.size() == 23 && back.size() == 12);
+    for (size_t i = 0; i < back.size() && i < 12; i++) EXPECT(back[i] == qs[i]);
+    // interpolation_test.cpp:29-55: nodes 0..7, coefficients 0..7
+    std::vector<RingElem> ys;
+    for (uint64_t xv = 0; xv < 8; xv++) {
+      uint64_t acc2 = 0;
+      for (int k = 7; k >= 0; k--) acc2 = acc2 * xv + (uint64_t)k;
+      ys.push_back(RingElem(acc2));
+    }
+    const std::vector<RingElem> cf = interpolate_on_domain(ys);
+    for (uint64_t k = 0; k < 8; k++) EXPECT(cf[k] == RingElem(k));
+  }
+
   if (fails) return 1;
   std::puts("adapter_run: OK");
   return 0;

@@ -563,3 +563,37 @@ def test_multipass_production_tile_matches_oracle_on_a_few_slots():
         exp = O.witness_map(prm.q[limb], ocs, limb, np.ascontiguousarray(a[:, limb, slot0:slot0 + ns]), threads=0)
         for k in ("A_io", "A_mid", "B_mid", "H"):
             assert (host(w[k])[:, limb, :] == exp[k]).all(), (k, limb)
+
+
+@pytest.mark.parametrize("name", ["toy", "toy49"])
+def test_poly_multiply_add_divide_match_oracle(name):
+    """Row a11 (util/polynomials.tcc:62-81): per-slot polynomial product / sum / quotient with ring-element
+    coefficients, non-monic per-slot divisors included, against the oracle's schoolbook restatement."""
+    from ringsnark_amd import _lib
+    dev = dev_for(name)
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    na, nb = 23, 9
+    a, b = ctx.random_ring(91, na), ctx.random_ring(92, nb)
+    a[5] = 0
+    prod = host(dev.poly_multiply(dev.put(a), dev.put(b)))
+    sm = host(dev.poly_add(dev.put(a), dev.put(b)))
+    num = ctx.random_ring(93, na + nb - 1)
+    quo = host(dev.poly_divide(dev.put(num), dev.put(b)))
+    for limb in range(prm.L):
+        q = prm.q[limb]
+        assert (prod[:, limb, :] == O.poly_mul(q, np.ascontiguousarray(a[:, limb, :]), np.ascontiguousarray(b[:, limb, :]))).all()
+        exp, n = O.poly_div_general(q, np.ascontiguousarray(num[:, limb, :]), np.ascontiguousarray(b[:, limb, :]))
+        assert (quo[:, limb, :] == exp[:quo.shape[0]]).all()
+    pad = np.zeros((na - nb,) + b.shape[1:], dtype=np.uint64)
+    assert (sm == ctx.ring_add(a, np.concatenate([b, pad]))).all()
+    # normalisation (Boost polynomial): trailing zero coefficients are stripped from operands and results
+    z = np.concatenate([a, np.zeros((3,) + a.shape[1:], dtype=np.uint64)])
+    assert dev.poly_multiply(dev.put(z), dev.put(b)).shape[0] == na + nb - 1
+    assert dev.poly_divide(dev.put(b), dev.put(a)).shape[0] == 0  # deg num < deg den: the zero polynomial
+    # the divisor's leading coefficient must be a unit of the ring
+    bad = b.copy()
+    bad[-1, 0, 3] = 0
+    with pytest.raises(_lib.RsError) as ei:
+        dev.poly_divide(dev.put(num), dev.put(bad))
+    assert ei.value.code == _lib.RS_ERR_NOT_INVERTIBLE and "element is not invertible in ring" in str(ei.value)

@@ -194,6 +194,8 @@ extern "C" {
 
 int rs_enc_decode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size_t count, uint64_t *d_rings, rs_stream stream) {
   RS_API_BEGIN_CTX(ctx)
+  if (ctx->use_int)
+    throw Error(RS_ERR_UNSUPPORTED, "rs_enc_decode: setup / verifier-side entry points (SURVEY.md 8(f) f2, f3) run on the FP64 arithmetic only (all moduli < 2^50)");
   RS_REQUIRE(ctx && d_sk && d_enc && d_rings, "null argument");
   if (count == 0) return RS_OK;
   WsScope ws_scope(ctx, S(stream));
@@ -253,6 +255,8 @@ int rs_enc_decode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size
 int rs_enc_encode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_rings, size_t count, uint64_t seed, uint64_t *d_enc,
                   rs_stream stream) {
   RS_API_BEGIN_CTX(ctx)
+  if (ctx->use_int)
+    throw Error(RS_ERR_UNSUPPORTED, "rs_enc_encode: setup / verifier-side entry points (SURVEY.md 8(f) f2, f3) run on the FP64 arithmetic only (all moduli < 2^50)");
   RS_REQUIRE(ctx && d_sk && d_rings && d_enc, "null argument");
   if (count == 0) return RS_OK;
   RS_REQUIRE(ctx->N_enc <= 16 * 1024, "encoding degree out of range");
@@ -438,6 +442,8 @@ extern "C" {
 int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, uint64_t *d_At, uint64_t *d_Bt, uint64_t *d_Ct,
                          uint64_t *d_Ht, uint64_t *d_Zt, rs_stream stream) {
   RS_API_BEGIN_CTX(ctx)
+  if (ctx->use_int)
+    throw Error(RS_ERR_UNSUPPORTED, "rs_instance_map_eval: setup / verifier-side entry points (SURVEY.md 8(f) f2, f3) run on the FP64 arithmetic only (all moduli < 2^50)");
   RS_REQUIRE(ctx && cs && d_s && d_At && d_Bt && d_Ct && d_Ht && d_Zt, "null argument");
   const size_t m = cs->m, SW = ctx->ring_words();
   const int L = ctx->L;

@@ -91,6 +91,15 @@ inline uint32_t bitrev(uint32_t x, int bits) {
   return r;
 }
 
+// Montgomery constants of intmod.hpp (R = 2^64)
+inline uint64_t mont_form(uint64_t v, uint64_t q) { return (uint64_t)((((u128)(v % q)) << 64) % q); }
+inline uint64_t mont_ninv(uint64_t q) {  // -q^-1 mod 2^64 (Newton iteration on odd q)
+  uint64_t x = q;
+  for (int i = 0; i < 6; i++) x *= 2 - q * x;
+  return (uint64_t)0 - x;
+}
+inline uint64_t mont_r2(uint64_t q) { return mont_form(mont_form(1, q), q); }
+
 // balanced representative as a double: value in (-q/2, q/2]
 inline double balanced(uint64_t v, uint64_t q) { return v > q / 2 ? -(double)(q - v) : (double)v; }
 

@@ -23,6 +23,7 @@
 // through the used-term counts.
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "ntt_core.hpp"
 #include "rs_internal.hpp"
@@ -53,38 +54,44 @@ struct PlainArgs {
 #define RS_PLAIN_MAXR 3
 #endif
 // grid (terms in tile, L, groups); EPT = max elements per thread (16 only for N_enc = 16384)
-template <int EPT, int LOGN_CT = 0>  // LOGN_CT != 0: transform length fixed at compile time (rounds specialised)
+// M: the context's arithmetic.  C rows are the centred plaintext INTEGERS (signed doubles / int64_t), so the
+// sum over a group's vectors is taken after the lift and one row serves all K data primes.
+template <int EPT, int LOGN_CT = 0, class M = Mod>  // LOGN_CT != 0: transform length fixed at compile time (rounds specialised)
 __global__ void __launch_bounds__(1024)
-plain_center_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t0, unsigned long long tile_terms,
-                    int N, int L, int logn_arg, const uint32_t *__restrict__ index_map, const NttTable *__restrict__ plain_tabs) {
+plain_center_kernel(PlainArgs args, typename ArithOf<M>::Lift *__restrict__ C, unsigned long long t0, unsigned long long tile_terms,
+                    int N, int L, int logn_arg, const uint32_t *__restrict__ index_map,
+                    const NttTableT<typename ArithOf<M>::T, M> *__restrict__ plain_tabs) {
+  using T = typename ArithOf<M>::T;
+  using Lift = typename ArithOf<M>::Lift;
+  constexpr bool FP = std::is_same<M, Mod>::value;
   const int logn = LOGN_CT ? LOGN_CT : logn_arg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *s = reinterpret_cast<double *>(smem);
+  T *s = reinterpret_cast<T *>(smem);
   const int n = 1 << logn;
   const unsigned long long tt = blockIdx.x, t = t0 + tt;
   const int limb = blockIdx.y, g = blockIdx.z;
   const PlainGroup &G = args.g[g];
-  const NttTable tab = plain_tabs[limb];
-  const Mod mod = tab.mod;
-  // wave-private inverse transform when every wave gets a block of >= 256 coefficients
+  const NttTableT<T, M> tab = plain_tabs[limb];
+  const M mod = tab.mod;
+  // wave-private inverse transform when every wave gets a block of >= 256 coefficients (FP64 arithmetic)
   int logw = 0;
   while ((64 << logw) < (int)blockDim.x) logw++;
-  const bool wp = logn - logw >= 8 && logw >= 1 && logw <= 4;
-  double acc[EPT];
+  const bool wp = FP && logn - logw >= 8 && logw >= 1 && logw <= 4;
+  Lift acc[EPT];
 #pragma unroll
-  for (int k = 0; k < EPT; k++) acc[k] = 0.0;
+  for (int k = 0; k < EPT; k++) acc[k] = Lift(0);
   for (int v = 0; v < G.n; v++) {
     if (t >= G.T[v]) continue;
     const int kind = G.kinds[v] ? (int)G.kinds[v][t] : RS_KIND_POLY;
     if (kind == RS_KIND_ONE) {  // Scalar 1: plaintext is the constant polynomial 1
       if (threadIdx.x == 0) {
-        acc[0] += 1.0;
+        acc[0] += Lift(1);
         if (G.nz[v]) atomicOr(&G.nz[v][t], 1u);
       }
       continue;
     }
     if (N < n) {  // slots beyond N stay zero (seal_ring.tcc:350-351); with N == n the scatter covers the tile
-      for (int p = threadIdx.x; p < n; p += blockDim.x) s[pidx(p)] = 0.0;
+      for (int p = threadIdx.x; p < n; p += blockDim.x) s[pidx(p)] = T(0);
       __syncthreads();
     }
     const uint64_t *src = G.coeff[v] + ((size_t)t * L + limb) * (size_t)N;
@@ -110,29 +117,33 @@ plain_center_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t
         const int x = tid + (k0 + k) * blockDim.x;
         if (x < N) {
           nz |= (val[k] != 0);
-          s[pidx((int)pos[k])] = from_u64(val[k]);
+          s[pidx((int)pos[k])] = from_res<T>(val[k]);
         }
       }
     }
     if (!__syncthreads_or(nz)) continue;  // is_zero term (this limb): contributes nothing
     if (threadIdx.x == 0 && G.nz[v]) atomicOr(&G.nz[v][t], 1u);
-    if (wp)
-      lds_ntt_inv_wp<RS_PLAIN_MAXR, TileBlockFactory, LdsIO, 3>(s, TileBlockFactory{s}, LdsIO{s}, logn, logw, tab.d_itw, mod, tab.inv_red_mask);
-    else
+    if constexpr (FP) {
+      if (wp)
+        lds_ntt_inv_wp<RS_PLAIN_MAXR, TileBlockFactory, LdsIO, 3>(s, TileBlockFactory{s}, LdsIO{s}, logn, logw, tab.d_itw, mod, tab.inv_red_mask);
+      else
+        lds_ntt_inv(s, logn, tab.d_itw, 1, mod, tab.inv_red_mask);
+    } else {
       lds_ntt_inv(s, logn, tab.d_itw, 1, mod, tab.inv_red_mask);
+    }
     tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int k = 0; k < EPT; k++) {
       const int p = tid + k * blockDim.x;
       if (p < n) {
-        const double c = canon(mulmod(reduce(s[pidx(p)], mod), tab.ninv, mod), mod);
-        acc[k] += center(c, mod);
+        const T c = canon(mulmod(reduce(s[pidx(p)], mod), tab.ninv, mod), mod);
+        acc[k] += lift_centered(c, mod);
       }
     }
     __syncthreads();
   }
-  double *dst = C + (((size_t)g * tile_terms + tt) * L + limb) * (size_t)n;
+  Lift *dst = C + (((size_t)g * tile_terms + tt) * L + limb) * (size_t)n;
 #pragma unroll
   for (int k = 0; k < EPT; k++) {
     const int p = threadIdx.x + k * blockDim.x;
@@ -141,29 +152,35 @@ plain_center_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t
 }
 
 // a5: BatchEncoder::encode -> canonical coefficient-form plaintext.  grid (count, L)
+template <class M>
 __global__ void __launch_bounds__(1024)
 batch_encode_kernel(const uint64_t *__restrict__ rings, uint64_t *__restrict__ plain, int N, int L, int logn,
-                    const uint32_t *__restrict__ index_map, const NttTable *__restrict__ plain_tabs) {
+                    const uint32_t *__restrict__ index_map, const NttTableT<typename ArithOf<M>::T, M> *__restrict__ plain_tabs) {
+  using T = typename ArithOf<M>::T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *s = reinterpret_cast<double *>(smem);
+  T *s = reinterpret_cast<T *>(smem);
   const int n = 1 << logn;
   const size_t k = blockIdx.x;
   const int limb = blockIdx.y;
-  const NttTable tab = plain_tabs[limb];
-  const Mod mod = tab.mod;
-  for (int p = threadIdx.x; p < n; p += blockDim.x) s[pidx(p)] = 0.0;
+  const NttTableT<T, M> tab = plain_tabs[limb];
+  const M mod = tab.mod;
+  for (int p = threadIdx.x; p < n; p += blockDim.x) s[pidx(p)] = T(0);
   __syncthreads();
   const uint64_t *src = rings + (k * L + limb) * (size_t)N;
-  for (int x = threadIdx.x; x < N; x += blockDim.x) s[pidx((int)index_map[x])] = from_u64(src[x]);
+  for (int x = threadIdx.x; x < N; x += blockDim.x) s[pidx((int)index_map[x])] = from_res<T>(src[x]);
   __syncthreads();
   lds_ntt_inv(s, logn, tab.d_itw, 1, mod, tab.inv_red_mask);
   uint64_t *dst = plain + (k * L + limb) * (size_t)n;
   for (int p = threadIdx.x; p < n; p += blockDim.x)
-    dst[p] = to_u64(canon(mulmod(reduce(s[pidx(p)], mod), tab.ninv, mod), mod));
+    dst[p] = to_res(canon(mulmod(reduce(s[pidx(p)], mod), tab.ninv, mod), mod));
 }
 
+template <class L_>
+struct alignas(16) LiftPair {
+  L_ x, y;
+};
 struct MacArgs {
-  const double *C[2];     // per group: [tile_terms][L][n]
+  const void *C[2];       // per group: [tile_terms][L][n] centred plaintext integers (double or int64_t)
   const uint64_t *crs[2]; // per CRS vector: element 0 of the tile, [terms][L][2][K][n]
   uint64_t *partial;      // [n_chunks][n_sets_total][L][2][K][n]
   int set_index[4];       // which set slot (c * n_groups + g) each accumulator set writes
@@ -177,11 +194,13 @@ struct MacArgs {
 };
 
 // The dominant kernel.  Accumulator set (c, g): sum_t crs[c][t] * NTT(C[g][t]).
-template <int NG, int NC, int PAIRS>
+template <int NG, int NC, int PAIRS, class M = Mod>
 __global__ void __launch_bounds__(1024)
-mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff_tabs) {
+mac_kernel(MacArgs a, int L, int K, int logn, const NttTableT<typename ArithOf<M>::T, M> *__restrict__ coeff_tabs) {
+  using T = typename ArithOf<M>::T;
+  using Lift = typename ArithOf<M>::Lift;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *s = reinterpret_cast<double *>(smem);
+  T *s = reinterpret_cast<T *>(smem);
   const int n = 1 << logn;
   // XCD-aware mapping: blocks b, b+8, b+16, ... (same XCD, dispatched back to back) take the K
   // primes of one (limb, chunk), so the K readers of a C row share it through that XCD's L2.
@@ -190,11 +209,11 @@ mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff
   const unsigned r = (b & 7u) + 8u * (b / (8u * (unsigned)K));
   if (r >= (unsigned)(a.n_chunks * L)) return;
   const int limb = (int)(r % (unsigned)L), chunk = (int)(r / (unsigned)L);
-  const NttTable tab = coeff_tabs[j];
-  const Mod mod = tab.mod;
+  const NttTableT<T, M> tab = coeff_tabs[j];
+  const M mod = tab.mod;
   constexpr int NS = NG * NC;
   // PAIRS = n / (2 * blockDim): 4, or 8 for N_enc = 16384
-  double acc[NS][2][2 * PAIRS];
+  T acc[NS][2][2 * PAIRS];
   const size_t enc_words = (size_t)L * 2 * K * n;
 #pragma unroll
   for (int st = 0; st < NS; st++)
@@ -202,14 +221,14 @@ mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int k = 0; k < PAIRS; k++) {
-        acc[st][c][2 * k] = acc[st][c][2 * k + 1] = 0.0;
+        acc[st][c][2 * k] = acc[st][c][2 * k + 1] = T(0);
         const int pp = threadIdx.x + k * blockDim.x;
         if (a.accumulate && pp < (n >> 1)) {
           const uint64_t *pv = a.partial + ((size_t)chunk * a.n_sets_total + a.set_index[st]) * enc_words +
                                (((size_t)limb * 2 + c) * K + j) * (size_t)n;
           const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(pv)[pp];
-          acc[st][c][2 * k] = from_u64(v.x);
-          acc[st][c][2 * k + 1] = from_u64(v.y);
+          acc[st][c][2 * k] = from_res<T>(v.x);
+          acc[st][c][2 * k + 1] = from_res<T>(v.y);
         }
       }
   const unsigned long long tbeg = (unsigned long long)chunk * a.terms_per_chunk;
@@ -219,13 +238,15 @@ mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff
 #pragma unroll
     for (int g = 0; g < NG; g++) {
       if (t >= a.terms[g]) continue;
-      // centred plaintext (|c| < members * q_i / 2) -> residues mod Q_j
-      const double2 *src = reinterpret_cast<const double2 *>(a.C[g] + ((size_t)t * L + limb) * (size_t)n);
+      // centred plaintext (|c| < members * q_i / 2) -> residues mod Q_j.  Integer arithmetic: the residue goes
+      // in as c*R, the transform is linear, so the spectrum comes out in Montgomery form and ct * spectrum below
+      // is ONE reduction per product.
+      const LiftPair<Lift> *src = reinterpret_cast<const LiftPair<Lift> *>(static_cast<const Lift *>(a.C[g]) + ((size_t)t * L + limb) * (size_t)n);
       for (int pp = threadIdx.x; pp < (n >> 1); pp += blockDim.x) {
-        const double2 v = src[pp];
+        const LiftPair<Lift> v = src[pp];
         const int pi = pidx(2 * pp);
-        s[pi] = reduce(v.x, mod);
-        s[pnext(pi)] = reduce(v.y, mod);
+        s[pi] = to_mont(lift_residue(v.x, mod), mod);
+        s[pnext(pi)] = to_mont(lift_residue(v.y, mod), mod);
       }
       __syncthreads();
       lds_ntt_fwd(s, logn, tab.d_tw, 1, mod, tab.fwd_red_mask);
@@ -234,7 +255,7 @@ mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff
         const int pp = threadIdx.x + k * blockDim.x;
         if (pp < (n >> 1)) {
           const int pi = pidx(2 * pp);
-          double u0 = s[pi], u1 = s[pnext(pi)];
+          T u0 = s[pi], u1 = s[pnext(pi)];
           if (a.reduce_u) {
             u0 = reduce(u0, mod);
             u1 = reduce(u1, mod);
@@ -246,8 +267,8 @@ mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff
               const uint64_t *ct = a.crs[cc] + (size_t)t * enc_words + (((size_t)limb * 2 + c) * K + j) * (size_t)n;
               const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(ct)[pp];
               const int st = cc * NG + g;
-              acc[st][c][2 * k] += mulmod(from_u64(v.x), u0, mod);
-              acc[st][c][2 * k + 1] += mulmod(from_u64(v.y), u1, mod);
+              acc[st][c][2 * k] = addm(acc[st][c][2 * k], mulmod(from_res<T>(v.x), u0, mod), mod);
+              acc[st][c][2 * k + 1] = addm(acc[st][c][2 * k + 1], mulmod(from_res<T>(v.y), u1, mod), mod);
             }
           }
         }
@@ -275,8 +296,8 @@ mac_kernel(MacArgs a, int L, int K, int logn, const NttTable *__restrict__ coeff
           uint64_t *pv = a.partial + ((size_t)chunk * a.n_sets_total + a.set_index[st]) * enc_words +
                          (((size_t)limb * 2 + c) * K + j) * (size_t)n;
           ulonglong2 o;
-          o.x = to_u64(canon(acc[st][c][2 * k], mod));
-          o.y = to_u64(canon(acc[st][c][2 * k + 1], mod));
+          o.x = to_res(canon(acc[st][c][2 * k], mod));
+          o.y = to_res(canon(acc[st][c][2 * k + 1], mod));
           reinterpret_cast<ulonglong2 *>(pv)[pp] = o;
         }
       }
@@ -457,11 +478,17 @@ reduce_kernel(const uint64_t *__restrict__ partial, uint64_t *__restrict__ out, 
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const size_t set = i / enc_words, w = i % enc_words;
-    const int j = (int)((w / (size_t)n) % (size_t)K);
-    uint64_t sum = 0;
-    for (int c = 0; c < n_chunks; c++) sum += partial[((size_t)c * n_sets + set) * enc_words + w];
-    if (add.addend[set]) sum += add.addend[set][w];
-    out[i] = sum % Qint[j];
+    const uint64_t Q = Qint[(w / (size_t)n) % (size_t)K];
+    uint64_t sum = 0;  // modular running sum: residues may be 61 bits wide, a plain sum of many of them would wrap
+    for (int c = 0; c < n_chunks; c++) {
+      sum += partial[((size_t)c * n_sets + set) * enc_words + w];
+      sum = sum >= Q ? sum - Q : sum;
+    }
+    if (add.addend[set]) {
+      sum += add.addend[set][w];
+      sum = sum >= Q ? sum - Q : sum;
+    }
+    out[i] = sum;
   }
 }
 
@@ -488,22 +515,40 @@ enc_reduce_kernel(uint64_t *__restrict__ x, size_t words, int n, int K, const ui
 static int tile_threads(int logn) { return std::max(64, std::min(1024, (1 << logn) >> 3)); }
 
 struct MsmScratch {
-  NttTable *d_plain_tabs = nullptr, *d_coeff_tabs = nullptr;
+  void *d_plain_tabs = nullptr, *d_coeff_tabs = nullptr;  // device copies of the context's tables (NttTable or NttTableI)
   uint64_t *d_Qint = nullptr;
+  template <class M>
+  const NttTableT<typename ArithOf<M>::T, M> *plain() const {
+    return static_cast<const NttTableT<typename ArithOf<M>::T, M> *>(d_plain_tabs);
+  }
+  template <class M>
+  const NttTableT<typename ArithOf<M>::T, M> *coeff() const {
+    return static_cast<const NttTableT<typename ArithOf<M>::T, M> *>(d_coeff_tabs);
+  }
 };
 
 static std::map<rs_ctx *, MsmScratch> g_scratch;
 static std::mutex g_scratch_mu;
 
+template <class Table>
+static void *copy_tables(const Table *h, int n) {
+  void *d = nullptr;
+  RS_HIP(hipMalloc(&d, sizeof(Table) * n));
+  RS_HIP(hipMemcpy(d, h, sizeof(Table) * n, hipMemcpyHostToDevice));
+  return d;
+}
 static MsmScratch &scratch_for(rs_ctx *ctx) {
   std::lock_guard<std::mutex> lk(g_scratch_mu);
   auto it = g_scratch.find(ctx);
   if (it != g_scratch.end()) return it->second;
   MsmScratch sc;
-  RS_HIP(hipMalloc(&sc.d_plain_tabs, sizeof(NttTable) * ctx->L));
-  RS_HIP(hipMemcpy(sc.d_plain_tabs, ctx->plain, sizeof(NttTable) * ctx->L, hipMemcpyHostToDevice));
-  RS_HIP(hipMalloc(&sc.d_coeff_tabs, sizeof(NttTable) * ctx->K));
-  RS_HIP(hipMemcpy(sc.d_coeff_tabs, ctx->coeff, sizeof(NttTable) * ctx->K, hipMemcpyHostToDevice));
+  if (ctx->use_int) {
+    sc.d_plain_tabs = copy_tables(ctx->plain_i, ctx->L);
+    sc.d_coeff_tabs = copy_tables(ctx->coeff_i, ctx->K);
+  } else {
+    sc.d_plain_tabs = copy_tables(ctx->plain, ctx->L);
+    sc.d_coeff_tabs = copy_tables(ctx->coeff, ctx->K);
+  }
   RS_HIP(hipMalloc(&sc.d_Qint, sizeof(uint64_t) * ctx->K));
   RS_HIP(hipMemcpy(sc.d_Qint, ctx->Q, sizeof(uint64_t) * ctx->K, hipMemcpyHostToDevice));
   return g_scratch[ctx] = sc;
@@ -518,14 +563,14 @@ void msm_scratch_release(rs_ctx *ctx) {
   g_scratch.erase(it);
 }
 
-template <int NG, int NC, int PAIRS>
+template <int NG, int NC, int PAIRS, class M>
 static void launch_mac(rs_ctx *ctx, const MacArgs &a, const MsmScratch &sc, hipStream_t st) {
   const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(double);
   const int rows = a.n_chunks * ctx->L;
   const unsigned blocks = (unsigned)(((rows + 7) / 8) * 8 * ctx->K);
-  RS_HIP(hipFuncSetAttribute((const void *)mac_kernel<NG, NC, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((mac_kernel<NG, NC, PAIRS>), dim3(blocks), dim3(tile_threads(ctx->logN_enc)), lds, st, a, ctx->L,
-                     ctx->K, ctx->logN_enc, sc.d_coeff_tabs);
+  RS_HIP(hipFuncSetAttribute((const void *)mac_kernel<NG, NC, PAIRS, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((mac_kernel<NG, NC, PAIRS, M>), dim3(blocks), dim3(tile_threads(ctx->logN_enc)), lds, st, a, ctx->L,
+                     ctx->K, ctx->logN_enc, sc.template coeff<M>());
   RS_HIP(hipGetLastError());
 }
 
@@ -536,7 +581,7 @@ static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, 
   const unsigned blocks = (unsigned)(((rows + 7) / 8) * 8 * ctx->K);
   if (g_mac_variant == 3 && ctx->logN_enc == 13) {  // 16 waves of 128 VGPRs (4 waves per SIMD), plaintext row not prefetched
     RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<1024, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((mac_kernel_v2<1024, 13>), dim3(blocks), dim3(1024), lds, st, a, ctx->L, ctx->K, ctx->logN_enc, sc.d_coeff_tabs);
+    hipLaunchKernelGGL((mac_kernel_v2<1024, 13>), dim3(blocks), dim3(1024), lds, st, a, ctx->L, ctx->K, ctx->logN_enc, sc.coeff<Mod>());
     RS_HIP(hipGetLastError());
     return;
   }
@@ -546,7 +591,7 @@ static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, 
     RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<512, 13, AB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                (int)lds));                                                                           \
     hipLaunchKernelGGL((mac_kernel_v2<512, 13, AB>), dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K,             \
-                       ctx->logN_enc, sc.d_coeff_tabs);                                                               \
+                       ctx->logN_enc, sc.coeff<Mod>());                                                               \
   } while (0)
 #ifdef RS_EXPERIMENTS  // timing-only ablations (wrong results): never part of the release library
     switch (g_mac_ablate) {
@@ -563,7 +608,7 @@ static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, 
     return;
   }
   RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(mac_kernel_v2<512>, dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K, ctx->logN_enc, sc.d_coeff_tabs);
+  hipLaunchKernelGGL(mac_kernel_v2<512>, dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K, ctx->logN_enc, sc.coeff<Mod>());
   RS_HIP(hipGetLastError());
 }
 
@@ -574,9 +619,12 @@ int g_mac_variant = 3;  // 3: streaming kernel, 1024-thread shape at N_enc = 819
 // elements added to the result (pk.alpha / pk.beta of groth16.tcc:95,103).
 // crs_window != 0: every CRS vector is stored as `crs_window` consecutive elements and logical
 // element t lives at index t % crs_window (tiled keys, see ringsnark_amd.h); tiles never straddle the wrap.
-void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
-             int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st,
-             size_t crs_window) {
+template <class M>
+static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
+                          int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st,
+                          size_t crs_window) {
+  using Lift = typename ArithOf<M>::Lift;
+  constexpr bool FP = std::is_same<M, Mod>::value;
   RS_REQUIRE(n_crs >= 1 && n_crs <= 2, "n_crs must be 1 or 2");
   RS_REQUIRE(n_groups >= 1 && n_groups <= MAX_GROUPS, "too many groups");
   RS_REQUIRE(n_crs * n_groups <= 12, "too many outputs");
@@ -641,7 +689,7 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
   auto crs_at = [&](int c, size_t t0) { return d_crs[c] + (crs_window ? t0 % crs_window : t0) * enc_words; };
   int n_chunks = (int)std::min<size_t>(tile_terms, (size_t)std::max(1, (768 + L * K - 1) / (L * K)));
   if (Tmax == 0) n_chunks = 1;
-  double *d_C = (double *)ws_get(ctx, 0, std::max<size_t>(256, tile_terms * c_bytes_per_term));
+  Lift *d_C = (Lift *)ws_get(ctx, 0, std::max<size_t>(256, tile_terms * c_bytes_per_term));
   uint64_t *d_partial = (uint64_t *)ws_get(ctx, 1, (size_t)n_chunks * n_sets * enc_words * sizeof(uint64_t));
   const size_t lds = padded_len((size_t)n) * sizeof(double);
   const int thr = tile_threads(ctx->logN_enc);
@@ -649,12 +697,11 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
   const bool plain16 = n >= 2048;  // 16 coefficients per thread, wave-private inverse transform
   const int plain_thr = plain16 ? n / 16 : thr;
   const bool plain13 = false;  // measured: no gain from a compile-time length here
-  if (plain13)
-    RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<16, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  else if (plain16)
-    RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  (void)plain13;
+  if (plain16)
+    RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<16, 0, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   else
-    RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<8, 0, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
   // rooflines: per (term, limb) a plaintext row costs one inverse transform of
   // length n, the batching scatter and the centred lift; per (term, limb, prime) the MAC reads two
@@ -670,18 +717,14 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
     {
     ProfScope prof_plain(ctx, st, "plain_center_kernel", rows_in * (double)ctx->N * 8.0 + (double)tt * L * n_groups * nd * 8.0,
                          rows_in * (ntt_fp64(nd, logn_d) + 14.0 * nd));
-    if (plain13)
-      hipLaunchKernelGGL((plain_center_kernel<16, 13>), dim3((unsigned)tt, L, n_groups), dim3(plain_thr), lds, st, pa, d_C,
+    if (plain16)
+      hipLaunchKernelGGL((plain_center_kernel<16, 0, M>), dim3((unsigned)tt, L, n_groups), dim3(plain_thr), lds, st, pa, d_C,
                          (unsigned long long)t0, (unsigned long long)tile_terms, ctx->N, L, ctx->logN_enc,
-                         ctx->d_index_map, sc.d_plain_tabs);
-    else if (plain16)
-      hipLaunchKernelGGL(plain_center_kernel<16>, dim3((unsigned)tt, L, n_groups), dim3(plain_thr), lds, st, pa, d_C,
-                         (unsigned long long)t0, (unsigned long long)tile_terms, ctx->N, L, ctx->logN_enc,
-                         ctx->d_index_map, sc.d_plain_tabs);
+                         ctx->d_index_map, sc.template plain<M>());
     else
-      hipLaunchKernelGGL(plain_center_kernel<8>, dim3((unsigned)tt, L, n_groups), dim3(thr), lds, st, pa, d_C,
+      hipLaunchKernelGGL((plain_center_kernel<8, 0, M>), dim3((unsigned)tt, L, n_groups), dim3(thr), lds, st, pa, d_C,
                          (unsigned long long)t0, (unsigned long long)tile_terms, ctx->N, L, ctx->logN_enc,
-                         ctx->d_index_map, sc.d_plain_tabs);
+                         ctx->d_index_map, sc.template plain<M>());
     }
     RS_HIP(hipGetLastError());
     MacArgs base;
@@ -716,23 +759,23 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
                      (double)tt * NC * (double)enc_words * 8.0 + units * nd * 8.0 / K + (double)NG * NC * (double)enc_words * 8.0,
                      units * (ntt_fp64(nd, logn_d) + NC * 15.0 * nd));
       if (big)
-        launch_mac<1, 1, 8>(ctx, a, sc, st);
+        launch_mac<1, 1, 8, M>(ctx, a, sc, st);
       else if (NG == 2 && NC == 1)
-        launch_mac<2, 1, 4>(ctx, a, sc, st);
+        launch_mac<2, 1, 4, M>(ctx, a, sc, st);
       else if (NG == 1 && NC == 2)
-        launch_mac<1, 2, 4>(ctx, a, sc, st);
+        launch_mac<1, 2, 4, M>(ctx, a, sc, st);
       else
-        launch_mac<1, 1, 4>(ctx, a, sc, st);
+        launch_mac<1, 1, 4, M>(ctx, a, sc, st);
     };
     // streaming kernel, one accumulator set (CRS vector c, group g) per launch.  With two CRS
     // vectors (Rinocchio's s_pows / alpha_s_pows) the plaintext transform is repeated per vector:
     // measured faster than the generic kernel that shares it (g_mac_variant == 2: generic for n_crs == 2).
-    const bool v2 = g_mac_variant >= 2 && (n_crs == 1 || g_mac_variant != 2) && n >= 2048 && n <= 8192;
+    const bool v2 = FP && g_mac_variant >= 2 && (n_crs == 1 || g_mac_variant != 2) && n >= 2048 && n <= 8192;
     if (v2) {
       for (int c = 0; c < n_crs; c++)
       for (int g = 0; g < n_groups; g++) {
         MacArgs2 a2;
-        a2.C = Cptr(g);
+        a2.C = reinterpret_cast<const double *>(Cptr(g));
         a2.terms = group_terms(g);
         a2.crs = crs_at(c, t0);
         a2.partial = d_partial + (size_t)(c * n_groups + g) * enc_words;
@@ -799,6 +842,13 @@ void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_le
   }
 }
 
+void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
+             int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st,
+             size_t crs_window) {
+  RS_DISPATCH_ARITH(ctx, (msm_run_arith<Mod>(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, addends, h_used, st, crs_window)),
+                    (msm_run_arith<ModI>(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, addends, h_used, st, crs_window)));
+}
+
 void enc_add_run(rs_ctx *ctx, uint64_t *dst, const uint64_t *x, const uint64_t *y, size_t count, hipStream_t st) {
   const size_t words = count * ctx->enc_words();
   if (!words) return;
@@ -820,9 +870,15 @@ int rs_batch_encode(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, siz
   if (count) {
     MsmScratch &sc = scratch_for(ctx);
     const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(double);
-    RS_HIP(hipFuncSetAttribute((const void *)batch_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(batch_encode_kernel, dim3((unsigned)count, ctx->L), dim3(tile_threads(ctx->logN_enc)), lds,
-                       S(stream), d_rings, d_plain, ctx->N, ctx->L, ctx->logN_enc, ctx->d_index_map, sc.d_plain_tabs);
+    if (ctx->use_int) {
+      RS_HIP(hipFuncSetAttribute((const void *)batch_encode_kernel<ModI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(batch_encode_kernel<ModI>, dim3((unsigned)count, ctx->L), dim3(tile_threads(ctx->logN_enc)), lds,
+                         S(stream), d_rings, d_plain, ctx->N, ctx->L, ctx->logN_enc, ctx->d_index_map, sc.plain<ModI>());
+    } else {
+      RS_HIP(hipFuncSetAttribute((const void *)batch_encode_kernel<Mod>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(batch_encode_kernel<Mod>, dim3((unsigned)count, ctx->L), dim3(tile_threads(ctx->logN_enc)), lds,
+                         S(stream), d_rings, d_plain, ctx->N, ctx->L, ctx->logN_enc, ctx->d_index_map, sc.plain<Mod>());
+    }
     RS_HIP(hipGetLastError());
   }
   RS_API_END

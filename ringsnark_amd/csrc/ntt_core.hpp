@@ -16,7 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "f64mod.hpp"
+#include "intmod.hpp"
 
 namespace rs {
 
@@ -68,12 +68,15 @@ constexpr int LDS_BLOCK_MIN = RS_LDS_SWIZZLE ? 256 : 128;
 // elements as base + e*step; for the LDS tile the mapped address splits into
 // pcomb(pidx(base), poff(e)) with poff uniform across the wave (round_poff below), so an access
 // costs one vector op; functors over global memory just use base + e*step.
-struct LdsIO {
-  double *s;
+// T: the value type of the arithmetic (double for f64mod.hpp, uint64_t for intmod.hpp)
+template <class T>
+struct LdsIOT {
+  T *s;
   __device__ __forceinline__ int pbase(int base) const { return pidx(base); }
-  __device__ __forceinline__ double load(int, int pb, int, int poff) const { return s[pcomb(pb, poff)]; }
-  __device__ __forceinline__ void store(int, int pb, int, int poff, double v) const { s[pcomb(pb, poff)] = v; }
+  __device__ __forceinline__ T load(int, int pb, int, int poff) const { return s[pcomb(pb, poff)]; }
+  __device__ __forceinline__ void store(int, int pb, int, int poff, T v) const { s[pcomb(pb, poff)] = v; }
 };
+using LdsIO = LdsIOT<double>;
 // mapped offset of element offset eoff = e*step inside a radix group of E elements
 __device__ __forceinline__ int round_poff(int eoff, int step, int E) {
 #if RS_LDS_SWIZZLE
@@ -112,9 +115,10 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int R, class In, class Out>
+// T, M: value and modulus type of the arithmetic, deduced from the twiddle table and the modulus
+template <int R, class In, class Out, class T, class M>
 __device__ __forceinline__ void fwd_round(const In in, const Out out, int logtot, int logsub, int s0,
-                                          const double *__restrict__ tw, int root, const Mod mod,
+                                          const T *__restrict__ tw, int root, const M mod,
                                           uint32_t red_mask, const Lanes ln = block_lanes()) {
   constexpr int E = 1 << R;
   const int lstep = logsub - s0 - R;  // log2 of the smallest gap in this round
@@ -128,7 +132,7 @@ __device__ __forceinline__ void fwd_round(const In in, const Out out, int logtot
     const int lo = grp & (sstep - 1), hi_all = grp >> lstep;
     const int hi = hi_all & ((1 << s0) - 1);
     const int base = (hi_all << (logsub - s0)) + lo;
-    double v[E];
+    T v[E];
     const int pbi = in.pbase(base), pbo = out.pbase(base);
 #pragma unroll
     for (int e = 0; e < E; e++) v[e] = in.load(base, pbi, e * sstep, round_poff(e * sstep, sstep, E));
@@ -142,14 +146,14 @@ __device__ __forceinline__ void fwd_round(const In in, const Out out, int logtot
       const int twbase = ((1 << (s0 + k)) * root) + (hi << k);
 #pragma unroll
       for (int blk = 0; blk < (1 << k); blk++) {
-        const double w = tw[twbase + blk];
+        const T w = tw[twbase + blk];
 #pragma unroll
         for (int e0 = 0; e0 < half; e0++) {
           const int ia = blk * 2 * half + e0, ib = ia + half;
-          const double t = mulmod(v[ib], w, mod);
-          const double a = v[ia];
-          v[ia] = a + t;
-          v[ib] = a - t;
+          const T t = mulmod(v[ib], w, mod);
+          const T a = v[ia];
+          v[ia] = addm(a, t, mod);
+          v[ib] = subm(a, t, mod);
         }
       }
     }
@@ -158,9 +162,9 @@ __device__ __forceinline__ void fwd_round(const In in, const Out out, int logtot
   }
 }
 
-template <int MAXR, class In, class Out>
+template <int MAXR, class In, class Out, class T, class M>
 __device__ __forceinline__ void fwd_round_dispatch(int R, const In in, const Out out, int logtot, int logsub, int s0,
-                                                   const double *__restrict__ tw, int root, const Mod mod,
+                                                   const T *__restrict__ tw, int root, const M mod,
                                                    uint32_t red_mask, const Lanes ln = block_lanes()) {
   if (MAXR >= 5 && R == 5)
     fwd_round<(MAXR >= 5 ? 5 : 1)>(in, out, logtot, logsub, s0, tw, root, mod, red_mask, ln);
@@ -177,11 +181,11 @@ __device__ __forceinline__ void fwd_round_dispatch(int R, const In in, const Out
 // Whole forward transform(s) of the LDS tile; ends with a barrier.  Caller must have synchronised
 // after filling the tile.  first_in / last_out replace the LDS tile for the first round's loads
 // and the last round's stores.
-template <int MAXR, class In, class Out>
-__device__ __forceinline__ void lds_ntt_fwd_io(double *s, const In first_in, const Out last_out, int logtot, int logsub,
-                                               const double *__restrict__ tw, int root, const Mod mod,
+template <int MAXR, class In, class Out, class T, class M>
+__device__ __forceinline__ void lds_ntt_fwd_io(T *s, const In first_in, const Out last_out, int logtot, int logsub,
+                                               const T *__restrict__ tw, int root, const M mod,
                                                uint32_t red_mask) {
-  const LdsIO lds{s};
+  const LdsIOT<T> lds{s};
   int st = 0;
   while (st < logsub) {
     const int R = pick_radix(logsub - st, MAXR);
@@ -198,24 +202,24 @@ __device__ __forceinline__ void lds_ntt_fwd_io(double *s, const In first_in, con
     st += R;
   }
 }
-template <int MAXR = 3>
-__device__ __forceinline__ void lds_ntt_fwd(double *s, int logn, const double *__restrict__ tw, int root,
-                                            const Mod mod, uint32_t red_mask) {
-  const LdsIO lds{s};
+template <int MAXR = 3, class T, class M>
+__device__ __forceinline__ void lds_ntt_fwd(T *s, int logn, const T *__restrict__ tw, int root,
+                                            const M mod, uint32_t red_mask) {
+  const LdsIOT<T> lds{s};
   lds_ntt_fwd_io<MAXR>(s, lds, lds, logn, logn, tw, root, mod, red_mask);
 }
-template <int MAXR = 3>
-__device__ __forceinline__ void lds_bntt_fwd(double *s, int logtot, int logsub, const double *__restrict__ tw,
-                                             const Mod mod, uint32_t red_mask) {
-  const LdsIO lds{s};
+template <int MAXR = 3, class T, class M>
+__device__ __forceinline__ void lds_bntt_fwd(T *s, int logtot, int logsub, const T *__restrict__ tw,
+                                             const M mod, uint32_t red_mask) {
+  const LdsIOT<T> lds{s};
   lds_ntt_fwd_io<MAXR>(s, lds, lds, logtot, logsub, tw, 1, mod, red_mask);
 }
 
 // ---- inverse (Gentleman-Sande, bit-reversed in -> natural out, NOT scaled by n^-1) -----------
 // inverse stage u (0-based) has gap 2^u and n >> (u+1) groups; (a, b) -> (a + b, (a - b)*w).
-template <int R, class In, class Out>
+template <int R, class In, class Out, class T, class M>
 __device__ __forceinline__ void inv_round(const In in, const Out out, int logtot, int logsub, int u0,
-                                          const double *__restrict__ itw, int root, const Mod mod,
+                                          const T *__restrict__ itw, int root, const M mod,
                                           uint32_t red_mask, const Lanes ln = block_lanes()) {
   constexpr int E = 1 << R;
   const int g0_ = 1 << u0;
@@ -227,7 +231,7 @@ __device__ __forceinline__ void inv_round(const In in, const Out out, int logtot
     const int lo = grp & (g0 - 1), hi_all = grp >> u0;
     const int hi = hi_all & ((1 << gpb_log) - 1);
     const int base = (hi_all << (u0 + R)) + lo;
-    double v[E];
+    T v[E];
     const int pbi = in.pbase(base), pbo = out.pbase(base);
 #pragma unroll
     for (int e = 0; e < E; e++) v[e] = in.load(base, pbi, e * g0, round_poff(e * g0, g0, E));
@@ -237,15 +241,15 @@ __device__ __forceinline__ void inv_round(const In in, const Out out, int logtot
 #pragma unroll
         for (int e = 0; e < E; e++) v[e] = reduce(v[e], mod);
       }
-      const int M = (1 << logsub) >> (u0 + k + 1);
-      const int twbase = M * root + (hi << (R - 1 - k));
+      const int Mg = (1 << logsub) >> (u0 + k + 1);
+      const int twbase = Mg * root + (hi << (R - 1 - k));
 #pragma unroll
       for (int e = 0; e < E; e++) {
         if (e & (1 << k)) continue;
-        const double w = itw[twbase + (e >> (k + 1))];
-        const double a = v[e], b = v[e + (1 << k)];
-        v[e] = a + b;
-        v[e + (1 << k)] = mulmod(a - b, w, mod);
+        const T w = itw[twbase + (e >> (k + 1))];
+        const T a = v[e], b = v[e + (1 << k)];
+        v[e] = addm(a, b, mod);
+        v[e + (1 << k)] = mulmod(subm(a, b, mod), w, mod);
       }
     }
 #pragma unroll
@@ -253,9 +257,9 @@ __device__ __forceinline__ void inv_round(const In in, const Out out, int logtot
   }
 }
 
-template <int MAXR, class In, class Out>
+template <int MAXR, class In, class Out, class T, class M>
 __device__ __forceinline__ void inv_round_dispatch(int R, const In in, const Out out, int logtot, int logsub, int u0,
-                                                   const double *__restrict__ itw, int root, const Mod mod,
+                                                   const T *__restrict__ itw, int root, const M mod,
                                                    uint32_t red_mask, const Lanes ln = block_lanes()) {
   if (MAXR >= 5 && R == 5)
     inv_round<(MAXR >= 5 ? 5 : 1)>(in, out, logtot, logsub, u0, itw, root, mod, red_mask, ln);
@@ -269,11 +273,11 @@ __device__ __forceinline__ void inv_round_dispatch(int R, const In in, const Out
     inv_round<1>(in, out, logtot, logsub, u0, itw, root, mod, red_mask, ln);
 }
 
-template <int MAXR, class In, class Out>
-__device__ __forceinline__ void lds_ntt_inv_io(double *s, const In first_in, const Out last_out, int logtot, int logsub,
-                                               const double *__restrict__ itw, int root, const Mod mod,
+template <int MAXR, class In, class Out, class T, class M>
+__device__ __forceinline__ void lds_ntt_inv_io(T *s, const In first_in, const Out last_out, int logtot, int logsub,
+                                               const T *__restrict__ itw, int root, const M mod,
                                                uint32_t red_mask) {
-  const LdsIO lds{s};
+  const LdsIOT<T> lds{s};
   int st = 0;
   while (st < logsub) {
     const int R = pick_radix(logsub - st, MAXR);
@@ -290,16 +294,16 @@ __device__ __forceinline__ void lds_ntt_inv_io(double *s, const In first_in, con
     st += R;
   }
 }
-template <int MAXR = 3>
-__device__ __forceinline__ void lds_ntt_inv(double *s, int logn, const double *__restrict__ itw, int root,
-                                            const Mod mod, uint32_t red_mask) {
-  const LdsIO lds{s};
+template <int MAXR = 3, class T, class M>
+__device__ __forceinline__ void lds_ntt_inv(T *s, int logn, const T *__restrict__ itw, int root,
+                                            const M mod, uint32_t red_mask) {
+  const LdsIOT<T> lds{s};
   lds_ntt_inv_io<MAXR>(s, lds, lds, logn, logn, itw, root, mod, red_mask);
 }
-template <int MAXR = 3>
-__device__ __forceinline__ void lds_bntt_inv(double *s, int logtot, int logsub, const double *__restrict__ itw,
-                                             const Mod mod, uint32_t red_mask) {
-  const LdsIO lds{s};
+template <int MAXR = 3, class T, class M>
+__device__ __forceinline__ void lds_bntt_inv(T *s, int logtot, int logsub, const T *__restrict__ itw,
+                                             const M mod, uint32_t red_mask) {
+  const LdsIOT<T> lds{s};
   lds_ntt_inv_io<MAXR>(s, lds, lds, logtot, logsub, itw, 1, mod, red_mask);
 }
 

@@ -12,21 +12,23 @@
 namespace rs {
 
 // out[k] = sum_i a[i] * b[k - i], one thread per (k, slot pair)
+template <class M>
 __global__ void __launch_bounds__(256)
 poly_mul_kernel(const uint64_t *__restrict__ a, size_t na, const uint64_t *__restrict__ b, size_t nb, uint64_t *__restrict__ out,
-                int N, int L, const Mod *__restrict__ qmod) {
+                int N, int L, const M *__restrict__ qmod) {
+  using T = typename ArithOf<M>::T;
   const size_t S = (size_t)L * N, k = blockIdx.x;
   const size_t pair = (size_t)blockIdx.y * blockDim.x + threadIdx.x;
   if (2 * pair >= S) return;
-  const Mod mod = qmod[(2 * pair) / (size_t)N];
+  const M mod = qmod[(2 * pair) / (size_t)N];
   const size_t i0 = k >= nb ? k - nb + 1 : 0, i1 = std::min(k, na - 1);
-  double a0 = 0.0, a1 = 0.0;
+  T a0 = T(0), a1 = T(0);
   int since = 0;
   for (size_t i = i0; i <= i1; i++) {
     const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(a + i * S)[pair];
     const ulonglong2 y = reinterpret_cast<const ulonglong2 *>(b + (k - i) * S)[pair];
-    a0 += mulmod(from_u64(x.x), center(from_u64(y.x), mod), mod);
-    a1 += mulmod(from_u64(x.y), center(from_u64(y.y), mod), mod);
+    a0 = addm(a0, mulmod_dd(from_res<T>(x.x), center(from_res<T>(y.x), mod), mod), mod);
+    a1 = addm(a1, mulmod_dd(from_res<T>(x.y), center(from_res<T>(y.y), mod), mod), mod);
     if (++since == 4) {
       since = 0;
       a0 = reduce(a0, mod);
@@ -34,39 +36,44 @@ poly_mul_kernel(const uint64_t *__restrict__ a, size_t na, const uint64_t *__res
     }
   }
   ulonglong2 o;
-  o.x = to_u64(canon(a0, mod));
-  o.y = to_u64(canon(a1, mod));
+  o.x = to_res(canon(a0, mod));
+  o.y = to_res(canon(a1, mod));
   reinterpret_cast<ulonglong2 *>(out + k * S)[pair] = o;
 }
 
 // Long division per slot: rem (a copy of the numerator, nn rows) is reduced in place, quot gets nn - nd + 1
 // rows.  lead_inv: inverse of the divisor's leading coefficient [L][N].  One thread per slot.
+template <class M>
 __global__ void __launch_bounds__(256)
 poly_div_kernel(uint64_t *__restrict__ rem, size_t nn, const uint64_t *__restrict__ den, size_t nd,
-                const uint64_t *__restrict__ lead_inv, uint64_t *__restrict__ quot, int N, int L, const Mod *__restrict__ qmod) {
+                const uint64_t *__restrict__ lead_inv, uint64_t *__restrict__ quot, int N, int L, const M *__restrict__ qmod) {
+  using T = typename ArithOf<M>::T;
   const size_t S = (size_t)L * N, sl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (sl >= S) return;
-  const Mod mod = qmod[sl / (size_t)N];
-  const double li = center(from_u64(lead_inv[sl]), mod);
+  const M mod = qmod[sl / (size_t)N];
+  const T li = to_mont(center(from_res<T>(lead_inv[sl]), mod), mod);  // used as a multiplier below
   for (size_t k = nn - nd + 1; k-- > 0;) {
-    const double qk = reduce(mulmod(center(from_u64(rem[(k + nd - 1) * S + sl]), mod), li, mod), mod);
-    quot[k * S + sl] = to_u64(canon(qk, mod));
+    const T qk = reduce(mulmod(center(from_res<T>(rem[(k + nd - 1) * S + sl]), mod), li, mod), mod);
+    quot[k * S + sl] = to_res(canon(qk, mod));
+    const T qk_m = to_mont(qk, mod);
     for (size_t j = 0; j < nd; j++) {
-      const double r = from_u64(rem[(k + j) * S + sl]) - mulmod(qk, center(from_u64(den[j * S + sl]), mod), mod);
-      rem[(k + j) * S + sl] = to_u64(canon(r, mod));
+      const T r = subm(from_res<T>(rem[(k + j) * S + sl]), mulmod(center(from_res<T>(den[j * S + sl]), mod), qk_m, mod), mod);
+      rem[(k + j) * S + sl] = to_res(canon(r, mod));
     }
   }
 }
 
+template <class M>
 __global__ void __launch_bounds__(256)
 poly_add_kernel(const uint64_t *__restrict__ a, size_t na, const uint64_t *__restrict__ b, size_t nb, uint64_t *__restrict__ out,
-                size_t S, int N, int L, const Mod *__restrict__ qmod) {
+                size_t S, int N, int L, const M *__restrict__ qmod) {
+  using T = typename ArithOf<M>::T;
   const size_t rows = std::max(na, nb), total = rows * S, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const size_t r = i / S, sl = i % S;
-    const Mod mod = qmod[sl / (size_t)N];
-    const double x = r < na ? from_u64(a[i]) : 0.0, y = r < nb ? from_u64(b[i]) : 0.0;
-    out[i] = to_u64(canon(x + y, mod));
+    const M mod = qmod[sl / (size_t)N];
+    const T x = r < na ? from_res<T>(a[i]) : T(0), y = r < nb ? from_res<T>(b[i]) : T(0);
+    out[i] = to_res(canon(addm(x, y, mod), mod));
   }
 }
 
@@ -111,7 +118,10 @@ int rs_poly_multiply(rs_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t
   if (na && nb) {
     const size_t rows = na + nb - 1;
     const unsigned by = (unsigned)((S_ / 2 + 255) / 256);
-    hipLaunchKernelGGL(poly_mul_kernel, dim3((unsigned)rows, by), dim3(256), 0, st, d_a, na, d_b, nb, d_out, ctx->N, ctx->L, ctx->d_qmod);
+    if (ctx->use_int)
+      hipLaunchKernelGGL(poly_mul_kernel<ModI>, dim3((unsigned)rows, by), dim3(256), 0, st, d_a, na, d_b, nb, d_out, ctx->N, ctx->L, ctx->d_qmod_i);
+    else
+      hipLaunchKernelGGL(poly_mul_kernel<Mod>, dim3((unsigned)rows, by), dim3(256), 0, st, d_a, na, d_b, nb, d_out, ctx->N, ctx->L, ctx->d_qmod);
     RS_HIP(hipGetLastError());
     len = normalised_len(ctx, d_out, rows, st);
   }
@@ -128,7 +138,10 @@ int rs_poly_add(rs_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t *d_b
   const size_t rows = std::max(na, nb), S_ = ctx->ring_words();
   if (rows) {
     const unsigned blocks = (unsigned)std::min<size_t>((rows * S_ + 255) / 256, 4096);
-    hipLaunchKernelGGL(poly_add_kernel, dim3(blocks), dim3(256), 0, st, d_a, na, d_b, nb, d_out, S_, ctx->N, ctx->L, ctx->d_qmod);
+    if (ctx->use_int)
+      hipLaunchKernelGGL(poly_add_kernel<ModI>, dim3(blocks), dim3(256), 0, st, d_a, na, d_b, nb, d_out, S_, ctx->N, ctx->L, ctx->d_qmod_i);
+    else
+      hipLaunchKernelGGL(poly_add_kernel<Mod>, dim3(blocks), dim3(256), 0, st, d_a, na, d_b, nb, d_out, S_, ctx->N, ctx->L, ctx->d_qmod);
     RS_HIP(hipGetLastError());
   }
   if (h_len) *h_len = normalised_len(ctx, d_out, rows, st);
@@ -166,8 +179,12 @@ int rs_poly_divide(rs_ctx *ctx, const uint64_t *d_num, size_t nn, const uint64_t
     RS_HIP(hipMalloc(&rem, nn * S_ * sizeof(uint64_t)));
     guard.b = rem;
     RS_HIP(hipMemcpyAsync(rem, d_num, nn * S_ * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(poly_div_kernel, dim3((unsigned)((S_ + 255) / 256)), dim3(256), 0, st, rem, nn, d_den, nd, lead_inv, d_quot,
-                       ctx->N, ctx->L, ctx->d_qmod);
+    if (ctx->use_int)
+      hipLaunchKernelGGL(poly_div_kernel<ModI>, dim3((unsigned)((S_ + 255) / 256)), dim3(256), 0, st, rem, nn, d_den, nd, lead_inv, d_quot,
+                         ctx->N, ctx->L, ctx->d_qmod_i);
+    else
+      hipLaunchKernelGGL(poly_div_kernel<Mod>, dim3((unsigned)((S_ + 255) / 256)), dim3(256), 0, st, rem, nn, d_den, nd, lead_inv, d_quot,
+                         ctx->N, ctx->L, ctx->d_qmod);
     RS_HIP(hipGetLastError());
     WsScope ws_scope(ctx, st);
     len = normalised_len(ctx, d_quot, nn - nd + 1, st);  // synchronises: rem / lead_inv may be freed

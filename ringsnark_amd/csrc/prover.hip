@@ -68,16 +68,18 @@ fill_uniform_kernel(uint64_t *__restrict__ dst, size_t words, size_t inner, int 
 }
 
 // x_{i+2} = x_i * x_{i+1}; one thread per slot, values carried in registers.
+template <class M>
 __global__ void __launch_bounds__(256)
-chain_kernel(uint64_t *__restrict__ asg, size_t m, int N, int L, const Mod *__restrict__ qmod) {
+chain_kernel(uint64_t *__restrict__ asg, size_t m, int N, int L, const M *__restrict__ qmod) {
+  using T = typename ArithOf<M>::T;
   const size_t S = (size_t)L * N;
   const size_t sl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (sl >= S) return;
-  const Mod mod = qmod[sl / (size_t)N];
-  double a = center(from_u64(asg[sl]), mod), b = center(from_u64(asg[S + sl]), mod);
+  const M mod = qmod[sl / (size_t)N];
+  T a = center(from_res<T>(asg[sl]), mod), b = center(from_res<T>(asg[S + sl]), mod);
   for (size_t i = 0; i < m; i++) {
-    const double c = reduce(mulmod(a, b, mod), mod);
-    asg[(i + 2) * S + sl] = to_u64(canon(c, mod));
+    const T c = reduce(mulmod_dd(a, b, mod), mod);
+    asg[(i + 2) * S + sl] = to_res(canon(c, mod));
     a = b;
     b = c;
   }
@@ -254,8 +256,12 @@ int rs_chain_assignment(rs_ctx *ctx, uint64_t *d_assignment, size_t m, rs_stream
   RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_assignment, "null argument");
   const size_t S_ = ctx->ring_words();
-  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((S_ + 255) / 256)), dim3(256), 0, S(stream), d_assignment, m, ctx->N,
-                     ctx->L, ctx->d_qmod);
+  if (ctx->use_int)
+    hipLaunchKernelGGL(chain_kernel<ModI>, dim3((unsigned)((S_ + 255) / 256)), dim3(256), 0, S(stream), d_assignment, m, ctx->N,
+                       ctx->L, ctx->d_qmod_i);
+  else
+    hipLaunchKernelGGL(chain_kernel<Mod>, dim3((unsigned)((S_ + 255) / 256)), dim3(256), 0, S(stream), d_assignment, m, ctx->N,
+                       ctx->L, ctx->d_qmod);
   RS_HIP(hipGetLastError());
   RS_API_END
 }

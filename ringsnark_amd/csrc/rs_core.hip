@@ -102,42 +102,42 @@ uint32_t inv_reduce_mask(uint64_t p, int logn) {
   return mask;
 }
 
-static double *upload_doubles(const std::vector<double> &h) {
-  double *d = nullptr;
-  RS_HIP(hipMalloc(&d, h.size() * sizeof(double)));
-  RS_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+template <class T>
+static T *upload_words(const std::vector<T> &h) {
+  T *d = nullptr;
+  RS_HIP(hipMalloc(&d, h.size() * sizeof(T)));
+  RS_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   return d;
 }
 
 // SEAL NTTTables layout: root = minimal primitive 2n-th root psi, tw[bitrev(i)] = psi^i.
-NttTable make_negacyclic_table(uint64_t p, int logn) {
+template <class M>
+NttTableT<typename HostArith<M>::T, M> make_negacyclic_table(uint64_t p, int logn) {
   using namespace host;
-  NttTable t;
+  using T = typename HostArith<M>::T;
+  NttTableT<T, M> t;
   t.p = p;
-  t.mod = Mod{(double)p, 1.0 / (double)p};
+  t.mod = HostArith<M>::make(p);
   t.logn = logn;
   const size_t n = (size_t)1 << logn;
   const uint64_t psi = minimal_primitive_root((uint64_t)2 << logn, p);
-  std::vector<double> tw(n), itw(n);
+  std::vector<T> tw(n), itw(n);
   uint64_t pw = 1;
   for (size_t i = 0; i < n; i++) {
     const uint32_t k = bitrev((uint32_t)i, logn);
-    tw[k] = balanced(pw, p);
-    itw[k] = balanced(invmod(pw, p), p);
+    tw[k] = HostArith<M>::konst(pw, p);
+    itw[k] = HostArith<M>::konst(invmod(pw, p), p);
     pw = mulmod(pw, psi, p);
   }
-  t.d_tw = upload_doubles(tw);
-  t.d_itw = upload_doubles(itw);
-  t.ninv = balanced(invmod((uint64_t)n % p, p), p);
+  t.d_tw = upload_words(tw);
+  t.d_itw = upload_words(itw);
+  t.ninv = HostArith<M>::konst(invmod((uint64_t)n % p, p), p);
   t.fwd_red_mask = fwd_reduce_mask(p, logn);
   t.inv_red_mask = inv_reduce_mask(p, logn);
   return t;
 }
-void free_table(NttTable &t) {
-  if (t.d_tw) (void)hipFree(t.d_tw);
-  if (t.d_itw) (void)hipFree(t.d_itw);
-  t.d_tw = t.d_itw = nullptr;
-}
+template NttTable make_negacyclic_table<Mod>(uint64_t, int);
+template NttTableI make_negacyclic_table<ModI>(uint64_t, int);
 
 // ---------------------------------------------------------------------------------------------
 // a4: batched negacyclic NTT.  One workgroup per polynomial; global <-> LDS traffic is one
@@ -371,6 +371,43 @@ ntt_fwd_stream_kernel(uint64_t *__restrict__ data, unsigned long long batch, int
   }
 }
 
+// The transform for ANY arithmetic (used by the integer contexts; the FP64 contexts run the tuned variants above):
+// one workgroup per polynomial, tile in LDS, radix-8 rounds with workgroup barriers.
+template <bool INV, class T, class M>
+__global__ void __launch_bounds__(1024) ntt_generic_kernel(uint64_t *__restrict__ data, int logn, const T *__restrict__ tw, M mod,
+                                                           T ninv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T *s = reinterpret_cast<T *>(smem);
+  const int n = 1 << logn;
+  uint64_t *poly = data + (size_t)blockIdx.x * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s[pidx(i)] = from_res<T>(poly[i]);
+  __syncthreads();
+  if (INV)
+    lds_ntt_inv<3>(s, logn, tw, 1, mod, 0u);
+  else
+    lds_ntt_fwd<3>(s, logn, tw, 1, mod, 0u);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    T v = s[pidx(i)];
+    if (INV) v = mulmod(reduce(v, mod), ninv, mod);
+    poly[i] = to_res(canon(v, mod));
+  }
+}
+void launch_ntt_int(rs_ctx *ctx, const NttTableI &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st) {
+  (void)ctx;
+  if (batch == 0) return;
+  const size_t lds = padded_len((size_t)1 << t.logn) * sizeof(uint64_t);
+  const int thr = std::max(64, std::min(1024, (1 << t.logn) >> 3));
+  if (inverse) {
+    RS_HIP(hipFuncSetAttribute((const void *)ntt_generic_kernel<true, uint64_t, ModI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((ntt_generic_kernel<true, uint64_t, ModI>), dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, t.d_itw, t.mod, t.ninv);
+  } else {
+    RS_HIP(hipFuncSetAttribute((const void *)ntt_generic_kernel<false, uint64_t, ModI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((ntt_generic_kernel<false, uint64_t, ModI>), dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, t.d_tw, t.mod, t.ninv);
+  }
+  RS_HIP(hipGetLastError());
+}
+
+bool g_force_int = false;  // tuning knob "force_int_arith" (tests: both arithmetics on the same primes)
 int g_ntt_variant = 12;  // tuning knob (rs_set_tuning("ntt_variant", v)): see launch_ntt
 
 template <bool INV, int MAXR, bool DIN, bool DOUT, int THREADS>
@@ -452,58 +489,67 @@ void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, 
 // ---------------------------------------------------------------------------------------------
 enum RingOp { OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_ADD_SCALAR, OP_MUL_SCALAR };
 
-struct ScalarPerLimb {
-  double v[RS_MAX_L];
+template <class T>
+struct ScalarPerLimbT {
+  T v[RS_MAX_L];
 };
 
-template <int OP>
-__device__ __forceinline__ uint64_t ring_apply(uint64_t a, uint64_t b, double sc, const Mod m) {
-  const double x = from_u64(a);
-  double r;
+template <int OP, class M>
+__device__ __forceinline__ uint64_t ring_apply(uint64_t a, uint64_t b, typename ArithOf<M>::T sc, const M m) {
+  using T = typename ArithOf<M>::T;
+  const T x = from_res<T>(a);
+  T r;
   if (OP == OP_ADD)
-    r = x + from_u64(b);
+    r = addm(x, from_res<T>(b), m);
   else if (OP == OP_SUB)
-    r = x - from_u64(b);
+    r = subm(x, from_res<T>(b), m);
   else if (OP == OP_MUL)
-    r = mulmod(x, center(from_u64(b), m), m);
+    r = mulmod_dd(x, center(from_res<T>(b), m), m);
   else if (OP == OP_NEG)
-    r = -x;
+    r = negm(x, m);
   else if (OP == OP_ADD_SCALAR)
-    r = x + sc;
+    r = addm(x, sc, m);  // sc: the scalar's residue as a data value
   else
-    r = mulmod(x, sc, m);
-  return to_u64(canon(r, m));
+    r = mulmod(x, sc, m);  // sc: the scalar's residue as a table constant
+  return to_res(canon(r, m));
 }
 
-template <int OP>
+template <int OP, class M>
 __global__ void __launch_bounds__(256) ring_pointwise_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ a,
                                                              const uint64_t *__restrict__ b, size_t pairs, int N, int L,
-                                                             const Mod *__restrict__ qmod, ScalarPerLimb sc) {
+                                                             const M *__restrict__ qmod, ScalarPerLimbT<typename ArithOf<M>::T> sc) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
     const int limb = (int)(((2 * i) / (size_t)N) % (size_t)L);
-    const Mod m = qmod[limb];
+    const M m = qmod[limb];
     const ulonglong2 va = reinterpret_cast<const ulonglong2 *>(a)[i];
     ulonglong2 vb = va;
     if (OP == OP_ADD || OP == OP_SUB || OP == OP_MUL) vb = reinterpret_cast<const ulonglong2 *>(b)[i];
     ulonglong2 o;
-    o.x = ring_apply<OP>(va.x, vb.x, sc.v[limb], m);
-    o.y = ring_apply<OP>(va.y, vb.y, sc.v[limb], m);
+    o.x = ring_apply<OP, M>(va.x, vb.x, sc.v[limb], m);
+    o.y = ring_apply<OP, M>(va.y, vb.y, sc.v[limb], m);
     reinterpret_cast<ulonglong2 *>(dst)[i] = o;
   }
 }
 
+template <int OP, class M>
+static void launch_pointwise_arith(rs_ctx *ctx, uint64_t *dst, const uint64_t *a, const uint64_t *b, size_t count,
+                                   uint64_t scalar, hipStream_t st) {
+  const size_t pairs = count * ctx->ring_words() / 2;
+  if (!pairs) return;
+  ScalarPerLimbT<typename ArithOf<M>::T> sc{};
+  for (int i = 0; i < ctx->L; i++)
+    sc.v[i] = OP == OP_MUL_SCALAR ? HostArith<M>::konst(scalar, ctx->q[i]) : HostArith<M>::plain(scalar, ctx->q[i]);
+  const unsigned blocks = (unsigned)std::min<size_t>((pairs + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL((ring_pointwise_kernel<OP, M>), dim3(blocks), dim3(256), 0, st, dst, a, b, pairs, ctx->N, ctx->L,
+                     CtxArith<M>::qmod(ctx), sc);
+  RS_HIP(hipGetLastError());
+}
 template <int OP>
 static void launch_pointwise(rs_ctx *ctx, uint64_t *dst, const uint64_t *a, const uint64_t *b, size_t count,
                              uint64_t scalar, hipStream_t st) {
-  const size_t pairs = count * ctx->ring_words() / 2;
-  if (!pairs) return;
-  ScalarPerLimb sc{};
-  for (int i = 0; i < ctx->L; i++) sc.v[i] = host::balanced(scalar % ctx->q[i], ctx->q[i]);
-  const unsigned blocks = (unsigned)std::min<size_t>((pairs + 255) / 256, 256 * 16);
-  hipLaunchKernelGGL(ring_pointwise_kernel<OP>, dim3(blocks), dim3(256), 0, st, dst, a, b, pairs, ctx->N, ctx->L,
-                     ctx->d_qmod, sc);
-  RS_HIP(hipGetLastError());
+  RS_DISPATCH_ARITH(ctx, (launch_pointwise_arith<OP, Mod>(ctx, dst, a, b, count, scalar, st)),
+                    (launch_pointwise_arith<OP, ModI>(ctx, dst, a, b, count, scalar, st)));
 }
 
 // slot-wise inverse by Fermat (a^(p-2)); flags[0] |= 1 if any slot is zero.
@@ -524,6 +570,24 @@ __global__ void __launch_bounds__(256) ring_inv_kernel(uint64_t *__restrict__ ds
       base = mulmod(base, base, m);
     }
     dst[i] = to_u64(canon(acc, m));
+  }
+  if (any_zero) atomicOr(flags, 1u);
+}
+// the same in the Montgomery domain: base and accumulator are kept as x*R, every product is one reduction
+__global__ void __launch_bounds__(256) ring_inv_kernel_int(uint64_t *__restrict__ dst, const uint64_t *__restrict__ a,
+                                                           size_t words, int N, int L, const ModI *__restrict__ qmod, unsigned *flags) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  bool any_zero = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) {
+    const ModI m = qmod[(i / (size_t)N) % (size_t)L];
+    const uint64_t e = m.p - 2, av = a[i];
+    any_zero |= (av == 0);
+    uint64_t base = to_mont(av, m), acc = to_mont(1, m);
+    for (int bit = 0; bit < 62; bit++) {
+      if ((e >> bit) & 1ull) acc = montmul(acc, base, m);
+      base = montmul(base, base, m);
+    }
+    dst[i] = montmul(acc, 1, m);
   }
   if (any_zero) atomicOr(flags, 1u);
 }
@@ -562,12 +626,13 @@ int rs_ctx_create(int device, int N, int L, const uint64_t *q, int N_enc, int K,
   if (ndev <= 0) throw Error(RS_ERR_HIP, "no HIP device: librs_hip has no CPU fallback");
   RS_REQUIRE(device >= 0 && device < ndev, "device index out of range");
   DeviceGuard device_guard(device);  // the caller's current device is restored on return
+  bool any_big = false;
   for (int i = 0; i < L + K; i++) {
     const uint64_t p = i < L ? q[i] : Q[i - L];
     RS_REQUIRE(host::is_prime(p), "modulus is not prime");
     RS_REQUIRE((p - 1) % (2 * (uint64_t)N_enc) == 0, "modulus must be 1 mod 2*N_enc (batching, seal_ring.hpp:297)");
-    if (p >= (1ull << 50))
-      throw Error(RS_ERR_UNSUPPORTED, "primes >= 2^50 need the integer Montgomery path, which is not built in this round");
+    RS_REQUIRE(p < (1ull << 62), "modulus must be below 2^62 (SEAL's own limit is 61 bits)");
+    if (p >= (1ull << 50)) any_big = true;  // beyond the exact-FP64 range: the whole context runs on Montgomery integers
     for (int k = 0; k < i; k++) RS_REQUIRE(p != (k < L ? q[k] : Q[k - L]), "moduli must be pairwise distinct");
   }
   rs_ctx *c = new rs_ctx();
@@ -578,21 +643,38 @@ int rs_ctx_create(int device, int N, int L, const uint64_t *q, int N_enc, int K,
   c->K = K;
   c->logN_enc = 0;
   while ((1 << c->logN_enc) < N_enc) c->logN_enc++;
-  std::vector<Mod> qm(L), Qm(K);
-  for (int i = 0; i < L; i++) {
-    c->q[i] = q[i];
-    c->plain[i] = make_negacyclic_table(q[i], c->logN_enc);
-    qm[i] = c->plain[i].mod;
+  c->use_int = any_big || g_force_int;
+  for (int i = 0; i < L; i++) c->q[i] = q[i];
+  for (int j = 0; j < K; j++) c->Q[j] = Q[j];
+  if (c->use_int) {
+    std::vector<ModI> qm(L), Qm(K);
+    for (int i = 0; i < L; i++) {
+      c->plain_i[i] = make_negacyclic_table<ModI>(q[i], c->logN_enc);
+      qm[i] = c->plain_i[i].mod;
+    }
+    for (int j = 0; j < K; j++) {
+      c->coeff_i[j] = make_negacyclic_table<ModI>(Q[j], c->logN_enc);
+      Qm[j] = c->coeff_i[j].mod;
+    }
+    RS_HIP(hipMalloc(&c->d_qmod_i, sizeof(ModI) * L));
+    RS_HIP(hipMemcpy(c->d_qmod_i, qm.data(), sizeof(ModI) * L, hipMemcpyHostToDevice));
+    RS_HIP(hipMalloc(&c->d_Qmod_i, sizeof(ModI) * K));
+    RS_HIP(hipMemcpy(c->d_Qmod_i, Qm.data(), sizeof(ModI) * K, hipMemcpyHostToDevice));
+  } else {
+    std::vector<Mod> qm(L), Qm(K);
+    for (int i = 0; i < L; i++) {
+      c->plain[i] = make_negacyclic_table<Mod>(q[i], c->logN_enc);
+      qm[i] = c->plain[i].mod;
+    }
+    for (int j = 0; j < K; j++) {
+      c->coeff[j] = make_negacyclic_table<Mod>(Q[j], c->logN_enc);
+      Qm[j] = c->coeff[j].mod;
+    }
+    RS_HIP(hipMalloc(&c->d_qmod, sizeof(Mod) * L));
+    RS_HIP(hipMemcpy(c->d_qmod, qm.data(), sizeof(Mod) * L, hipMemcpyHostToDevice));
+    RS_HIP(hipMalloc(&c->d_Qmod, sizeof(Mod) * K));
+    RS_HIP(hipMemcpy(c->d_Qmod, Qm.data(), sizeof(Mod) * K, hipMemcpyHostToDevice));
   }
-  for (int j = 0; j < K; j++) {
-    c->Q[j] = Q[j];
-    c->coeff[j] = make_negacyclic_table(Q[j], c->logN_enc);
-    Qm[j] = c->coeff[j].mod;
-  }
-  RS_HIP(hipMalloc(&c->d_qmod, sizeof(Mod) * L));
-  RS_HIP(hipMemcpy(c->d_qmod, qm.data(), sizeof(Mod) * L, hipMemcpyHostToDevice));
-  RS_HIP(hipMalloc(&c->d_Qmod, sizeof(Mod) * K));
-  RS_HIP(hipMemcpy(c->d_Qmod, Qm.data(), sizeof(Mod) * K, hipMemcpyHostToDevice));
   // BatchEncoder slot map (SEAL batchencoder.cpp populate_matrix_reps_index_map): generator 3
   // of Z_{2n}^*, row 0 = powers 3^i, row 1 = their negatives, bit-reversed positions.
   {
@@ -621,10 +703,12 @@ void rs_ctx_destroy(rs_ctx *c) {
   (void)hipSetDevice(c->device);
   rs_witness_plans_destroy(c);
   rs::msm_scratch_release(c);
-  for (int i = 0; i < c->L; i++) free_table(c->plain[i]);
-  for (int j = 0; j < c->K; j++) free_table(c->coeff[j]);
+  for (int i = 0; i < c->L; i++) free_table(c->plain[i]), free_table(c->plain_i[i]);
+  for (int j = 0; j < c->K; j++) free_table(c->coeff[j]), free_table(c->coeff_i[j]);
   if (c->d_qmod) (void)hipFree(c->d_qmod);
   if (c->d_Qmod) (void)hipFree(c->d_Qmod);
+  if (c->d_qmod_i) (void)hipFree(c->d_qmod_i);
+  if (c->d_Qmod_i) (void)hipFree(c->d_Qmod_i);
   if (c->d_index_map) (void)hipFree(c->d_index_map);
   for (auto &r : c->prof) {
     (void)hipEventDestroy(r.e0);
@@ -672,24 +756,24 @@ int rs_sync(rs_ctx *ctx, rs_stream stream) {
   RS_API_END
 }
 
-static const NttTable &pick_table(rs_ctx *ctx, int modset, int index) {
+static void ntt_entry(rs_ctx *ctx, int modset, int index, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st) {
   RS_REQUIRE(ctx, "null context");
-  if (modset == RS_MOD_PLAIN) {
-    RS_REQUIRE(index >= 0 && index < ctx->L, "limb index out of range");
-    return ctx->plain[index];
-  }
-  RS_REQUIRE(modset == RS_MOD_COEFF && index >= 0 && index < ctx->K, "prime index out of range");
-  return ctx->coeff[index];
+  RS_REQUIRE(modset == RS_MOD_PLAIN || modset == RS_MOD_COEFF, "bad modulus set");
+  RS_REQUIRE(index >= 0 && index < (modset == RS_MOD_PLAIN ? ctx->L : ctx->K), "modulus index out of range");
+  if (ctx->use_int)
+    launch_ntt_int(ctx, modset == RS_MOD_PLAIN ? ctx->plain_i[index] : ctx->coeff_i[index], d_data, batch, inverse, st);
+  else
+    launch_ntt(ctx, modset == RS_MOD_PLAIN ? ctx->plain[index] : ctx->coeff[index], d_data, batch, inverse, st);
 }
 
 int rs_ntt_forward(rs_ctx *ctx, int modset, int index, uint64_t *d_data, size_t batch, rs_stream stream) {
   RS_API_BEGIN_CTX(ctx)
-  launch_ntt(ctx, pick_table(ctx, modset, index), d_data, batch, false, S(stream));
+  ntt_entry(ctx, modset, index, d_data, batch, false, S(stream));
   RS_API_END
 }
 int rs_ntt_inverse(rs_ctx *ctx, int modset, int index, uint64_t *d_data, size_t batch, rs_stream stream) {
   RS_API_BEGIN_CTX(ctx)
-  launch_ntt(ctx, pick_table(ctx, modset, index), d_data, batch, true, S(stream));
+  ntt_entry(ctx, modset, index, d_data, batch, true, S(stream));
   RS_API_END
 }
 
@@ -735,8 +819,12 @@ int rs_ring_inv(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, size_t count,
     RS_HIP(hipMemsetAsync(flags, 0, 4, S(stream)));
     RS_HIP(hipMemcpyAsync(qint, ctx->q, sizeof(uint64_t) * ctx->L, hipMemcpyHostToDevice, S(stream)));
     const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(ring_inv_kernel, dim3(blocks), dim3(256), 0, S(stream), d_dst, d_a, words, ctx->N, ctx->L,
-                       ctx->d_qmod, qint, flags);
+    if (ctx->use_int)
+      hipLaunchKernelGGL(ring_inv_kernel_int, dim3(blocks), dim3(256), 0, S(stream), d_dst, d_a, words, ctx->N, ctx->L,
+                         ctx->d_qmod_i, flags);
+    else
+      hipLaunchKernelGGL(ring_inv_kernel, dim3(blocks), dim3(256), 0, S(stream), d_dst, d_a, words, ctx->N, ctx->L,
+                         ctx->d_qmod, qint, flags);
     unsigned h = 0;
     RS_HIP(hipMemcpyAsync(&h, flags, 4, hipMemcpyDeviceToHost, S(stream)));
     RS_HIP(hipStreamSynchronize(S(stream)));
@@ -766,6 +854,8 @@ int rs_set_tuning(const char *key, int value) {
   RS_REQUIRE(key, "null argument");
   if (std::string(key) == "ntt_variant")
     g_ntt_variant = value;
+  else if (std::string(key) == "force_int_arith")  // contexts created from now on use the Montgomery path regardless of prime size
+    g_force_int = value != 0;
 #ifdef RS_EXPERIMENTS  // these two CHANGE THE RESULTS (timing experiments, tools/): `make experiments` only
   else if (std::string(key) == "ntt_repeat")
     g_ntt_repeat = value;

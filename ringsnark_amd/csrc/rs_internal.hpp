@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "../../include/ringsnark_amd.h"
-#include "f64mod.hpp"
+#include "intmod.hpp"
 #include "host_math.hpp"
 
 namespace rs {
@@ -57,14 +57,37 @@ void set_last_error(const std::string &m);
 // node k of the radix-2 decimation tree (stage with M groups, group i -> k = M + i), balanced
 // doubles.  Negacyclic tables: tw[k] = psi^{bitrev(k, log n)}  (SEAL NTTTables order).
 // Cyclic tables (witness map): tw[M+i] = w_{2M}^{bitrev(i, log M)}, independent of n.
-struct NttTable {
+// T / M: value and modulus type of the arithmetic (double / Mod: exact FP64, f64mod.hpp; uint64_t / ModI:
+// Montgomery integers, intmod.hpp -- table entries are then in Montgomery form).
+template <class T, class M>
+struct NttTableT {
   uint64_t p = 0;
-  Mod mod{0, 0};
+  M mod{};
   int logn = 0;
-  double *d_tw = nullptr;   // forward, n entries (entry 0 unused)
-  double *d_itw = nullptr;  // inverse twiddles (element-wise inverses)
-  double ninv = 0;          // n^{-1} mod p, balanced
-  uint32_t fwd_red_mask = 0, inv_red_mask = 0;  // stages before which values are re-reduced
+  T *d_tw = nullptr;   // forward, n entries (entry 0 unused)
+  T *d_itw = nullptr;  // inverse twiddles (element-wise inverses)
+  T ninv = 0;          // n^{-1} mod p as a table constant
+  uint32_t fwd_red_mask = 0, inv_red_mask = 0;  // stages before which values are re-reduced (FP64 only)
+};
+using NttTable = NttTableT<double, Mod>;
+using NttTableI = NttTableT<uint64_t, ModI>;
+
+// host side of the two arithmetics: modulus constants and the encoding of a table constant
+template <class M>
+struct HostArith;
+template <>
+struct HostArith<Mod> {
+  using T = double;
+  static Mod make(uint64_t p) { return Mod{(double)p, 1.0 / (double)p}; }
+  static double konst(uint64_t v, uint64_t p) { return host::balanced(v % p, p); }
+  static double plain(uint64_t v, uint64_t p) { return (double)(v % p); }  // a data value (not a multiplier): canonical
+};
+template <>
+struct HostArith<ModI> {
+  using T = uint64_t;
+  static ModI make(uint64_t p) { return ModI{p, host::mont_ninv(p), host::mont_r2(p)}; }
+  static uint64_t konst(uint64_t v, uint64_t p) { return host::mont_form(v, p); }
+  static uint64_t plain(uint64_t v, uint64_t p) { return v % p; }
 };
 
 // A cached workspace buffer of the context.  Workspaces are shared by every call on the context;
@@ -114,8 +137,14 @@ struct rs_ctx {
   int device = 0;
   int N = 0, L = 0, N_enc = 0, K = 0, logN_enc = 0;
   uint64_t q[RS_MAX_L] = {0}, Q[RS_MAX_K] = {0};
+  // Arithmetic of the whole context: exact FP64 when every modulus is < 2^50, Montgomery integers otherwise
+  // (one choice per context: a plaintext lifted from a 54-bit q_i does not fit the FP64 operand bounds of a
+  // 49-bit Q_j either).  Exactly one of the two table sets below is populated.
+  bool use_int = false;
   rs::NttTable plain[RS_MAX_L];  // mod q_i, length N_enc
   rs::NttTable coeff[RS_MAX_K];  // mod Q_j, length N_enc
+  rs::NttTableI plain_i[RS_MAX_L], coeff_i[RS_MAX_K];
+  rs::ModI *d_qmod_i = nullptr, *d_Qmod_i = nullptr;
   uint32_t *d_index_map = nullptr;  // BatchEncoder slot map, first N entries used
   // constant device arrays of per-limb / per-prime moduli for pointwise kernels
   rs::Mod *d_qmod = nullptr;  // [L]
@@ -136,6 +165,36 @@ struct rs_ctx {
 };
 
 namespace rs {
+// per-arithmetic views of the context
+template <class M>
+struct CtxArith;
+template <>
+struct CtxArith<Mod> {
+  using T = double;
+  using Table = NttTable;
+  static const Table *plain(const rs_ctx *c) { return c->plain; }
+  static const Table *coeff(const rs_ctx *c) { return c->coeff; }
+  static const Mod *qmod(const rs_ctx *c) { return c->d_qmod; }
+  static const Mod *Qmod(const rs_ctx *c) { return c->d_Qmod; }
+};
+template <>
+struct CtxArith<ModI> {
+  using T = uint64_t;
+  using Table = NttTableI;
+  static const Table *plain(const rs_ctx *c) { return c->plain_i; }
+  static const Table *coeff(const rs_ctx *c) { return c->coeff_i; }
+  static const ModI *qmod(const rs_ctx *c) { return c->d_qmod_i; }
+  static const ModI *Qmod(const rs_ctx *c) { return c->d_Qmod_i; }
+};
+// run `f(Mod{})` or `f(ModI{})` according to the context's arithmetic
+#define RS_DISPATCH_ARITH(ctx, CALL_FP, CALL_INT) \
+  do {                                            \
+    if ((ctx)->use_int) {                         \
+      CALL_INT;                                   \
+    } else {                                      \
+      CALL_FP;                                    \
+    }                                             \
+  } while (0)
 void *ws_get(rs_ctx *ctx, int slot, size_t bytes);
 // Holds the context lock for one API call on `st` and, on exit, stamps every workspace buffer the
 // call touched with an event on `st` (see DeviceBuf).  Every entry point that calls ws_get owns one.
@@ -171,8 +230,14 @@ struct WsScope {
   }
   ~WsScope();
 };
-NttTable make_negacyclic_table(uint64_t p, int logn);
-void free_table(NttTable &t);
+template <class M>
+NttTableT<typename HostArith<M>::T, M> make_negacyclic_table(uint64_t p, int logn);
+template <class T, class M>
+void free_table(NttTableT<T, M> &t) {
+  if (t.d_tw) (void)hipFree(t.d_tw);
+  if (t.d_itw) (void)hipFree(t.d_itw);
+  t.d_tw = t.d_itw = nullptr;
+}
 uint32_t fwd_reduce_mask(uint64_t p, int logn);
 uint32_t inv_reduce_mask(uint64_t p, int logn);
 inline hipStream_t S(rs_stream s) { return (hipStream_t)s; }
@@ -185,4 +250,5 @@ extern int g_witness_tree_ct;             // witness.hip: level-unrolled product
 extern int g_witness_col_budget_mib;       // witness.hip: column workspace of one chunk of the witness map
 extern int g_witness_lds_logM;           // witness.hip: largest column (log2) handled inside one LDS tile
 void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st);
+void launch_ntt_int(rs_ctx *ctx, const NttTableI &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st);
 }  // namespace rs

@@ -23,6 +23,7 @@
 // Requires q_i = 1 mod 4M (cyclic NTT of length 2M) and M <= 8192 in this round.
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "ntt_core.hpp"
 #include "rs_internal.hpp"
@@ -31,16 +32,17 @@ namespace rs {
 
 constexpr int SCHOOL_LEVELS = 4;  // tree levels with node size <= 8 use schoolbook products
 
+// Device tables of one limb: arrays of 8-byte TABLE CONSTANTS of the context's arithmetic (balanced doubles for
+// the FP64 arithmetic, Montgomery-form integers for the integer one; the zero constant is the zero word in both).
 struct LimbPlan {
   uint64_t p = 0;
-  Mod mod{0, 0};
-  double *d_tw = nullptr, *d_itw = nullptr;  // cyclic tables, 2M entries
-  double *d_invfact = nullptr;               // [M]  1/j! (0 for j >= m)
-  double *d_ehat = nullptr;                  // [2M] spectrum of (-1)^k/k!, scaled by 1/(2M)
-  double *d_dhat = nullptr;                  // [logM+1][M] spectra of D_left per level, scaled by 1/n
-  double *d_dlow = nullptr;                  // [SCHOOL_LEVELS+1][M/2] low coefficients of D_left
-  double *d_shat = nullptr;                  // [2M] spectrum of rev(Z)^-1 mod x^(m-1), scaled 1/(2M)^2
-  double *d_ztab = nullptr;                  // [M] Z_k (0 beyond m)
+  void *d_tw = nullptr, *d_itw = nullptr;  // cyclic tables, 2M entries
+  void *d_invfact = nullptr;               // [M]  1/j! (0 for j >= m)
+  void *d_ehat = nullptr;                  // [2M] spectrum of (-1)^k/k!, scaled by 1/(2M)
+  void *d_dhat = nullptr;                  // [logM+1][M] spectra of D_left per level, scaled by 1/n
+  void *d_dlow = nullptr;                  // [SCHOOL_LEVELS+1][M/2] low coefficients of D_left
+  void *d_shat = nullptr;                  // [2M] spectrum of rev(Z)^-1 mod x^(m-1), scaled 1/(2M)^2
+  void *d_ztab = nullptr;                  // [M] Z_k (0 beyond m)
   uint32_t fwd_mask2 = 0, inv_mask2 = 0;     // reduce masks for length 2M
   std::vector<uint64_t> Z;                   // m+1 coefficients of the vanishing polynomial
 };
@@ -138,11 +140,24 @@ static std::vector<uint64_t> polymul(const std::vector<uint64_t> &a, const std::
 }
 }  // namespace hostw
 
-static double *up(const std::vector<double> &h) {
-  double *d = nullptr;
-  RS_HIP(hipMalloc(&d, std::max<size_t>(1, h.size()) * sizeof(double)));
-  if (!h.empty()) RS_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+static void *up(const std::vector<uint64_t> &h) {
+  void *d = nullptr;
+  RS_HIP(hipMalloc(&d, std::max<size_t>(1, h.size()) * sizeof(uint64_t)));
+  if (!h.empty()) RS_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   return d;
+}
+// the 8-byte word of a table constant / of a data value in the context's arithmetic
+static uint64_t word_of(double d) {
+  uint64_t u;
+  memcpy(&u, &d, 8);
+  return u;
+}
+static uint64_t word_of(uint64_t u) { return u; }
+static uint64_t konst_word(const rs_ctx *ctx, uint64_t v, uint64_t p) {
+  return ctx->use_int ? word_of(HostArith<ModI>::konst(v, p)) : word_of(HostArith<Mod>::konst(v, p));
+}
+static uint64_t plain_word(const rs_ctx *ctx, uint64_t v, uint64_t p) {
+  return ctx->use_int ? word_of(HostArith<ModI>::plain(v, p)) : word_of(HostArith<Mod>::plain(v, p));
 }
 
 static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
@@ -164,11 +179,10 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
       throw Error(RS_ERR_UNSUPPORTED, "ring prime lacks the 2-adicity for the quasi-linear witness map (need q = 1 mod 2*next_pow2(m)*2)");
     RS_REQUIRE(p > 2 * M, "ring prime too small for the evaluation domain");
     lp.p = p;
-    lp.mod = Mod{(double)p, 1.0 / (double)p};
     const CycTab T = make_cyc(p, logM + 1);
-    auto bal = [&](uint64_t v) { return host::balanced(v, p); };
+    auto bal = [&](uint64_t v) { return konst_word(ctx, v, p); };
     {
-      std::vector<double> tw(2 * M), itw(2 * M);
+      std::vector<uint64_t> tw(2 * M), itw(2 * M);
       for (size_t k = 0; k < 2 * M; k++) tw[k] = bal(T.tw[k]), itw[k] = bal(T.itw[k]);
       lp.d_tw = up(tw);
       lp.d_itw = up(itw);
@@ -182,14 +196,14 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
     ifact[M - 1] = invmod(fact[M - 1], p);
     for (size_t j = M - 1; j > 0; j--) ifact[j - 1] = mulmod(ifact[j], (uint64_t)j % p, p);
     {
-      std::vector<double> v(M, 0.0);
+      std::vector<uint64_t> v(M, 0);
       for (size_t j = 0; j < m; j++) v[j] = bal(ifact[j]);
       lp.d_invfact = up(v);
       std::vector<uint64_t> e(2 * M, 0);
       for (size_t k = 0; k < m; k++) e[k] = (k & 1) ? (p - ifact[k]) % p : ifact[k];
       ntt_fwd(e, logM + 1, T);
       const uint64_t s2 = invmod((uint64_t)(2 * M) % p, p);
-      std::vector<double> eh(2 * M);
+      std::vector<uint64_t> eh(2 * M);
       for (size_t k = 0; k < 2 * M; k++) eh[k] = bal(mulmod(e[k], s2, p));
       lp.d_ehat = up(eh);
     }
@@ -211,7 +225,7 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
     }
     // D_left spectra (levels > SCHOOL_LEVELS) and low coefficients (levels <= SCHOOL_LEVELS)
     {
-      std::vector<double> dhat((size_t)(logM + 1) * M, 0.0), dlow((size_t)(SCHOOL_LEVELS + 1) * (M / 2 + 1), 0.0);
+      std::vector<uint64_t> dhat((size_t)(logM + 1) * M, 0), dlow((size_t)(SCHOOL_LEVELS + 1) * (M / 2 + 1), 0);
       for (int l = 1; l <= logM; l++) {
         const size_t n = (size_t)1 << l, h = n >> 1;
         for (size_t i = 0; i < (M >> l); i++) {
@@ -246,7 +260,7 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
       }
       RS_REQUIRE(Z.size() == m + 1 && start == m, "internal: vanishing polynomial size");
       lp.Z = Z;
-      std::vector<double> zt(M, 0.0);
+      std::vector<uint64_t> zt(M, 0);
       for (size_t k = 0; k < M && k <= m; k++) zt[k] = bal(Z[k]);
       lp.d_ztab = up(zt);
       // S = rev(Z)^-1 mod x^(m-1) (Newton iteration): quo(P, Z) = rev(rev(P) * S mod x^(m-1)) for
@@ -272,7 +286,7 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
         const uint64_t s2 = invmod((uint64_t)(2 * M) % p, p), s4 = mulmod(s2, s2, p);
         for (auto &x : shat) x = mulmod(x, s4, p);
       }
-      std::vector<double> sh(2 * M);
+      std::vector<uint64_t> sh(2 * M);
       for (size_t k = 0; k < 2 * M; k++) sh[k] = bal(shat[k]);
       lp.d_shat = up(sh);
     }
@@ -282,8 +296,8 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
 
 static void free_plan(WitnessPlan *P) {
   for (auto &lp : P->limb) {
-    double *ptrs[] = {lp.d_tw, lp.d_itw, lp.d_invfact, lp.d_ehat, lp.d_dhat, lp.d_dlow, lp.d_shat, lp.d_ztab};
-    for (double *q : ptrs)
+    void *ptrs[] = {lp.d_tw, lp.d_itw, lp.d_invfact, lp.d_ehat, lp.d_dhat, lp.d_dlow, lp.d_shat, lp.d_ztab};
+    for (void *q : ptrs)
       if (q) (void)hipFree(q);
   }
   delete P;
@@ -299,15 +313,25 @@ WitnessPlan *get_plan(rs_ctx *ctx, size_t m) {
 
 // ---- device kernels ----------------------------------------------------------------------------
 
-struct ColPlan {  // per-limb device pointers handed to the column kernels
-  Mod mod;
-  const double *tw, *itw, *invfact, *ehat, *dhat, *dlow, *shat, *ztab;
+// per-limb device pointers handed to the column kernels; M: the context's arithmetic (tables hold table
+// constants of that arithmetic: balanced doubles, or Montgomery-form integers)
+template <class M_>
+struct ColPlanT {
+  using M = M_;
+  using T = typename ArithOf<M_>::T;
+  M mod;
+  const T *tw, *itw, *invfact, *ehat, *dhat, *dlow, *shat, *ztab;
   uint32_t fwd_mask2, inv_mask2;
-  uint32_t fmask[24], imask[24];  // reduce masks for transforms of length 2^l
+  uint32_t fmask[24], imask[24];  // reduce masks for transforms of length 2^l (FP64 arithmetic)
 };
-struct ColPlans {
-  ColPlan l[RS_MAX_L];
+template <class M_>
+struct ColPlansT {
+  using M = M_;
+  using T = typename ArithOf<M_>::T;
+  ColPlanT<M_> l[RS_MAX_L];
 };
+using ColPlan = ColPlanT<Mod>;
+using ColPlans = ColPlansT<Mod>;
 struct ColBlockFactory {
   double *s;
   __device__ __forceinline__ LdsBlockIO operator()(int off) const { return LdsBlockIO{s + pidx(off)}; }
@@ -333,14 +357,15 @@ struct ColMap {
 };
 
 // [rows][S] u64 (term-major, S = L*N) -> [S][M] f64 (column-major), rows >= m zero-filled.
-__global__ void __launch_bounds__(256) transpose_in_kernel(const uint64_t *__restrict__ src, double *__restrict__ dst,
+template <class T>
+__global__ void __launch_bounds__(256) transpose_in_kernel(const uint64_t *__restrict__ src, T *__restrict__ dst,
                                                            size_t m, size_t S, size_t M) {
-  __shared__ double tile[32][33];
+  __shared__ T tile[32][33];
   const size_t s0 = (size_t)blockIdx.x * 32, r0 = (size_t)blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int k = ty; k < 32; k += 8) {
     const size_t r = r0 + k, sl = s0 + tx;
-    tile[k][tx] = (r < m && sl < S) ? from_u64(src[r * S + sl]) : 0.0;
+    tile[k][tx] = (r < m && sl < S) ? from_res<T>(src[r * S + sl]) : T(0);
   }
   __syncthreads();
   for (int k = ty; k < 32; k += 8) {
@@ -349,14 +374,15 @@ __global__ void __launch_bounds__(256) transpose_in_kernel(const uint64_t *__res
   }
 }
 // [C][M] f64 canonical columns -> [rows][L][out_N] u64 for rows < m_out
-__global__ void __launch_bounds__(256) transpose_out_kernel(const double *__restrict__ src, uint64_t *__restrict__ dst,
+template <class T>
+__global__ void __launch_bounds__(256) transpose_out_kernel(const T *__restrict__ src, uint64_t *__restrict__ dst,
                                                             size_t m_out, size_t C, size_t M, ColMap cm) {
-  __shared__ double tile[32][33];
+  __shared__ T tile[32][33];
   const size_t s0 = (size_t)blockIdx.x * 32, r0 = (size_t)blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int k = ty; k < 32; k += 8) {
     const size_t c = s0 + k, r = r0 + tx;
-    tile[k][tx] = (c < C && r < M) ? src[c * M + r] : 0.0;
+    tile[k][tx] = (c < C && r < M) ? src[c * M + r] : T(0);
   }
   __syncthreads();
   const size_t c = s0 + tx;
@@ -366,23 +392,25 @@ __global__ void __launch_bounds__(256) transpose_out_kernel(const double *__rest
   const size_t o = cm.out_index(limb, slot), So = cm.out_stride();
   for (int k = ty; k < 32; k += 8) {
     const size_t r = r0 + k;
-    if (r < m_out) dst[r * So + o] = to_u64(tile[tx][k]);
+    if (r < m_out) dst[r * So + o] = to_res(tile[tx][k]);
   }
 }
 
 // Product-tree levels 1..SCHOOL_LEVELS by schoolbook products in registers, on 2^logB consecutive
 // Newton coefficients at column position pos0 held in the (offset) tile s; one thread per node of
 // size 2^SCHOOL_LEVELS, executed by the lanes `ln` (a workgroup or one wave).
-__device__ __forceinline__ void school_levels_lds(double *s, int logB, int logM, int pos0, const ColPlan &P, const Lanes ln) {
-  const Mod mod = P.mod;
+template <class CP>
+__device__ __forceinline__ void school_levels_lds(typename CP::T *s, int logB, int logM, int pos0, const CP &P, const Lanes ln) {
+  using T = typename CP::T;
+  const typename CP::M mod = P.mod;
   const int Bn = 1 << logB, M = 1 << logM;
   const int lv = logB < SCHOOL_LEVELS ? logB : SCHOOL_LEVELS;
   const int nn = 1 << lv;
   const int dstride = M / 2 + 1;
   for (int node = ln.tid; node < (Bn >> lv); node += ln.nthr) {
-    double v[1 << SCHOOL_LEVELS];
+    T v[1 << SCHOOL_LEVELS];
 #pragma unroll
-    for (int k = 0; k < (1 << SCHOOL_LEVELS); k++) v[k] = (k < nn) ? s[pidx(node * nn + k)] : 0.0;
+    for (int k = 0; k < (1 << SCHOOL_LEVELS); k++) v[k] = (k < nn) ? s[pidx(node * nn + k)] : T(0);
 #pragma unroll
     for (int l = 1; l <= SCHOOL_LEVELS; l++) {
       if (l > lv) break;
@@ -391,22 +419,22 @@ __device__ __forceinline__ void school_levels_lds(double *s, int logB, int logM,
       for (int sub = 0; sub < ((1 << SCHOOL_LEVELS) >> l); sub++) {
         if (sub * n >= nn) break;
         const int gnode = ((pos0 + node * nn) >> l) + sub;  // node index at level l within the column
-        const double *dl = P.dlow + (size_t)l * dstride + (size_t)gnode * h;
-        double out[1 << SCHOOL_LEVELS];
+        const T *dl = P.dlow + (size_t)l * dstride + (size_t)gnode * h;
+        T out[1 << SCHOOL_LEVELS];
 #pragma unroll
-        for (int k = 0; k < n; k++) out[k] = 0.0;
+        for (int k = 0; k < n; k++) out[k] = T(0);
         // D_left * F_right, D_left = x^h + sum dl[a] x^a
 #pragma unroll
         for (int b = 0; b < h; b++) {
-          const double fr = v[sub * n + h + b];
-          out[h + b] += fr;
+          const T fr = v[sub * n + h + b];
+          out[h + b] = addm(out[h + b], fr, mod);
 #pragma unroll
-          for (int a = 0; a < h; a++) out[a + b] += mulmod(dl[a], fr, mod);
+          for (int a = 0; a < h; a++) out[a + b] = addm(out[a + b], mulmod(fr, dl[a], mod), mod);
         }
 #pragma unroll
         for (int k = 0; k < n; k++) {
-          const double left = (k < h) ? v[sub * n + k] : 0.0;
-          v[sub * n + k] = reduce(out[k] + left, mod);
+          const T left = (k < h) ? v[sub * n + k] : T(0);
+          v[sub * n + k] = reduce(addm(out[k], left, mod), mod);
         }
       }
     }
@@ -421,30 +449,32 @@ __device__ __forceinline__ void school_levels_lds(double *s, int logB, int logM,
 // second half [Bn, 2Bn) is scratch.  Runs levels 1..logB (node sizes 2..Bn).  Tables are
 // indexed by the position inside the whole column (length M = 2^logM).
 __host__ __device__ __forceinline__ int tree_scratch_offset(int Bn) { return Bn >= LDS_BLOCK_MIN ? Bn : LDS_BLOCK_MIN; }
-__device__ __forceinline__ void tree_levels_lds(double *s, int logB, int logM, int pos0, const ColPlan &P) {
-  const Mod mod = P.mod;
+template <class CP>
+__device__ __forceinline__ void tree_levels_lds(typename CP::T *s, int logB, int logM, int pos0, const CP &P) {
+  using T = typename CP::T;
+  const typename CP::M mod = P.mod;
   const int Bn = 1 << logB, M = 1 << logM;
   school_levels_lds(s, logB, logM, pos0, P, block_lanes());
   __syncthreads();
   // transform levels: B[node] = (F_right, 0) -> batched length-n transforms -> * spectrum of D_left
   // -> inverse -> + F_left.  B is an offset tile starting at a multiple of LDS_BLOCK_MIN.
-  double *Bt = s + pidx(tree_scratch_offset(Bn));
+  T *Bt = s + pidx(tree_scratch_offset(Bn));
   for (int l = SCHOOL_LEVELS + 1; l <= logB; l++) {
     const int n = 1 << l, h = n >> 1;
     for (int i = threadIdx.x; i < Bn; i += blockDim.x) {
       const int k = i & (n - 1);
-      Bt[pidx(i)] = (k < h) ? s[pidx(i + h)] : 0.0;
+      Bt[pidx(i)] = (k < h) ? s[pidx(i + h)] : T(0);
     }
     __syncthreads();
     lds_bntt_fwd(Bt, logB, l, P.tw, mod, P.fmask[l]);
-    const double *dh = P.dhat + (size_t)l * M + pos0;
+    const T *dh = P.dhat + (size_t)l * M + pos0;
     for (int i = threadIdx.x; i < Bn; i += blockDim.x) Bt[pidx(i)] = mulmod(reduce(Bt[pidx(i)], mod), dh[i], mod);
     __syncthreads();
     lds_bntt_inv(Bt, logB, l, P.itw, mod, P.imask[l]);
     for (int i = threadIdx.x; i < Bn; i += blockDim.x) {
       const int k = i & (n - 1);
-      const double left = (k < h) ? s[pidx(i)] : 0.0;
-      s[pidx(i)] = reduce(Bt[pidx(i)] + left, mod);
+      const T left = (k < h) ? s[pidx(i)] : T(0);
+      s[pidx(i)] = reduce(addm(Bt[pidx(i)], left, mod), mod);
     }
     __syncthreads();
   }
@@ -453,19 +483,21 @@ __device__ __forceinline__ void tree_levels_lds(double *s, int logB, int logM, i
 // One workgroup per column: values at 0..m-1 (cols[col][0..M)) -> monomial coefficients in place.
 // LDS: 2M padded doubles (A = [0,M) current polynomials, B = [M,2M) scratch).
 // Column c belongs to limb (c % S) / slots_per_limb (several vectors of S columns are batched).
+template <class CPS>
 __global__ void __launch_bounds__(1024)
-interp_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned slots_per_limb, ColPlans plans) {
+interp_columns_kernel(typename CPS::T *__restrict__ cols, int logM, unsigned S, unsigned slots_per_limb, CPS plans) {
+  using T = typename CPS::T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *s = reinterpret_cast<double *>(smem);
+  T *s = reinterpret_cast<T *>(smem);
   const int M = 1 << logM;
   const size_t col = blockIdx.x;
-  const ColPlan &P = plans.l[(col % S) / slots_per_limb];
-  const Mod mod = P.mod;
-  double *c = cols + col * (size_t)M;
+  const ColPlanT<typename CPS::M> &P = plans.l[(col % S) / slots_per_limb];
+  const typename CPS::M mod = P.mod;
+  T *c = cols + col * (size_t)M;
   // 1. g_j = y_j / j!  (zero for j >= m), zero-padded to 2M
   for (int j = threadIdx.x; j < M; j += blockDim.x) {
     s[pidx(j)] = mulmod(c[j], P.invfact[j], mod);
-    s[pidx(M + j)] = 0.0;
+    s[pidx(M + j)] = T(0);
   }
   __syncthreads();
   lds_ntt_fwd<4>(s, logM + 1, P.tw, 1, mod, P.fwd_mask2);
@@ -475,8 +507,8 @@ interp_columns_kernel(double *__restrict__ cols, int logM, unsigned S, unsigned 
   // Newton coefficients f_k = s[k], k < m; everything at k >= m is discarded (invfact is zero
   // there only for the INPUT; the convolution tail must be cleared explicitly).
   for (int j = threadIdx.x; j < M; j += blockDim.x) {
-    const double inv_nonzero = P.invfact[j];
-    s[pidx(j)] = (inv_nonzero != 0.0) ? reduce(s[pidx(j)], mod) : 0.0;
+    const T inv_nonzero = P.invfact[j];
+    s[pidx(j)] = (inv_nonzero != T(0)) ? reduce(s[pidx(j)], mod) : T(0);
   }
   __syncthreads();
   tree_levels_lds(s, logM, logM, 0, P);
@@ -680,25 +712,25 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
 //     rev(H) = rev(P) * rev(Z)^-1  mod x^(m-1)
 // i.e. five length-2M cyclic transforms per column against the precomputed spectrum `shat`.
 // A, B: [cols][M] canonical doubles; H: [cols][M].  d1,d2,d3: ring elements [L][N] (u64) or NULL.
-template <int LOGM_CT = 0>
+template <class CPS>
 __global__ void __launch_bounds__(1024)
-h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, double *__restrict__ H, int logM_arg, int m,
-                 unsigned slots_per_limb, ColPlans plans, const uint64_t *__restrict__ d1,
+h_columns_kernel(const typename CPS::T *__restrict__ A, const typename CPS::T *__restrict__ Bc, typename CPS::T *__restrict__ H,
+                 int logM, int m, unsigned slots_per_limb, CPS plans, const uint64_t *__restrict__ d1,
                  const uint64_t *__restrict__ d2, const uint64_t *__restrict__ d3, ColMap cm) {
+  using T = typename CPS::T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *s = reinterpret_cast<double *>(smem);
-  const int logM = LOGM_CT ? LOGM_CT : logM_arg;
+  T *s = reinterpret_cast<T *>(smem);
   const int M = 1 << logM, M2 = 2 * M;
   const size_t col = blockIdx.x;
-  const ColPlan &P = plans.l[col / slots_per_limb];
-  const Mod mod = P.mod;
-  const double *srcA = A + col * (size_t)M, *srcB = Bc + col * (size_t)M;
-  double r[16];  // this thread's slice of a spectrum: positions tid + k*blockDim
+  const ColPlanT<typename CPS::M> &P = plans.l[col / slots_per_limb];
+  const typename CPS::M mod = P.mod;
+  const T *srcA = A + col * (size_t)M, *srcB = Bc + col * (size_t)M;
+  T r[16];  // this thread's slice of a spectrum: positions tid + k*blockDim
   for (int pass = 0; pass < 2; pass++) {
-    const double *src = pass ? srcB : srcA;
+    const T *src = pass ? srcB : srcA;
     for (int k = threadIdx.x; k < M; k += blockDim.x) {
       s[pidx(k)] = center(src[k], mod);
-      s[pidx(M + k)] = 0.0;
+      s[pidx(M + k)] = T(0);
     }
     __syncthreads();
     lds_ntt_fwd<4>(s, logM + 1, P.tw, 1, mod, P.fwd_mask2);
@@ -708,8 +740,8 @@ h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, do
     for (int k = 0; k < 16; k++) {
       const int p = tid + k * blockDim.x;
       if (p < M2) {
-        const double v = reduce(s[pidx(p)], mod);
-        r[k] = pass ? mulmod(r[k], v, mod) : v;
+        const T v = reduce(s[pidx(p)], mod);
+        r[k] = pass ? mulmod_dd(r[k], v, mod) : v;  // spectrum of A times spectrum of B: data x data
       }
     }
     __syncthreads();
@@ -725,7 +757,7 @@ h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, do
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const int i = threadIdx.x + k * blockDim.x;
-    if (i < M2) r[k] = (i < m - 1) ? reduce(s[pidx(2 * m - 2 - i)], mod) : 0.0;
+    if (i < M2) r[k] = (i < m - 1) ? reduce(s[pidx(2 * m - 2 - i)], mod) : T(0);
   }
   __syncthreads();
 #pragma unroll
@@ -738,23 +770,24 @@ h_columns_kernel(const double *__restrict__ A, const double *__restrict__ Bc, do
   for (int i = threadIdx.x; i < M2; i += blockDim.x) s[pidx(i)] = mulmod(reduce(s[pidx(i)], mod), P.shat[i], mod);
   __syncthreads();
   lds_ntt_inv<4>(s, logM + 1, P.itw, 1, mod, P.inv_mask2);  // U_i = rev(H)_i, i < m-1
-  double e1 = 0.0, e2 = 0.0, e3 = 0.0, e12 = 0.0;
+  T e1 = T(0), e2 = T(0), e3 = T(0), e12 = T(0);
   const bool zk = d1 != nullptr;
   if (zk) {
     int dlimb, dslot;
     cm.locate(col, dlimb, dslot);
     const size_t di = cm.in_index(dlimb, dslot);
-    e1 = center(from_u64(d1[di]), mod);
-    e2 = center(from_u64(d2[di]), mod);
-    e3 = center(from_u64(d3[di]), mod);
-    e12 = mulmod(e1, e2, mod);
+    e1 = center(from_res<T>(d1[di]), mod);
+    e2 = center(from_res<T>(d2[di]), mod);
+    e3 = center(from_res<T>(d3[di]), mod);
+    e12 = mulmod_dd(e1, e2, mod);
   }
-  double *dst = H + col * (size_t)M;
+  T *dst = H + col * (size_t)M;
   for (int k = threadIdx.x; k < M; k += blockDim.x) {
-    double h = (k <= m - 2) ? reduce(s[pidx(m - 2 - k)], mod) : 0.0;
+    T h = (k <= m - 2) ? reduce(s[pidx(m - 2 - k)], mod) : T(0);
     if (zk) {
-      h += mulmod(e2, center(srcA[k], mod), mod) + mulmod(e1, center(srcB[k], mod), mod) + mulmod(e12, P.ztab[k], mod);
-      if (k == 0) h -= e3;
+      h = addm(h, addm(addm(mulmod_dd(e2, center(srcA[k], mod), mod), mulmod_dd(e1, center(srcB[k], mod), mod), mod),
+                       mulmod(e12, P.ztab[k], mod), mod), mod);
+      if (k == 0) h = subm(h, e3, mod);
     }
     dst[k] = canon(h, mod);
   }
@@ -943,27 +976,29 @@ struct IoDesc {
   const int *column;  // column index into Lcols
   int count;
 };
+template <class M>
 __global__ void __launch_bounds__(256)
-io_coeff_kernel(IoDesc io, const double *__restrict__ Lcols /* [ncols][Ltot][M] */, const uint64_t *__restrict__ asg,
-                uint64_t *__restrict__ out, size_t C, size_t M, const Mod *__restrict__ qmod, ColMap cm) {
+io_coeff_kernel(IoDesc io, const typename ArithOf<M>::T *__restrict__ Lcols /* [ncols][Ltot][M] */, const uint64_t *__restrict__ asg,
+                uint64_t *__restrict__ out, size_t C, size_t Mlen, const M *__restrict__ qmod, ColMap cm) {
+  using T = typename ArithOf<M>::T;
   const size_t t = blockIdx.x;
   const size_t c = 2 * ((size_t)blockIdx.y * blockDim.x + threadIdx.x);
   if (c >= C) return;
   int limb, slot;
   cm.locate(c, limb, slot);
   const size_t pair = cm.in_index(limb, slot) >> 1, Si = cm.in_stride();
-  const Mod mod = qmod[limb];
-  double a0 = 0.0, a1 = 0.0;
+  const M mod = qmod[limb];
+  T a0 = T(0), a1 = T(0);
   for (int k = 0; k < io.count; k++) {
-    const double lv = center(Lcols[((size_t)io.column[k] * cm.L + limb) * M + t], mod);
+    const T lv = center(Lcols[((size_t)io.column[k] * cm.L + limb) * Mlen + t], mod);
     const int v_ = io.k[k];
     if (v_ == 0) {
-      a0 += lv;
-      a1 += lv;
+      a0 = addm(a0, lv, mod);
+      a1 = addm(a1, lv, mod);
     } else {
       const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(v_ - 1) * Si)[pair];
-      a0 += mulmod(from_u64(v.x), lv, mod);
-      a1 += mulmod(from_u64(v.y), lv, mod);
+      a0 = addm(a0, mulmod_dd(from_res<T>(v.x), lv, mod), mod);
+      a1 = addm(a1, mulmod_dd(from_res<T>(v.y), lv, mod), mod);
     }
     if ((k & 3) == 3) {
       a0 = reduce(a0, mod);
@@ -971,8 +1006,8 @@ io_coeff_kernel(IoDesc io, const double *__restrict__ Lcols /* [ncols][Ltot][M] 
     }
   }
   ulonglong2 o;
-  o.x = to_u64(canon(a0, mod));
-  o.y = to_u64(canon(a1, mod));
+  o.x = to_res(canon(a0, mod));
+  o.y = to_res(canon(a1, mod));
   reinterpret_cast<ulonglong2 *>(out + t * cm.out_stride())[cm.out_index(limb, slot) >> 1] = o;
 }
 
@@ -982,17 +1017,19 @@ io_coeff_kernel(IoDesc io, const double *__restrict__ Lcols /* [ncols][Ltot][M] 
 // i.e. transpose + io + mid fused: the column tile is transposed through LDS, the io value is
 // computed where it is needed, and both results are written once (16 bytes per lane).
 // grid (C/64, M/32).
+template <class M>
 __global__ void __launch_bounds__(256)
-io_mid_out_kernel(const double *__restrict__ cols, IoDesc io, const double *__restrict__ Lcols /* [ncols][Ltot][M] */,
-                  const uint64_t *__restrict__ asg, const double *__restrict__ cst /* [Ltot][M] or null */,
-                  uint64_t *__restrict__ io_out /* or null */, uint64_t *__restrict__ mid_out, size_t m, size_t C,
-                  size_t M, const Mod *__restrict__ qmod, ColMap cm) {
-  __shared__ double tile[64][33];  // [column][row]
+io_mid_out_kernel(const typename ArithOf<M>::T *__restrict__ cols, IoDesc io,
+                  const typename ArithOf<M>::T *__restrict__ Lcols /* [ncols][Ltot][M] */, const uint64_t *__restrict__ asg,
+                  const typename ArithOf<M>::T *__restrict__ cst /* [Ltot][M] or null */, uint64_t *__restrict__ io_out /* or null */,
+                  uint64_t *__restrict__ mid_out, size_t m, size_t C, size_t Mlen, const M *__restrict__ qmod, ColMap cm) {
+  using T = typename ArithOf<M>::T;
+  __shared__ T tile[64][33];  // [column][row]
   const size_t s0 = (size_t)blockIdx.x * 64, r0 = (size_t)blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int k = ty; k < 64; k += 8) {
     const size_t c = s0 + k, r = r0 + tx;
-    tile[k][tx] = (c < C && r < M) ? cols[c * M + r] : 0.0;
+    tile[k][tx] = (c < C && r < Mlen) ? cols[c * Mlen + r] : T(0);
   }
   __syncthreads();
   const size_t c = s0 + 2 * tx;  // this lane's column pair (ns is even: both slots in one limb)
@@ -1001,21 +1038,21 @@ io_mid_out_kernel(const double *__restrict__ cols, IoDesc io, const double *__re
   cm.locate(c, limb, slot);
   const size_t pair = cm.in_index(limb, slot) >> 1, Si = cm.in_stride();
   const size_t opair = cm.out_index(limb, slot) >> 1, So = cm.out_stride();
-  const Mod mod = qmod[limb];
+  const M mod = qmod[limb];
   for (int k = ty; k < 32; k += 8) {
     const size_t r = r0 + k;
     if (r >= m) continue;
-    double a0 = 0.0, a1 = 0.0;
+    T a0 = T(0), a1 = T(0);
     for (int e = 0; e < io.count; e++) {
-      const double lv = center(Lcols[((size_t)io.column[e] * cm.L + limb) * M + r], mod);
+      const T lv = center(Lcols[((size_t)io.column[e] * cm.L + limb) * Mlen + r], mod);
       const int kk = io.k[e];
       if (kk == 0) {
-        a0 += lv;
-        a1 += lv;
+        a0 = addm(a0, lv, mod);
+        a1 = addm(a1, lv, mod);
       } else {
         const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(kk - 1) * Si)[pair];
-        a0 += mulmod(from_u64(v.x), lv, mod);
-        a1 += mulmod(from_u64(v.y), lv, mod);
+        a0 = addm(a0, mulmod_dd(from_res<T>(v.x), lv, mod), mod);
+        a1 = addm(a1, mulmod_dd(from_res<T>(v.y), lv, mod), mod);
       }
       if ((e & 3) == 3) {
         a0 = reduce(a0, mod);
@@ -1026,60 +1063,59 @@ io_mid_out_kernel(const double *__restrict__ cols, IoDesc io, const double *__re
     a1 = canon(a1, mod);
     if (io_out) {
       ulonglong2 o;
-      o.x = to_u64(a0);
-      o.y = to_u64(a1);
+      o.x = to_res(a0);
+      o.y = to_res(a1);
       reinterpret_cast<ulonglong2 *>(io_out + r * So)[opair] = o;
     }
-    const double cc = cst ? cst[(size_t)limb * M + r] : 0.0;
+    const T cc = cst ? cst[(size_t)limb * Mlen + r] : T(0);
     ulonglong2 o;
-    o.x = to_u64(canon(tile[2 * tx][k] - a0 + cc, mod));
-    o.y = to_u64(canon(tile[2 * tx + 1][k] - a1 + cc, mod));
+    o.x = to_res(canon(addm(subm(tile[2 * tx][k], a0, mod), cc, mod), mod));
+    o.y = to_res(canon(addm(subm(tile[2 * tx + 1][k], a1, mod), cc, mod), mod));
     reinterpret_cast<ulonglong2 *>(mid_out + r * So)[opair] = o;
   }
 }
 
 // coefficients_for_X_mid = interp(full) - interp(io) + interp(constant part), in place over `full`.
 // (The reference evaluates index-0 terms in BOTH the io and the mid pass, r1cs_to_qrp.tcc:175-201.)
+template <class CPS>
 __global__ void __launch_bounds__(256)
-mid_kernel(double *__restrict__ full, const double *__restrict__ io, const double *__restrict__ cst /* [Ltot][M] or null */,
-           size_t M, size_t S, unsigned slots_per_limb, ColPlans plans, int limb0) {
+mid_kernel(typename CPS::T *__restrict__ full, const typename CPS::T *__restrict__ io,
+           const typename CPS::T *__restrict__ cst /* [Ltot][M] or null */, size_t M, size_t S, unsigned slots_per_limb, CPS plans,
+           int limb0) {
+  using T = typename CPS::T;
   const size_t total = S * M, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const size_t col = i / M, k = i % M;
     const int limb = (int)(col / slots_per_limb);  // chunk-local: plans are shifted by limb0
-    const Mod mod = plans.l[limb].mod;
-    double v = full[i] - io[i];
-    if (cst) v += cst[(size_t)(limb0 + limb) * M + k];
+    const typename CPS::M mod = plans.l[limb].mod;
+    T v = subm(full[i], io[i], mod);
+    if (cst) v = addm(v, cst[(size_t)(limb0 + limb) * M + k], mod);
     full[i] = canon(v, mod);
   }
 }
 
-// a14: linear_combination::evaluate for every constraint (relations/variable.tcc:246-254).
-// grid (m, ceil(L*N/512)); each thread handles two adjacent slots.
-__global__ void __launch_bounds__(256)
-r1cs_eval_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const double *__restrict__ coeff,
-                 size_t nnz, const uint64_t *__restrict__ asg, uint64_t *__restrict__ out, int N, int L, int mode,
-                 unsigned n_inputs, const Mod *__restrict__ qmod) {
-  const size_t row = blockIdx.x;
-  const size_t S = (size_t)L * N;
-  const size_t pair = (size_t)blockIdx.y * blockDim.x + threadIdx.x;
-  if (2 * pair >= S) return;
-  const int limb = (int)((2 * pair) / (size_t)N);
-  const Mod mod = qmod[limb];
-  double a0 = 0.0, a1 = 0.0;
+// one row of linear_combination::evaluate for a slot pair: sum_e coeff_e * x_{col_e} (index 0 = the constant one)
+template <class M>
+__device__ __forceinline__ void eval_row_pair(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
+                                              const typename ArithOf<M>::T *__restrict__ coeff_limb, size_t row,
+                                              const uint64_t *__restrict__ asg, size_t Si, size_t pair, int mode, unsigned n_inputs,
+                                              const M mod, typename ArithOf<M>::T &o0, typename ArithOf<M>::T &o1) {
+  using T = typename ArithOf<M>::T;
+  T a0 = T(0), a1 = T(0);
   int since = 0;
   for (uint32_t e = row_ptr[row]; e < row_ptr[row + 1]; e++) {
-    const uint32_t c = col[e];
-    const double cf = coeff[(size_t)limb * nnz + e];
-    if (c == 0) {
-      a0 += cf;
-      a1 += cf;
+    const uint32_t cv = col[e];
+    const T cf = coeff_limb[e];  // a table constant
+    if (cv == 0) {
+      const T one_times = konst_value(cf, mod);
+      a0 = addm(a0, one_times, mod);
+      a1 = addm(a1, one_times, mod);
     } else {
-      const bool is_input = (c - 1) < n_inputs;
+      const bool is_input = (cv - 1) < n_inputs;
       if ((mode == RS_EVAL_IO && !is_input) || (mode == RS_EVAL_MID && is_input)) continue;
-      const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(c - 1) * S)[pair];
-      a0 += mulmod(from_u64(v.x), cf, mod);
-      a1 += mulmod(from_u64(v.y), cf, mod);
+      const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(cv - 1) * Si)[pair];
+      a0 = addm(a0, mulmod(from_res<T>(v.x), cf, mod), mod);
+      a1 = addm(a1, mulmod(from_res<T>(v.y), cf, mod), mod);
     }
     if (++since == 4) {
       since = 0;
@@ -1087,21 +1123,42 @@ r1cs_eval_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restric
       a1 = reduce(a1, mod);
     }
   }
-  ulonglong2 o;
-  o.x = to_u64(canon(a0, mod));
-  o.y = to_u64(canon(a1, mod));
-  reinterpret_cast<ulonglong2 *>(out + row * S)[pair] = o;
+  o0 = canon(a0, mod);
+  o1 = canon(a1, mod);
 }
 
+// a14: linear_combination::evaluate for every constraint (relations/variable.tcc:246-254).
+// grid (m, ceil(L*N/512)); each thread handles two adjacent slots.
+template <class M>
+__global__ void __launch_bounds__(256)
+r1cs_eval_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
+                 const typename ArithOf<M>::T *__restrict__ coeff, size_t nnz, const uint64_t *__restrict__ asg,
+                 uint64_t *__restrict__ out, int N, int L, int mode, unsigned n_inputs, const M *__restrict__ qmod) {
+  using T = typename ArithOf<M>::T;
+  const size_t row = blockIdx.x;
+  const size_t S = (size_t)L * N;
+  const size_t pair = (size_t)blockIdx.y * blockDim.x + threadIdx.x;
+  if (2 * pair >= S) return;
+  const int limb = (int)((2 * pair) / (size_t)N);
+  T a0, a1;
+  eval_row_pair<M>(row_ptr, col, coeff + (size_t)limb * nnz, row, asg, S, pair, mode, n_inputs, qmod[limb], a0, a1);
+  ulonglong2 o;
+  o.x = to_res(a0);
+  o.y = to_res(a1);
+  reinterpret_cast<ulonglong2 *>(out + row * S)[pair] = o;
+}
 
 // linear_combination::evaluate straight into the column-major layout of the witness map
 // (r1cs_eval_kernel + transpose fused; rows >= m are the zero padding of the columns).
 // grid (C/64, M/32): 64 columns x 32 rows per workgroup.
+template <class M>
 __global__ void __launch_bounds__(256)
-r1cs_eval_cols_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const double *__restrict__ coeff,
-                      size_t nnz, const uint64_t *__restrict__ asg, double *__restrict__ cols, size_t m, size_t C, size_t M,
-                      int mode, unsigned n_inputs, const Mod *__restrict__ qmod, ColMap cm) {
-  __shared__ double tile[64][33];  // [column][row]
+r1cs_eval_cols_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
+                      const typename ArithOf<M>::T *__restrict__ coeff, size_t nnz, const uint64_t *__restrict__ asg,
+                      typename ArithOf<M>::T *__restrict__ cols, size_t m, size_t C, size_t Mlen, int mode, unsigned n_inputs,
+                      const M *__restrict__ qmod, ColMap cm) {
+  using T = typename ArithOf<M>::T;
+  __shared__ T tile[64][33];  // [column][row]
   const size_t s0 = (size_t)blockIdx.x * 64, r0 = (size_t)blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const size_t c = s0 + 2 * tx;  // column pair of this lane, 16-byte loads of the assignment
@@ -1109,34 +1166,11 @@ r1cs_eval_cols_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__re
     int limb, slot;
     cm.locate(c, limb, slot);
     const size_t pair = cm.in_index(limb, slot) >> 1, Si = cm.in_stride();
-    const Mod mod = qmod[limb];
+    const M mod = qmod[limb];
     for (int k = ty; k < 32; k += 8) {
       const size_t row = r0 + k;
-      double a0 = 0.0, a1 = 0.0;
-      if (row < m) {
-        int since = 0;
-        for (uint32_t e = row_ptr[row]; e < row_ptr[row + 1]; e++) {
-          const uint32_t cv = col[e];
-          const double cf = coeff[(size_t)limb * nnz + e];
-          if (cv == 0) {
-            a0 += cf;
-            a1 += cf;
-          } else {
-            const bool is_input = (cv - 1) < n_inputs;
-            if ((mode == RS_EVAL_IO && !is_input) || (mode == RS_EVAL_MID && is_input)) continue;
-            const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(cv - 1) * Si)[pair];
-            a0 += mulmod(from_u64(v.x), cf, mod);
-            a1 += mulmod(from_u64(v.y), cf, mod);
-          }
-          if (++since == 4) {
-            since = 0;
-            a0 = reduce(a0, mod);
-            a1 = reduce(a1, mod);
-          }
-        }
-        a0 = canon(a0, mod);
-        a1 = canon(a1, mod);
-      }
+      T a0 = T(0), a1 = T(0);
+      if (row < m) eval_row_pair<M>(row_ptr, col, coeff + (size_t)limb * nnz, row, asg, Si, pair, mode, n_inputs, mod, a0, a1);
       tile[2 * tx][k] = a0;
       tile[2 * tx + 1][k] = a1;
     }
@@ -1144,23 +1178,25 @@ r1cs_eval_cols_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__re
   __syncthreads();
   for (int k = ty; k < 64; k += 8) {
     const size_t cc = s0 + k, r = r0 + tx;
-    if (cc < C && r < M) cols[cc * M + r] = tile[k][tx];
+    if (cc < C && r < Mlen) cols[cc * Mlen + r] = tile[k][tx];
   }
 }
 
 // H[m] when m == M (the column tile holds M rows only): d1*d2*Z[m] = d1*d2 (Z monic), zero without ZK
+template <class M>
 __global__ void __launch_bounds__(256)
 h_top_kernel(uint64_t *__restrict__ top, const uint64_t *__restrict__ d1, const uint64_t *__restrict__ d2, size_t C,
-             const Mod *__restrict__ qmod, ColMap cm) {
+             const M *__restrict__ qmod, ColMap cm) {
+  using T = typename ArithOf<M>::T;
   const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   int limb, slot;
   cm.locate(c, limb, slot);
-  const Mod mod = qmod[limb];
+  const M mod = qmod[limb];
   uint64_t v = 0;
   if (d1) {
     const size_t di = cm.in_index(limb, slot);
-    v = to_u64(canon(mulmod(center(from_u64(d1[di]), mod), center(from_u64(d2[di]), mod), mod), mod));
+    v = to_res(canon(mulmod_dd(center(from_res<T>(d1[di]), mod), center(from_res<T>(d2[di]), mod), mod), mod));
   }
   top[cm.out_index(limb, slot)] = v;
 }
@@ -1174,14 +1210,16 @@ h_top_kernel(uint64_t *__restrict__ top, const uint64_t *__restrict__ d1, const 
 // Both reuse the round functions of ntt_core.hpp (global-memory functors / `root`).
 // =============================================================================================
 struct TabPtrs {
-  const double *t[RS_MAX_L];
+  const void *t[RS_MAX_L];  // tables of the context's arithmetic (8-byte words)
 };
-struct GlobalF64IO {
-  double *p;
+template <class T>
+struct GlobalIOT {
+  T *p;
   __device__ __forceinline__ int pbase(int) const { return 0; }
-  __device__ __forceinline__ double load(int base, int, int eoff, int) const { return p[base + eoff]; }
-  __device__ __forceinline__ void store(int base, int, int eoff, int, double v) const { p[base + eoff] = v; }
+  __device__ __forceinline__ T load(int base, int, int eoff, int) const { return p[base + eoff]; }
+  __device__ __forceinline__ void store(int base, int, int eoff, int, T v) const { p[base + eoff] = v; }
 };
+using GlobalF64IO = GlobalIOT<double>;
 
 // ---- cross passes with fused sources and sinks ----------------------------------------------------
 // The first forward pass of a transform reads its input through a source functor (padding,
@@ -1192,42 +1230,44 @@ struct GlobalF64IO {
 enum CrossSrc { CS_PLAIN = 0, CS_SCALE_PAD, CS_FILL_RIGHT, CS_PAD_CENTER, CS_REV_TRUNC };
 enum CrossDst { CD_PLAIN = 0, CD_TAKE_LOW, CD_COMBINE, CD_COMBINE_CANON, CD_H_FINISH };
 struct CrossArgs {
-  double *W;          // workspace columns [ncols][2^logtot]
-  const double *src;  // source columns (CS_*): [ncols][M] (CS_REV_TRUNC: [ncols][2M])
-  double *dst;        // sink columns (CD_*): [ncols][M]
+  void *W;          // workspace columns [ncols][2^logtot]   (8-byte words of the context's arithmetic)
+  const void *src;  // source columns (CS_*): [ncols][M] (CS_REV_TRUNC: [ncols][2M])
+  void *dst;        // sink columns (CD_*): [ncols][M]
   int logtot, logsub, s0, logM, l, m;
   size_t col0;
   unsigned S, slots_per_limb;
 };
-template <int SRC>
+template <int SRC, class Mt>
 struct CrossIn {
-  const double *p;  // this column of the source
-  const double *invfact;
-  Mod mod;
+  using T = typename ArithOf<Mt>::T;
+  const T *p;  // this column of the source
+  const T *invfact;
+  Mt mod;
   int M, m, n, h;
   __device__ __forceinline__ int pbase(int) const { return 0; }
-  __device__ __forceinline__ double load(int base, int, int eoff, int) const {
+  __device__ __forceinline__ T load(int base, int, int eoff, int) const {
     const int k = base + eoff;
-    if (SRC == CS_SCALE_PAD) return k < M ? mulmod(p[k], invfact[k], mod) : 0.0;  // values * 1/k!, zero padded
-    if (SRC == CS_FILL_RIGHT) return (k & (n - 1)) < h ? p[k + h] : 0.0;         // per node: (F_right, 0)
-    if (SRC == CS_PAD_CENTER) return k < M ? center(p[k], mod) : 0.0;
-    if (SRC == CS_REV_TRUNC) return k < m - 1 ? reduce(p[2 * m - 2 - k], mod) : 0.0;  // T_k = P_{2m-2-k}, k < m-1
+    if (SRC == CS_SCALE_PAD) return k < M ? mulmod(p[k], invfact[k], mod) : T(0);  // values * 1/k!, zero padded
+    if (SRC == CS_FILL_RIGHT) return (k & (n - 1)) < h ? p[k + h] : T(0);         // per node: (F_right, 0)
+    if (SRC == CS_PAD_CENTER) return k < M ? center(p[k], mod) : T(0);
+    if (SRC == CS_REV_TRUNC) return k < m - 1 ? reduce(p[2 * m - 2 - k], mod) : T(0);  // T_k = P_{2m-2-k}, k < m-1
     return p[k];
   }
 };
-template <int DST>
+template <int DST, class Mt>
 struct CrossOut {
-  double *p;  // this column of the sink
-  const double *invfact;
-  Mod mod;
+  using T = typename ArithOf<Mt>::T;
+  T *p;  // this column of the sink
+  const T *invfact;
+  Mt mod;
   int M, m, n, h;
   __device__ __forceinline__ int pbase(int) const { return 0; }
-  __device__ __forceinline__ void store(int base, int, int eoff, int, double v) const {
+  __device__ __forceinline__ void store(int base, int, int eoff, int, T v) const {
     const int k = base + eoff;
     if (DST == CD_TAKE_LOW) {  // Newton coefficients k < m of the length-2M convolution
-      if (k < M) p[k] = (invfact[k] != 0.0) ? reduce(v, mod) : 0.0;
+      if (k < M) p[k] = (invfact[k] != T(0)) ? reduce(v, mod) : T(0);
     } else if (DST == CD_COMBINE || DST == CD_COMBINE_CANON) {  // F_node = (F_left, 0) + D_left * F_right
-      const double f = reduce(v + ((k & (n - 1)) < h ? p[k] : 0.0), mod);
+      const T f = reduce(addm(v, ((k & (n - 1)) < h ? p[k] : T(0)), mod), mod);
       p[k] = DST == CD_COMBINE_CANON ? canon(f, mod) : f;
     } else if (DST == CD_H_FINISH) {  // H_j = U_{m-2-j}; positions j > m-2 are cleared by h_patch_kernel
       if (k <= m - 2) p[m - 2 - k] = reduce(v, mod);
@@ -1239,18 +1279,20 @@ struct CrossOut {
 
 // cross stages [s0, s0+R) of batched length-2^logsub transforms inside columns of length 2^logtot.
 // grid (x, columns).  MODE: CrossSrc for forward passes, CrossDst for inverse passes.
-template <bool INV, int R, int MODE>
-__global__ void __launch_bounds__(256) cross_kernel(CrossArgs a, ColPlans plans) {
+template <bool INV, int R, int MODE, class CPS>
+__global__ void __launch_bounds__(256) cross_kernel(CrossArgs a, CPS plans) {
+  using T = typename CPS::T;
+  using Mt = typename CPS::M;
   const size_t col = blockIdx.y;
-  const ColPlan &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
-  const GlobalF64IO io{a.W + (col << a.logtot)};
+  const ColPlanT<Mt> &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const GlobalIOT<T> io{static_cast<T *>(a.W) + (col << a.logtot)};
   const Lanes ln{(int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x)};
   const int M = 1 << a.logM, n = 1 << a.l;
   if (INV) {
     if (MODE == CD_PLAIN) {
       inv_round<R>(io, io, a.logtot, a.logsub, a.s0, P.itw, 1, P.mod, P.imask[a.logsub], ln);
     } else {
-      const CrossOut<MODE> out{a.dst + (col << a.logM), P.invfact, P.mod, M, a.m, n, n >> 1};
+      const CrossOut<MODE, Mt> out{static_cast<T *>(a.dst) + (col << a.logM), P.invfact, P.mod, M, a.m, n, n >> 1};
       inv_round<R>(io, out, a.logtot, a.logsub, a.s0, P.itw, 1, P.mod, P.imask[a.logsub], ln);
     }
   } else {
@@ -1258,7 +1300,7 @@ __global__ void __launch_bounds__(256) cross_kernel(CrossArgs a, ColPlans plans)
       fwd_round<R>(io, io, a.logtot, a.logsub, a.s0, P.tw, 1, P.mod, P.fmask[a.logsub], ln);
     } else {
       const size_t stride = MODE == CS_REV_TRUNC ? (size_t)2 << a.logM : (size_t)1 << a.logM;
-      const CrossIn<MODE> in{a.src + col * stride, P.invfact, P.mod, M, a.m, n, n >> 1};
+      const CrossIn<MODE, Mt> in{static_cast<const T *>(a.src) + col * stride, P.invfact, P.mod, M, a.m, n, n >> 1};
       fwd_round<R>(in, io, a.logtot, a.logsub, a.s0, P.tw, 1, P.mod, P.fmask[a.logsub], ln);
     }
   }
@@ -1268,52 +1310,60 @@ __global__ void __launch_bounds__(256) cross_kernel(CrossArgs a, ColPlans plans)
 // multiply by tab[(blk % tab_period) * Bn + j], inverse (fused); 3: like 2 with a per-column table
 // (another workspace of the same shape, lazily reduced): tab[blk * Bn + j].  Block blk belongs to column
 // blk / blocks_per_col; inside its transform (n1 = 2^log_n1 blocks) it is block blk % n1.
-template <int MODE>
+template <int MODE, class CPS>
 __global__ void __launch_bounds__(1024)
-sub_ntt_kernel(double *__restrict__ X, int logB, int log_n1, TabPtrs tabs, unsigned tab_period,
-               unsigned blocks_per_col, size_t col0, unsigned S, unsigned slots_per_limb, ColPlans plans) {
+sub_ntt_kernel(typename CPS::T *__restrict__ X, int logB, int log_n1, TabPtrs tabs, unsigned tab_period,
+               unsigned blocks_per_col, size_t col0, unsigned S, unsigned slots_per_limb, CPS plans) {
+  using T = typename CPS::T;
+  using Mt = typename CPS::M;
+  constexpr bool FP = std::is_same<Mt, Mod>::value;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *s = reinterpret_cast<double *>(smem);
+  T *s = reinterpret_cast<T *>(smem);
   const int Bn = 1 << logB;
   const size_t blk = blockIdx.x;
   const size_t col = blk / blocks_per_col;
   const int limb = (int)(((col0 + col) % S) / slots_per_limb);
-  const ColPlan &P = plans.l[limb];
-  const Mod mod = P.mod;
+  const ColPlanT<Mt> &P = plans.l[limb];
+  const Mt mod = P.mod;
   const int root = (1 << log_n1) + (int)(blk & ((1u << log_n1) - 1));
   const int logn = logB + log_n1;
-  double *x = X + blk * (size_t)Bn;
+  T *x = X + blk * (size_t)Bn;
   for (int i = threadIdx.x; i < Bn; i += blockDim.x) s[pidx(i)] = x[i];
   __syncthreads();
   int logw = 0;
   while ((64 << logw) < (int)blockDim.x) logw++;
-  const bool wp = logw >= 1 && logw <= 4 && logB - logw >= 8;
-  const ColBlockFactory bf{s};
-  const LdsIO lds{s};
+  const bool wp = FP && logw >= 1 && logw <= 4 && logB - logw >= 8;
   if (MODE == 0 || MODE >= 2) {
-    if (wp) {
-      lds_ntt_fwd_wp<4, LdsIO, ColBlockFactory, 3>(s, lds, bf, logB, logw, P.tw, mod, P.fmask[logn] >> log_n1, root);
-      __syncthreads();
-    } else {
-      lds_ntt_fwd<3>(s, logB, P.tw, root, mod, P.fmask[logn] >> log_n1);
+    bool done = false;
+    if constexpr (FP) {
+      if (wp) {
+        lds_ntt_fwd_wp<4, LdsIO, ColBlockFactory, 3>(s, LdsIO{s}, ColBlockFactory{s}, logB, logw, P.tw, mod, P.fmask[logn] >> log_n1, root);
+        __syncthreads();
+        done = true;
+      }
     }
+    if (!done) lds_ntt_fwd<3>(s, logB, P.tw, root, mod, P.fmask[logn] >> log_n1);
   }
-  if (MODE == 2) {
-    const double *tab = tabs.t[limb] + (size_t)(blk % tab_period) * Bn;
+  if (MODE == 2) {  // table of slot-constant spectra: a table constant
+    const T *tab = static_cast<const T *>(tabs.t[limb]) + (size_t)(blk % tab_period) * Bn;
     for (int i = threadIdx.x; i < Bn; i += blockDim.x) s[pidx(i)] = mulmod(reduce(s[pidx(i)], mod), tab[i], mod);
     __syncthreads();
   }
-  if (MODE == 3) {
-    const double *tab = tabs.t[0] + blk * (size_t)Bn;
+  if (MODE == 3) {  // the other workspace: a spectrum computed on the device (data x data)
+    const T *tab = static_cast<const T *>(tabs.t[0]) + blk * (size_t)Bn;
     for (int i = threadIdx.x; i < Bn; i += blockDim.x)
-      s[pidx(i)] = mulmod(reduce(s[pidx(i)], mod), reduce(tab[i], mod), mod);
+      s[pidx(i)] = mulmod_dd(reduce(s[pidx(i)], mod), reduce(tab[i], mod), mod);
     __syncthreads();
   }
   if (MODE >= 1) {
-    if (wp)
-      lds_ntt_inv_wp<4, ColBlockFactory, LdsIO, 3>(s, bf, lds, logB, logw, P.itw, mod, P.imask[logn], root);
-    else
-      lds_ntt_inv<3>(s, logB, P.itw, root, mod, P.imask[logn]);
+    bool done = false;
+    if constexpr (FP) {
+      if (wp) {
+        lds_ntt_inv_wp<4, ColBlockFactory, LdsIO, 3>(s, ColBlockFactory{s}, LdsIO{s}, logB, logw, P.itw, mod, P.imask[logn], root);
+        done = true;
+      }
+    }
+    if (!done) lds_ntt_inv<3>(s, logB, P.itw, root, mod, P.imask[logn]);
   }
   for (int i = threadIdx.x; i < Bn; i += blockDim.x) x[i] = s[pidx(i)];
 }
@@ -1375,54 +1425,59 @@ sub_ntt_ct_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab
     return;
   }
   if (MODE == 2) {
-    const double *tab = tabs.t[limb] + (size_t)(blk % tab_period) * Bn;
+    const double *tab = static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * Bn;
     lds_ntt_fwd_wp<RS_SUB_MAXR, GlobalF64IO, TreeMulFactory, 3>(s, gio, TreeMulFactory{s, tab, mod}, LOGB, LOGW, P.tw, mod, fmask, root);
   } else {
-    const double *tab = tabs.t[0] + blk * (size_t)Bn;
+    const double *tab = static_cast<const double *>(tabs.t[0]) + blk * (size_t)Bn;
     lds_ntt_fwd_wp<RS_SUB_MAXR, GlobalF64IO, SubMulLazyFactory, 3>(s, gio, SubMulLazyFactory{s, tab, mod}, LOGB, LOGW, P.tw, mod, fmask, root);
   }
   lds_ntt_inv_wp<RS_SUB_MAXR, ColBlockFactory, GlobalF64IO, 3>(s, bf, gio, LOGB, LOGW, P.itw, mod, imask, root);
 }
 
 // ZK patch of the multi-pass H: H += d2*A + d1*B + d1*d2*Z, H[0] -= d3; then canonical form.
+template <class CPS>
 __global__ void __launch_bounds__(256)
-h_patch_kernel(double *__restrict__ H, const double *__restrict__ A, const double *__restrict__ B, int logM, int m, size_t cols,
-               size_t col0, unsigned S, unsigned slots_per_limb, ColPlans plans, const uint64_t *__restrict__ d1,
+h_patch_kernel(typename CPS::T *__restrict__ H, const typename CPS::T *__restrict__ A, const typename CPS::T *__restrict__ B, int logM,
+               int m, size_t cols, size_t col0, unsigned S, unsigned slots_per_limb, CPS plans, const uint64_t *__restrict__ d1,
                const uint64_t *__restrict__ d2, const uint64_t *__restrict__ d3, ColMap cm) {
+  using T = typename CPS::T;
   const size_t M = (size_t)1 << logM, total = cols * M, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const size_t col = i / M, k = i % M, gcol = (col0 + col) % S;
-    const ColPlan &P = plans.l[gcol / slots_per_limb];
-    const Mod mod = P.mod;
-    double h = ((long long)k <= (long long)m - 2) ? H[i] : 0.0;
+    const ColPlanT<typename CPS::M> &P = plans.l[gcol / slots_per_limb];
+    const typename CPS::M mod = P.mod;
+    T h = ((long long)k <= (long long)m - 2) ? H[i] : T(0);
     if (d1) {
       int dlimb, dslot;
       cm.locate(gcol, dlimb, dslot);
       const size_t di = cm.in_index(dlimb, dslot);
-      const double e1 = center(from_u64(d1[di]), mod), e2 = center(from_u64(d2[di]), mod);
-      h += mulmod(e2, center(A[i], mod), mod) + mulmod(e1, center(B[i], mod), mod) + mulmod(mulmod(e1, e2, mod), P.ztab[k], mod);
-      if (k == 0) h -= center(from_u64(d3[di]), mod);
+      const T e1 = center(from_res<T>(d1[di]), mod), e2 = center(from_res<T>(d2[di]), mod);
+      h = addm(h, addm(addm(mulmod_dd(e2, center(A[i], mod), mod), mulmod_dd(e1, center(B[i], mod), mod), mod),
+                       mulmod(mulmod_dd(e1, e2, mod), P.ztab[k], mod), mod), mod);
+      if (k == 0) h = subm(h, center(from_res<T>(d3[di]), mod), mod);
     }
     H[i] = canon(h, mod);
   }
 }
 
 // Column plans of limbs limb0, limb0+1, ...: entry k serves the k-th limb of a chunk
-static ColPlans make_colplans(rs_ctx *ctx, const WitnessPlan *P, int limb0 = 0) {
-  ColPlans cp;
+template <class M>
+static ColPlansT<M> make_colplans(rs_ctx *ctx, const WitnessPlan *P, int limb0 = 0) {
+  using T = typename ArithOf<M>::T;
+  ColPlansT<M> cp;
   memset(&cp, 0, sizeof(cp));
   for (int i = limb0; i < ctx->L; i++) {
     const LimbPlan &lp = P->limb[i];
-    ColPlan &c = cp.l[i - limb0];
-    c.mod = lp.mod;
-    c.tw = lp.d_tw;
-    c.itw = lp.d_itw;
-    c.invfact = lp.d_invfact;
-    c.ehat = lp.d_ehat;
-    c.dhat = lp.d_dhat;
-    c.dlow = lp.d_dlow;
-    c.shat = lp.d_shat;
-    c.ztab = lp.d_ztab;
+    ColPlanT<M> &c = cp.l[i - limb0];
+    c.mod = HostArith<M>::make(lp.p);
+    c.tw = static_cast<const T *>(lp.d_tw);
+    c.itw = static_cast<const T *>(lp.d_itw);
+    c.invfact = static_cast<const T *>(lp.d_invfact);
+    c.ehat = static_cast<const T *>(lp.d_ehat);
+    c.dhat = static_cast<const T *>(lp.d_dhat);
+    c.dlow = static_cast<const T *>(lp.d_dlow);
+    c.shat = static_cast<const T *>(lp.d_shat);
+    c.ztab = static_cast<const T *>(lp.d_ztab);
     c.fwd_mask2 = lp.fwd_mask2;
     c.inv_mask2 = lp.inv_mask2;
     for (int l = 0; l < 24; l++) {
@@ -1490,13 +1545,46 @@ static void launch_tree_tiles(rs_ctx *ctx, double *cols, size_t ncols, size_t co
   RS_HIP(hipGetLastError());
 }
 
-template <bool INV, int MODE>
-static void launch_cross_pass(int R, const dim3 &grid, const CrossArgs &a, const ColPlans &cp, hipStream_t st) {
+// The same tile work for any arithmetic (the integer contexts): levels 1..logT of the product tree on tiles of
+// 2^logT Newton coefficients, tile + scratch in LDS, all-barrier rounds.
+template <class CPS>
+__global__ void __launch_bounds__(1024)
+tree_tiles_generic_kernel(typename CPS::T *__restrict__ cols, int logM, int logT, size_t col0, unsigned S, unsigned slots_per_limb,
+                          CPS plans) {
+  using T = typename CPS::T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T *s = reinterpret_cast<T *>(smem);
+  const unsigned nb = 1u << (logM - logT);
+  const size_t col = blockIdx.x / nb;
+  const int pos0 = (int)(blockIdx.x % nb) << logT, Tn = 1 << logT;
+  const ColPlanT<typename CPS::M> &P = plans.l[((col0 + col) % S) / slots_per_limb];
+  T *c = cols + col * ((size_t)1 << logM) + pos0;
+  for (int i = threadIdx.x; i < Tn; i += blockDim.x) s[pidx(i)] = c[i];
+  __syncthreads();
+  tree_levels_lds(s, logT, logM, pos0, P);
+  for (int i = threadIdx.x; i < Tn; i += blockDim.x) c[i] = reduce(s[pidx(i)], P.mod);
+}
+template <class M>
+static void launch_tree_tiles_generic(rs_ctx *ctx, typename ArithOf<M>::T *cols, size_t ncols, size_t col0, int logM, int logT, size_t S,
+                                      size_t slots_per_limb, const ColPlansT<M> &cp, hipStream_t st) {
+  const size_t T = (size_t)1 << logT;
+  const size_t lds = padded_len(tree_scratch_offset((int)T) + T) * sizeof(uint64_t);
+  ProfScope prof(ctx, st, "tree_tiles_generic_kernel", (double)(ncols << (logM - logT)) * (double)T * 16.0,
+                 (double)(ncols << (logM - logT)) * tree_fp64((double)T, logT));
+  RS_HIP(hipFuncSetAttribute((const void *)tree_tiles_generic_kernel<ColPlansT<M>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(tree_tiles_generic_kernel<ColPlansT<M>>, dim3((unsigned)(ncols << (logM - logT))), dim3(col_threads(2 * T)), lds, st,
+                     cols, logM, logT, col0, (unsigned)S, (unsigned)slots_per_limb, cp);
+  RS_HIP(hipGetLastError());
+}
+
+template <bool INV, int MODE, class M>
+static void launch_cross_pass(int R, const dim3 &grid, const CrossArgs &a, const ColPlansT<M> &cp, hipStream_t st) {
+  using CPS = ColPlansT<M>;
   switch (R) {
-    case 4: hipLaunchKernelGGL((cross_kernel<INV, 4, MODE>), grid, dim3(256), 0, st, a, cp); break;
-    case 3: hipLaunchKernelGGL((cross_kernel<INV, 3, MODE>), grid, dim3(256), 0, st, a, cp); break;
-    case 2: hipLaunchKernelGGL((cross_kernel<INV, 2, MODE>), grid, dim3(256), 0, st, a, cp); break;
-    default: hipLaunchKernelGGL((cross_kernel<INV, 1, MODE>), grid, dim3(256), 0, st, a, cp); break;
+    case 4: hipLaunchKernelGGL((cross_kernel<INV, 4, MODE, CPS>), grid, dim3(256), 0, st, a, cp); break;
+    case 3: hipLaunchKernelGGL((cross_kernel<INV, 3, MODE, CPS>), grid, dim3(256), 0, st, a, cp); break;
+    case 2: hipLaunchKernelGGL((cross_kernel<INV, 2, MODE, CPS>), grid, dim3(256), 0, st, a, cp); break;
+    default: hipLaunchKernelGGL((cross_kernel<INV, 1, MODE, CPS>), grid, dim3(256), 0, st, a, cp); break;
   }
 }
 
@@ -1511,8 +1599,8 @@ static double cross_words(const CrossArgs &a, bool special) {
   if (!INV) return n + (MODE == CS_FILL_RIGHT ? M / 2.0 : M);                  // source words + workspace written
   return n + (MODE == CD_COMBINE || MODE == CD_COMBINE_CANON ? 1.5 * M : M);  // workspace read + sink traffic
 }
-template <bool INV, int MODE>
-static void launch_cross(rs_ctx *ctx, CrossArgs a, size_t ncols, int logB, const ColPlans &cp, hipStream_t st) {
+template <bool INV, int MODE, class M>
+static void launch_cross(rs_ctx *ctx, CrossArgs a, size_t ncols, int logB, const ColPlansT<M> &cp, hipStream_t st) {
   const int ncross = a.logsub - logB;
   const size_t groups = ((size_t)1 << a.logtot);
   int done = 0;
@@ -1525,17 +1613,18 @@ static void launch_cross(rs_ctx *ctx, CrossArgs a, size_t ncols, int logB, const
     ProfScope prof(ctx, st, "cross_kernel", (double)ncols * 8.0 * cross_words<INV, MODE>(a, special),
                    (double)ncols * ntt_fp64((double)groups, R));
     if (special)
-      launch_cross_pass<INV, MODE>(R, grid, a, cp, st);
+      launch_cross_pass<INV, MODE, M>(R, grid, a, cp, st);
     else
-      launch_cross_pass<INV, 0>(R, grid, a, cp, st);
+      launch_cross_pass<INV, 0, M>(R, grid, a, cp, st);
     done += R;
   }
   RS_HIP(hipGetLastError());
 }
 
-template <int MODE>
-static void launch_sub(rs_ctx *ctx, double *X, size_t ncols, size_t col0, int logtot, int logsub, int logB, const TabPtrs *tabs,
-                       size_t tab_period, size_t S, size_t spl, const ColPlans &cp, hipStream_t st) {
+template <int MODE, class M>
+static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, size_t col0, int logtot, int logsub, int logB,
+                       const TabPtrs *tabs, size_t tab_period, size_t S, size_t spl, const ColPlansT<M> &cp, hipStream_t st) {
+  constexpr bool FP = std::is_same<M, Mod>::value;
   const size_t lds = padded_len((size_t)1 << logB) * sizeof(double);
   const size_t bpc = (size_t)1 << (logtot - logB);
   static const char *const names[4] = {"sub_ntt_kernel<0>", "sub_ntt_kernel<1>", "sub_ntt_kernel<2>", "sub_ntt_kernel<3>"};
@@ -1544,25 +1633,30 @@ static void launch_sub(rs_ctx *ctx, double *X, size_t ncols, size_t col0, int lo
                  blocks * ((MODE >= 2 ? 2.0 : 1.0) * ntt_fp64(Bn, logB) + (MODE >= 2 ? 7.0 * Bn : 0.0)));
   static TabPtrs none{};
   const TabPtrs &tp = tabs ? *tabs : none;
-  if (logB == 13 && MODE != 1 && g_witness_sub_ct) {
-    RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_ct_kernel<MODE, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((sub_ntt_ct_kernel<MODE, 13>), dim3((unsigned)(ncols * bpc)), dim3(512), lds, st, X, logsub - logB, tp,
-                       (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp);
-    RS_HIP(hipGetLastError());
-    return;
+  if constexpr (FP) {
+    if (logB == 13 && MODE != 1 && g_witness_sub_ct) {
+      RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_ct_kernel<MODE, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((sub_ntt_ct_kernel<MODE, 13>), dim3((unsigned)(ncols * bpc)), dim3(512), lds, st, X, logsub - logB, tp,
+                         (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp);
+      RS_HIP(hipGetLastError());
+      return;
+    }
   }
-  RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_kernel<MODE, ColPlansT<M>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, ((size_t)1 << logB) / 16));
-  hipLaunchKernelGGL(sub_ntt_kernel<MODE>, dim3((unsigned)(ncols * bpc)), dim3(thr), lds, st, X, logB, logsub - logB, tp,
+  hipLaunchKernelGGL((sub_ntt_kernel<MODE, ColPlansT<M>>), dim3((unsigned)(ncols * bpc)), dim3(thr), lds, st, X, logB, logsub - logB, tp,
                      (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp);
   RS_HIP(hipGetLastError());
 }
 
 // multi-pass interpolation of `ncols` columns X[ncols][M] in place; W: workspace [ncols][2M]
-static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, double *X, double *W, size_t ncols, size_t col0,
-                       size_t S, size_t spl, int limb0, hipStream_t st) {
+template <class M>
+static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, typename ArithOf<M>::T *X, typename ArithOf<M>::T *W,
+                       size_t ncols, size_t col0, size_t S, size_t spl, int limb0, hipStream_t st) {
+  using T = typename ArithOf<M>::T;
+  constexpr bool FP = std::is_same<M, Mod>::value;
   const int logM = P->logM, logB = std::min(g_witness_lds_logM, logM);
-  const size_t M = P->M;
+  const size_t Mlen = P->M;
   CrossArgs a{};
   a.W = W;
   a.src = X;
@@ -1576,33 +1670,38 @@ static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, do
   TabPtrs tp{};
   // values -> Newton coefficients: one cyclic convolution of length 2M
   a.logtot = a.logsub = logM + 1;
-  launch_cross<false, CS_SCALE_PAD>(ctx, a, ncols, logB, cp, st);
+  launch_cross<false, CS_SCALE_PAD, M>(ctx, a, ncols, logB, cp, st);
   for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_ehat;
-  launch_sub<2>(ctx, W, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * M) >> logB, S, spl, cp, st);
-  launch_cross<true, CD_TAKE_LOW>(ctx, a, ncols, logB, cp, st);
+  launch_sub<2, M>(ctx, W, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * Mlen) >> logB, S, spl, cp, st);
+  launch_cross<true, CD_TAKE_LOW, M>(ctx, a, ncols, logB, cp, st);
   // product tree: levels <= logB inside LDS tiles
-  launch_tree_tiles(ctx, X, ncols, col0, logM, logB, S, spl, cp, st);
+  if constexpr (FP)
+    launch_tree_tiles(ctx, X, ncols, col0, logM, logB, S, spl, cp, st);
+  else
+    launch_tree_tiles_generic<M>(ctx, X, ncols, col0, logM, logB, S, spl, cp, st);
   // levels above: F_node = F_left + D_left * F_right with multi-pass transforms of length 2^l
   a.logtot = logM;
   for (int l = logB + 1; l <= logM; l++) {
     a.l = l;
     a.logsub = l;
-    launch_cross<false, CS_FILL_RIGHT>(ctx, a, ncols, logB, cp, st);
-    for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_dhat + (size_t)l * M;
-    launch_sub<2>(ctx, W, ncols, col0, logM, l, logB, &tp, M >> logB, S, spl, cp, st);
+    launch_cross<false, CS_FILL_RIGHT, M>(ctx, a, ncols, logB, cp, st);
+    for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = static_cast<const T *>(P->limb[i].d_dhat) + (size_t)l * Mlen;
+    launch_sub<2, M>(ctx, W, ncols, col0, logM, l, logB, &tp, Mlen >> logB, S, spl, cp, st);
     if (l == logM)
-      launch_cross<true, CD_COMBINE_CANON>(ctx, a, ncols, logB, cp, st);
+      launch_cross<true, CD_COMBINE_CANON, M>(ctx, a, ncols, logB, cp, st);
     else
-      launch_cross<true, CD_COMBINE>(ctx, a, ncols, logB, cp, st);
+      launch_cross<true, CD_COMBINE, M>(ctx, a, ncols, logB, cp, st);
   }
 }
 
 // multi-pass H = quo(A*B, Z) (+ ZK patch) for `ncols` columns; W1, W2: workspaces [ncols][2M]
-static void big_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const double *A, const double *B, double *H,
-                  double *W1, double *W2, size_t ncols, size_t col0, size_t S, size_t spl, const uint64_t *d1,
-                  const uint64_t *d2, const uint64_t *d3, const ColMap &cm, int limb0, hipStream_t st) {
+template <class M>
+static void big_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, const typename ArithOf<M>::T *A,
+                  const typename ArithOf<M>::T *B, typename ArithOf<M>::T *H, typename ArithOf<M>::T *W1, typename ArithOf<M>::T *W2,
+                  size_t ncols, size_t col0, size_t S, size_t spl, const uint64_t *d1, const uint64_t *d2, const uint64_t *d3,
+                  const ColMap &cm, int limb0, hipStream_t st) {
   const int logM = P->logM, logB = std::min(g_witness_lds_logM, logM);
-  const size_t M = P->M;
+  const size_t Mlen = P->M;
   CrossArgs a{};
   a.logM = logM;
   a.l = 1;
@@ -1615,26 +1714,26 @@ static void big_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const d
   // W1 = spectrum of A; W2 = A * B (spectrum product inside the sub-transform kernel of B)
   a.W = W1;
   a.src = A;
-  launch_cross<false, CS_PAD_CENTER>(ctx, a, ncols, logB, cp, st);
-  launch_sub<0>(ctx, W1, ncols, col0, logM + 1, logM + 1, logB, nullptr, 1, S, spl, cp, st);
+  launch_cross<false, CS_PAD_CENTER, M>(ctx, a, ncols, logB, cp, st);
+  launch_sub<0, M>(ctx, W1, ncols, col0, logM + 1, logM + 1, logB, nullptr, 1, S, spl, cp, st);
   a.W = W2;
   a.src = B;
-  launch_cross<false, CS_PAD_CENTER>(ctx, a, ncols, logB, cp, st);
+  launch_cross<false, CS_PAD_CENTER, M>(ctx, a, ncols, logB, cp, st);
   tp.t[0] = W1;
-  launch_sub<3>(ctx, W2, ncols, col0, logM + 1, logM + 1, logB, &tp, 1, S, spl, cp, st);
-  launch_cross<true, CD_PLAIN>(ctx, a, ncols, logB, cp, st);
+  launch_sub<3, M>(ctx, W2, ncols, col0, logM + 1, logM + 1, logB, &tp, 1, S, spl, cp, st);
+  launch_cross<true, CD_PLAIN, M>(ctx, a, ncols, logB, cp, st);
   // U = rev(P) * rev(Z)^-1 mod x^(m-1)
   a.W = W1;
   a.src = W2;
-  launch_cross<false, CS_REV_TRUNC>(ctx, a, ncols, logB, cp, st);
+  launch_cross<false, CS_REV_TRUNC, M>(ctx, a, ncols, logB, cp, st);
   for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_shat;
-  launch_sub<2>(ctx, W1, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * M) >> logB, S, spl, cp, st);
+  launch_sub<2, M>(ctx, W1, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * Mlen) >> logB, S, spl, cp, st);
   a.dst = H;
-  launch_cross<true, CD_H_FINISH>(ctx, a, ncols, logB, cp, st);
-  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((ncols * M + 255) / 256, 256 * 16));
-  ProfScope prof(ctx, st, "h_patch_kernel", (double)ncols * (double)M * (d1 ? 32.0 : 16.0), d1 ? 24.0 * (double)ncols * (double)M : 0.0);
-  hipLaunchKernelGGL(h_patch_kernel, dim3(blocks), dim3(256), 0, st, H, A, B, logM, (int)P->m, ncols, col0, (unsigned)S, (unsigned)spl, cp,
-                     d1, d2, d3, cm);
+  launch_cross<true, CD_H_FINISH, M>(ctx, a, ncols, logB, cp, st);
+  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((ncols * Mlen + 255) / 256, 256 * 16));
+  ProfScope prof(ctx, st, "h_patch_kernel", (double)ncols * (double)Mlen * (d1 ? 32.0 : 16.0), d1 ? 24.0 * (double)ncols * (double)Mlen : 0.0);
+  hipLaunchKernelGGL(h_patch_kernel<ColPlansT<M>>, dim3(blocks), dim3(256), 0, st, H, A, B, logM, (int)P->m, ncols, col0, (unsigned)S,
+                     (unsigned)spl, cp, d1, d2, d3, cm);
   RS_HIP(hipGetLastError());
 }
 
@@ -1654,76 +1753,86 @@ static bool single_tile_ok(int logM) {
 
 // Interpolate `ncols` columns in place.  Column c belongs to chunk-local limb (c % S) / slots_per_limb
 // (several vectors of S columns are batched); cp is shifted so that entry 0 is limb0.
-static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, double *cols, size_t ncols, size_t S,
+template <class M>
+static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, typename ArithOf<M>::T *cols, size_t ncols, size_t S,
                           size_t slots_per_limb, int limb0, hipStream_t st) {
-  if (single_tile_ok(P->logM)) {
-    // one launch, tile = M, two workgroups per CU: Newton conversion by the two rooted M-point
-    // sub-transforms, then the product tree in place
-    launch_tree_tiles(ctx, cols, ncols, 0, P->logM, P->logM, S, slots_per_limb, cp, st, true);
-    return;
+  using T = typename ArithOf<M>::T;
+  constexpr bool FP = std::is_same<M, Mod>::value;
+  if constexpr (FP) {
+    if (single_tile_ok(P->logM)) {
+      // one launch, tile = M, two workgroups per CU: Newton conversion by the two rooted M-point
+      // sub-transforms, then the product tree in place
+      launch_tree_tiles(ctx, cols, ncols, 0, P->logM, P->logM, S, slots_per_limb, cp, st, true);
+      return;
+    }
   }
   if (P->logM <= g_witness_lds_logM) {
     // the 2M convolution tile, or the product tree's tile + scratch when M is below the LDS block size
     const size_t lds = std::max(padded_len(2 * P->M), padded_len(tree_scratch_offset((int)P->M) + P->M)) * sizeof(double);
-    RS_HIP(hipFuncSetAttribute((const void *)interp_columns_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RS_HIP(hipFuncSetAttribute((const void *)interp_columns_kernel<ColPlansT<M>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope prof(ctx, st, "interp_columns_kernel", (double)ncols * (double)P->M * 16.0,
                    (double)ncols * (2.0 * ntt_fp64(2.0 * (double)P->M, P->logM + 1) + 21.0 * (double)P->M + tree_fp64((double)P->M, P->logM)));
-    hipLaunchKernelGGL(interp_columns_kernel, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds, st, cols, P->logM,
+    hipLaunchKernelGGL(interp_columns_kernel<ColPlansT<M>>, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds, st, cols, P->logM,
                        (unsigned)S, (unsigned)slots_per_limb, cp);
     RS_HIP(hipGetLastError());
     return;
   }
   const size_t chunk = std::min(ncols, big_chunk_cols(P));
-  double *W = (double *)ws_get(ctx, 12, chunk * 2 * P->M * sizeof(double));
+  T *W = (T *)ws_get(ctx, 12, chunk * 2 * P->M * sizeof(double));
   for (size_t c0 = 0; c0 < ncols; c0 += chunk) {
     const size_t nc = std::min(chunk, ncols - c0);
-    big_interp(ctx, P, cp, cols + c0 * P->M, W, nc, c0, S, slots_per_limb, limb0, st);
+    big_interp<M>(ctx, P, cp, cols + c0 * P->M, W, nc, c0, S, slots_per_limb, limb0, st);
   }
 }
 
 // H for the S columns of a chunk (A, B, H: [S][M]); `spl` columns per limb, cm locates d1..d3
-static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const double *A, const double *B, double *H,
-                     size_t S, size_t spl, const uint64_t *d1, const uint64_t *d2, const uint64_t *d3, const ColMap &cm,
-                     hipStream_t st) {
-  const size_t M = P->M;
-  if (single_tile_ok(P->logM)) {
-    const size_t lds1 = padded_len(M) * sizeof(double);
-    const int thr = (int)(M / 16);
-    // ten M-point transforms, four pointwise products, the ZK patch
-    ProfScope prof(ctx, st, "h_tile_kernel", (double)S * (double)M * 24.0,
-                   (double)S * (10.0 * ntt_fp64((double)M, P->logM) + (d1 ? 52.0 : 28.0) * (double)M));
+template <class M>
+static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, const typename ArithOf<M>::T *A,
+                     const typename ArithOf<M>::T *B, typename ArithOf<M>::T *H, size_t S, size_t spl, const uint64_t *d1,
+                     const uint64_t *d2, const uint64_t *d3, const ColMap &cm, hipStream_t st) {
+  using T = typename ArithOf<M>::T;
+  constexpr bool FP = std::is_same<M, Mod>::value;
+  const size_t Mlen = P->M;
+  if constexpr (FP) {
+    if (single_tile_ok(P->logM)) {
+      const size_t lds1 = padded_len(Mlen) * sizeof(double);
+      const int thr = (int)(Mlen / 16);
+      // ten M-point transforms, four pointwise products, the ZK patch
+      ProfScope prof(ctx, st, "h_tile_kernel", (double)S * (double)Mlen * 24.0,
+                     (double)S * (10.0 * ntt_fp64((double)Mlen, P->logM) + (d1 ? 52.0 : 28.0) * (double)Mlen));
 #define RS_H_LAUNCH(KERN)                                                                                            \
   do {                                                                                                               \
     RS_HIP(hipFuncSetAttribute((const void *)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));         \
     hipLaunchKernelGGL(KERN, dim3((unsigned)S), dim3(thr), lds1, st, A, B, H, P->logM, (int)P->m, (unsigned)spl, cp, \
                        d1, d2, d3, cm);                                                                              \
   } while (0)
-    if (thr == 1024) RS_H_LAUNCH((h_tile_kernel<1024, 0>));
-    else if (thr == 512 && g_witness_tree_ct) RS_H_LAUNCH((h_tile_kernel<512, 13>));
-    else if (thr == 512) RS_H_LAUNCH((h_tile_kernel<512, 0>));
-    else if (thr == 256) RS_H_LAUNCH((h_tile_kernel<256, 0>));
-    else if (thr == 128) RS_H_LAUNCH((h_tile_kernel<128, 0>));
-    else RS_H_LAUNCH((h_tile_kernel<64, 0>));
+      if (thr == 1024) RS_H_LAUNCH((h_tile_kernel<1024, 0>));
+      else if (thr == 512 && g_witness_tree_ct) RS_H_LAUNCH((h_tile_kernel<512, 13>));
+      else if (thr == 512) RS_H_LAUNCH((h_tile_kernel<512, 0>));
+      else if (thr == 256) RS_H_LAUNCH((h_tile_kernel<256, 0>));
+      else if (thr == 128) RS_H_LAUNCH((h_tile_kernel<128, 0>));
+      else RS_H_LAUNCH((h_tile_kernel<64, 0>));
 #undef RS_H_LAUNCH
-    RS_HIP(hipGetLastError());
-    return;
+      RS_HIP(hipGetLastError());
+      return;
+    }
   }
   if (P->logM <= g_witness_lds_logM) {
-    const size_t lds = padded_len(2 * M) * sizeof(double);
-    RS_HIP(hipFuncSetAttribute((const void *)h_columns_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ProfScope prof(ctx, st, "h_columns_kernel", (double)S * (double)M * 24.0,
-                   (double)S * (5.0 * ntt_fp64(2.0 * (double)M, P->logM + 1) + (d1 ? 52.0 : 28.0) * (double)M));
-    hipLaunchKernelGGL(h_columns_kernel<0>, dim3((unsigned)S), dim3(col_threads(2 * M)), lds, st, A, B, H, P->logM, (int)P->m,
+    const size_t lds = padded_len(2 * Mlen) * sizeof(double);
+    RS_HIP(hipFuncSetAttribute((const void *)h_columns_kernel<ColPlansT<M>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope prof(ctx, st, "h_columns_kernel", (double)S * (double)Mlen * 24.0,
+                   (double)S * (5.0 * ntt_fp64(2.0 * (double)Mlen, P->logM + 1) + (d1 ? 52.0 : 28.0) * (double)Mlen));
+    hipLaunchKernelGGL(h_columns_kernel<ColPlansT<M>>, dim3((unsigned)S), dim3(col_threads(2 * Mlen)), lds, st, A, B, H, P->logM, (int)P->m,
                        (unsigned)spl, cp, d1, d2, d3, cm);
     RS_HIP(hipGetLastError());
     return;
   }
   const size_t chunk = std::min(S, big_chunk_cols(P));
-  double *W1 = (double *)ws_get(ctx, 12, chunk * 2 * M * sizeof(double));
-  double *W2 = (double *)ws_get(ctx, 13, chunk * 2 * M * sizeof(double));
+  T *W1 = (T *)ws_get(ctx, 12, chunk * 2 * Mlen * sizeof(double));
+  T *W2 = (T *)ws_get(ctx, 13, chunk * 2 * Mlen * sizeof(double));
   for (size_t c0 = 0; c0 < S; c0 += chunk) {
     const size_t nc = std::min(chunk, S - c0);
-    big_h(ctx, P, cp, A + c0 * M, B + c0 * M, H + c0 * M, W1, W2, nc, c0, S, spl, d1, d2, d3, cm, cm.limb0, st);
+    big_h<M>(ctx, P, cp, A + c0 * Mlen, B + c0 * Mlen, H + c0 * Mlen, W1, W2, nc, c0, S, spl, d1, d2, d3, cm, cm.limb0, st);
   }
 }
 
@@ -1731,19 +1840,25 @@ void r1cs_evaluate_run(rs_ctx *ctx, const rs_r1cs *cs, int which, int mode, cons
                        hipStream_t st) {
   const size_t S = ctx->ring_words();
   const unsigned by = (unsigned)((S / 2 + 255) / 256);
-  hipLaunchKernelGGL(r1cs_eval_kernel, dim3((unsigned)cs->m, by), dim3(256), 0, st, cs->d_row_ptr[which], cs->d_col[which],
-                     cs->d_coeff[which], cs->nnz[which], d_asg, d_out, ctx->N, ctx->L, mode, (unsigned)cs->n_inputs,
-                     ctx->d_qmod);
+  if (ctx->use_int)
+    hipLaunchKernelGGL(r1cs_eval_kernel<ModI>, dim3((unsigned)cs->m, by), dim3(256), 0, st, cs->d_row_ptr[which], cs->d_col[which],
+                       reinterpret_cast<const uint64_t *>(cs->d_coeff[which]), cs->nnz[which], d_asg, d_out, ctx->N, ctx->L, mode,
+                       (unsigned)cs->n_inputs, ctx->d_qmod_i);
+  else
+    hipLaunchKernelGGL(r1cs_eval_kernel<Mod>, dim3((unsigned)cs->m, by), dim3(256), 0, st, cs->d_row_ptr[which], cs->d_col[which],
+                       cs->d_coeff[which], cs->nnz[which], d_asg, d_out, ctx->N, ctx->L, mode, (unsigned)cs->n_inputs, ctx->d_qmod);
   RS_HIP(hipGetLastError());
 }
 
 constexpr size_t IO_SHORTCUT_MAX_INPUTS = 64;
 
 // Per-circuit cache for the io shortcut: L_k = interp(column k of X), k = 0 (constant) .. n_inputs.
-static void build_io_cache(rs_ctx *ctx, const rs_r1cs *cs, const WitnessPlan *P, const ColPlans &cp, hipStream_t st) {
+template <class M_>
+static void build_io_cache(rs_ctx *ctx, const rs_r1cs *cs, const WitnessPlan *P, const ColPlansT<M_> &cp, hipStream_t st) {
+  using T = typename ArithOf<M_>::T;
   if (cs->io_built) return;
   const size_t m = cs->m, M = P->M, L = (size_t)ctx->L;
-  std::vector<double> cols;  // [ncols][L][M]
+  std::vector<T> cols;  // [ncols][L][M] data values
   std::vector<int> hk[3], hc[3];
   int ncols = 0;
   for (int w = 0; w < 3; w++) {
@@ -1760,9 +1875,9 @@ static void build_io_cache(rs_ctx *ctx, const rs_r1cs *cs, const WitnessPlan *P,
               any = any || c != 0;
             }
       if (!any) continue;
-      cols.resize((size_t)(ncols + 1) * L * M, 0.0);
+      cols.resize((size_t)(ncols + 1) * L * M, T(0));
       for (size_t i = 0; i < L; i++)
-        for (size_t r = 0; r < m; r++) cols[((size_t)ncols * L + i) * M + r] = (double)y[i * m + r];
+        for (size_t r = 0; r < m; r++) cols[((size_t)ncols * L + i) * M + r] = HostArith<M_>::plain(y[i * m + r], ctx->q[i]);
       hk[w].push_back((int)k);
       hc[w].push_back(ncols);
       ncols++;
@@ -1772,7 +1887,7 @@ static void build_io_cache(rs_ctx *ctx, const rs_r1cs *cs, const WitnessPlan *P,
   RS_HIP(hipMalloc(&mc->d_io_cols, std::max<size_t>(1, cols.size()) * sizeof(double)));
   if (ncols) {
     RS_HIP(hipMemcpy(mc->d_io_cols, cols.data(), cols.size() * sizeof(double), hipMemcpyHostToDevice));
-    launch_interp(ctx, P, cp, mc->d_io_cols, (size_t)ncols * L, L, 1, 0, st);
+    launch_interp<M_>(ctx, P, cp, reinterpret_cast<T *>(mc->d_io_cols), (size_t)ncols * L, L, 1, 0, st);
     RS_HIP(hipStreamSynchronize(st));
   }
   for (int w = 0; w < 3; w++) {
@@ -1794,12 +1909,20 @@ static void build_io_cache(rs_ctx *ctx, const rs_r1cs *cs, const WitnessPlan *P,
 int g_witness_col_budget_mib = 16 * 1024;  // column workspace of one chunk (tuning knob "witness_col_budget_mib")
 
 // One chunk of the witness map: limbs [limb0, limb0 + nl), slots [cm.slot0, cm.slot0 + cm.ns) of each.
+template <class M_>
 static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const uint64_t *d_asg, const uint64_t *d1,
                           const uint64_t *d2, const uint64_t *d3, uint64_t *const outs[7], const ColMap &cm, int nl,
-                          const double *d_const, hipStream_t st) {
+                          const void *d_const_, hipStream_t st) {
+  using T = typename ArithOf<M_>::T;
+  using CPS = ColPlansT<M_>;
+  const T *d_const = static_cast<const T *>(d_const_);
+  const T *io_cols = reinterpret_cast<const T *>(cs->d_io_cols);
+  const T *coeff[3] = {reinterpret_cast<const T *>(cs->d_coeff[0]), reinterpret_cast<const T *>(cs->d_coeff[1]),
+                       reinterpret_cast<const T *>(cs->d_coeff[2])};
+  const M_ *qmod = CtxArith<M_>::qmod(ctx);
   const size_t m = cs->m, M = P->M;
   const size_t C = (size_t)nl * cm.ns;  // columns in this chunk
-  const ColPlans cp = make_colplans(ctx, P, cm.limb0);
+  const CPS cp = make_colplans<M_>(ctx, P, cm.limb0);
   const bool needH = outs[6] != nullptr;
   const bool shortcut = cs->n_inputs <= IO_SHORTCUT_MAX_INPUTS;
   bool need_io[3], need_full[3];
@@ -1812,7 +1935,7 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
   int slot_of[7], nvec = 0;
   for (int k = 0; k < 7; k++) slot_of[k] = needed(k) ? nvec++ : -1;
   const size_t vec = C * M;
-  double *colbuf = (double *)ws_get(ctx, 5, std::max<size_t>(1, (size_t)nvec * vec) * sizeof(double));
+  T *colbuf = (T *)ws_get(ctx, 5, std::max<size_t>(1, (size_t)nvec * vec) * sizeof(T));
   auto colv = [&](int k) { return colbuf + (size_t)slot_of[k] * vec; };
   const dim3 tgrid((unsigned)((C + 31) / 32), (unsigned)((M + 31) / 32));
   const dim3 tgrid64((unsigned)((C + 63) / 64), (unsigned)((M + 31) / 32));
@@ -1821,49 +1944,48 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
       if (!needed(3 * full + w)) continue;
       // per (row, slot): 8 bytes of assignment per non-zero + 8 bytes of column written
       ProfScope prof(ctx, st, "r1cs_eval_cols_kernel", (double)C * 8.0 * ((double)cs->nnz[w] + (double)M), 7.0 * (double)C * (double)cs->nnz[w]);
-      hipLaunchKernelGGL(r1cs_eval_cols_kernel, tgrid64, dim3(256), 0, st, cs->d_row_ptr[w], cs->d_col[w], cs->d_coeff[w],
+      hipLaunchKernelGGL(r1cs_eval_cols_kernel<M_>, tgrid64, dim3(256), 0, st, cs->d_row_ptr[w], cs->d_col[w], coeff[w],
                          cs->nnz[w], d_asg, colv(3 * full + w), m, C, M, full ? (int)RS_EVAL_FULL : (int)RS_EVAL_IO,
-                         (unsigned)cs->n_inputs, ctx->d_qmod, cm);
+                         (unsigned)cs->n_inputs, qmod, cm);
     }
   RS_HIP(hipGetLastError());
   // one batched interpolation: the needed io / full vectors are adjacent in the workspace
   {
     int n6 = 0;
     for (int k = 0; k < 6; k++) n6 += needed(k);
-    if (n6) launch_interp(ctx, P, cp, colbuf, (size_t)n6 * C, C, (size_t)cm.ns, cm.limb0, st);
+    if (n6) launch_interp<M_>(ctx, P, cp, colbuf, (size_t)n6 * C, C, (size_t)cm.ns, cm.limb0, st);
   }
-  if (needH) launch_h(ctx, P, cp, colv(3), colv(4), colv(6), C, (size_t)cm.ns, d1, d2, d3, cm, st);
+  if (needH) launch_h<M_>(ctx, P, cp, colv(3), colv(4), colv(6), C, (size_t)cm.ns, d1, d2, d3, cm, st);
   const unsigned eb = (unsigned)std::min<size_t>((vec + 255) / 256, 256 * 16);
   if (!shortcut) {
     // fallback: X_mid = interp(full) - interp(io) + interp(constant part), combined in column-major form
     for (int w = 0; w < 3; w++) {
       if (!outs[3 + w]) continue;
-      const double *cst = (d_const && cs->has_const[w]) ? d_const + (size_t)w * ctx->L * M : nullptr;
+      const T *cst = (d_const && cs->has_const[w]) ? d_const + (size_t)w * ctx->L * M : nullptr;
       ProfScope prof(ctx, st, "mid_kernel", (double)vec * 24.0, 3.0 * (double)vec);
-      hipLaunchKernelGGL(mid_kernel, dim3(eb), dim3(256), 0, st, colv(3 + w), colv(w), cst, M, C, (unsigned)cm.ns, cp, cm.limb0);
+      hipLaunchKernelGGL(mid_kernel<CPS>, dim3(eb), dim3(256), 0, st, colv(3 + w), colv(w), cst, M, C, (unsigned)cm.ns, cp, cm.limb0);
     }
     RS_HIP(hipGetLastError());
     for (int k = 0; k < 6; k++)
       if (outs[k]) {
         ProfScope prof(ctx, st, "transpose_out_kernel", (double)C * (double)m * 16.0, 0.0);
-        hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(k), outs[k], m, C, M, cm);
+        hipLaunchKernelGGL(transpose_out_kernel<T>, tgrid, dim3(256), 0, st, colv(k), outs[k], m, C, M, cm);
       }
   } else {
     for (int w = 0; w < 3; w++) {
       if (!need_io[w]) continue;
       IoDesc io{cs->d_io_k[w], cs->d_io_c[w], cs->io_count[w]};
       if (outs[3 + w]) {  // io (if wanted) and mid in one pass over the interpolated columns
-        const double *cst = cs->io_const_col[w] >= 0 ? cs->d_io_cols + (size_t)cs->io_const_col[w] * ctx->L * M : nullptr;
+        const T *cst = cs->io_const_col[w] >= 0 ? io_cols + (size_t)cs->io_const_col[w] * ctx->L * M : nullptr;
         // 8 bytes of column read, 8 or 16 written, the primary inputs re-read per row (L2 resident)
         ProfScope prof(ctx, st, "io_mid_out_kernel", (double)C * (double)m * (outs[w] ? 24.0 : 16.0),
                        (double)C * (double)m * (7.0 * io.count + 4.0));
-        hipLaunchKernelGGL(io_mid_out_kernel, tgrid64, dim3(256), 0, st, colv(3 + w), io, cs->d_io_cols, d_asg, cst, outs[w],
-                           outs[3 + w], m, C, M, ctx->d_qmod, cm);
+        hipLaunchKernelGGL(io_mid_out_kernel<M_>, tgrid64, dim3(256), 0, st, colv(3 + w), io, io_cols, d_asg, cst, outs[w],
+                           outs[3 + w], m, C, M, qmod, cm);
       } else {  // io alone: no column work at all
         const unsigned by = (unsigned)((C / 2 + 255) / 256);
         ProfScope prof(ctx, st, "io_coeff_kernel", (double)C * (double)m * 8.0, (double)C * (double)m * 7.0 * io.count);
-        hipLaunchKernelGGL(io_coeff_kernel, dim3((unsigned)m, by), dim3(256), 0, st, io, cs->d_io_cols, d_asg, outs[w], C, M,
-                           ctx->d_qmod, cm);
+        hipLaunchKernelGGL(io_coeff_kernel<M_>, dim3((unsigned)m, by), dim3(256), 0, st, io, io_cols, d_asg, outs[w], C, M, qmod, cm);
       }
     }
   }
@@ -1871,11 +1993,11 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
   if (needH) {
     {
       ProfScope prof(ctx, st, "transpose_out_kernel", (double)C * (double)m * 16.0, 0.0);
-      hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, st, colv(6), outs[6], std::min(m + 1, M), C, M, cm);
+      hipLaunchKernelGGL(transpose_out_kernel<T>, tgrid, dim3(256), 0, st, colv(6), outs[6], std::min(m + 1, M), C, M, cm);
     }
     if (m == M)  // row m does not exist in the M-row column tile
-      hipLaunchKernelGGL(h_top_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, outs[6] + m * cm.out_stride(), d1, d2, C,
-                         ctx->d_qmod, cm);
+      hipLaunchKernelGGL(h_top_kernel<M_>, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, outs[6] + m * cm.out_stride(), d1, d2, C,
+                         qmod, cm);
     RS_HIP(hipGetLastError());
   }
 }
@@ -1885,9 +2007,11 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
 // [t][L][nslots] (a slot-sharded rank) instead of the full [t][L][N].  The columns are
 // worked through in chunks whose column-major workspace stays within g_witness_col_budget_mib
 // (at m = 2^16 and the headline ring that is one limb at a time: 3 x 4 GiB instead of 7 x 16 GiB).
-void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const uint64_t *d1, const uint64_t *d2,
-                 const uint64_t *d3, uint64_t *const outs[7], uint64_t *h_Z, hipStream_t st, int slot0 = 0, int nslots = -1,
-                 bool compact = false) {
+template <class M_>
+static void witness_run_arith(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const uint64_t *d1, const uint64_t *d2,
+                              const uint64_t *d3, uint64_t *const outs[7], uint64_t *h_Z, hipStream_t st, int slot0, int nslots,
+                              bool compact) {
+  using T = typename ArithOf<M_>::T;
   RS_REQUIRE((d1 && d2 && d3) || (!d1 && !d2 && !d3), "d1,d2,d3 must be all set or all null");
   if (nslots < 0) nslots = ctx->N - slot0;
   RS_REQUIRE(slot0 >= 0 && nslots >= 2 && slot0 + nslots <= ctx->N && !(slot0 & 1) && !(nslots & 1),
@@ -1899,18 +2023,18 @@ void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const ui
   if (h_Z)
     for (int i = 0; i < L; i++) memcpy(h_Z + (size_t)i * (m + 1), P->limb[i].Z.data(), sizeof(uint64_t) * (m + 1));
   const bool shortcut = cs->n_inputs <= IO_SHORTCUT_MAX_INPUTS;
-  if (shortcut) build_io_cache(ctx, cs, P, make_colplans(ctx, P), st);
+  if (shortcut) build_io_cache<M_>(ctx, cs, P, make_colplans<M_>(ctx, P), st);
   // fallback path: interpolated constant parts [3][L][M], once per call
-  double *d_const = nullptr;
+  T *d_const = nullptr;
   if (!shortcut && (cs->has_const[0] || cs->has_const[1] || cs->has_const[2]) && (outs[3] || outs[4] || outs[5])) {
-    std::vector<double> hc((size_t)3 * L * M, 0.0);
+    std::vector<T> hc((size_t)3 * L * M, T(0));
     for (int w = 0; w < 3; w++)
       for (int i = 0; i < L; i++)
-        for (size_t r = 0; r < m; r++) hc[((size_t)w * L + i) * M + r] = (double)cs->h_const[w][(size_t)i * m + r];
-    d_const = (double *)ws_get(ctx, 4, hc.size() * sizeof(double));
-    RS_HIP(hipMemcpyAsync(d_const, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        for (size_t r = 0; r < m; r++) hc[((size_t)w * L + i) * M + r] = HostArith<M_>::plain(cs->h_const[w][(size_t)i * m + r], ctx->q[i]);
+    d_const = (T *)ws_get(ctx, 4, hc.size() * sizeof(T));
+    RS_HIP(hipMemcpyAsync(d_const, hc.data(), hc.size() * sizeof(T), hipMemcpyHostToDevice, st));
     RS_HIP(hipStreamSynchronize(st));  // hc goes out of scope
-    launch_interp(ctx, P, make_colplans(ctx, P), d_const, (size_t)3 * L, (size_t)L, 1, 0, st);
+    launch_interp<M_>(ctx, P, make_colplans<M_>(ctx, P), d_const, (size_t)3 * L, (size_t)L, 1, 0, st);
   }
   // chunking: as many whole limbs as fit the budget, else pieces of one limb (multiples of 64 slots)
   int nvec = 0;
@@ -1929,7 +2053,7 @@ void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const ui
     const int per = (int)std::max<size_t>(1, std::min<size_t>((size_t)L, budget_cols / (size_t)nslots));
     for (int l0 = 0; l0 < L; l0 += per) {
       cm.limb0 = l0;
-      witness_chunk(ctx, cs, P, d_asg, d1, d2, d3, outs, cm, std::min(per, L - l0), d_const, st);
+      witness_chunk<M_>(ctx, cs, P, d_asg, d1, d2, d3, outs, cm, std::min(per, L - l0), d_const, st);
     }
   } else {
     const int piece = (int)std::max<size_t>(64, (budget_cols / 64) * 64);
@@ -1938,9 +2062,30 @@ void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const ui
         cm.limb0 = l0;
         cm.slot0 = slot0 + s0;
         cm.ns = std::min(piece, nslots - s0);
-        witness_chunk(ctx, cs, P, d_asg, d1, d2, d3, outs, cm, 1, d_const, st);
+        witness_chunk<M_>(ctx, cs, P, d_asg, d1, d2, d3, outs, cm, 1, d_const, st);
       }
   }
+}
+void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const uint64_t *d1, const uint64_t *d2,
+                 const uint64_t *d3, uint64_t *const outs[7], uint64_t *h_Z, hipStream_t st, int slot0 = 0, int nslots = -1,
+                 bool compact = false) {
+  RS_DISPATCH_ARITH(ctx, (witness_run_arith<Mod>(ctx, cs, d_asg, d1, d2, d3, outs, h_Z, st, slot0, nslots, compact)),
+                    (witness_run_arith<ModI>(ctx, cs, d_asg, d1, d2, d3, outs, h_Z, st, slot0, nslots, compact)));
+}
+
+template <class M_>
+static void interpolate_arith(rs_ctx *ctx, const uint64_t *d_y, uint64_t *d_out, size_t n, hipStream_t st) {
+  using T = typename ArithOf<M_>::T;
+  WitnessPlan *P = get_plan(ctx, n);
+  const ColPlansT<M_> cp = make_colplans<M_>(ctx, P);
+  const size_t M = P->M, S_ = ctx->ring_words();
+  T *colbuf = (T *)ws_get(ctx, 5, S_ * M * sizeof(T));
+  const dim3 tgrid((unsigned)((S_ + 31) / 32), (unsigned)((M + 31) / 32));
+  const ColMap cm{0, ctx->N, 0, ctx->N, ctx->L, ctx->N, 0};
+  hipLaunchKernelGGL(transpose_in_kernel<T>, tgrid, dim3(256), 0, st, d_y, colbuf, n, S_, M);
+  launch_interp<M_>(ctx, P, cp, colbuf, S_, S_, (size_t)ctx->N, 0, st);
+  hipLaunchKernelGGL(transpose_out_kernel<T>, tgrid, dim3(256), 0, st, colbuf, d_out, n, S_, M, cm);
+  RS_HIP(hipGetLastError());
 }
 
 }  // namespace rs
@@ -1979,13 +2124,13 @@ int rs_r1cs_create(rs_ctx *ctx, size_t m, size_t n_vars, size_t n_inputs, const 
     cs->h_coeff[w].assign(h_coeff[w], h_coeff[w] + (size_t)ctx->L * z);
     cs->h_const[w].assign((size_t)ctx->L * m, 0);
     cs->has_const[w] = false;
-    std::vector<double> cf((size_t)ctx->L * std::max<size_t>(z, 1), 0.0);
+    std::vector<uint64_t> cf((size_t)ctx->L * std::max<size_t>(z, 1), 0);  // table constants of the context's arithmetic
     for (size_t r = 0; r < m; r++)
       for (uint32_t e = h_row_ptr[w][r]; e < h_row_ptr[w][r + 1]; e++) {
         RS_REQUIRE(h_col[w][e] <= n_vars, "column index out of range");
         for (int i = 0; i < ctx->L; i++) {
           const uint64_t c = h_coeff[w][(size_t)i * z + e] % ctx->q[i];
-          cf[(size_t)i * z + e] = host::balanced(c, ctx->q[i]);
+          cf[(size_t)i * z + e] = konst_word(ctx, c, ctx->q[i]);
           if (h_col[w][e] == 0) {
             cs->h_const[w][(size_t)i * m + r] = host::addmod(cs->h_const[w][(size_t)i * m + r], c, ctx->q[i]);
             if (c) cs->has_const[w] = true;
@@ -2054,16 +2199,7 @@ int rs_interpolate(rs_ctx *ctx, const uint64_t *d_y, uint64_t *d_out, size_t n, 
   RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_y && d_out && n >= 1, "null argument");
   WsScope ws_scope(ctx, S(stream));
-  WitnessPlan *P = get_plan(ctx, n);
-  const ColPlans cp = make_colplans(ctx, P);
-  const size_t M = P->M, S_ = ctx->ring_words();
-  double *colbuf = (double *)ws_get(ctx, 5, S_ * M * sizeof(double));
-  const dim3 tgrid((unsigned)((S_ + 31) / 32), (unsigned)((M + 31) / 32));
-  const ColMap cm{0, ctx->N, 0, ctx->N, ctx->L, ctx->N, 0};
-  hipLaunchKernelGGL(transpose_in_kernel, tgrid, dim3(256), 0, S(stream), d_y, colbuf, n, S_, M);
-  launch_interp(ctx, P, cp, colbuf, S_, S_, (size_t)ctx->N, 0, S(stream));
-  hipLaunchKernelGGL(transpose_out_kernel, tgrid, dim3(256), 0, S(stream), colbuf, d_out, n, S_, M, cm);
-  RS_HIP(hipGetLastError());
+  RS_DISPATCH_ARITH(ctx, (interpolate_arith<Mod>(ctx, d_y, d_out, n, S(stream))), (interpolate_arith<ModI>(ctx, d_y, d_out, n, S(stream))));
   RS_API_END
 }
 

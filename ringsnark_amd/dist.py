@@ -229,6 +229,8 @@ def groth16_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_loc
         c = backend.enc_add(c, c2[0])
     piece = torch.cat([ab.reshape((2,) + tuple(ab.shape[-4:])), c.reshape((1,) + tuple(c.shape[-4:]))], dim=0).contiguous()
     if plan.term_shards > 1:
+        if hasattr(backend, "check_allreduce_headroom"):
+            backend.check_allreduce_headroom(plan.term_shards)
         dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=term_group)
         piece = backend.enc_reduce(piece)
     return _gather_limbs(plan, piece, 3)
@@ -269,6 +271,8 @@ def rinocchio_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_l
     piece = torch.cat([mo.reshape((10,) + enc_shape), f], dim=0).contiguous()
     counts = torch.tensor(list(used) + [used_f], dtype=torch.int64)
     if plan.term_shards > 1:
+        if hasattr(backend, "check_allreduce_headroom"):
+            backend.check_allreduce_headroom(plan.term_shards)
         dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=term_group)
         piece = backend.enc_reduce(piece)
         cnt = counts.to(piece.device) if dist.get_backend(term_group) != "gloo" else counts
@@ -331,6 +335,10 @@ class DeviceBackend:
 
     def enc_reduce(self, piece):
         return self.dev.enc_reduce(piece)
+
+    def check_allreduce_headroom(self, shards):
+        """The all-reduce adds `shards` canonical residues as int64: needs shards * max(Q_j) < 2^63."""
+        assert shards * max(int(x) for x in self.dev.prm.Q) < 2**63, "too many term shards for these moduli"
 
     def broadcast_scalars(self, z):
         """[L][rows] host residues -> ring elements [rows][L][N] with the value in every slot."""

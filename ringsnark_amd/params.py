@@ -157,9 +157,15 @@ def preset(name: str) -> RingParams:
                            ring_factor=1 << 20, name="C4")
     if name == "C5":  # logistic regression as in the reference file: N=2048 L=1, N_enc=16384 K=8
         return make_params(2048, BFV_DEFAULT_BITS[2048], 16384, BFV_DEFAULT_BITS[16384][:-1], name="C5")
-    if name == "C5s":  # C5's shape with a 49-bit ring prime (the FP64 arithmetic path needs q < 2^50)
+    if name == "C5s":  # C5's shape with a 49-bit ring prime (runs on the FP64 arithmetic; C5 itself runs on the integer one)
         return make_params(2048, [49], 16384, BFV_DEFAULT_BITS[16384][:-1], name="C5s",
                            notes="C5 with the 54-bit BFVDefault(2048) prime replaced by a 49-bit one")
+    if name == "toy54":  # C5's moduli at test scale: a 54-bit ring prime (integer Montgomery path), 48/49-bit encoding primes
+        return make_params(32, [54], 64, [48, 49, 49], ring_factor=1 << 12, name="toy54")
+    if name == "toy60":  # the {59,60,60}-bit primes of the reference's microbench.cpp:35-36, everywhere
+        return make_params(32, [59, 60], 64, [60, 60, 59], ring_factor=1 << 12, name="toy60")
+    if name == "micro60":  # microbench.cpp:33-36: N = 16384, coefficient primes of {59, 60, 60} bits
+        return make_params(16384, [59], 16384, [60, 60], name="micro60")
     if name == "toy":  # CPU-test scale
         return make_params(32, [30, 30], 64, [40, 40, 41], ring_factor=1 << 12, name="toy")
     if name == "toy44":  # small ring, headline-size primes (= 1 mod 2^20): large-m witness-map tests

@@ -14,9 +14,19 @@ _DEV = {}
 
 
 def dev_for(name):
+    """Device per preset.  "<preset>+int": the same preset on the integer (Montgomery) arithmetic, which contexts
+    otherwise select only when a modulus is >= 2^50 (tuning knob force_int_arith, read at context creation)."""
+    from ringsnark_amd import _lib
     from ringsnark_amd.device import Device
     if name not in _DEV:
-        _DEV[name] = Device(P.preset(name))
+        base, force = (name[:-4], True) if name.endswith("+int") else (name, False)
+        if force:
+            _lib.check(_lib.load().rs_set_tuning(b"force_int_arith", 1))
+        try:
+            _DEV[name] = Device(P.preset(base))
+        finally:
+            if force:
+                _lib.check(_lib.load().rs_set_tuning(b"force_int_arith", 0))
     return _DEV[name]
 
 
@@ -25,7 +35,7 @@ def host(t):
     return to_host(t)
 
 
-@pytest.mark.parametrize("name", ["toy", "toy49", "C2", "C3", "C5s"])
+@pytest.mark.parametrize("name", ["toy", "toy49", "C2", "C3", "C5s", "toy54", "toy60", "micro60", "C5", "toy+int", "toy49+int"])
 def test_ntt_matches_oracle(name):
     from ringsnark_amd import _lib
     dev = dev_for(name)
@@ -47,7 +57,7 @@ def test_ntt_matches_oracle(name):
             assert (host(d) == a).all()
 
 
-@pytest.mark.parametrize("name", ["toy", "toy49", "C2"])
+@pytest.mark.parametrize("name", ["toy", "toy49", "C2", "toy54", "toy60", "micro60", "toy+int"])
 def test_ring_ops_match_oracle(name):
     dev = dev_for(name)
     ctx = H.oracle_ctx(dev.prm)
@@ -72,7 +82,7 @@ def test_ring_ops_match_oracle(name):
     assert ei.value.code == RS_ERR_NOT_INVERTIBLE and "not invertible in ring" in str(ei.value)
 
 
-@pytest.mark.parametrize("name", ["toy", "toy49", "C2"])
+@pytest.mark.parametrize("name", ["toy", "toy49", "C2", "toy54", "toy60", "toy49+int"])
 def test_batch_encode_and_enc_ops(name):
     dev = dev_for(name)
     ctx = H.oracle_ctx(dev.prm)
@@ -89,7 +99,8 @@ def test_batch_encode_and_enc_ops(name):
     assert (host(dev.enc_add(de[0], de[1])) == ctx.enc_add(e[0], e[1])).all()
 
 
-@pytest.mark.parametrize("name,T", [("toy", 1), ("toy", 37), ("toy49", 50), ("C2", 5)])
+@pytest.mark.parametrize("name,T", [("toy", 1), ("toy", 37), ("toy49", 50), ("C2", 5), ("toy54", 37), ("toy60", 50), ("C5", 3),
+                                    ("toy+int", 37), ("toy49+int", 20)])
 def test_inner_product_matches_oracle(name, T):
     dev = dev_for(name)
     ctx = H.oracle_ctx(dev.prm)
@@ -134,7 +145,11 @@ def test_grouped_msm_equals_sum_of_inner_products():
 @pytest.mark.parametrize("name,m,kind", [("toy", 1, "chain"), ("toy", 2, "chain"), ("toy", 3, "wide"), ("toy", 7, "wide"),
                                           ("toy", 16, "wide"), ("toy", 100, "wide"), ("toy", 100, "many_inputs"),
                                           ("toy", 600, "wide"),  # M = 1024: split Newton / in-place product-tree kernels
-                                          ("toy49", 33, "wide"), ("toy49", 64, "chain"), ("toy49", 90, "many_inputs")])
+                                          ("toy49", 33, "wide"), ("toy49", 64, "chain"), ("toy49", 90, "many_inputs"),
+                                          # primes >= 2^50: the integer (Montgomery) arithmetic, generic kernels
+                                          ("toy54", 1, "chain"), ("toy54", 7, "wide"), ("toy54", 100, "wide"), ("toy54", 100, "many_inputs"),
+                                          ("toy60", 16, "wide"), ("toy60", 64, "chain"), ("toy60", 600, "wide"), ("toy60", 90, "many_inputs"),
+                                          ("toy+int", 33, "wide"), ("toy49+int", 64, "chain")])
 def test_witness_map_matches_oracle(name, m, kind):
     from ringsnark_amd import _lib
     dev = dev_for(name)
@@ -182,7 +197,8 @@ def test_interpolate_known_answer_on_device():
         assert (got[k] == k).all()
 
 
-@pytest.mark.parametrize("name,m,kind", [("toy", 6, "wide"), ("toy", 16, "chain"), ("toy49", 21, "wide")])
+@pytest.mark.parametrize("name,m,kind", [("toy", 6, "wide"), ("toy", 16, "chain"), ("toy49", 21, "wide"), ("toy54", 12, "wide"),
+                                          ("toy60", 21, "wide"), ("toy+int", 16, "chain")])
 def test_groth16_prover_matches_oracle(name, m, kind):
     dev = dev_for(name)
     prm = dev.prm
@@ -197,7 +213,8 @@ def test_groth16_prover_matches_oracle(name, m, kind):
     assert (host(got) == exp).all()
 
 
-@pytest.mark.parametrize("name,m,zk", [("toy", 5, False), ("toy", 12, True), ("toy49", 16, True)])
+@pytest.mark.parametrize("name,m,zk", [("toy", 5, False), ("toy", 12, True), ("toy49", 16, True), ("toy54", 9, True), ("toy60", 12, True),
+                                       ("toy60", 5, False)])
 def test_rinocchio_prover_matches_oracle(name, m, zk):
     dev = dev_for(name)
     prm = dev.prm
@@ -221,11 +238,12 @@ def _set_tuning(key, value):
     _lib.check(_lib.load().rs_set_tuning(key, value))
 
 
-@pytest.mark.parametrize("m,kind,zk", [(70, "wide", False), (300, "wide", True), (1000, "chain", True), (513, "many_inputs", False)])
-def test_witness_map_multipass_matches_oracle(m, kind, zk):
+@pytest.mark.parametrize("name,m,kind,zk", [("toy", 70, "wide", False), ("toy", 300, "wide", True), ("toy", 1000, "chain", True),
+                                             ("toy", 513, "many_inputs", False), ("toy60", 300, "wide", True), ("toy54", 513, "many_inputs", False)])
+def test_witness_map_multipass_matches_oracle(name, m, kind, zk):
     """The multi-pass (column does not fit one LDS tile) path, forced at small sizes by shrinking the
-    tile to 2^6 so the complete oracle comparison stays cheap."""
-    dev = dev_for("toy")
+    tile to 2^6 so the complete oracle comparison stays cheap (both arithmetics)."""
+    dev = dev_for(name)
     prm = dev.prm
     ctx = H.oracle_ctx(prm)
     cs = {"wide": lambda: R.wide_r1cs(m, prm.q), "chain": lambda: R.chain_r1cs(m, prm.q),
@@ -565,7 +583,7 @@ def test_multipass_production_tile_matches_oracle_on_a_few_slots():
             assert (host(w[k])[:, limb, :] == exp[k]).all(), (k, limb)
 
 
-@pytest.mark.parametrize("name", ["toy", "toy49"])
+@pytest.mark.parametrize("name", ["toy", "toy49", "toy54", "toy60"])
 def test_poly_multiply_add_divide_match_oracle(name):
     """Row a11 (util/polynomials.tcc:62-81): per-slot polynomial product / sum / quotient with ring-element
     coefficients, non-monic per-slot divisors included, against the oracle's schoolbook restatement."""

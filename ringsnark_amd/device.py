@@ -115,6 +115,7 @@ class Device:
 
     # ---- a1-a3
     def _bin(self, fn, a, b):
+        a, b = a.contiguous(), b.contiguous()
         out = torch.empty_like(a)
         _lib.check(fn(self.h, _ptr(out), _ptr(a), _ptr(b), self._count(a, self.ring_words), self.stream()))
         return out
@@ -134,11 +135,13 @@ class Device:
         return out
 
     def ring_add_scalar(self, a, s):
+        a = a.contiguous()
         out = torch.empty_like(a)
         _lib.check(self.lib.rs_ring_add_scalar(self.h, _ptr(out), _ptr(a), s, self._count(a, self.ring_words), self.stream()))
         return out
 
     def ring_mul_scalar(self, a, s):
+        a = a.contiguous()
         out = torch.empty_like(a)
         _lib.check(self.lib.rs_ring_mul_scalar(self.h, _ptr(out), _ptr(a), s, self._count(a, self.ring_words), self.stream()))
         return out

@@ -78,3 +78,79 @@ def solve_forward(cs: R1CS, x0, x1, ring_mul, ring_lincomb):
         a_val = ring_lincomb("a", i, asg)
         asg.append(ring_mul(a_val, asg[i + 1]))
     return asg
+
+
+def logreg_r1cs(q: List[int], num_features: int = 256) -> R1CS:
+    """The circuit of the reference's benchmarks/bench_logistic_regression_inference.cpp:72-125 (BASELINE.json
+    configs[4]), variable for variable: per feature i two input ciphertexts in1[i], in2[i] of two ring elements each
+    (allocated interleaved, :78-82), five outputs, the four products per feature, s02 and s11.  With 256 features:
+    1031 constraints, 2055 variables, set_input_sizes(2*256+5 = 517) (:72,85).
+
+      per feature (:94-107)   in1[i][0]*in2[i][0] = p00[i];  in1[i][0]*in2[i][1] = p01[i];
+                              in1[i][1]*in2[i][0] = p10[i];  in1[i][1]*in2[i][1] = p11[i]
+      sums (linear)           s0 = sum p00,  s1 = sum (p01 + p10),  s2 = sum p11     (the ciphertext product's components)
+      degree-2 sigmoid (:116-125)  s0*s0 = out0;  (2 s0)*s1 = out1;  s0*s2 = s02;  s1*s1 = s11;
+                              1 * (2 s02 + s11) = out2;  s1*s2 = out3;  s2*s2 = out4
+    Variable k (1-based, 0 = the constant one): in1[i][j] = 4i+1+j, in2[i][j] = 4i+3+j, out[k] = 4F+1+k,
+    p00[i] = 4F+6+i, p01[i] = 5F+6+i, p10[i] = 6F+6+i, p11[i] = 7F+6+i, s02 = 8F+6, s11 = 8F+7."""
+    F = num_features
+    in1 = lambda i, j: 4 * i + 1 + j
+    in2 = lambda i, j: 4 * i + 3 + j
+    out = lambda k: 4 * F + 1 + k
+    p = lambda which, i: (4 + which) * F + 6 + i
+    s02, s11 = 8 * F + 6, 8 * F + 7
+    rows = {"a": [], "b": [], "c": []}
+
+    def add(a, b, c):
+        rows["a"].append(a)
+        rows["b"].append(b)
+        rows["c"].append(c)
+
+    for i in range(F):
+        add([(in1(i, 0), 1)], [(in2(i, 0), 1)], [(p(0, i), 1)])
+        add([(in1(i, 0), 1)], [(in2(i, 1), 1)], [(p(1, i), 1)])
+        add([(in1(i, 1), 1)], [(in2(i, 0), 1)], [(p(2, i), 1)])
+        add([(in1(i, 1), 1)], [(in2(i, 1), 1)], [(p(3, i), 1)])
+    s0 = [(p(0, i), 1) for i in range(F)]
+    s1 = sorted([(p(1, i), 1) for i in range(F)] + [(p(2, i), 1) for i in range(F)])
+    s2 = [(p(3, i), 1) for i in range(F)]
+    add(s0, s0, [(out(0), 1)])
+    add([(k, 2) for k, _ in s0], s1, [(out(1), 1)])
+    add(s0, s2, [(s02, 1)])
+    add(s1, s1, [(s11, 1)])
+    add([(0, 1)], [(s02, 2), (s11, 1)], [(out(2), 1)])
+    add(s1, s2, [(out(3), 1)])
+    add(s2, s2, [(out(4), 1)])
+    n_vars = 8 * F + 7
+    return from_rows(4 * F + 7, n_vars, 2 * F + 5, rows, q)
+
+
+def logreg_assignment(num_features, inputs, ring_mul, ring_add, ring_mul_scalar):
+    """Full assignment [n_vars] of logreg_r1cs from the 4F input ring elements (in1[i][0], in1[i][1], in2[i][0],
+    in2[i][1] per feature; bench_logistic_regression_inference.cpp:147-205).  The ring operations are supplied by
+    the caller (CPU oracle in tests, batched device ops in the bench); they must accept leading batch dimensions."""
+    F = num_features
+    x = inputs.reshape((F, 4) + tuple(inputs.shape[1:]))
+    a0, a1, b0, b1 = x[:, 0], x[:, 1], x[:, 2], x[:, 3]
+    p00, p01, p10, p11 = ring_mul(a0, b0), ring_mul(a0, b1), ring_mul(a1, b0), ring_mul(a1, b1)
+
+    def total(v):  # pairwise tree sum of F ring elements
+        while v.shape[0] > 1:
+            h = v.shape[0] // 2
+            head = ring_add(v[:h], v[h:2 * h])
+            v = head if v.shape[0] == 2 * h else _cat([head, v[2 * h:]])
+        return v[0]
+
+    s0, s1, s2 = total(p00), total(ring_add(p01, p10)), total(p11)
+    s_02, s_11 = ring_mul(s0, s2), ring_mul(s1, s1)
+    outs = [ring_mul(s0, s0), ring_mul(ring_mul_scalar(s0, 2), s1), ring_add(ring_mul_scalar(s_02, 2), s_11), ring_mul(s1, s2),
+            ring_mul(s2, s2)]
+    parts = [inputs] + [o[None] for o in outs] + [p00, p01, p10, p11, s_02[None], s_11[None]]
+    return _cat(parts)
+
+
+def _cat(parts):
+    if isinstance(parts[0], np.ndarray):
+        return np.ascontiguousarray(np.concatenate(parts))
+    import torch
+    return torch.cat(parts).contiguous()

@@ -39,13 +39,14 @@ from ringsnark_amd import r1cs as R  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_PEAK_T = 39.3     # vector FP64 FMA issue peak, T lane-ops/s: 256 CUs x 64 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md)
 # kernels bounded by FP64 issue (LDS-resident transforms); everything else is bounded by HBM
-FP64_KERNELS = ("tree_columns_kernel", "h_tile_kernel", "h_columns_kernel", "interp_columns_kernel", "sub_ntt_kernel",
-                "plain_center_kernel")
+FP64_KERNELS = ("tree_columns_kernel", "tree_tiles_generic_kernel", "h_tile_kernel", "h_columns_kernel", "interp_columns_kernel",
+                "sub_ntt_kernel", "sub_ntt_ct_kernel", "plain_center_kernel")
 
 
 def rocprof_name(name):
-    """Profile-record name -> the kernel name rocprofv3 prints (prefix match on `rs::<name>`)."""
-    return "rs::" + name.split("<")[0]
+    """Profile-record name -> prefix of the kernel name rocprofv3 prints (the library records `<name>` such that
+    `rs::<name>` is that prefix, template arguments included where several instantiations exist)."""
+    return "rs::" + name
 
 
 def kernel_roofline(k, pmc):
@@ -66,8 +67,7 @@ def kernel_roofline(k, pmc):
     # keyed by the exact kernel family; null when the committed file does not hold this kernel
     traffic = None
     if pmc:
-        fam = [v for n, v in pmc.get("kernels", {}).items() if n.startswith(rocprof_name(k["name"])) and
-               (("<" not in k["name"]) or k["name"].split("<")[1].rstrip(">") in n)]
+        fam = [v for n, v in pmc.get("kernels", {}).items() if n.startswith(rocprof_name(k["name"]))]
         if fam:
             traffic = int(sum(v["hbm_bytes"] for v in fam) / max(1, sum(v["launches_per_proof"] for v in fam)))
     out["traffic"] = traffic

@@ -788,7 +788,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
         // every ciphertext word of the group's terms once, every plaintext row once (shared by the K
         // prime workgroups through L2), the accumulator set written once
         const double terms = (double)a2.terms;
-        ProfScope prof(ctx, st, "mac_kernel_v2", terms * ((double)enc_words * 8.0 + (double)L * nd * 8.0) + (double)enc_words * 8.0,
+        ProfScope prof(ctx, st, (g_mac_variant == 3 && ctx->logN_enc == 13) ? "mac_kernel_v2<1024, 13, 0>" : "mac_kernel_v2", terms * ((double)enc_words * 8.0 + (double)L * nd * 8.0) + (double)enc_words * 8.0,
                        terms * L * K * (ntt_fp64(nd, logn_d) + 15.0 * nd));
         launch_mac_v2(ctx, a2, sc, st);
       }

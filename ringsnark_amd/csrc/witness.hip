@@ -1510,8 +1510,11 @@ static void launch_tree_tiles(rs_ctx *ctx, double *cols, size_t ncols, size_t co
   const double tiles = (double)(ncols << (logM - logT));
   // Newton conversion (single-tile columns): two passes of forward + inverse M-point transforms and two pointwise products
   const double newton_fp64 = newton ? 4.0 * ntt_fp64((double)T, logT) + 31.0 * (double)T : 0.0;
-  ProfScope prof(ctx, st, newton ? "tree_columns_kernel<NEWTON>" : "tree_columns_kernel", tiles * (double)T * 16.0,
-                 tiles * (tree_fp64((double)T, logT) + newton_fp64));
+  // names as rocprofv3 prints them (a prefix of "rs::<name>") so that profiles/ and the live record can be joined
+  const bool ct13 = logT == 13 && g_witness_tree_ct;
+  const char *pname = ct13 ? (newton ? "tree_columns_kernel<512, 13, true>" : "tree_columns_kernel<512, 13, false>")
+                           : (newton ? "tree_columns_kernel<NEWTON>" : "tree_columns_kernel");
+  ProfScope prof(ctx, st, pname, tiles * (double)T * 16.0, tiles * (tree_fp64((double)T, logT) + newton_fp64));
   const size_t lds1 = padded_len(T) * sizeof(double);
   const unsigned grid = (unsigned)(ncols << (logM - logT));
   const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, T / 16));  // 1024 only for a 2^14 tile (one workgroup per CU)
@@ -1627,9 +1630,11 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
   constexpr bool FP = std::is_same<M, Mod>::value;
   const size_t lds = padded_len((size_t)1 << logB) * sizeof(double);
   const size_t bpc = (size_t)1 << (logtot - logB);
-  static const char *const names[4] = {"sub_ntt_kernel<0>", "sub_ntt_kernel<1>", "sub_ntt_kernel<2>", "sub_ntt_kernel<3>"};
+  static const char *const names[4] = {"sub_ntt_kernel<0", "sub_ntt_kernel<1", "sub_ntt_kernel<2", "sub_ntt_kernel<3"};
+  static const char *const names_ct[4] = {"sub_ntt_ct_kernel<0, 13>", "sub_ntt_ct_kernel<1, 13>", "sub_ntt_ct_kernel<2, 13>", "sub_ntt_ct_kernel<3, 13>"};
+  const bool ct = FP && logB == 13 && MODE != 1 && g_witness_sub_ct;
   const double Bn = (double)((size_t)1 << logB), blocks = (double)(ncols * bpc);
-  ProfScope prof(ctx, st, names[MODE], blocks * Bn * (MODE == 3 ? 24.0 : 16.0),
+  ProfScope prof(ctx, st, ct ? names_ct[MODE] : names[MODE], blocks * Bn * (MODE == 3 ? 24.0 : 16.0),
                  blocks * ((MODE >= 2 ? 2.0 : 1.0) * ntt_fp64(Bn, logB) + (MODE >= 2 ? 7.0 * Bn : 0.0)));
   static TabPtrs none{};
   const TabPtrs &tp = tabs ? *tabs : none;

@@ -35,6 +35,9 @@ namespace rs {
 #ifndef RS_LDS_SWIZZLE
 #define RS_LDS_SWIZZLE 0
 #endif
+#ifndef RS_UNIFORM_TWIDDLES
+#define RS_UNIFORM_TWIDDLES 1
+#endif
 constexpr int PAD_SHIFT = 4;
 #if RS_LDS_SWIZZLE
 __host__ __device__ __forceinline__ int pidx(int i) {
@@ -129,7 +132,15 @@ __device__ __forceinline__ void fwd_round(const In in, const Out out, int logtot
     // all of them (dozens per round, several rounds) costs far more registers than recomputing.
     int grp = grp_, sstep = sstep_;
     if (ln.opaque) asm volatile("" : "+v"(grp), "+s"(sstep));
-    const int lo = grp & (sstep - 1), hi_all = grp >> lstep;
+    const int lo = grp & (sstep - 1);
+    int hi_all = grp >> lstep;
+#if RS_UNIFORM_TWIDDLES
+    // The 64 lanes of a wave hold 64 consecutive groups (tid = 64*wave + lane, strides are multiples of 64), so
+    // with a smallest gap of >= 64 they sit in ONE aligned block of 2^lstep groups: hi_all, and with it every
+    // twiddle index of the round, is wave-uniform.  Saying so turns the twiddle fetches into scalar loads
+    // (no vector address arithmetic, no VMEM issue slots, operands straight from SGPRs).
+    if (lstep >= 6) hi_all = __builtin_amdgcn_readfirstlane(hi_all);
+#endif
     const int hi = hi_all & ((1 << s0) - 1);
     const int base = (hi_all << (logsub - s0)) + lo;
     T v[E];
@@ -228,7 +239,11 @@ __device__ __forceinline__ void inv_round(const In in, const Out out, int logtot
   for (int grp_ = ln.tid; grp_ < ngroups; grp_ += ln.nthr) {
     int grp = grp_, g0 = g0_;
     if (ln.opaque) asm volatile("" : "+v"(grp), "+s"(g0));
-    const int lo = grp & (g0 - 1), hi_all = grp >> u0;
+    const int lo = grp & (g0 - 1);
+    int hi_all = grp >> u0;
+#if RS_UNIFORM_TWIDDLES
+    if (u0 >= 6) hi_all = __builtin_amdgcn_readfirstlane(hi_all);  // wave-uniform, as in fwd_round
+#endif
     const int hi = hi_all & ((1 << gpb_log) - 1);
     const int base = (hi_all << (u0 + R)) + lo;
     T v[E];

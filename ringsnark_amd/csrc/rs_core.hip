@@ -316,6 +316,14 @@ ntt_fwd_stream_kernel(uint64_t *__restrict__ data, unsigned long long batch, int
   const LdsBlockIO blk{s + pidx(off)};
   const Lanes wl = wave_lanes(true);
   uint64_t pre[G][4];
+  // The finished polynomial leaves through registers ONE ITERATION LATE: its stores are issued after the next
+  // polynomial's first round has consumed the prefetched loads.  gfx9-family counters track loads and stores in
+  // one vmcnt and they complete out of order with respect to each other, so waiting for a load that was issued
+  // before stores means vmcnt(0), i.e. draining those stores; issued in this order the only stores in flight at
+  // the wait are a whole transform old.
+  constexpr int NOUT = 2 * G;  // 16-byte pairs per lane of a wave block: (n / 16) / 2 / 64
+  ulonglong2 outr[NOUT];
+  unsigned long long p_out = ~0ull;
   unsigned long long p = blockIdx.x;
   if (p < batch) {
     const uint64_t *src = data + p * (size_t)n;
@@ -343,6 +351,11 @@ ntt_fwd_stream_kernel(uint64_t *__restrict__ data, unsigned long long batch, int
       s[pcomb(pb, pidx(3 * q))] = a2 - u;
     }
     __syncthreads();
+    if (p_out != ~0ull) {  // the previous polynomial, held in registers since the end of the last iteration
+      ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(data + p_out * (size_t)n + off);
+#pragma unroll
+      for (int k = 0; k < NOUT; k++) dst[lane + 64 * k] = outr[k];
+    }
     const unsigned long long pn = p + gridDim.x;
     if (pn < batch) {
       const uint64_t *src = data + pn * (size_t)n;
@@ -359,15 +372,19 @@ ntt_fwd_stream_kernel(uint64_t *__restrict__ data, unsigned long long batch, int
       wave_sync();
       st += R;
     }
-    ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(data + p * (size_t)n + off);
-    for (int i = lane; i < (bsz >> 1); i += 64) {
-      const int pi = pidx(off + 2 * i);
-      ulonglong2 o;
-      o.x = to_u64(canon(s[pi], mod));
-      o.y = to_u64(canon(s[pnext(pi)], mod));
-      dst[i] = o;
+#pragma unroll
+    for (int k = 0; k < NOUT; k++) {
+      const int pi = pidx(off + 2 * (lane + 64 * k));
+      outr[k].x = to_u64(canon(s[pi], mod));
+      outr[k].y = to_u64(canon(s[pnext(pi)], mod));
     }
+    p_out = p;
     __syncthreads();
+  }
+  if (p_out != ~0ull) {
+    ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(data + p_out * (size_t)n + off);
+#pragma unroll
+    for (int k = 0; k < NOUT; k++) dst[lane + 64 * k] = outr[k];
   }
 }
 

@@ -881,7 +881,10 @@ int rs_set_tuning(const char *key, int value) {
 #endif
   else if (std::string(key) == "mac_variant")
     g_mac_variant = value;
-  else if (std::string(key) == "witness_sub_ct")
+  else if (std::string(key) == "witness_force_bc") {
+    RS_REQUIRE(value == 0 || (value >= 5 && value <= 20), "witness_force_bc must be 0 or in [5, 20]");
+    g_witness_force_bc = value;  // takes effect for plans built afterwards (plans are cached per context and size)
+  } else if (std::string(key) == "witness_sub_ct")
     g_witness_sub_ct = value;
   else if (std::string(key) == "witness_tree_ct")
     g_witness_tree_ct = value;

@@ -43,6 +43,11 @@ struct LimbPlan {
   void *d_dlow = nullptr;                  // [SCHOOL_LEVELS+1][M/2] low coefficients of D_left
   void *d_shat = nullptr;                  // [2M] spectrum of rev(Z)^-1 mod x^(m-1), scaled 1/(2M)^2
   void *d_ztab = nullptr;                  // [M] Z_k (0 beyond m)
+  // block-convolution path (WitnessPlan::bcLog != 0): spectra of the B-coefficient blocks of the same polynomials,
+  // transform length 2B = 2^bcLog, scaled by 1/(2B)
+  void *d_bc_e = nullptr;                  // [M/B][2B] blocks of (-1)^k/k!
+  void *d_bc_s = nullptr;                  // [M/B][2B] blocks of rev(Z)^-1 mod x^(m-1)
+  void *d_bc_d = nullptr;                  // [logM - bcLog][M] per level l > bcLog: [node][block][2B] blocks of D_left's low part
   uint32_t fwd_mask2 = 0, inv_mask2 = 0;     // reduce masks for length 2M
   std::vector<uint64_t> Z;                   // m+1 coefficients of the vanishing polynomial
 };
@@ -50,6 +55,12 @@ struct LimbPlan {
 struct WitnessPlan {
   size_t m = 0, M = 0;
   int logM = 0;
+  // 0: every ring prime has a 2M-th root of unity (q = 1 mod 2M): full-length transforms.  Otherwise the largest
+  // transform length every prime supports is 2^bcLog < 2M (capped at 2^13, one LDS tile) and every product longer
+  // than that is a BLOCK convolution over blocks of B = 2^(bcLog-1) coefficients (see "block convolutions" below):
+  // what makes the witness map work for the primes the reference's own recipe produces, which only guarantee
+  // q = 1 mod 2*N_inner (seal/seal_util.hpp:20-32).
+  int bcLog = 0;
   std::vector<LimbPlan> limb;
 };
 
@@ -59,11 +70,13 @@ using namespace host;
 
 struct CycTab {
   uint64_t p;
+  int logmax;                     // transforms up to length 2^logmax
   std::vector<uint64_t> tw, itw;  // tw[Mg + i] = w_{2Mg}^{bitrev(i)}
 };
 static CycTab make_cyc(uint64_t p, int logn_max) {
   CycTab t;
   t.p = p;
+  t.logmax = logn_max;
   const size_t n = (size_t)1 << logn_max;
   t.tw.assign(n, 1);
   t.itw.assign(n, 1);
@@ -128,6 +141,32 @@ static std::vector<uint64_t> polymul(const std::vector<uint64_t> &a, const std::
     return o;
   }
   const int lg = clog2(need);
+  if (lg > t.logmax) {
+    // the prime has no root of unity of that order: block convolution over blocks of Bh = 2^(logmax-1)
+    // coefficients (each block product fits one transform of length 2 Bh), overlap-added
+    const size_t Bh = (size_t)1 << (t.logmax - 1);
+    const size_t nab = (a.size() + Bh - 1) / Bh, nbb = (b.size() + Bh - 1) / Bh;
+    auto spectra = [&](const std::vector<uint64_t> &x, size_t nb) {
+      std::vector<std::vector<uint64_t>> sp(nb);
+      for (size_t i = 0; i < nb; i++) {
+        sp[i].assign(2 * Bh, 0);
+        for (size_t k = 0; k < Bh && i * Bh + k < x.size(); k++) sp[i][k] = x[i * Bh + k];
+        ntt_fwd(sp[i], t.logmax, t);
+      }
+      return sp;
+    };
+    const auto sa = spectra(a, nab), sb = spectra(b, nbb);
+    std::vector<uint64_t> o(need + 2 * Bh, 0);
+    for (size_t k = 0; k + 1 < nab + nbb; k++) {
+      std::vector<uint64_t> acc(2 * Bh, 0);
+      for (size_t i = (k >= nbb ? k - nbb + 1 : 0); i <= k && i < nab; i++)
+        for (size_t x = 0; x < 2 * Bh; x++) acc[x] = addmod(acc[x], mulmod(sa[i][x], sb[k - i][x], t.p), t.p);
+      ntt_inv(acc, t.logmax, t);
+      for (size_t x = 0; x < 2 * Bh; x++) o[k * Bh + x] = addmod(o[k * Bh + x], acc[x], t.p);
+    }
+    o.resize(need);
+    return o;
+  }
   std::vector<uint64_t> fa(a), fb(b);
   fa.resize((size_t)1 << lg, 0);
   fb.resize((size_t)1 << lg, 0);
@@ -160,6 +199,8 @@ static uint64_t plain_word(const rs_ctx *ctx, uint64_t v, uint64_t p) {
   return ctx->use_int ? word_of(HostArith<ModI>::plain(v, p)) : word_of(HostArith<Mod>::plain(v, p));
 }
 
+int g_witness_force_bc = 0;  // tuning knob "witness_force_bc": pretend the ring primes have only this 2-adicity (tests)
+
 static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
   using namespace hostw;
   RS_REQUIRE(m >= 1, "need at least one constraint");
@@ -172,21 +213,41 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
   if (logM > 20)
     throw Error(RS_ERR_UNSUPPORTED, "witness map beyond 2^20 constraints is not supported");
   P->limb.resize(ctx->L);
+  int vmin = 64;
+  for (int li = 0; li < ctx->L; li++) vmin = std::min(vmin, host::two_adicity(ctx->q[li]));
+  if (g_witness_force_bc > 0) vmin = std::min(vmin, g_witness_force_bc);  // tests: the block path on well-endowed primes
+  const bool blocked = vmin < logM + 1;
+  P->bcLog = blocked ? std::min(vmin, 13) : 0;
+  // every context prime is 1 mod 2*N_enc with N_enc >= 16, so the 2-adicity is at least 5
+  RS_REQUIRE(!blocked || P->bcLog > SCHOOL_LEVELS, "ring prime with too little 2-adicity for the witness map");
+  const int tabLog = blocked ? P->bcLog : logM + 1;  // longest transform the device tables serve
+  const size_t Bc = blocked ? (size_t)1 << (P->bcLog - 1) : 0, nblk = blocked ? std::max<size_t>(1, M / Bc) : 0;
   for (int li = 0; li < ctx->L; li++) {
     LimbPlan &lp = P->limb[li];
     const uint64_t p = ctx->q[li];
-    if (host::two_adicity(p) < logM + 1)
-      throw Error(RS_ERR_UNSUPPORTED, "ring prime lacks the 2-adicity for the quasi-linear witness map (need q = 1 mod 2*next_pow2(m)*2)");
     RS_REQUIRE(p > 2 * M, "ring prime too small for the evaluation domain");
     lp.p = p;
-    const CycTab T = make_cyc(p, logM + 1);
+    const CycTab T = make_cyc(p, tabLog);
     auto bal = [&](uint64_t v) { return konst_word(ctx, v, p); };
     {
-      std::vector<uint64_t> tw(2 * M), itw(2 * M);
-      for (size_t k = 0; k < 2 * M; k++) tw[k] = bal(T.tw[k]), itw[k] = bal(T.itw[k]);
+      const size_t tn = (size_t)1 << tabLog;
+      std::vector<uint64_t> tw(tn), itw(tn);
+      for (size_t k = 0; k < tn; k++) tw[k] = bal(T.tw[k]), itw[k] = bal(T.itw[k]);
       lp.d_tw = up(tw);
       lp.d_itw = up(itw);
     }
+    // spectra (scaled by 1/(2 Bc)) of the Bc-coefficient blocks of a polynomial: [blocks][2 Bc]
+    auto block_spectra = [&](const std::vector<uint64_t> &poly, size_t blocks) {
+      std::vector<uint64_t> out(blocks * 2 * Bc, 0);
+      const uint64_t sc = invmod((uint64_t)(2 * Bc) % p, p);
+      for (size_t b = 0; b < blocks; b++) {
+        std::vector<uint64_t> f(2 * Bc, 0);
+        for (size_t k = 0; k < Bc && b * Bc + k < poly.size(); k++) f[k] = poly[b * Bc + k];
+        ntt_fwd(f, P->bcLog, T);
+        for (size_t k = 0; k < 2 * Bc; k++) out[b * 2 * Bc + k] = bal(mulmod(f[k], sc, p));
+      }
+      return out;
+    };
     lp.fwd_mask2 = fwd_reduce_mask(p, logM + 1);
     lp.inv_mask2 = inv_reduce_mask(p, logM + 1);
     // factorials
@@ -201,11 +262,16 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
       lp.d_invfact = up(v);
       std::vector<uint64_t> e(2 * M, 0);
       for (size_t k = 0; k < m; k++) e[k] = (k & 1) ? (p - ifact[k]) % p : ifact[k];
-      ntt_fwd(e, logM + 1, T);
-      const uint64_t s2 = invmod((uint64_t)(2 * M) % p, p);
-      std::vector<uint64_t> eh(2 * M);
-      for (size_t k = 0; k < 2 * M; k++) eh[k] = bal(mulmod(e[k], s2, p));
-      lp.d_ehat = up(eh);
+      if (blocked) {
+        e.resize(M);
+        lp.d_bc_e = up(block_spectra(e, nblk));
+      } else {
+        ntt_fwd(e, logM + 1, T);
+        const uint64_t s2 = invmod((uint64_t)(2 * M) % p, p);
+        std::vector<uint64_t> eh(2 * M);
+        for (size_t k = 0; k < 2 * M; k++) eh[k] = bal(mulmod(e[k], s2, p));
+        lp.d_ehat = up(eh);
+      }
     }
     // subproduct tree: prod[l][i] = prod_{j in [i 2^l, (i+1) 2^l)} (x - j), low 2^l coefficients
     std::vector<std::vector<std::vector<uint64_t>>> prod(logM + 1);
@@ -226,12 +292,17 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
     // D_left spectra (levels > SCHOOL_LEVELS) and low coefficients (levels <= SCHOOL_LEVELS)
     {
       std::vector<uint64_t> dhat((size_t)(logM + 1) * M, 0), dlow((size_t)(SCHOOL_LEVELS + 1) * (M / 2 + 1), 0);
+      std::vector<uint64_t> bcd(blocked && logM > P->bcLog ? (size_t)(logM - P->bcLog) * M : 0, 0);
       for (int l = 1; l <= logM; l++) {
         const size_t n = (size_t)1 << l, h = n >> 1;
         for (size_t i = 0; i < (M >> l); i++) {
           const auto &dl = prod[l - 1][2 * i];  // h low coefficients, monic of degree h
           if (l <= SCHOOL_LEVELS) {
             for (size_t k = 0; k < h; k++) dlow[(size_t)l * (M / 2 + 1) + i * h + k] = bal(dl[k]);
+          } else if (blocked && l > P->bcLog) {
+            // node i of level l: the h / Bc blocks of D_left's low part (the monic x^h term is added by the sink)
+            const std::vector<uint64_t> sp = block_spectra(dl, h / Bc);
+            std::copy(sp.begin(), sp.end(), bcd.begin() + (size_t)(l - P->bcLog - 1) * M + i * n);
           } else {
             std::vector<uint64_t> f(n, 0);
             for (size_t k = 0; k < h; k++) f[k] = dl[k];
@@ -244,6 +315,7 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
       }
       lp.d_dhat = up(dhat);
       lp.d_dlow = up(dlow);
+      if (!bcd.empty()) lp.d_bc_d = up(bcd);
     }
     // Z = prod_{j<m} (x - j): product of the maximal aligned blocks of [0, m)
     {
@@ -282,13 +354,20 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
           g = ng;
         }
         for (size_t i2 = 0; i2 < g.size(); i2++) shat[i2] = g[i2];
-        ntt_fwd(shat, logM + 1, T);
-        const uint64_t s2 = invmod((uint64_t)(2 * M) % p, p), s4 = mulmod(s2, s2, p);
-        for (auto &x : shat) x = mulmod(x, s4, p);
+        if (!blocked) {
+          ntt_fwd(shat, logM + 1, T);
+          const uint64_t s2 = invmod((uint64_t)(2 * M) % p, p), s4 = mulmod(s2, s2, p);
+          for (auto &x : shat) x = mulmod(x, s4, p);
+        }
       }
-      std::vector<uint64_t> sh(2 * M);
-      for (size_t k = 0; k < 2 * M; k++) sh[k] = bal(shat[k]);
-      lp.d_shat = up(sh);
+      if (blocked) {
+        shat.resize(M);  // S itself, m - 1 <= M coefficients
+        lp.d_bc_s = up(block_spectra(shat, nblk));
+      } else {
+        std::vector<uint64_t> sh(2 * M);
+        for (size_t k = 0; k < 2 * M; k++) sh[k] = bal(shat[k]);
+        lp.d_shat = up(sh);
+      }
     }
   }
   return P;
@@ -296,7 +375,7 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
 
 static void free_plan(WitnessPlan *P) {
   for (auto &lp : P->limb) {
-    void *ptrs[] = {lp.d_tw, lp.d_itw, lp.d_invfact, lp.d_ehat, lp.d_dhat, lp.d_dlow, lp.d_shat, lp.d_ztab};
+    void *ptrs[] = {lp.d_tw, lp.d_itw, lp.d_invfact, lp.d_ehat, lp.d_dhat, lp.d_dlow, lp.d_shat, lp.d_ztab, lp.d_bc_e, lp.d_bc_s, lp.d_bc_d};
     for (void *q : ptrs)
       if (q) (void)hipFree(q);
   }
@@ -321,6 +400,8 @@ struct ColPlanT {
   using T = typename ArithOf<M_>::T;
   M mod;
   const T *tw, *itw, *invfact, *ehat, *dhat, *dlow, *shat, *ztab;
+  const T *bc_e, *bc_s, *bc_d;  // block-convolution path (LimbPlan)
+  T bc_inv2b;                   // 1 / (2B) as a table constant
   uint32_t fwd_mask2, inv_mask2;
   uint32_t fmask[24], imask[24];  // reduce masks for transforms of length 2^l (FP64 arithmetic)
 };
@@ -1478,6 +1559,10 @@ static ColPlansT<M> make_colplans(rs_ctx *ctx, const WitnessPlan *P, int limb0 =
     c.dlow = static_cast<const T *>(lp.d_dlow);
     c.shat = static_cast<const T *>(lp.d_shat);
     c.ztab = static_cast<const T *>(lp.d_ztab);
+    c.bc_e = static_cast<const T *>(lp.d_bc_e);
+    c.bc_s = static_cast<const T *>(lp.d_bc_s);
+    c.bc_d = static_cast<const T *>(lp.d_bc_d);
+    c.bc_inv2b = P->bcLog ? HostArith<M>::konst(host::invmod(((uint64_t)1 << P->bcLog) % lp.p, lp.p), lp.p) : T(0);
     c.fwd_mask2 = lp.fwd_mask2;
     c.inv_mask2 = lp.inv_mask2;
     for (int l = 0; l < 24; l++) {
@@ -1654,6 +1739,137 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
   RS_HIP(hipGetLastError());
 }
 
+// =============================================================================================
+// Block convolutions: the witness map for ring primes WITHOUT a 2M-th root of unity.
+// The reference's recipe (seal/seal_util.hpp:20-32) only makes q_i = 1 mod 2*N_inner, and its O(m^2) algorithm
+// works for any prime; the transforms above need q_i = 1 mod 2M (2^17 at the headline).  When a ring prime falls
+// short, every product longer than the largest supported transform (2^bcLog = 2B) is computed blockwise:
+//     X = sum_i X_i x^(iB),  Y = sum_j Y_j x^(jB)   (blocks of B coefficients)
+//     X*Y = sum_k x^(kB) * ( sum_{i+j=k} X_i*Y_j ),   each X_i*Y_j (< 2B coefficients) by one cyclic transform of length 2B
+// i.e. forward transforms of the blocks (bc_fwd_kernel), per output block pair k the sum of pointwise products and ONE
+// inverse transform (bc_mac_kernel), and an overlap-add with the step's sink (bc_out_kernel).  Exact, hence
+// bit-identical; (n/B)^2 pointwise products instead of n log n butterflies for the part above 2B.
+// =============================================================================================
+enum BcSrc { BS_SCALE = 0, BS_CENTER, BS_REVTRUNC, BS_RIGHT };
+enum BcY { BY_E = 0, BY_S, BY_D, BY_DATA };
+enum BcDst { BD_NEWTON = 0, BD_PLAIN_SCALED, BD_HFIN, BD_COMBINE, BD_COMBINE_CANON };
+struct BcArgs {
+  const void *src;   // source columns
+  void *Xhat;        // [ncols * units][nxb][2B] spectra of the source blocks
+  const void *Yhat;  // BY_DATA: [ncols][nyb][2B] spectra of the other operand
+  void *Wc;          // [ncols * units][nk][2B] block-pair products
+  void *dst;
+  int bcLog, logM, m, l;  // l: tree level (node size 2^l) for BS_RIGHT / BY_D / BD_COMBINE
+  int nxb, nyb, nk, units;
+  size_t col0;
+  unsigned S, slots_per_limb;
+};
+
+template <int SRC, class CPS>
+__global__ void __launch_bounds__(1024) bc_fwd_kernel(BcArgs a, CPS plans) {
+  using T = typename CPS::T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T *s = reinterpret_cast<T *>(smem);
+  const int B = 1 << (a.bcLog - 1);
+  const size_t bid = blockIdx.x;
+  const int blk = (int)(bid % a.nxb), unit = (int)((bid / a.nxb) % a.units);
+  const size_t col = bid / ((size_t)a.nxb * a.units), M = (size_t)1 << a.logM;
+  const ColPlanT<typename CPS::M> &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const typename CPS::M mod = P.mod;
+  const T *src = static_cast<const T *>(a.src);
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const size_t k = (size_t)blk * B + i;
+    T v = T(0);
+    if (SRC == BS_SCALE) {
+      if (k < M) v = mulmod(src[col * M + k], P.invfact[k], mod);
+    } else if (SRC == BS_CENTER) {
+      if (k < M) v = center(src[col * M + k], mod);
+    } else if (SRC == BS_REVTRUNC) {  // T_k = P_{2m-2-k}, k < m-1, from a [ncols][2M] buffer
+      if ((long long)k < (long long)a.m - 1) v = reduce(src[col * 2 * M + (size_t)(2 * a.m - 2) - k], mod);
+    } else {  // BS_RIGHT: F_right of node `unit` at level l
+      const size_t n = (size_t)1 << a.l, h = n >> 1;
+      if (k < h) v = src[col * M + (size_t)unit * n + h + k];
+    }
+    s[pidx(i)] = v;
+    s[pidx(B + i)] = T(0);
+  }
+  __syncthreads();
+  lds_ntt_fwd<3>(s, a.bcLog, P.tw, 1, mod, P.fmask[a.bcLog]);
+  T *out = static_cast<T *>(a.Xhat) + bid * (size_t)(2 * B);
+  for (int i = threadIdx.x; i < 2 * B; i += blockDim.x) out[i] = reduce(s[pidx(i)], mod);
+}
+
+template <int YK, class CPS>
+__global__ void __launch_bounds__(1024) bc_mac_kernel(BcArgs a, CPS plans) {
+  using T = typename CPS::T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T *s = reinterpret_cast<T *>(smem);
+  const int B2 = 1 << a.bcLog;
+  const size_t bid = blockIdx.x;
+  const int k = (int)(bid % a.nk), unit = (int)((bid / a.nk) % a.units);
+  const size_t col = bid / ((size_t)a.nk * a.units);
+  const ColPlanT<typename CPS::M> &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const typename CPS::M mod = P.mod;
+  const T *X = static_cast<const T *>(a.Xhat) + (col * a.units + unit) * (size_t)a.nxb * B2;
+  const T *Y;
+  if (YK == BY_E)
+    Y = P.bc_e;
+  else if (YK == BY_S)
+    Y = P.bc_s;
+  else if (YK == BY_D)
+    Y = P.bc_d + (size_t)(a.l - a.bcLog - 1) * ((size_t)1 << a.logM) + (size_t)unit * ((size_t)1 << a.l);
+  else
+    Y = static_cast<const T *>(a.Yhat) + col * (size_t)a.nyb * B2;
+  const int i0 = k >= a.nyb ? k - a.nyb + 1 : 0, i1 = k < a.nxb ? k : a.nxb - 1;
+  for (int e = threadIdx.x; e < B2; e += blockDim.x) {
+    T acc = T(0);
+    int since = 0;
+    for (int ib = i0; ib <= i1; ib++) {
+      const T x = X[(size_t)ib * B2 + e], y = Y[(size_t)(k - ib) * B2 + e];
+      acc = addm(acc, YK == BY_DATA ? mulmod_dd(x, y, mod) : mulmod(x, y, mod), mod);
+      if (++since == 4) {
+        since = 0;
+        acc = reduce(acc, mod);
+      }
+    }
+    s[pidx(e)] = reduce(acc, mod);
+  }
+  __syncthreads();
+  lds_ntt_inv<3>(s, a.bcLog, P.itw, 1, mod, P.imask[a.bcLog]);
+  T *out = static_cast<T *>(a.Wc) + bid * (size_t)B2;
+  for (int e = threadIdx.x; e < B2; e += blockDim.x) out[e] = reduce(s[pidx(e)], mod);
+}
+
+// overlap-add of the block-pair products + the step's sink; one thread per output coefficient
+template <int DST, class CPS>
+__global__ void __launch_bounds__(256) bc_out_kernel(BcArgs a, CPS plans, size_t ncols, size_t per_unit) {
+  using T = typename CPS::T;
+  const int B = 1 << (a.bcLog - 1);
+  const size_t M = (size_t)1 << a.logM, total = ncols * a.units * per_unit, stride = (size_t)gridDim.x * blockDim.x;
+  const T *W = static_cast<const T *>(a.Wc);
+  T *dst = static_cast<T *>(a.dst);
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const size_t t = idx % per_unit, cu = idx / per_unit, unit = cu % a.units, col = cu / a.units;
+    const ColPlanT<typename CPS::M> &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+    const typename CPS::M mod = P.mod;
+    const size_t kb = t / B, r = t % B;
+    T v = T(0);
+    if (kb < (size_t)a.nk) v = W[(cu * a.nk + kb) * (size_t)(2 * B) + r];
+    if (kb >= 1 && kb - 1 < (size_t)a.nk) v = addm(v, W[(cu * a.nk + kb - 1) * (size_t)(2 * B) + B + r], mod);
+    if (DST == BD_NEWTON) {  // Newton coefficients: the low M terms, zero beyond m
+      dst[col * M + t] = (P.invfact[t] != T(0)) ? reduce(v, mod) : T(0);
+    } else if (DST == BD_PLAIN_SCALED) {  // data x data product: the 1/(2B) of the inverse transform is applied here
+      dst[col * 2 * M + t] = mulmod(reduce(v, mod), P.bc_inv2b, mod);
+    } else if (DST == BD_HFIN) {  // H_j = U_{m-2-j}
+      if ((long long)t <= (long long)a.m - 2) dst[col * M + (size_t)(a.m - 2) - t] = reduce(v, mod);
+    } else {  // F_node = (F_left, 0) + x^h F_right + d * F_right: both extra terms sit at this very position
+      const size_t pos = col * M + unit * ((size_t)1 << a.l) + t;
+      const T f = reduce(addm(v, dst[pos], mod), mod);
+      dst[pos] = DST == BD_COMBINE_CANON ? canon(f, mod) : f;
+    }
+  }
+}
+
 // multi-pass interpolation of `ncols` columns X[ncols][M] in place; W: workspace [ncols][2M]
 template <class M>
 static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, typename ArithOf<M>::T *X, typename ArithOf<M>::T *W,
@@ -1756,6 +1972,127 @@ static bool single_tile_ok(int logM) {
   return logM <= g_witness_lds_logM || (logM == 14 && g_witness_lds_logM == 13);
 }
 
+// ---- block-convolution path: host side ---------------------------------------------------------------------
+template <int SRC, int YK, int DST, class M>
+static void bc_conv(rs_ctx *ctx, BcArgs a, size_t ncols, size_t per_unit, const ColPlansT<M> &cp, hipStream_t st) {
+  using CPS = ColPlansT<M>;
+  const size_t B2 = (size_t)1 << a.bcLog, lds = padded_len(B2) * sizeof(uint64_t);
+  const int thr = col_threads(B2);
+  const double nfwd = (double)ncols * a.units * a.nxb, nmac = (double)ncols * a.units * a.nk;
+  double pairs = 0;  // pointwise block products
+  for (int k = 0; k < a.nk; k++) pairs += std::min(k, a.nxb - 1) - std::max(0, k - a.nyb + 1) + 1;
+  {
+    ProfScope prof(ctx, st, "bc_fwd_kernel", nfwd * (double)B2 * 12.0, nfwd * ntt_fp64((double)B2, a.bcLog));
+    RS_HIP(hipFuncSetAttribute((const void *)bc_fwd_kernel<SRC, CPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((bc_fwd_kernel<SRC, CPS>), dim3((unsigned)(ncols * a.units * a.nxb)), dim3(thr), lds, st, a, cp);
+  }
+  {
+    ProfScope prof(ctx, st, "bc_mac_kernel", nmac * (double)B2 * 8.0 + (double)ncols * a.units * pairs * (double)B2 * 8.0,
+                   nmac * ntt_fp64((double)B2, a.bcLog) + (double)ncols * a.units * pairs * (double)B2 * 7.0);
+    RS_HIP(hipFuncSetAttribute((const void *)bc_mac_kernel<YK, CPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((bc_mac_kernel<YK, CPS>), dim3((unsigned)(ncols * a.units * a.nk)), dim3(thr), lds, st, a, cp);
+  }
+  {
+    const size_t total = ncols * a.units * per_unit;
+    ProfScope prof(ctx, st, "bc_out_kernel", (double)total * 24.0, (double)total * 3.0);
+    hipLaunchKernelGGL((bc_out_kernel<DST, CPS>), dim3((unsigned)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 256 * 32))), dim3(256), 0,
+                       st, a, cp, ncols, per_unit);
+  }
+  RS_HIP(hipGetLastError());
+}
+
+// columns per chunk such that the block workspaces (spectra + pair products, up to ~8M words per column) stay within ~6 GiB
+static size_t bc_chunk_cols(const WitnessPlan *P) { return std::max<size_t>(1, ((size_t)6 << 30) / (10 * P->M * sizeof(double))); }
+
+template <class M>
+static void bc_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, typename ArithOf<M>::T *X, size_t ncols, size_t col0,
+                      size_t S, size_t spl, hipStream_t st) {
+  using T = typename ArithOf<M>::T;
+  const int logM = P->logM, bc = P->bcLog;
+  const size_t Mlen = P->M, B = (size_t)1 << (bc - 1);
+  T *Xhat = (T *)ws_get(ctx, 12, ncols * 2 * Mlen * sizeof(T));
+  T *Wc = (T *)ws_get(ctx, 13, ncols * 2 * Mlen * sizeof(T));
+  BcArgs a{};
+  a.src = X;
+  a.dst = X;
+  a.Xhat = Xhat;
+  a.Wc = Wc;
+  a.bcLog = bc;
+  a.logM = logM;
+  a.m = (int)P->m;
+  a.col0 = col0;
+  a.S = (unsigned)S;
+  a.slots_per_limb = (unsigned)spl;
+  // values -> Newton coefficients: low M terms of (y_k / k!) * ((-1)^k / k!)
+  a.units = 1;
+  a.nxb = a.nyb = a.nk = (int)(Mlen / B);
+  bc_conv<BS_SCALE, BY_E, BD_NEWTON, M>(ctx, a, ncols, Mlen, cp, st);
+  // product tree: levels <= bc inside LDS tiles (transforms of length <= 2^bc) ...
+  launch_tree_tiles_generic<M>(ctx, X, ncols, col0, logM, bc, S, spl, cp, st);
+  // ... and above: F_node = F_left + (x^h + d) * F_right with d * F_right as a block convolution
+  for (int l = bc + 1; l <= logM; l++) {
+    a.l = l;
+    a.units = (int)(Mlen >> l);
+    a.nxb = a.nyb = (int)(((size_t)1 << (l - 1)) / B);
+    a.nk = 2 * a.nxb - 1;
+    if (l == logM)
+      bc_conv<BS_RIGHT, BY_D, BD_COMBINE_CANON, M>(ctx, a, ncols, (size_t)1 << l, cp, st);
+    else
+      bc_conv<BS_RIGHT, BY_D, BD_COMBINE, M>(ctx, a, ncols, (size_t)1 << l, cp, st);
+  }
+}
+
+template <class M>
+static void bc_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, const typename ArithOf<M>::T *A, const typename ArithOf<M>::T *Bc,
+                 typename ArithOf<M>::T *H, size_t ncols, size_t col0, size_t S, size_t spl, const uint64_t *d1, const uint64_t *d2,
+                 const uint64_t *d3, const ColMap &cm, hipStream_t st) {
+  using T = typename ArithOf<M>::T;
+  using CPS = ColPlansT<M>;
+  const int logM = P->logM, bc = P->bcLog;
+  const size_t Mlen = P->M, B = (size_t)1 << (bc - 1), B2 = 2 * B, nb = Mlen / B;
+  T *Xhat = (T *)ws_get(ctx, 12, ncols * 2 * Mlen * sizeof(T));
+  T *Wc = (T *)ws_get(ctx, 13, ncols * 4 * Mlen * sizeof(T));
+  T *Yhat = (T *)ws_get(ctx, 6, ncols * 2 * Mlen * sizeof(T));
+  T *Pbuf = (T *)ws_get(ctx, 15, ncols * 2 * Mlen * sizeof(T));
+  BcArgs a{};
+  a.bcLog = bc;
+  a.logM = logM;
+  a.m = (int)P->m;
+  a.col0 = col0;
+  a.S = (unsigned)S;
+  a.slots_per_limb = (unsigned)spl;
+  a.units = 1;
+  a.nxb = a.nyb = (int)nb;
+  // spectra of B's blocks (the "other operand" of the data x data product): a forward pass on its own
+  {
+    BcArgs b = a;
+    b.src = Bc;
+    b.Xhat = Yhat;
+    const size_t lds = padded_len(B2) * sizeof(uint64_t);
+    ProfScope prof(ctx, st, "bc_fwd_kernel", (double)ncols * nb * (double)B2 * 12.0, (double)ncols * nb * ntt_fp64((double)B2, bc));
+    RS_HIP(hipFuncSetAttribute((const void *)bc_fwd_kernel<BS_CENTER, CPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((bc_fwd_kernel<BS_CENTER, CPS>), dim3((unsigned)(ncols * nb)), dim3(col_threads(B2)), lds, st, b, cp);
+  }
+  // P = A * B, 2M coefficients
+  a.src = A;
+  a.Xhat = Xhat;
+  a.Yhat = Yhat;
+  a.Wc = Wc;
+  a.dst = Pbuf;
+  a.nk = 2 * (int)nb - 1;
+  bc_conv<BS_CENTER, BY_DATA, BD_PLAIN_SCALED, M>(ctx, a, ncols, 2 * Mlen, cp, st);
+  // U = rev(P) * rev(Z)^-1 mod x^(m-1);  H_j = U_{m-2-j}
+  a.src = Pbuf;
+  a.dst = H;
+  a.nk = (int)nb;
+  bc_conv<BS_REVTRUNC, BY_S, BD_HFIN, M>(ctx, a, ncols, Mlen, cp, st);
+  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((ncols * Mlen + 255) / 256, 256 * 16));
+  ProfScope prof(ctx, st, "h_patch_kernel", (double)ncols * (double)Mlen * (d1 ? 32.0 : 16.0), d1 ? 24.0 * (double)ncols * (double)Mlen : 0.0);
+  hipLaunchKernelGGL(h_patch_kernel<CPS>, dim3(blocks), dim3(256), 0, st, H, A, Bc, logM, (int)P->m, ncols, col0, (unsigned)S, (unsigned)spl, cp,
+                     d1, d2, d3, cm);
+  RS_HIP(hipGetLastError());
+}
+
 // Interpolate `ncols` columns in place.  Column c belongs to chunk-local limb (c % S) / slots_per_limb
 // (several vectors of S columns are batched); cp is shifted so that entry 0 is limb0.
 template <class M>
@@ -1763,6 +2100,12 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> 
                           size_t slots_per_limb, int limb0, hipStream_t st) {
   using T = typename ArithOf<M>::T;
   constexpr bool FP = std::is_same<M, Mod>::value;
+  if (P->bcLog) {  // a ring prime without a 2M-th root of unity: block convolutions
+    const size_t chunk = std::min(ncols, bc_chunk_cols(P));
+    for (size_t c0 = 0; c0 < ncols; c0 += chunk)
+      bc_interp<M>(ctx, P, cp, cols + c0 * P->M, std::min(chunk, ncols - c0), c0, S, slots_per_limb, st);
+    return;
+  }
   if constexpr (FP) {
     if (single_tile_ok(P->logM)) {
       // one launch, tile = M, two workgroups per CU: Newton conversion by the two rooted M-point
@@ -1798,6 +2141,12 @@ static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, 
   using T = typename ArithOf<M>::T;
   constexpr bool FP = std::is_same<M, Mod>::value;
   const size_t Mlen = P->M;
+  if (P->bcLog) {
+    const size_t chunk = std::min(S, bc_chunk_cols(P));
+    for (size_t c0 = 0; c0 < S; c0 += chunk)
+      bc_h<M>(ctx, P, cp, A + c0 * Mlen, B + c0 * Mlen, H + c0 * Mlen, std::min(chunk, S - c0), c0, S, spl, d1, d2, d3, cm, st);
+    return;
+  }
   if constexpr (FP) {
     if (single_tile_ok(P->logM)) {
       const size_t lds1 = padded_len(Mlen) * sizeof(double);

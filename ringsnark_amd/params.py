@@ -166,6 +166,11 @@ def preset(name: str) -> RingParams:
         return make_params(32, [59, 60], 64, [60, 60, 59], ring_factor=1 << 12, name="toy60")
     if name == "micro60":  # microbench.cpp:33-36: N = 16384, coefficient primes of {59, 60, 60} bits
         return make_params(16384, [59], 16384, [60, 60], name="micro60")
+    if name == "toyR":  # the reference's recipe verbatim: ring primes only = 1 mod 2*N_enc (seal_util.hpp:20-32), no extra 2-adicity
+        return make_params(32, [30, 30], 64, [40, 40, 41], name="toyR")
+    if name == "C3R":  # the headline shape with recipe primes (q_i = 1 mod 2*N_enc = 2^14 only): the witness map runs on block convolutions
+        return make_params(8192, BFV_DEFAULT_BITS[8192][:-1], 8192, BFV_DEFAULT_BITS[8192][:-1], name="C3R",
+                           notes="default_double_batching_modulus(8192, 8192): what a SEAL-produced headline key has")
     if name == "toy":  # CPU-test scale
         return make_params(32, [30, 30], 64, [40, 40, 41], ring_factor=1 << 12, name="toy")
     if name == "toy44":  # small ring, headline-size primes (= 1 mod 2^20): large-m witness-map tests

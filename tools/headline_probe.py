@@ -12,7 +12,7 @@ from ringsnark_amd.device import Device  # noqa: E402
 logm = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 logw = int(sys.argv[2]) if len(sys.argv) > 2 else 13
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-prm = P.preset("C3")
+prm = P.preset(sys.argv[4] if len(sys.argv) > 4 else "C3")
 dev = Device(prm)
 m, W = 1 << logm, 1 << logw
 t0 = time.time()

@@ -597,6 +597,10 @@ interp_columns_kernel(typename CPS::T *__restrict__ cols, int logM, unsigned S, 
 }
 
 
+// radix of the LDS rounds of the product tree's level transforms (stages per LDS round trip)
+#ifndef RS_TREE_MAXR
+#define RS_TREE_MAXR 3
+#endif
 // Source / sink functors of the product tree's wave-private levels (block-local indices).
 // First forward round of a level-l transform: element offset eoff inside the node is a left
 // position iff eoff < h; the transform's input there is F_right (the node's right half), zero above.
@@ -748,19 +752,19 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
       const TreeRightIn rin{sb, h};
       const TreeMulOut mout{sb, dh, mod};
       for (int st = 0; st < l;) {
-        const int R = pick_radix(l - st, 3);
+        const int R = pick_radix(l - st, RS_TREE_MAXR);
         if (st == 0)
-          fwd_round_dispatch<3>(R, rin, blk, logb, l, st, P.tw, 1, mod, P.fmask[l], wl);
+          fwd_round_dispatch<RS_TREE_MAXR>(R, rin, blk, logb, l, st, P.tw, 1, mod, P.fmask[l], wl);
         else if (st + R >= l)
-          fwd_round_dispatch<3>(R, blk, mout, logb, l, st, P.tw, 1, mod, P.fmask[l], wl);
+          fwd_round_dispatch<RS_TREE_MAXR>(R, blk, mout, logb, l, st, P.tw, 1, mod, P.fmask[l], wl);
         else
-          fwd_round_dispatch<3>(R, blk, blk, logb, l, st, P.tw, 1, mod, P.fmask[l], wl);
+          fwd_round_dispatch<RS_TREE_MAXR>(R, blk, blk, logb, l, st, P.tw, 1, mod, P.fmask[l], wl);
         wave_sync();
         st += R;
       }
       for (int st = 0; st < l;) {
-        const int R = pick_radix(l - st, 3);
-        inv_round_dispatch<3>(R, blk, blk, logb, l, st, P.itw, 1, mod, P.imask[l], wl);
+        const int R = pick_radix(l - st, RS_TREE_MAXR);
+        inv_round_dispatch<RS_TREE_MAXR>(R, blk, blk, logb, l, st, P.itw, 1, mod, P.imask[l], wl);
         wave_sync();
         st += R;
       }
@@ -768,9 +772,9 @@ tree_columns_kernel(double *__restrict__ cols, int logM, int logT_arg, size_t co
       // nodes span 2^(l - logb) waves: only that many top stages cross waves (workgroup barriers); the
       // rest of the forward transform, and the bottom of the inverse, stay inside the wave's block
       __syncthreads();
-      lds_bntt_fwd_wp<3, TreeRightIn, TreeMulFactory, 3>(s, TreeRightIn{s, h}, TreeMulFactory{s, dh - off, mod}, logT, LOGW, l,
+      lds_bntt_fwd_wp<RS_TREE_MAXR, TreeRightIn, TreeMulFactory, 3>(s, TreeRightIn{s, h}, TreeMulFactory{s, dh - off, mod}, logT, LOGW, l,
                                                          P.tw, mod, P.fmask[l]);
-      lds_bntt_inv_wp<3, ColBlockFactory, LdsIO, 3>(s, ColBlockFactory{s}, LdsIO{s}, logT, LOGW, l, P.itw, mod, P.imask[l]);
+      lds_bntt_inv_wp<RS_TREE_MAXR, ColBlockFactory, LdsIO, 3>(s, ColBlockFactory{s}, LdsIO{s}, logT, LOGW, l, P.itw, mod, P.imask[l]);
     }
 #pragma unroll
     for (int j = 0; j < EPT; j++)

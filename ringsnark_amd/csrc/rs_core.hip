@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "ntt_core.hpp"
+#include "ntt_wide.hpp"
 #include "rs_internal.hpp"
 
 namespace rs {
@@ -425,7 +426,7 @@ void launch_ntt_int(rs_ctx *ctx, const NttTableI &t, uint64_t *d_data, size_t ba
 }
 
 bool g_force_int = false;  // tuning knob "force_int_arith" (tests: both arithmetics on the same primes)
-int g_ntt_variant = 12;  // tuning knob (rs_set_tuning("ntt_variant", v)): see launch_ntt
+int g_ntt_variant = 14;  // tuning knob (rs_set_tuning("ntt_variant", v)): see launch_ntt
 
 template <bool INV, int MAXR, bool DIN, bool DOUT, int THREADS>
 static void launch_ntt_variant(const NttTable &t, uint64_t *d_data, size_t batch, hipStream_t st) {
@@ -439,6 +440,37 @@ static void launch_ntt_variant(const NttTable &t, uint64_t *d_data, size_t batch
   RS_HIP(hipGetLastError());
 }
 
+// ntt_wide.hpp kernels: persistent, two workgroups of 256 threads per CU
+int g_ntt_wide_grid = 256;  // tuning knob "ntt_wide_grid": CUs to fill (workgroups = this x what fits one CU)
+template <int LOGN, bool RED>
+static void launch_ntt_wide_shape(const NttTable &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st) {
+  using S = WideShape<LOGN>;
+  const int lds = (int)S::LDS_BYTES;
+  const size_t per_cu = std::min<size_t>(8 / (S::T / 64), (size_t)(160 * 1024) / S::LDS_BYTES);  // 2 waves per SIMD
+  const unsigned grid = (unsigned)std::min<size_t>(batch, (size_t)g_ntt_wide_grid * per_cu);
+  if (inverse) {
+    auto kern = ntt_inv_wide_kernel<LOGN, RED>;
+    RS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(S::T), lds, st, d_data, (unsigned long long)batch, t.d_itw, t.mod, t.ninv,
+                       t.inv_red_mask);
+  } else {
+    auto kern = ntt_fwd_wide_kernel<LOGN, RED>;
+    RS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(S::T), lds, st, d_data, (unsigned long long)batch, t.d_tw, t.mod, t.fwd_red_mask);
+  }
+  RS_HIP(hipGetLastError());
+}
+static bool launch_ntt_wide(const NttTable &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st) {
+  const bool red = (inverse ? t.inv_red_mask : t.fwd_red_mask) != 0;
+  if (t.logn == 13)
+    red ? launch_ntt_wide_shape<13, true>(t, d_data, batch, inverse, st) : launch_ntt_wide_shape<13, false>(t, d_data, batch, inverse, st);
+  else if (t.logn == 12)
+    red ? launch_ntt_wide_shape<12, true>(t, d_data, batch, inverse, st) : launch_ntt_wide_shape<12, false>(t, d_data, batch, inverse, st);
+  else
+    return false;
+  return true;
+}
+
 void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st) {
   (void)ctx;
   if (batch == 0) return;
@@ -449,7 +481,8 @@ void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, 
     else                                                                               \
       launch_ntt_variant<false, MAXR, DIN_F, DOUT_F, THR>(t, d_data, batch, st);       \
     break;
-  if (g_ntt_variant == 12 && !inverse && t.logn >= 12 && t.logn <= 13 && t.fwd_red_mask < 4) {
+  if (g_ntt_variant == 14 && launch_ntt_wide(t, d_data, batch, inverse, st)) return;
+  if ((g_ntt_variant == 12 || g_ntt_variant == 14) && !inverse && t.logn >= 12 && t.logn <= 13 && t.fwd_red_mask < 4) {
     const size_t lds = (padded_len((size_t)1 << t.logn) + ((size_t)1 << t.logn)) * sizeof(double);
     const unsigned grid = (unsigned)std::min<size_t>(batch, 256);
     if (t.logn == 13) {
@@ -466,10 +499,11 @@ void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, 
   }
   const int wp_waves = (g_ntt_variant == 9 || g_ntt_variant == 13) ? 16 : (g_ntt_variant == 10 ? 4 : 8);
   const bool wp_ok = (1 << t.logn) >= wp_waves * LDS_BLOCK_MIN;  // wave-private blocks need n / W >= LDS_BLOCK_MIN
-  if (wp_ok && g_ntt_variant >= 8 && g_ntt_variant <= 13) {
+  if (wp_ok && g_ntt_variant >= 8 && g_ntt_variant <= 14) {
     switch (g_ntt_variant) {
       case 8:
       case 12:  // streaming forward kernel not applicable (inverse, or shape): wave-private kernel
+      case 14:  // wide kernels not applicable (shape)
         inverse ? launch_ntt_wp<true, 4, 512>(t, d_data, batch, st) : launch_ntt_wp<false, 4, 512>(t, d_data, batch, st);
         break;
       case 9:
@@ -881,6 +915,8 @@ int rs_set_tuning(const char *key, int value) {
 #endif
   else if (std::string(key) == "mac_variant")
     g_mac_variant = value;
+  else if (std::string(key) == "ntt_wide_grid")
+    g_ntt_wide_grid = std::max(1, value);
   else if (std::string(key) == "witness_force_bc") {
     RS_REQUIRE(value == 0 || (value >= 5 && value <= 20), "witness_force_bc must be 0 or in [5, 20]");
     g_witness_force_bc = value;  // takes effect for plans built afterwards (plans are cached per context and size)

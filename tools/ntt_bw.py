@@ -9,7 +9,11 @@ from ringsnark_amd.device import Device  # noqa: E402
 
 prm = P.preset(sys.argv[1] if len(sys.argv) > 1 else "C3")
 dev = Device(prm)
-for gib in (0.25, 1, 4):
+if len(sys.argv) > 2:
+    _lib.check(_lib.load().rs_set_tuning(b"ntt_variant", int(sys.argv[2])))
+if len(sys.argv) > 3:
+    _lib.check(_lib.load().rs_set_tuning(b"ntt_wide_grid", int(sys.argv[3])))
+for gib in (0.25, 0.5, 1, 2, 4, 1):
     batch = int(gib * (1 << 30)) // (prm.N_enc * 8)
     polys = torch.empty((batch, prm.N_enc), dtype=torch.int64, device=dev.device).random_(0, int(prm.Q[0]))
     for inverse in (False, True):

@@ -265,18 +265,23 @@ def main():
         from ringsnark_amd import _lib
         batch = (1 << 30) // (prm.N_enc * 8)
         polys = torch.empty((batch, prm.N_enc), dtype=torch.int64, device=dev.device).random_(0, int(prm.Q[0]))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(2):
-            dev.ntt(polys, _lib.RS_MOD_COEFF, 0)
-        reps = 5
-        e0.record()  # the library launches on torch's current stream (device.py passes it down)
-        for _ in range(reps):
-            dev.ntt(polys, _lib.RS_MOD_COEFF, 0)
-        e1.record()
-        torch.cuda.synchronize()
-        gbs = batch * prm.N_enc * 16 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        ntt_roofline = {"bound": "hbm", "kernel": "forward NTT, %d transforms of %d points per launch (1 GiB in place)" % (batch, prm.N_enc),
-                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        reps = 20
+
+        def ntt_gbs(inverse):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(10):  # steady state: the first launches after an idle stretch run at a lower clock
+                dev.ntt(polys, _lib.RS_MOD_COEFF, 0, inverse=inverse)
+            e0.record()  # the library launches on torch's current stream (device.py passes it down)
+            for _ in range(reps):
+                dev.ntt(polys, _lib.RS_MOD_COEFF, 0, inverse=inverse)
+            e1.record()
+            torch.cuda.synchronize()
+            return batch * prm.N_enc * 16 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+        gbs, gbs_inv = ntt_gbs(False), ntt_gbs(True)
+        ntt_roofline = {"bound": "hbm", "kernel": "forward NTT, %d transforms of %d points per launch (1 GiB in place), mean of %d launches" % (batch, prm.N_enc, reps),
+                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "inverse": {"achieved": round(gbs_inv, 1), "frac": round(gbs_inv / HBM_PEAK_GBS, 4)}}
         del polys
 
     # ---- untimed post-run check of the timed proof against the CPU oracle

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "ntt_core.hpp"
+#include "ntt_wide.hpp"
 #include "rs_internal.hpp"
 
 namespace rs {
@@ -148,6 +149,204 @@ plain_center_kernel(PlainArgs args, typename ArithOf<M>::Lift *__restrict__ C, u
   for (int k = 0; k < EPT; k++) {
     const int p = threadIdx.x + k * blockDim.x;
     if (p < n) dst[p] = acc[k];
+  }
+}
+
+// plain_center_kernel in the wide form of ntt_wide.hpp (N_enc = 8192, FP64): 256 threads x 32 coefficients, persistent
+// (a workgroup keeps one ring limb: its per-lane twiddles and the mapped scatter addresses of the batching index map
+// stay in registers), two workgroups per CU.  The scatter fills the tile, the inverse transform runs in three rounds
+// (4, 5, 4 stages, n^-1 folded into the last stage) and leaves thread t with coefficients 2t+c + 512 e, which are
+// lifted, summed over the group's vectors and stored with 16-byte accesses.
+// PAIRED rows (the layout mac_kernel_v3 reads): word 2 n' + {0, 1} = coefficient n' + {0, 4096}, n' < 4096, so the
+// two operands of the forward transform's first stage arrive in one 16-byte load.
+// MULTI = false (every group has one vector): no accumulators, and the next item's coefficients are requested while
+// the current one is transformed.
+struct PlainTwPtrs {
+  const double *itw[RS_MAX_L];  // inverse twiddle tables of the ring primes (kernel-argument pointers: global loads)
+};
+template <bool MULTI, bool PAIRED>
+__global__ void __launch_bounds__(256, 2)
+plain_center_wide_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t0, unsigned long long tile_terms,
+                         unsigned long long tt_count, int n_groups, int N, int L, const uint32_t *__restrict__ index_map,
+                         const NttTable *__restrict__ plain_tabs, PlainTwPtrs twp) {
+  using S = WideShape<13>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  double *twl = s + S::TILE;
+  const int t = threadIdx.x;
+  const int limb = (int)(blockIdx.x % (unsigned)L), slot = (int)(blockIdx.x / (unsigned)L), nslots = (int)(gridDim.x / (unsigned)L);
+  const Mod mod = plain_tabs[limb].mod;
+  const double *__restrict__ itw = twp.itw[limb];
+  const double ninv = uniform_f64(plain_tabs[limb].ninv);
+  const uint32_t red_mask = plain_tabs[limb].inv_red_mask;
+  for (int i = t; i < S::TWL; i += 256) twl[i] = itw[i];
+  // round 1 (inverse stages 0..3 on 16 consecutive points): 15 twiddles per group that only this lane uses.  They are
+  // re-read from the (L2-resident) table for every transform instead of living in 60 registers: the accumulators of
+  // a multi-vector group and a 32-point register tile do not fit beside them.
+  auto load_tw1 = [&](double (&tw1)[2][15]) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      int g = t + 256 * j;
+      asm volatile("" : "+v"(g));  // opaque: the loads must not be hoisted out of the item loop (that is 60 live registers)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const double *p = itw + (S::N >> (k + 1)) + (g << (3 - k));
+        if (k == 3) {
+          tw1[j][14] = p[0];
+        } else {
+#pragma unroll
+          for (int i = 0; i < (4 >> k); i++) {
+            const double2 v2 = reinterpret_cast<const double2 *>(p)[i];
+            tw1[j][16 - (16 >> k) + 2 * i] = v2.x;
+            tw1[j][16 - (16 >> k) + 2 * i + 1] = v2.y;
+          }
+        }
+      }
+    }
+  };
+  double tw3[14];  // last round, stages 9..11: block e >> (k+1) of the 8 >> k blocks of stage 9+k (uniform)
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int i = 0; i < (8 >> k); i++) tw3[16 - (16 >> k) + i] = uniform_f64(itw[(8 >> k) + i]);
+  const double w_last = uniform_f64(mulmod(itw[1], ninv, mod));
+  // mapped tile addresses of the slots this thread scatters to: ring slot x = 2t+c + 512 e -> px(index_map[x]), two per word
+  const int ne = N >> 9;  // 16-byte coefficient pairs per thread: 16 at N = 8192
+  uint32_t spos[16];
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    spos[e] = 0;
+    if (e < ne) {
+      const uint2 m2 = reinterpret_cast<const uint2 *>(index_map)[t + 256 * e];
+      spos[e] = (uint32_t)S::px((int)m2.x) | ((uint32_t)S::px((int)m2.y) << 16);
+    }
+  }
+  __syncthreads();
+  const unsigned long long items = tt_count * (unsigned long long)n_groups;
+  u64x2 pre[16];
+  auto src_of = [&](unsigned long long item, int v) -> const uint64_t * {
+    const int g = (int)(item % (unsigned)n_groups);
+    const unsigned long long term = t0 + item / (unsigned)n_groups;
+    return args.g[g].coeff[v] + ((size_t)term * L + limb) * (size_t)N;
+  };
+  auto issue_loads = [&](const uint64_t *src) {
+    const u64x2 *s2 = reinterpret_cast<const u64x2 *>(src) + t;
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+      if (e < ne) pre[e] = stream_load(s2 + 256 * e);
+  };
+  unsigned long long item = (unsigned long long)slot;
+  // MULTI == false: the single vector of every group; a term beyond its length or a constant-1 term has nothing to load
+  auto loadable = [&](unsigned long long it) {
+    const PlainGroup &G = args.g[it % (unsigned)n_groups];
+    const unsigned long long term = t0 + it / (unsigned)n_groups;
+    return term < G.T[0] && !(G.kinds[0] && G.kinds[0][term] == RS_KIND_ONE);
+  };
+  if (!MULTI && item < items && loadable(item)) issue_loads(src_of(item, 0));
+  for (; item < items; item += (unsigned long long)nslots) {
+    const int g = (int)(item % (unsigned)n_groups);
+    const unsigned long long tt = item / (unsigned)n_groups, term = t0 + tt;
+    const PlainGroup &G = args.g[g];
+    double acc[2][16];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[c][e] = 0.0;
+    const int nv = MULTI ? G.n : 1;
+    for (int v = 0; v < nv; v++) {
+      if (term >= G.T[v]) continue;
+      const int kind = G.kinds[v] ? (int)G.kinds[v][term] : RS_KIND_POLY;
+      if (kind == RS_KIND_ONE) {  // Scalar 1: the plaintext is the constant polynomial 1
+        if (t == 0) {
+          acc[0][0] += 1.0;
+          if (G.nz[v]) atomicOr(&G.nz[v][term], 1u);
+        }
+        continue;
+      }
+      double tw1[2][15];
+      if (!MULTI) load_tw1(tw1);  // before the prefetch below: waiting for them leaves the younger loads in flight
+      if (MULTI) issue_loads(src_of(item, v));
+      if (N < S::N) {  // slots beyond N stay zero (seal_ring.tcc:350-351)
+        for (int i = t; i < S::TILE; i += 256) s[i] = 0.0;
+        __syncthreads();
+      }
+      bool nz = false;
+#pragma unroll
+      for (int e = 0; e < 16; e++)
+        if (e < ne) {
+          nz |= (pre[e].x | pre[e].y) != 0;
+          s[spos[e] & 0xffffu] = from_u64(pre[e].x);
+          s[spos[e] >> 16] = from_u64(pre[e].y);
+        }
+      mem_fence();
+      if (MULTI) load_tw1(tw1);  // after the scatter: the coefficient registers are free
+      if (!MULTI) {  // next item's coefficients: in flight during this transform
+        const unsigned long long nxt = item + (unsigned long long)nslots;
+        if (nxt < items && loadable(nxt)) issue_loads(src_of(nxt, 0));
+      }
+      mem_fence();
+      const bool any = __syncthreads_or(nz);
+      if (!any) continue;  // is_zero term (this limb): contributes nothing; nobody reads the tile
+      if (t == 0 && G.nz[v]) atomicOr(&G.nz[v][term], 1u);
+      // round 1: inverse stages 0..3 on 16 consecutive points
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int pb = S::px(16 * (t + 256 * j));
+        double x[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) x[e] = s[pb + e];
+        reg_inv_stages<4, true>(x, mod, red_mask, [&](int k, int i) { return tw1[j][16 - (16 >> k) + i]; });
+#pragma unroll
+        for (int e = 0; e < 16; e++) s[pb + e] = x[e];
+      }
+      __syncthreads();
+      {  // round 2: inverse stages 4..8 on hi*512 + lo + 16 e
+        const int lo = t & 15, hi = t >> 4;
+        const int pb = hi * S::SP + lo;
+        double x[32];
+#pragma unroll
+        for (int e = 0; e < 32; e++) x[e] = s[pb + 17 * e];
+        reg_inv_stages<5, true>(x, mod, red_mask >> 4, [&](int k, int i) { return twl[(S::N >> (5 + k)) + (hi << (4 - k)) + i]; });
+#pragma unroll
+        for (int e = 0; e < 32; e++) s[pb + 17 * e] = x[e];
+      }
+      __syncthreads();
+      double w[2][16];
+      {  // round 3: inverse stages 9..12 on 2t+c + 512 e, the scaling folded into the last stage
+        const int pb = S::px(2 * t);
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          w[0][e] = s[pb + S::SP * e];
+          w[1][e] = s[pb + S::SP * e + 1];
+        }
+      }
+      __syncthreads();  // the tile may be refilled
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        reg_inv_stages<4, true, 3>(w[c], mod, red_mask >> 9, [&](int k, int i) { return tw3[16 - (16 >> k) + i]; });
+        if ((red_mask >> 12) & 1u) {
+#pragma unroll
+          for (int e = 0; e < 16; e++) w[c][e] = reduce(w[c][e], mod);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const double a = w[c][e], b = w[c][e + 8];
+          acc[c][e] += lift_centered(canon(mulmod(a + b, ninv, mod), mod), mod);
+          acc[c][e + 8] += lift_centered(canon(mulmod(a - b, w_last, mod), mod), mod);
+        }
+      }
+    }
+    double *dst = C + (((size_t)g * tile_terms + tt) * L + limb) * (size_t)S::N;
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
+    if (PAIRED) {
+#pragma unroll
+      for (int e = 0; e < 8; e++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) d2[2 * t + c + 512 * e] = make_double2(acc[c][e], acc[c][e + 8]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; e++) d2[t + 256 * e] = make_double2(acc[0][e], acc[1][e]);
+    }
   }
 }
 
@@ -467,6 +666,252 @@ mac_kernel_v2(MacArgs2 a, int L, int K, int logn_arg, const NttTable *__restrict
       }
 }
 
+// mac_kernel_v3 (N_enc = 8192, FP64): the wide form of ntt_wide.hpp applied to the inner product.
+// A polynomial's accumulators (2 components x 8192) do not fit beside a 32-coefficient-per-thread transform, so a
+// workgroup of 256 threads owns HALF of the spectrum of one (limb, prime): the first stage (gap 4096) is applied
+// while the plaintext row is loaded -- half h keeps x[n] + w*x[n+4096] (h = 0) or x[n] - w*x[n+4096] (h = 1) -- and
+// the remaining 12 stages are the 4096-point sub-transform rooted at node 2 + h, in three radix-16 rounds with 16
+// coefficients per thread: two tile exchanges per term, the lane's own (round-3) twiddles in registers for the whole chunk.
+// The spectrum half is exactly the contiguous half [4096 h, 4096 h + 4096) of both ciphertext components, which the
+// workgroup streams with 16-byte loads issued before the transform; a wave-private pass turns round 3's 16
+// consecutive points per thread into the lane-contiguous layout of those loads.  The plaintext row is read by both
+// halves (from L2: it is shared by the 2 K workgroups of a (term, limb)) and stage 0's multiply is done twice:
+// +8 % FP64 work against five fewer LDS passes per term and two independent workgroups per CU.
+// Up to two groups that multiply the SAME key vector (A and B of groth16.tcc:89-103 against s_pows) run in one
+// launch as neighbouring workgroups of one XCD, so the second read of a ciphertext word is served on-die.
+// 1: the next plaintext row is requested before the multiply-accumulate (64 more live registers: spills at 256)
+#ifndef RS_MAC3_ABLATE
+#define RS_MAC3_ABLATE 0
+#endif
+struct MacArgs3 {
+  const double *C[2];        // [tile_terms][L][n] plaintext rows per group
+  uint64_t *partial[2];      // accumulator set per group: [n_chunks] stride part_stride
+  unsigned long long terms[2];
+  const uint64_t *crs;       // first ciphertext of the tile
+  size_t part_stride;
+  int n_groups, terms_per_chunk, n_chunks, accumulate, acc_period, reduce_u;
+  int paired;                // rows in plain_center_wide_kernel's paired layout
+  uint32_t red_mask[RS_MAX_K];  // bit s: reduce before stage s of the forward transform mod Q_j (start bound = max |C|)
+};
+template <bool PAIRED>
+__global__ void __launch_bounds__(256, 2)
+mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs) {
+  constexpr int n = 8192, H = 4096;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  // block -> XCD slot x (blocks go to XCDs round-robin) and a position q in that XCD's sequence.  The 2K workgroups
+  // that read one plaintext row (both halves of every prime) and the groups that read the same ciphertext words are
+  // consecutive in ONE XCD's sequence: one of them fetches from memory, the others hit that XCD's L2.
+  const unsigned b = blockIdx.x, x = b & 7u;
+  unsigned q = b >> 3;
+  const int g = (int)(q % (unsigned)a.n_groups);
+  q /= (unsigned)a.n_groups;
+  const unsigned hj = q % (2u * (unsigned)K);
+  const unsigned rr = (q / (2u * (unsigned)K)) * 8u + x;  // (chunk, limb)
+  const int h = (int)(hj & 1u), j = (int)(hj >> 1);
+  const int limb = (int)(rr % (unsigned)L), chunk = (int)(rr / (unsigned)L);
+  if (chunk >= a.n_chunks) return;
+  const Mod mod = coeff_tabs[j].mod;
+  const double *__restrict__ tw = coeff_tabs[j].d_tw;
+  const uint32_t red_mask = a.red_mask[j];
+  const int root = 2 + h;
+  // per-lane twiddles of rounds 2 and 3, fixed for the whole chunk
+  const int lo = t & 15, hi = t >> 4;
+  // round-2 twiddles tw[(root << (4+k)) + (hi << k) + b] (16 lanes share each) come from an LDS copy of the table's
+  // first 1024 entries; the round-3 twiddles are the lane's own and stay in registers
+  double *twl = s + 2 * (H + H / 16);
+  for (int i = t; i < 1024; i += 256) twl[i] = tw[i];
+  __syncthreads();
+  double tw3[15];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int bk = 0; bk < (1 << k); bk++) tw3[(1 << k) - 1 + bk] = tw[(root << (8 + k)) + (t << k) + bk];
+#pragma unroll
+  for (int i = 0; i < 15; i++) pin(tw3[i]);
+  // wave-uniform twiddles of stage 0 and round 1, as scalar registers: fetched through the table pointer inside the
+  // term loop they would be vector loads, and waiting for the youngest vector load drains the ciphertext stream
+  const double w0 = uniform_f64(tw[1]);
+  double tw1[15];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int bk = 0; bk < (1 << k); bk++) tw1[(1 << k) - 1 + bk] = uniform_f64(tw[(root << k) + bk]);
+  const size_t enc_words = (size_t)L * 2 * K * n;
+  const size_t slab = (((size_t)limb * 2) * K + j) * (size_t)n + (size_t)h * H;  // component 0; component 1 is + K*n
+  const size_t comp = (size_t)K * n;
+  uint64_t *part = a.partial[g] + (size_t)chunk * a.part_stride + slab;
+  const int r0 = wave * 1024;  // the wave's range of the half spectrum: 64 round-3 groups
+  double acc[2][16];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      acc[c][2 * i] = acc[c][2 * i + 1] = 0.0;
+      if (a.accumulate) {
+        const u64x2 v = reinterpret_cast<const u64x2 *>(part + c * comp + r0)[lane + 64 * i];
+        acc[c][2 * i] = from_u64(v.x);
+        acc[c][2 * i + 1] = from_u64(v.y);
+      }
+    }
+  const unsigned long long tbeg = (unsigned long long)chunk * a.terms_per_chunk;
+  const unsigned long long tend = min(tbeg + (unsigned long long)a.terms_per_chunk, a.terms[g]);
+  const double *crow = a.C[g] + ((size_t)tbeg * L + limb) * (size_t)n + (PAIRED ? 2 * t : t);
+  const uint64_t *ctp = a.crs + (size_t)tbeg * enc_words + slab + r0;
+  double cl[16], ch[16];
+  // The row in two batches of 32 registers, the first requested before the previous term's multiply-accumulate and
+  // the second after it (all 64 at once do not fit beside it).  Paired rows (plain_center_wide_kernel): one 16-byte
+  // load brings x[n'] and x[n' + 4096]; plain rows: the multiplied operands x[n' + 4096] first.
+  auto load_row_a = [&]() {
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+#if RS_MAC3_ABLATE & 1  // experiment: no plaintext-row traffic (wrong results)
+      if (PAIRED ? e < 8 : true) ch[e] = 5.0 + t;
+      if (PAIRED && e < 8) cl[e] = 3.0 + e;
+#else
+      if (PAIRED) {
+        if (e < 8) {
+          const double2 x2 = reinterpret_cast<const double2 *>(crow)[256 * e];
+          cl[e] = x2.x;
+          ch[e] = x2.y;
+        }
+      } else {
+        ch[e] = crow[256 * e + H];
+      }
+#endif
+    }
+  };
+  auto load_row_b = [&]() {
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+#if RS_MAC3_ABLATE & 1
+      if (PAIRED ? e >= 8 : true) cl[e] = 3.0 + e;
+      if (PAIRED && e >= 8) ch[e] = 5.0 + t;
+#else
+      if (PAIRED) {
+        if (e >= 8) {
+          const double2 x2 = reinterpret_cast<const double2 *>(crow)[256 * e];
+          cl[e] = x2.x;
+          ch[e] = x2.y;
+        }
+      } else {
+        cl[e] = crow[256 * e];
+      }
+#endif
+    }
+  };
+  // Software pipeline over the terms of the chunk, one term deep: the spectrum of term t is parked in tile t % 2 and
+  // multiplied into the accumulators during iteration t + 1, AFTER that iteration's plaintext-row loads have been
+  // issued and BEFORE its transform, so the ciphertext loads of term t (issued before the transform of term t) have a
+  // whole term to land and the row loads of term t + 1 fly during the multiply-accumulate.
+  u64x2 ct[2][8];
+  auto issue_ct = [&]() {
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+#if RS_MAC3_ABLATE & 2  // experiment: no ciphertext traffic (wrong results)
+        ct[c][i] = u64x2{12345ull + i, 6789ull + c};
+#else
+        ct[c][i] = stream_load(reinterpret_cast<const u64x2 *>(ctp + c * comp) + lane + 64 * i);
+#endif
+      }
+    ctp += enc_words;
+  };
+  int since = 0;
+  auto mac = [&](const double *tile) {
+    const int p0 = r0 + (r0 >> 4) + 2 * lane + (lane >> 3);  // px(r0 + 2 lane)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const double u0 = tile[p0 + 136 * i], u1 = tile[p0 + 136 * i + 1];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        acc[c][2 * i] += mulmod(from_u64(ct[c][i].x), u0, mod);
+        acc[c][2 * i + 1] += mulmod(from_u64(ct[c][i].y), u1, mod);
+      }
+    }
+    if (++since >= a.acc_period) {
+      since = 0;
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[c][i] = reduce(acc[c][i], mod);
+    }
+  };
+  constexpr int TILE = H + H / 16;
+  for (unsigned long long tt = tbeg; tt < tend; tt++) {
+    double *tile = s + (int)((tt - tbeg) & 1) * TILE;
+    load_row_a();
+    mem_fence();
+    if (tt > tbeg) mac(s + (int)((tt - tbeg + 1) & 1) * TILE);  // term tt - 1
+    mem_fence();
+    load_row_b();
+    crow += (size_t)L * n;
+    mem_fence();
+    double v[16];
+    // stage 0 (gap 4096): this half's operand of the 4096-point sub-transform
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      double bq = ch[e];
+      if (red_mask & 1u) bq = reduce(bq, mod);
+      ch[e] = mulmod(bq, w0, mod);
+      pin(ch[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      double aq = cl[e];
+      if (red_mask & 1u) aq = reduce(aq, mod);
+      v[e] = h ? aq - ch[e] : aq + ch[e];
+      pin(v[e]);
+    }
+    mem_fence();
+    issue_ct();  // after the row registers are dead: the two never overlap
+    mem_fence();
+#if RS_MAC3_ABLATE & 4  // experiment: no transform (wrong results)
+    tile[17 * t] = v[0] + v[5] + v[9] + v[15];
+    wave_sync();
+    continue;
+#endif
+    // round 1: stages 1..4 on elements t + 256 e (uniform twiddles)
+    reg_fwd_stages<4, true>(v, mod, red_mask >> 1, [&](int k, int bk) { return tw1[(1 << k) - 1 + bk]; });
+    {  // tile tt % 2 was last read by the multiply-accumulate of term tt - 2, two barriers ago
+      const int pb = t + (t >> 4);
+#pragma unroll
+      for (int e = 0; e < 16; e++) tile[pb + 272 * e] = v[e];
+    }
+    __syncthreads();
+    {  // round 2: stages 5..8 on hi*256 + lo + 16 e
+      const int pb = hi * 272 + lo;
+#pragma unroll
+      for (int e = 0; e < 16; e++) v[e] = tile[pb + 17 * e];
+      reg_fwd_stages<4, true>(v, mod, red_mask >> 5, [&](int k, int bk) { return twl[(root << (4 + k)) + (hi << k) + bk]; });
+#pragma unroll
+      for (int e = 0; e < 16; e++) tile[pb + 17 * e] = v[e];
+    }
+    __syncthreads();
+    {  // round 3: stages 9..12 on 16 consecutive points, parked for the wave-private transposition
+      const int pb = 17 * t;
+#pragma unroll
+      for (int e = 0; e < 16; e++) v[e] = tile[pb + e];
+      reg_fwd_stages<4, true>(v, mod, red_mask >> 9, [&](int k, int bk) { return tw3[(1 << k) - 1 + bk]; });
+#pragma unroll
+      for (int e = 0; e < 16; e++) tile[pb + e] = a.reduce_u ? reduce(v[e], mod) : v[e];
+    }
+    wave_sync();
+  }
+  if (tend > tbeg) mac(s + (int)((tend - tbeg + 1) & 1) * TILE);  // the last term
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      u64x2 o;
+      o.x = to_u64(canon(acc[c][2 * i], mod));
+      o.y = to_u64(canon(acc[c][2 * i + 1], mod));
+      reinterpret_cast<u64x2 *>(part + c * comp + r0)[lane + 64 * i] = o;
+    }
+}
+
 // out[set] = sum_chunk partial[chunk][set] (+ addend[set]) mod Q_j
 struct ReduceArgs {
   const uint64_t *addend[12];
@@ -574,7 +1019,7 @@ static void launch_mac(rs_ctx *ctx, const MacArgs &a, const MsmScratch &sc, hipS
   RS_HIP(hipGetLastError());
 }
 
-extern int g_mac_variant, g_mac_ablate;
+extern int g_mac_variant, g_mac_ablate, g_plain_variant;
 static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, hipStream_t st) {
   const size_t lds = (padded_len((size_t)ctx->N_enc) + (size_t)ctx->N_enc) * sizeof(double);
   const int rows = a.n_chunks * ctx->L;
@@ -612,8 +1057,39 @@ static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, 
   RS_HIP(hipGetLastError());
 }
 
+// Reduction points of the forward transform mod p when the inputs are bounded by |x| <= b0 (not by p): bit s = every value
+// is brought back to |v| <= p/2 before stage s, so that multiplier operands stay below 2^50 (f64mod.hpp).
+static uint32_t fwd_reduce_mask_from(uint64_t p, int logn, double b0, double *end_bound) {
+  const double lim = 1125899906842624.0 / (double)p;
+  double B = b0 / (double)p;
+  uint32_t mask = 0;
+  for (int s = 0; s < logn; s++) {
+    if (B > lim) {
+      mask |= 1u << s;
+      B = 0.51;
+    }
+    B += 0.75;
+  }
+  *end_bound = B * (double)p;  // bound of the spectrum values
+  return mask;
+}
+static void launch_mac_v3(rs_ctx *ctx, const MacArgs3 &a, const MsmScratch &sc, hipStream_t st) {
+  const size_t lds = (size_t)(2 * (4096 + 256) + 1024) * sizeof(double);  // two tiles + round-2 twiddles
+  const unsigned rows = (unsigned)ctx->L * (unsigned)a.n_chunks;  // (chunk, limb), spread over the XCDs
+  const unsigned blocks = ((rows + 7) / 8) * 8 * 2u * (unsigned)ctx->K * (unsigned)a.n_groups;
+  if (a.paired) {
+    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mac_kernel_v3<true>, dim3(blocks), dim3(256), lds, st, a, ctx->L, ctx->K, sc.coeff<Mod>());
+  } else {
+    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mac_kernel_v3<false>, dim3(blocks), dim3(256), lds, st, a, ctx->L, ctx->K, sc.coeff<Mod>());
+  }
+  RS_HIP(hipGetLastError());
+}
+
 int g_mac_ablate = 0;
-int g_mac_variant = 3;  // 3: streaming kernel, 1024-thread shape at N_enc = 8192 (else as 2); 2: 512-thread streaming kernel; 1: generic kernel
+int g_plain_variant = 1;  // 1: plain_center_wide_kernel at N_enc = 8192; 0: plain_center_kernel
+int g_mac_variant = 5;  // 5: half-spectrum wide kernel at N_enc = 8192 (else as 3); 3: streaming kernel, 1024-thread shape at N_enc = 8192 (else as 2); 2: 512-thread streaming kernel; 1: generic kernel
 
 // Core grouped MSM.  addends: optional per-output (n_crs * n_groups) device pointers to encoding
 // elements added to the result (pk.alpha / pk.beta of groth16.tcc:95,103).
@@ -698,6 +1174,14 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
   const int plain_thr = plain16 ? n / 16 : thr;
   const bool plain13 = false;  // measured: no gain from a compile-time length here
   (void)plain13;
+  bool v3 = false, plain_wide = false;
+  if constexpr (FP) {
+    v3 = g_mac_variant == 5 && n == 8192;
+    plain_wide = g_plain_variant == 1 && n == 8192 && ctx->N >= 512 && ctx->N % 512 == 0;
+  }
+  const bool paired = v3 && plain_wide;  // row layout of this call: written by the plaintext kernel, read by the MAC
+  bool multi = false;
+  for (int g = 0; g < n_groups; g++) multi = multi || pa.g[g].n > 1;
   if (plain16)
     RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<16, 0, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   else
@@ -715,9 +1199,32 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     double rows_in = 0;  // coefficient rows (term, limb) read by this tile
     for (int v = 0; v < n_vecs; v++) rows_in += (double)(vecs[v].T > t0 ? std::min(tt, vecs[v].T - t0) : 0) * L;
     {
-    ProfScope prof_plain(ctx, st, "plain_center_kernel", rows_in * (double)ctx->N * 8.0 + (double)tt * L * n_groups * nd * 8.0,
+    ProfScope prof_plain(ctx, st, plain_wide ? "plain_center_wide_kernel" : "plain_center_kernel", rows_in * (double)ctx->N * 8.0 + (double)tt * L * n_groups * nd * 8.0,
                          rows_in * (ntt_fp64(nd, logn_d) + 14.0 * nd));
-    if (plain16)
+    if (plain_wide) {
+      if constexpr (FP) {
+        const int wl = (int)WideShape<13>::LDS_BYTES;
+        const unsigned long long items = (unsigned long long)tt * n_groups;
+        const unsigned slots = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>(items, (512 + L - 1) / L));
+        const dim3 grid(slots * (unsigned)L);
+        PlainTwPtrs twp;
+        memset(&twp, 0, sizeof(twp));
+        for (int i = 0; i < L; i++) twp.itw[i] = ctx->plain[i].d_itw;
+#define RS_PLAIN_WIDE(MULTI_, PAIRED_)                                                                                        \
+  do {                                                                                                                        \
+    RS_HIP(hipFuncSetAttribute((const void *)plain_center_wide_kernel<MULTI_, PAIRED_>,                                       \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, wl));                                              \
+    hipLaunchKernelGGL((plain_center_wide_kernel<MULTI_, PAIRED_>), grid, dim3(256), wl, st, pa, reinterpret_cast<double *>(d_C), \
+                       (unsigned long long)t0, (unsigned long long)tile_terms, (unsigned long long)tt, n_groups, ctx->N, L,   \
+                       ctx->d_index_map, sc.plain<Mod>(), twp);                                                               \
+  } while (0)
+        if (multi && paired) RS_PLAIN_WIDE(true, true);
+        else if (multi) RS_PLAIN_WIDE(true, false);
+        else if (paired) RS_PLAIN_WIDE(false, true);
+        else RS_PLAIN_WIDE(false, false);
+#undef RS_PLAIN_WIDE
+      }
+    } else if (plain16)
       hipLaunchKernelGGL((plain_center_kernel<16, 0, M>), dim3((unsigned)tt, L, n_groups), dim3(plain_thr), lds, st, pa, d_C,
                          (unsigned long long)t0, (unsigned long long)tile_terms, ctx->N, L, ctx->logN_enc,
                          ctx->d_index_map, sc.template plain<M>());
@@ -771,7 +1278,49 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     // vectors (Rinocchio's s_pows / alpha_s_pows) the plaintext transform is repeated per vector:
     // measured faster than the generic kernel that shares it (g_mac_variant == 2: generic for n_crs == 2).
     const bool v2 = FP && g_mac_variant >= 2 && (n_crs == 1 || g_mac_variant != 2) && n >= 2048 && n <= 8192;
-    if (v2) {
+    if (v3) {
+      if constexpr (FP) {
+        // bound of a plaintext row: the sum of the centred lifts of the group's vectors
+        uint64_t maxq = 0;
+        for (int i = 0; i < L; i++) maxq = std::max(maxq, ctx->q[i]);
+        const double b0 = 0.5 * (double)maxq * MAX_GROUP_VECS + (double)MAX_GROUP_VECS;
+        // chunks: two workgroups per CU in one wave of workgroups (512), shared by the groups of a launch
+        for (int c = 0; c < n_crs; c++)
+          for (int g0 = 0; g0 < n_groups; g0 += 2) {
+            const int ng = std::min(2, n_groups - g0);
+            MacArgs3 a3;
+            memset(&a3, 0, sizeof(a3));
+            unsigned long long tmax = 0;
+            for (int gi = 0; gi < ng; gi++) {
+              a3.C[gi] = reinterpret_cast<const double *>(Cptr(g0 + gi));
+              a3.terms[gi] = group_terms(g0 + gi);
+              a3.partial[gi] = d_partial + (size_t)(c * n_groups + g0 + gi) * enc_words;
+              tmax = std::max(tmax, a3.terms[gi]);
+            }
+            a3.crs = crs_at(c, t0);
+            a3.part_stride = (size_t)n_sets * enc_words;
+            a3.n_groups = ng;
+            a3.paired = paired;
+            a3.n_chunks = base.n_chunks;
+            a3.terms_per_chunk = base.terms_per_chunk;
+            a3.accumulate = base.accumulate;
+            a3.acc_period = base.acc_period;
+            a3.reduce_u = 0;
+            for (int jj = 0; jj < K; jj++) {
+              double end = 0;
+              a3.red_mask[jj] = fwd_reduce_mask_from(ctx->Q[jj], ctx->logN_enc, b0, &end);
+              if (end > 562949953421312.0) a3.reduce_u = 1;  // a spectrum value times a canonical ciphertext word: |u| <= 2^49
+            }
+            double terms = 0;
+            for (int gi = 0; gi < ng; gi++) terms += (double)a3.terms[gi];
+            // ciphertext words once per launch (the second group's read is served on-die), every plaintext row once,
+            // the accumulator sets written once
+            ProfScope prof(ctx, st, "mac_kernel_v3", (double)tmax * (double)enc_words * 8.0 + terms * (double)L * nd * 8.0 + ng * (double)enc_words * 8.0,
+                           terms * L * K * (ntt_fp64(nd, logn_d) + 8.0 * nd / 2.0 + 15.0 * nd));
+            launch_mac_v3(ctx, a3, sc, st);
+          }
+      }
+    } else if (v2) {
       for (int c = 0; c < n_crs; c++)
       for (int g = 0; g < n_groups; g++) {
         MacArgs2 a2;

@@ -97,6 +97,34 @@ __device__ __forceinline__ void reg_inv_stages(double (&v)[1 << R], const Mod mo
   }
 }
 
+// 16-byte streaming accesses.  RS_WIDE_NT = 1 marks them non-temporal (the data is touched once per launch).
+#ifndef RS_WIDE_NT
+#define RS_WIDE_NT 1
+#endif
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u64x2 stream_load(const u64x2 *p) {
+#if RS_WIDE_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void stream_store(u64x2 *p, u64x2 v) {
+#if RS_WIDE_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
+// a wave-uniform value as scalar registers
+__device__ __forceinline__ double uniform_f64(double x) {
+  union { double d; int i[2]; } u;
+  u.d = x;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+  u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
 __device__ __forceinline__ double u64_bits_as_double(uint64_t u) {
   union { uint64_t u; double d; } x;
   x.u = u;
@@ -126,13 +154,13 @@ __device__ __forceinline__ void wide_fwd_flush(const double *s, uint64_t *__rest
   for (int j = 0; j < 2; j++) {
     const int r0 = (j * S::T + wave * 64) * 16;
     const int p0 = S::px(r0 + 2 * lane);
-    ulonglong2 *d2 = reinterpret_cast<ulonglong2 *>(dst + r0) + lane;
+    u64x2 *d2 = reinterpret_cast<u64x2 *>(dst + r0) + lane;
 #pragma unroll
     for (int i = 0; i < 8; i++) {  // elements r0 + 2*lane + 128*i (+1)
-      ulonglong2 o;
+      u64x2 o;
       o.x = double_bits_as_u64(s[p0 + S::px128(i)]);
       o.y = double_bits_as_u64(s[p0 + S::px128(i) + 1]);
-      d2[64 * i] = o;
+      stream_store(d2 + 64 * i, o);
     }
   }
 }
@@ -210,11 +238,11 @@ ntt_fwd_wide_kernel(uint64_t *__restrict__ data, unsigned long long batch, const
   for (int j = 0; j < 2; j++)
 #pragma unroll
     for (int i = 0; i < 15; i++) pin(tw3[j][i]);
-  ulonglong2 pre[16];
+  u64x2 pre[16];
   auto issue_loads = [&](unsigned long long q) {
-    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(data + q * (size_t)S::N) + t;
+    const u64x2 *src = reinterpret_cast<const u64x2 *>(data + q * (size_t)S::N) + t;
 #pragma unroll
-    for (int e = 0; e < 16; e++) pre[e] = src[(S::S / 2) * e];
+    for (int e = 0; e < 16; e++) pre[e] = stream_load(src + (S::S / 2) * e);
   };
   unsigned long long p = blockIdx.x;
   if (p < batch) issue_loads(p);
@@ -229,11 +257,13 @@ ntt_fwd_wide_kernel(uint64_t *__restrict__ data, unsigned long long batch, const
       pin(v[1][e]);
     }
     mem_fence();
+#ifndef RS_WIDE_EXP_NOMEM
     if (p_out != ~0ull) wide_fwd_flush<LOGN>(s, data + p_out * (size_t)S::N);
     mem_fence();
     const unsigned long long pn = p + gridDim.x;
     if (pn < batch) issue_loads(pn);
     mem_fence();
+#endif
     wide_fwd_body<LOGN, RED>(s, twl, tw3, v, tw, mod, red_mask);
     p_out = p;
   }
@@ -268,26 +298,26 @@ ntt_inv_wide_kernel(uint64_t *__restrict__ data, unsigned long long batch, const
     for (int i = 0; i < 15; i++) pin(tw1[j][i]);
   // n^-1 folded into the last stage: (a + b) * ninv and (a - b) * (w * ninv)
   const double w_last = mulmod(itw[1], ninv, mod);
-  ulonglong2 pre[16];
+  u64x2 pre[16];
   auto issue_loads = [&](unsigned long long q) {
     const uint64_t *src = data + q * (size_t)S::N;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int r0 = (j * S::T + wave * 64) * 16;
-      const ulonglong2 *s2 = reinterpret_cast<const ulonglong2 *>(src + r0) + lane;
+      const u64x2 *s2 = reinterpret_cast<const u64x2 *>(src + r0) + lane;
 #pragma unroll
-      for (int i = 0; i < 8; i++) pre[j * 8 + i] = s2[64 * i];
+      for (int i = 0; i < 8; i++) pre[j * 8 + i] = stream_load(s2 + 64 * i);
     }
   };
   double v[2][16];
   auto store_out = [&](unsigned long long q) {
-    ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(data + q * (size_t)S::N) + t;
+    u64x2 *dst = reinterpret_cast<u64x2 *>(data + q * (size_t)S::N) + t;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-      ulonglong2 o;
+      u64x2 o;
       o.x = to_u64(canon(v[0][e], mod));
       o.y = to_u64(canon(v[1][e], mod));
-      dst[(S::S / 2) * e] = o;
+      stream_store(dst + (S::S / 2) * e, o);
     }
   };
   unsigned long long p = blockIdx.x;

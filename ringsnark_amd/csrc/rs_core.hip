@@ -915,6 +915,8 @@ int rs_set_tuning(const char *key, int value) {
 #endif
   else if (std::string(key) == "mac_variant")
     g_mac_variant = value;
+  else if (std::string(key) == "plain_variant")
+    g_plain_variant = value;
   else if (std::string(key) == "ntt_wide_grid")
     g_ntt_wide_grid = std::max(1, value);
   else if (std::string(key) == "witness_force_bc") {

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "ntt_core.hpp"
+#include "ntt_wide.hpp"
 #include "rs_internal.hpp"
 
 namespace rs {
@@ -1519,6 +1520,190 @@ sub_ntt_ct_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab
   lds_ntt_inv_wp<RS_SUB_MAXR, ColBlockFactory, GlobalF64IO, 3>(s, bf, gio, LOGB, LOGW, P.itw, mod, imask, root);
 }
 
+// sub_ntt_ct_kernel in the wide form of ntt_wide.hpp (g_witness_sub_ct == 2): 256 threads x 32 coefficients per block of
+// 2^13, persistent, two workgroups per CU.  Forward rounds (4, 5, 4 stages); round 3 leaves every thread with 16
+// CONSECUTIVE spectrum points per group, which is exactly the operand set of the inverse's first round, so the table
+// product and inverse stages 0..3 follow in registers: the fused forward-multiply-inverse exchanges the tile four
+// times (eight LDS passes) instead of seven.  The twiddles of a block depend on its position in the long transform
+// (root), so they are fetched per block from the L2-resident table.  Same stage arithmetic and reduction points as
+// sub_ntt_ct_kernel: the stored (lazily reduced) values are identical.
+struct SubTw {  // twiddle fetch: 2^k consecutive table entries, 16-byte loads where the run allows
+  template <int CNT>
+  __device__ static __forceinline__ void run(const double *__restrict__ p, double *dst) {
+    if (CNT == 1) {
+      dst[0] = p[0];
+    } else {
+#pragma unroll
+      for (int i = 0; i < CNT / 2; i++) {
+        const double2 v = reinterpret_cast<const double2 *>(p)[i];
+        dst[2 * i] = v.x;
+        dst[2 * i + 1] = v.y;
+      }
+    }
+  }
+};
+template <int MODE>
+__global__ void __launch_bounds__(256, 2)
+sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab_period, unsigned blocks_per_col, size_t col0,
+                    unsigned S_, unsigned slots_per_limb, ColPlans plans, unsigned long long nblocks) {
+  using S = WideShape<13>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int t = threadIdx.x;
+  u64x2 pre[16];
+  auto issue_loads = [&](unsigned long long b) {
+    const u64x2 *src = reinterpret_cast<const u64x2 *>(X + b * (size_t)S::N) + t;
+#pragma unroll
+    for (int e = 0; e < 16; e++) pre[e] = src[(S::S / 2) * e];
+  };
+  unsigned long long blk = blockIdx.x;
+  if (blk < nblocks) issue_loads(blk);
+  for (; blk < nblocks; blk += gridDim.x) {
+    const size_t col = blk / blocks_per_col;
+    const int limb = (int)(((col0 + col) % S_) / slots_per_limb);
+    const ColPlan &P = plans.l[limb];
+    const Mod mod = P.mod;
+    const int root = (1 << log_n1) + (int)(blk & ((1u << log_n1) - 1));
+    const int logn = 13 + log_n1;
+    const uint32_t fmask = P.fmask[logn] >> log_n1, imask = P.imask[logn];
+    const double *__restrict__ tw = P.tw;
+    const double *__restrict__ itw = P.itw;
+    double v[2][16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      v[0][e] = u64_bits_as_double(pre[e].x);
+      v[1][e] = u64_bits_as_double(pre[e].y);
+      pin(v[0][e]);
+      pin(v[1][e]);
+    }
+    mem_fence();
+    const unsigned long long bn = blk + gridDim.x;
+    if (bn < nblocks) issue_loads(bn);
+    mem_fence();
+    // ---- forward round 1: stages 0..3 on elements 2t+c + 512e, twiddles tw[2^k root + blk] (uniform)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+      reg_fwd_stages<4, true>(v[c], mod, fmask, [&](int k, int b) { return tw[(root << k) + b]; });
+    __syncthreads();  // the previous block's last-round reads of the tile are done
+    {
+      const int pb = S::px(2 * t);
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        s[pb + S::SP * e] = v[0][e];
+        s[pb + S::SP * e + 1] = v[1][e];
+      }
+    }
+    __syncthreads();
+    // ---- forward round 2: stages 4..8 on hi*512 + lo + 16e
+    {
+      const int lo = t & 15, hi = t >> 4;
+      const int pb = hi * S::SP + lo;
+      double w[31];
+      SubTw::run<1>(tw + (root << 4) + hi, w);
+      SubTw::run<2>(tw + (root << 5) + (hi << 1), w + 1);
+      SubTw::run<4>(tw + (root << 6) + (hi << 2), w + 3);
+      SubTw::run<8>(tw + (root << 7) + (hi << 3), w + 7);
+      SubTw::run<16>(tw + (root << 8) + (hi << 4), w + 15);
+      double x[32];
+#pragma unroll
+      for (int e = 0; e < 32; e++) x[e] = s[pb + 17 * e];
+      reg_fwd_stages<5, true>(x, mod, fmask >> 4, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
+#pragma unroll
+      for (int e = 0; e < 32; e++) s[pb + 17 * e] = x[e];
+    }
+    __syncthreads();
+    // ---- forward round 3 (stages 9..12) on 16 consecutive points, table product, inverse round 1 (stages 0..3)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int g = t + 256 * j;
+      const int pb = S::px(16 * g);
+      double w[15];
+      SubTw::run<1>(tw + (root << 9) + g, w);
+      SubTw::run<2>(tw + (root << 10) + (g << 1), w + 1);
+      SubTw::run<4>(tw + (root << 11) + (g << 2), w + 3);
+      SubTw::run<8>(tw + (root << 12) + (g << 3), w + 7);
+      double x[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) x[e] = s[pb + e];
+      reg_fwd_stages<4, true>(x, mod, fmask >> 9, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) s[pb + e] = x[e];
+        continue;
+      }
+      {
+        double tb[16];
+        if (MODE == 2) {
+          SubTw::run<16>(static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * S::N + 16 * g, tb);
+#pragma unroll
+          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), tb[e], mod);
+        } else {
+          SubTw::run<16>(static_cast<const double *>(tabs.t[0]) + blk * (size_t)S::N + 16 * g, tb);
+#pragma unroll
+          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), reduce(tb[e], mod), mod);
+        }
+      }
+      // inverse stage k of the block: twiddle itw[(n >> (k+1)) root + (position >> (k+1))]
+      SubTw::run<8>(itw + ((size_t)root << 12) + (g << 3), w);
+      SubTw::run<4>(itw + ((size_t)root << 11) + (g << 2), w + 8);
+      SubTw::run<2>(itw + ((size_t)root << 10) + (g << 1), w + 12);
+      SubTw::run<1>(itw + ((size_t)root << 9) + g, w + 14);
+      reg_inv_stages<4, true>(x, mod, imask, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[pb + e] = x[e];
+    }
+    if (MODE == 0) {  // forward only: every wave streams out the ranges its own groups cover
+      wave_sync();
+      const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int r0 = (j * 256 + wave * 64) * 16;
+        const int p0 = S::px(r0 + 2 * lane);
+        double2 *d2 = reinterpret_cast<double2 *>(X + blk * (size_t)S::N + r0) + lane;
+#pragma unroll
+        for (int i = 0; i < 8; i++) d2[64 * i] = make_double2(s[p0 + S::px128(i)], s[p0 + S::px128(i) + 1]);
+      }
+      continue;
+    }
+    __syncthreads();
+    // ---- inverse round 2: stages 4..8; block of stage 4+k: (hi << (4-k)) + (e >> (k+1))
+    {
+      const int lo = t & 15, hi = t >> 4;
+      const int pb = hi * S::SP + lo;
+      double w[31];
+      SubTw::run<16>(itw + ((size_t)root << 8) + (hi << 4), w);
+      SubTw::run<8>(itw + ((size_t)root << 7) + (hi << 3), w + 16);
+      SubTw::run<4>(itw + ((size_t)root << 6) + (hi << 2), w + 24);
+      SubTw::run<2>(itw + ((size_t)root << 5) + (hi << 1), w + 28);
+      SubTw::run<1>(itw + ((size_t)root << 4) + hi, w + 30);
+      double x[32];
+#pragma unroll
+      for (int e = 0; e < 32; e++) x[e] = s[pb + 17 * e];
+      reg_inv_stages<5, true>(x, mod, imask >> 4, [&](int k, int i) { return w[32 - (32 >> k) + i]; });
+#pragma unroll
+      for (int e = 0; e < 32; e++) s[pb + 17 * e] = x[e];
+    }
+    __syncthreads();
+    // ---- inverse round 3: stages 9..12 on elements 2t+c + 512e; block of stage 9+k: e >> (k+1) of 8 >> k
+    {
+      const int pb = S::px(2 * t);
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        v[0][e] = s[pb + S::SP * e];
+        v[1][e] = s[pb + S::SP * e + 1];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+      reg_inv_stages<4, true>(v[c], mod, imask >> 9, [&](int k, int i) { return itw[((8 >> k) * root) + i]; });
+    {
+      double2 *dst = reinterpret_cast<double2 *>(X + blk * (size_t)S::N) + t;
+#pragma unroll
+      for (int e = 0; e < 16; e++) dst[(S::S / 2) * e] = make_double2(v[0][e], v[1][e]);
+    }
+  }
+}
+
 // ZK patch of the multi-pass H: H += d2*A + d1*B + d1*d2*Z, H[0] -= d3; then canonical form.
 template <class CPS>
 __global__ void __launch_bounds__(256)
@@ -1721,13 +1906,23 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
   const size_t bpc = (size_t)1 << (logtot - logB);
   static const char *const names[4] = {"sub_ntt_kernel<0", "sub_ntt_kernel<1", "sub_ntt_kernel<2", "sub_ntt_kernel<3"};
   static const char *const names_ct[4] = {"sub_ntt_ct_kernel<0, 13>", "sub_ntt_ct_kernel<1, 13>", "sub_ntt_ct_kernel<2, 13>", "sub_ntt_ct_kernel<3, 13>"};
+  static const char *const names_wide[4] = {"sub_ntt_wide_kernel<0>", "sub_ntt_wide_kernel<1>", "sub_ntt_wide_kernel<2>", "sub_ntt_wide_kernel<3>"};
   const bool ct = FP && logB == 13 && MODE != 1 && g_witness_sub_ct;
   const double Bn = (double)((size_t)1 << logB), blocks = (double)(ncols * bpc);
-  ProfScope prof(ctx, st, ct ? names_ct[MODE] : names[MODE], blocks * Bn * (MODE == 3 ? 24.0 : 16.0),
+  ProfScope prof(ctx, st, ct ? (g_witness_sub_ct == 2 ? names_wide[MODE] : names_ct[MODE]) : names[MODE], blocks * Bn * (MODE == 3 ? 24.0 : 16.0),
                  blocks * ((MODE >= 2 ? 2.0 : 1.0) * ntt_fp64(Bn, logB) + (MODE >= 2 ? 7.0 * Bn : 0.0)));
   static TabPtrs none{};
   const TabPtrs &tp = tabs ? *tabs : none;
   if constexpr (FP) {
+    if (logB == 13 && MODE != 1 && g_witness_sub_ct == 2) {
+      const int wl = (int)(WideShape<13>::TILE * sizeof(double));
+      const unsigned long long nb = (unsigned long long)(ncols * bpc);
+      RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_wide_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+      hipLaunchKernelGGL((sub_ntt_wide_kernel<MODE>), dim3((unsigned)std::min<unsigned long long>(nb, 512)), dim3(256), wl, st, X,
+                         logsub - logB, tp, (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp, nb);
+      RS_HIP(hipGetLastError());
+      return;
+    }
     if (logB == 13 && MODE != 1 && g_witness_sub_ct) {
       RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_ct_kernel<MODE, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((sub_ntt_ct_kernel<MODE, 13>), dim3((unsigned)(ncols * bpc)), dim3(512), lds, st, X, logsub - logB, tp,

@@ -542,8 +542,9 @@ def test_msm_with_a_tiled_key_equals_the_explicit_key():
 
 @pytest.mark.parametrize("m,zk", [(20000, True), (40000, False)])
 def test_multipass_tuned_sub_transform_kernel_equals_generic(m, zk):
-    """M >= 2^15: the multi-pass path runs its 2^13-point sub-transforms through sub_ntt_ct_kernel (direct global
-    I/O, table product fused into the last forward round); it must reproduce the generic kernel bit for bit."""
+    """M >= 2^15: the multi-pass path runs its 2^13-point sub-transforms through sub_ntt_wide_kernel (32 coefficients
+    per thread, forward - table product - inverse fused through registers) or sub_ntt_ct_kernel (wave-private rounds);
+    both must reproduce the generic kernel bit for bit."""
     dev = dev_for("toy44")
     prm = dev.prm
     ctx = H.oracle_ctx(prm)
@@ -554,14 +555,17 @@ def test_multipass_tuned_sub_transform_kernel_equals_generic(m, zk):
     ds = [dev.put(ctx.random_ring(60 + k)) for k in range(3)] if zk else [None] * 3
     dcs = dev.r1cs(cs)
     keys = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
-    tuned = {k: host(v) for k, v in dev.witness_map(dcs, asg, *ds).items() if k in keys}
-    _set_tuning(b"witness_sub_ct", 0)
+    from ringsnark_amd.witness_knobs import SUB_CT_DEFAULT
+    runs = {}
     try:
-        generic = {k: host(v) for k, v in dev.witness_map(dcs, asg, *ds).items() if k in keys}
+        for variant in (0, 1, 2):  # generic, wave-private tuned (sub_ntt_ct_kernel), wide (sub_ntt_wide_kernel)
+            _set_tuning(b"witness_sub_ct", variant)
+            runs[variant] = {k: host(v) for k, v in dev.witness_map(dcs, asg, *ds).items() if k in keys}
     finally:
-        _set_tuning(b"witness_sub_ct", 1)
-    for k in keys:
-        assert (tuned[k] == generic[k]).all(), k
+        _set_tuning(b"witness_sub_ct", SUB_CT_DEFAULT)
+    for variant in (1, 2):
+        for k in keys:
+            assert (runs[variant][k] == runs[0][k]).all(), (variant, k)
 
 
 def test_multipass_production_tile_matches_oracle_on_a_few_slots():

@@ -14,6 +14,11 @@ logw = int(sys.argv[2]) if len(sys.argv) > 2 else 13
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 prm = P.preset(sys.argv[4] if len(sys.argv) > 4 else "C3")
 dev = Device(prm)
+import os  # noqa: E402
+from ringsnark_amd import _lib  # noqa: E402
+for kv in os.environ.get("RS_TUNING", "").split(","):  # e.g. RS_TUNING=witness_sub_ct=2,ntt_variant=12
+    if "=" in kv:
+        _lib.check(_lib.load().rs_set_tuning(kv.split("=")[0].encode(), int(kv.split("=")[1])))
 m, W = 1 << logm, 1 << logw
 t0 = time.time()
 cs = R.chain_r1cs(m, prm.q)
@@ -36,5 +41,8 @@ for _ in range(steps):
     dev.groth16_prove(dcs, pk, asg, want_empty=False, window=W)
     torch.cuda.synchronize()
     print("proof %.1f ms" % ((time.time() - t0) * 1e3), dev.last_timings(), flush=True)
+for k in dev.profile_read():
+    if k["total_ms"] > 2.0 * steps:
+        print("  %-44s %4d launches %8.2f ms/proof" % (k["name"], k["launches"] // steps, k["total_ms"] / steps))
 print("peak torch GiB %.1f" % (torch.cuda.max_memory_allocated() / 2**30), "free/total GiB",
       [x / 2**30 for x in torch.cuda.mem_get_info()], flush=True)

@@ -1766,7 +1766,7 @@ static int col_threads(size_t M) { return (int)std::max<size_t>(64, std::min<siz
 
 int g_witness_lds_logM = 13;  // columns up to 2^13 run entirely inside one LDS tile
 int g_witness_tree_ct = 1;    // 1: level-unrolled product-tree kernel for 2^13 tiles
-int g_witness_sub_ct = 1;     // 1: compile-time-length sub-transform kernel for 2^13 blocks of the multi-pass path
+int g_witness_sub_ct = 2;     // 1: compile-time-length sub-transform kernel for 2^13 blocks of the multi-pass path
 
 // Newton -> monomial levels 1..logT on tiles of 2^logT coefficients of [ncols][M] columns; with
 // `newton` (logT == logM) the tiles hold values and the Newton conversion runs first, in the same launch

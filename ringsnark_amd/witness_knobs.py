@@ -1,2 +1,2 @@
 """Defaults of the witness-map kernel-shape knobs (rs_set_tuning), for tests and tools that flip and restore them."""
-SUB_CT_DEFAULT = 1  # witness_sub_ct: 0 generic, 1 sub_ntt_ct_kernel, 2 sub_ntt_wide_kernel
+SUB_CT_DEFAULT = 2  # witness_sub_ct: 0 generic, 1 sub_ntt_ct_kernel, 2 sub_ntt_wide_kernel

@@ -164,7 +164,7 @@ plain_center_kernel(PlainArgs args, typename ArithOf<M>::Lift *__restrict__ C, u
 struct PlainTwPtrs {
   const double *itw[RS_MAX_L];  // inverse twiddle tables of the ring primes (kernel-argument pointers: global loads)
 };
-template <bool MULTI, bool PAIRED>
+template <bool MULTI, bool PAIRED, int NE>  // NE = N / 512: 16-byte coefficient pairs per thread (16 at N = 8192)
 __global__ void __launch_bounds__(256, 2)
 plain_center_wide_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t0, unsigned long long tile_terms,
                          unsigned long long tt_count, int n_groups, int N, int L, const uint32_t *__restrict__ index_map,
@@ -211,19 +211,15 @@ plain_center_wide_kernel(PlainArgs args, double *__restrict__ C, unsigned long l
     for (int i = 0; i < (8 >> k); i++) tw3[16 - (16 >> k) + i] = uniform_f64(itw[(8 >> k) + i]);
   const double w_last = uniform_f64(mulmod(itw[1], ninv, mod));
   // mapped tile addresses of the slots this thread scatters to: ring slot x = 2t+c + 512 e -> px(index_map[x]), two per word
-  const int ne = N >> 9;  // 16-byte coefficient pairs per thread: 16 at N = 8192
-  uint32_t spos[16];
+  uint32_t spos[NE];
 #pragma unroll
-  for (int e = 0; e < 16; e++) {
-    spos[e] = 0;
-    if (e < ne) {
-      const uint2 m2 = reinterpret_cast<const uint2 *>(index_map)[t + 256 * e];
-      spos[e] = (uint32_t)S::px((int)m2.x) | ((uint32_t)S::px((int)m2.y) << 16);
-    }
+  for (int e = 0; e < NE; e++) {
+    const uint2 m2 = reinterpret_cast<const uint2 *>(index_map)[t + 256 * e];
+    spos[e] = (uint32_t)S::px((int)m2.x) | ((uint32_t)S::px((int)m2.y) << 16);
   }
   __syncthreads();
   const unsigned long long items = tt_count * (unsigned long long)n_groups;
-  u64x2 pre[16];
+  u64x2 pre[NE];
   auto src_of = [&](unsigned long long item, int v) -> const uint64_t * {
     const int g = (int)(item % (unsigned)n_groups);
     const unsigned long long term = t0 + item / (unsigned)n_groups;
@@ -232,8 +228,7 @@ plain_center_wide_kernel(PlainArgs args, double *__restrict__ C, unsigned long l
   auto issue_loads = [&](const uint64_t *src) {
     const u64x2 *s2 = reinterpret_cast<const u64x2 *>(src) + t;
 #pragma unroll
-    for (int e = 0; e < 16; e++)
-      if (e < ne) pre[e] = stream_load(s2 + 256 * e);
+    for (int e = 0; e < NE; e++) pre[e] = stream_load(s2 + 256 * e);
   };
   unsigned long long item = (unsigned long long)slot;
   // MULTI == false: the single vector of every group; a term beyond its length or a constant-1 term has nothing to load
@@ -266,18 +261,17 @@ plain_center_wide_kernel(PlainArgs args, double *__restrict__ C, unsigned long l
       double tw1[2][15];
       if (!MULTI) load_tw1(tw1);  // before the prefetch below: waiting for them leaves the younger loads in flight
       if (MULTI) issue_loads(src_of(item, v));
-      if (N < S::N) {  // slots beyond N stay zero (seal_ring.tcc:350-351)
+      if (NE < 16) {  // slots beyond N stay zero (seal_ring.tcc:350-351)
         for (int i = t; i < S::TILE; i += 256) s[i] = 0.0;
         __syncthreads();
       }
       bool nz = false;
 #pragma unroll
-      for (int e = 0; e < 16; e++)
-        if (e < ne) {
-          nz |= (pre[e].x | pre[e].y) != 0;
-          s[spos[e] & 0xffffu] = from_u64(pre[e].x);
-          s[spos[e] >> 16] = from_u64(pre[e].y);
-        }
+      for (int e = 0; e < NE; e++) {
+        nz |= (pre[e].x | pre[e].y) != 0;
+        s[spos[e] & 0xffffu] = from_u64(pre[e].x);
+        s[spos[e] >> 16] = from_u64(pre[e].y);
+      }
       mem_fence();
       if (MULTI) load_tw1(tw1);  // after the scatter: the coefficient registers are free
       if (!MULTI) {  // next item's coefficients: in flight during this transform
@@ -1177,7 +1171,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
   bool v3 = false, plain_wide = false;
   if constexpr (FP) {
     v3 = g_mac_variant == 5 && n == 8192;
-    plain_wide = g_plain_variant == 1 && n == 8192 && ctx->N >= 512 && ctx->N % 512 == 0;
+    plain_wide = g_plain_variant == 1 && n == 8192 && (ctx->N == 8192 || ctx->N == 4096);
   }
   const bool paired = v3 && plain_wide;  // row layout of this call: written by the plaintext kernel, read by the MAC
   bool multi = false;
@@ -1210,18 +1204,24 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
         PlainTwPtrs twp;
         memset(&twp, 0, sizeof(twp));
         for (int i = 0; i < L; i++) twp.itw[i] = ctx->plain[i].d_itw;
-#define RS_PLAIN_WIDE(MULTI_, PAIRED_)                                                                                        \
+#define RS_PLAIN_WIDE_NE(MULTI_, PAIRED_, NE_)                                                                                \
   do {                                                                                                                        \
-    RS_HIP(hipFuncSetAttribute((const void *)plain_center_wide_kernel<MULTI_, PAIRED_>,                                       \
+    RS_HIP(hipFuncSetAttribute((const void *)plain_center_wide_kernel<MULTI_, PAIRED_, NE_>,                                  \
                                hipFuncAttributeMaxDynamicSharedMemorySize, wl));                                              \
-    hipLaunchKernelGGL((plain_center_wide_kernel<MULTI_, PAIRED_>), grid, dim3(256), wl, st, pa, reinterpret_cast<double *>(d_C), \
-                       (unsigned long long)t0, (unsigned long long)tile_terms, (unsigned long long)tt, n_groups, ctx->N, L,   \
-                       ctx->d_index_map, sc.plain<Mod>(), twp);                                                               \
+    hipLaunchKernelGGL((plain_center_wide_kernel<MULTI_, PAIRED_, NE_>), grid, dim3(256), wl, st, pa,                         \
+                       reinterpret_cast<double *>(d_C), (unsigned long long)t0, (unsigned long long)tile_terms,               \
+                       (unsigned long long)tt, n_groups, ctx->N, L, ctx->d_index_map, sc.plain<Mod>(), twp);                  \
+  } while (0)
+#define RS_PLAIN_WIDE(MULTI_, PAIRED_)                     \
+  do {                                                     \
+    if (ctx->N == 8192) RS_PLAIN_WIDE_NE(MULTI_, PAIRED_, 16); \
+    else RS_PLAIN_WIDE_NE(MULTI_, PAIRED_, 8);             \
   } while (0)
         if (multi && paired) RS_PLAIN_WIDE(true, true);
         else if (multi) RS_PLAIN_WIDE(true, false);
         else if (paired) RS_PLAIN_WIDE(false, true);
         else RS_PLAIN_WIDE(false, false);
+#undef RS_PLAIN_WIDE_NE
 #undef RS_PLAIN_WIDE
       }
     } else if (plain16)

@@ -118,6 +118,18 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// A source functor may declare `static constexpr bool zero_upper = true`: it feeds the FIRST round of a transform
+// whose upper half is zero padding, so elements e >= E/2 are known zeros and the first stage is a copy
+// (x + w*0, x - w*0) -- no loads, no multiplies, bit-identical.
+template <class F, class = void>
+struct zero_upper_of {
+  static constexpr bool value = false;
+};
+template <class F>
+struct zero_upper_of<F, decltype((void)F::zero_upper)> {
+  static constexpr bool value = F::zero_upper;
+};
+
 // T, M: value and modulus type of the arithmetic, deduced from the twiddle table and the modulus
 template <int R, class In, class Out, class T, class M>
 __device__ __forceinline__ void fwd_round(const In in, const Out out, int logtot, int logsub, int s0,
@@ -144,14 +156,20 @@ __device__ __forceinline__ void fwd_round(const In in, const Out out, int logtot
     const int hi = hi_all & ((1 << s0) - 1);
     const int base = (hi_all << (logsub - s0)) + lo;
     T v[E];
+    constexpr bool ZU = zero_upper_of<In>::value;
     const int pbi = in.pbase(base), pbo = out.pbase(base);
 #pragma unroll
-    for (int e = 0; e < E; e++) v[e] = in.load(base, pbi, e * sstep, round_poff(e * sstep, sstep, E));
+    for (int e = 0; e < (ZU ? E / 2 : E); e++) v[e] = in.load(base, pbi, e * sstep, round_poff(e * sstep, sstep, E));
 #pragma unroll
     for (int k = 0; k < R; k++) {
       if ((red_mask >> (s0 + k)) & 1u) {
 #pragma unroll
-        for (int e = 0; e < E; e++) v[e] = reduce(v[e], mod);
+        for (int e = 0; e < ((ZU && k == 0) ? E / 2 : E); e++) v[e] = reduce(v[e], mod);
+      }
+      if (ZU && k == 0) {
+#pragma unroll
+        for (int e = 0; e < E / 2; e++) v[e + E / 2] = v[e];
+        continue;
       }
       const int half = E >> (k + 1);
       const int twbase = ((1 << (s0 + k)) * root) + (hi << k);

@@ -606,6 +606,7 @@ interp_columns_kernel(typename CPS::T *__restrict__ cols, int logM, unsigned S, 
 // First forward round of a level-l transform: element offset eoff inside the node is a left
 // position iff eoff < h; the transform's input there is F_right (the node's right half), zero above.
 struct TreeRightIn {
+  static constexpr bool zero_upper = true;
   const double *sb;
   int h;
   __device__ __forceinline__ int pbase(int base) const { return base; }

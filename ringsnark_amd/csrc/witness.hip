@@ -1531,6 +1531,11 @@ sub_ntt_ct_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab
 struct SubTw {  // twiddle fetch: 2^k consecutive table entries, 16-byte loads where the run allows
   template <int CNT>
   __device__ static __forceinline__ void run(const double *__restrict__ p, double *dst) {
+#ifdef RS_SUBW_ABLATE_TW  // experiment: no twiddle / table traffic (wrong results)
+#pragma unroll
+    for (int i = 0; i < CNT; i++) dst[i] = 3.0 + i + (double)threadIdx.x;
+    return;
+#endif
     if (CNT == 1) {
       dst[0] = p[0];
     } else {

@@ -269,7 +269,7 @@ def main():
 
         def ntt_gbs(inverse):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for _ in range(10):  # steady state: the first launches after an idle stretch run at a lower clock
+            for _ in range(40):  # steady state: the first launches after an idle stretch run at a lower clock
                 dev.ntt(polys, _lib.RS_MOD_COEFF, 0, inverse=inverse)
             e0.record()  # the library launches on torch's current stream (device.py passes it down)
             for _ in range(reps):

@@ -39,7 +39,7 @@ from ringsnark_amd import r1cs as R  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_PEAK_T = 39.3     # vector FP64 FMA issue peak, T lane-ops/s: 256 CUs x 64 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md)
 # kernels bounded by FP64 issue (LDS-resident transforms); everything else is bounded by HBM
-FP64_KERNELS = ("tree_columns_kernel", "tree_tiles_generic_kernel", "h_tile_kernel", "h_columns_kernel", "interp_columns_kernel",
+FP64_KERNELS = ("tree_columns_kernel", "tree_wide_kernel", "tree_tiles_generic_kernel", "h_tile_kernel", "h_columns_kernel", "interp_columns_kernel",
                 "sub_ntt_kernel", "sub_ntt_ct_kernel", "sub_ntt_wide_kernel", "plain_center_kernel")
 
 

@@ -854,6 +854,11 @@ __device__ __forceinline__ void reg_fwd_stages_zu(double (&v)[1 << R], const Mod
 // 2^k consecutive table entries -> registers, 16-byte loads where the run allows
 template <int CNT>
 __device__ __forceinline__ void tw_run(const double *__restrict__ p, double *dst) {
+#ifdef RS_TREEW_ABLATE_TW  // experiment: no per-lane table traffic (wrong results)
+#pragma unroll
+  for (int i = 0; i < CNT; i++) dst[i] = 3.0 + i + (double)threadIdx.x;
+  return;
+#endif
   if (CNT == 1) {
     dst[0] = p[0];
   } else {
@@ -866,9 +871,8 @@ __device__ __forceinline__ void tw_run(const double *__restrict__ p, double *dst
   }
 }
 // The lane's own twiddles of the middle of level LV (thread u of the node): forward stages LV-5..LV-1 / inverse stages 0..4.
-// They are REQUESTED EARLY -- the forward set at the start of the level, before the cross round, the inverse set as soon as
-// the forward stages have consumed the registers: the exchanges' fences keep the compiler from hoisting a load above them,
-// and at two waves per SIMD an L2 round trip in front of every phase is the difference between 58 % and 80 % VALU use.
+// (Requesting them earlier -- before the cross round, before the product -- was tried: no gain in time, and the extra
+// live registers push F_left of levels 11..13 into scratch, 100 GiB of HBM traffic per proof.)
 template <int LV>
 __device__ __forceinline__ void tree_wide_mid_tw_fwd(const ColPlan &P, int u, double (&w)[31]) {
   constexpr int c = LV - 5;
@@ -890,31 +894,27 @@ __device__ __forceinline__ void tree_wide_mid_tw_inv(const ColPlan &P, int u, do
   tw_run<2>(itw + (n >> 4) + (u << 1), w + 28);
   tw_run<1>(itw + (n >> 5) + u, w + 30);
 }
-// The middle of a level on the consecutive layout: forward stages l-5..l-1 (twiddles wf, preloaded), product with the
-// spectrum of D_left, inverse stages 0..4.  u = thread index inside the node (0 for l = 5), b = the thread's 32 coefficients.
+// The middle of a level on the consecutive layout: forward stages l-5..l-1, product with the spectrum of D_left,
+// inverse stages 0..4.  u = thread index inside the node (0 for l = 5), b = the thread's 32 coefficients.
 template <int LV, bool ZU>
-__device__ __forceinline__ void tree_wide_middle(double (&b)[32], double (&wf)[31], const ColPlan &P, const Mod mod,
-                                                 const double *__restrict__ dh, int u) {
+__device__ __forceinline__ void tree_wide_middle(double (&b)[32], const ColPlan &P, const Mod mod, const double *__restrict__ dh, int u) {
   constexpr int c = LV - 5;
   const uint32_t fmask = P.fmask[LV] >> c, imask = P.imask[LV];
-  double d[32];
-  tw_run<16>(dh, d);  // lands during the forward stages
+  double w[31];
+  tree_wide_mid_tw_fwd<LV>(P, u, w);
   if (ZU)
-    reg_fwd_stages_zu<5>(b, mod, fmask, [&](int k, int blk) { return wf[(1 << k) - 1 + blk]; });
+    reg_fwd_stages_zu<5>(b, mod, fmask, [&](int k, int blk) { return w[(1 << k) - 1 + blk]; });
   else
-    reg_fwd_stages<5, true>(b, mod, fmask, [&](int k, int blk) { return wf[(1 << k) - 1 + blk]; });
-  mem_fence();
-  tw_run<16>(dh + 16, d + 16);  // the forward twiddles' registers are free: the second half of the spectrum
-  mem_fence();
+    reg_fwd_stages<5, true>(b, mod, fmask, [&](int k, int blk) { return w[(1 << k) - 1 + blk]; });
 #pragma unroll
-  for (int e = 0; e < 16; e++) b[e] = mulmod(reduce(b[e], mod), d[e], mod);
-  mem_fence();
-  double wi[31];
-  tree_wide_mid_tw_inv<LV>(P, u, wi);  // ... and, the first half consumed, the inverse twiddles
-  mem_fence();
+  for (int q = 0; q < 4; q++) {
+    double d[8];
+    tw_run<8>(dh + 8 * q, d);
 #pragma unroll
-  for (int e = 16; e < 32; e++) b[e] = mulmod(reduce(b[e], mod), d[e], mod);
-  reg_inv_stages<5, true>(b, mod, imask, [&](int k, int i) { return wi[32 - (32 >> k) + i]; });
+    for (int e = 0; e < 8; e++) b[8 * q + e] = mulmod(reduce(b[8 * q + e], mod), d[e], mod);
+  }
+  tree_wide_mid_tw_inv<LV>(P, u, w);
+  reg_inv_stages<5, true>(b, mod, imask, [&](int k, int i) { return w[32 - (32 >> k) + i]; });
 }
 
 // One level 6 <= LV <= 10: the node's W = 2^(LV-5) <= 32 threads, one cross round of LV-5 stages each way.
@@ -925,8 +925,6 @@ __device__ __forceinline__ void tree_wide_level(double *s, const ColPlan &P, con
   const int u = t & (W - 1), tb = t - u;
   const double *__restrict__ tw = P.tw;
   const double *__restrict__ itw = P.itw;
-  double wf[31];
-  tree_wide_mid_tw_fwd<LV>(P, u, wf);
   double X[Q][W], Lf[Q][W / 2];
 #pragma unroll
   for (int k = 0; k < Q; k++)
@@ -947,7 +945,7 @@ __device__ __forceinline__ void tree_wide_level(double *s, const ColPlan &P, con
     double b[32];
 #pragma unroll
     for (int e = 0; e < 32; e++) b[e] = s[33 * t + e];
-    tree_wide_middle<LV, false>(b, wf, P, mod, dh_tile + 32 * t, u);
+    tree_wide_middle<LV, false>(b, P, mod, dh_tile + 32 * t, u);
 #pragma unroll
     for (int e = 0; e < 32; e++) s[33 * t + e] = b[e];
   }
@@ -979,12 +977,6 @@ __device__ __forceinline__ void tree_wide_level_big(double *s, const ColPlan &P,
   const double *__restrict__ itw = P.itw;
   const uint32_t fmask = P.fmask[LV], imask = P.imask[LV];
   const int th2 = a >> 5, e2 = a & 31;  // round X2: thread (tn_hi, e) holds all 32 tn_lo
-  double w2[31];  // its twiddles, stage c1 + k: block (tn >> (5 - k)) = (tn_hi << k) + (tn_lo >> (5 - k)); requested now
-  tw_run<1>(tw + (1 << c1) + th2, w2);
-  tw_run<2>(tw + (2 << c1) + (th2 << 1), w2 + 1);
-  tw_run<4>(tw + (4 << c1) + (th2 << 2), w2 + 3);
-  tw_run<8>(tw + (8 << c1) + (th2 << 3), w2 + 7);
-  tw_run<16>(tw + (16 << c1) + (th2 << 4), w2 + 15);
   // round X1: register (k, tn_hi) = element (tn_hi, m = a + W k), m = 32 tn_lo + e
   double X[Q1][R1], Lf[Q1][R1 / 2];
   auto x1_addr = [&](int k, int tn_hi) {
@@ -1005,15 +997,17 @@ __device__ __forceinline__ void tree_wide_level_big(double *s, const ColPlan &P,
     for (int th = 0; th < R1; th++) s[x1_addr(k, th)] = X[k][th];
   }
   tw_sync<WG>();
-  double wf[31];
   {
-    double y[32];
+    double y[32], w2[31];
+    // stage c1 + k: block (tn >> (5 - k)) = (tn_hi << k) + (tn_lo >> (5 - k))
+    tw_run<1>(tw + (1 << c1) + th2, w2);
+    tw_run<2>(tw + (2 << c1) + (th2 << 1), w2 + 1);
+    tw_run<4>(tw + (4 << c1) + (th2 << 2), w2 + 3);
+    tw_run<8>(tw + (8 << c1) + (th2 << 3), w2 + 7);
+    tw_run<16>(tw + (16 << c1) + (th2 << 4), w2 + 15);
 #pragma unroll
     for (int tl = 0; tl < 32; tl++) y[tl] = s[tw_addr(32 * (tb + 32 * th2 + tl) + e2)];
     reg_fwd_stages<5, true>(y, mod, fmask >> c1, [&](int k, int blk) { return w2[(1 << k) - 1 + blk]; });
-    mem_fence();
-    tree_wide_mid_tw_fwd<LV>(P, a, wf);  // the middle's, into the registers this round's twiddles leave: lands during the exchange
-    mem_fence();
 #pragma unroll
     for (int tl = 0; tl < 32; tl++) s[tw_addr(32 * (tb + 32 * th2 + tl) + e2)] = y[tl];
   }
@@ -1022,21 +1016,19 @@ __device__ __forceinline__ void tree_wide_level_big(double *s, const ColPlan &P,
     double b[32];
 #pragma unroll
     for (int e = 0; e < 32; e++) b[e] = s[33 * t + e];
-    tree_wide_middle<LV, false>(b, wf, P, mod, dh_tile + 32 * t, a);
-    mem_fence();
-    // inverse round X2, stage 5 + k: block tn >> (k+1) = (tn_hi << (4-k)) + (tn_lo >> (k+1)) of the n >> (6+k); requested now
-    tw_run<16>(itw + (n >> 6) + (th2 << 4), w2);
-    tw_run<8>(itw + (n >> 7) + (th2 << 3), w2 + 16);
-    tw_run<4>(itw + (n >> 8) + (th2 << 2), w2 + 24);
-    tw_run<2>(itw + (n >> 9) + (th2 << 1), w2 + 28);
-    tw_run<1>(itw + (n >> 10) + th2, w2 + 30);
-    mem_fence();
+    tree_wide_middle<LV, false>(b, P, mod, dh_tile + 32 * t, a);
 #pragma unroll
     for (int e = 0; e < 32; e++) s[33 * t + e] = b[e];
   }
   tw_sync<WG>();
   {
-    double y[32];
+    double y[32], w2[31];
+    // inverse stage 5 + k: block tn >> (k+1) = (tn_hi << (4-k)) + (tn_lo >> (k+1)) of the n >> (6+k)
+    tw_run<16>(itw + (n >> 6) + (th2 << 4), w2);
+    tw_run<8>(itw + (n >> 7) + (th2 << 3), w2 + 16);
+    tw_run<4>(itw + (n >> 8) + (th2 << 2), w2 + 24);
+    tw_run<2>(itw + (n >> 9) + (th2 << 1), w2 + 28);
+    tw_run<1>(itw + (n >> 10) + th2, w2 + 30);
 #pragma unroll
     for (int tl = 0; tl < 32; tl++) y[tl] = s[tw_addr(32 * (tb + 32 * th2 + tl) + e2)];
     reg_inv_stages<5, true>(y, mod, imask >> 5, [&](int k, int i) { return w2[32 - (32 >> k) + i]; });
@@ -1122,9 +1114,7 @@ tree_wide_kernel(double *__restrict__ cols, int logM, size_t col0, unsigned S, u
       double b[32];
 #pragma unroll
       for (int e = 0; e < 16; e++) b[e] = r[16 + e];
-      double wf[31];
-      tree_wide_mid_tw_fwd<5>(P, 0, wf);
-      tree_wide_middle<5, true>(b, wf, P, mod, P.dhat + (size_t)5 * M + pos0 + 32 * t, 0);
+      tree_wide_middle<5, true>(b, P, mod, P.dhat + (size_t)5 * M + pos0 + 32 * t, 0);
 #pragma unroll
       for (int e = 0; e < 32; e++) s[33 * t + e] = reduce(b[e] + (e < 16 ? r[e] : 0.0), mod);
     }

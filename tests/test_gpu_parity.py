@@ -142,6 +142,61 @@ def test_grouped_msm_equals_sum_of_inner_products():
         assert (got[c, 1] == ctx.inner_product(crs, v[2])[0]).all()
 
 
+@pytest.mark.parametrize("name", ["C2", "C3"])
+def test_wide_kernels_equal_their_predecessors_and_the_oracle(name):
+    """N_enc = 8192: the wide NTT (ntt_variant 14), the half-spectrum MAC (mac_variant 5) and the wide plaintext kernel
+    with paired rows (plain_variant 1) against the kernels they replaced, on a grouped inner product with a zero term, a
+    one-limb-zero term, a Scalar-1 term and a short vector; one configuration also against the oracle.  C2 has
+    N = 4096 < N_enc (slots beyond N stay zero), C3 N = N_enc."""
+    import torch
+    from ringsnark_amd import _lib
+    dev = dev_for(name)
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    # transforms, both moduli sets, odd batch
+    for modset, idx, q in ((_lib.RS_MOD_COEFF, prm.K - 1, prm.Q[-1]), (_lib.RS_MOD_PLAIN, 0, prm.q[0])):
+        src = torch.empty((37, prm.N_enc), dtype=torch.int64, device=dev.device).random_(0, int(q))
+        outs = []
+        try:
+            for v in (0, 12, 14):
+                _set_tuning(b"ntt_variant", v)
+                d = src.clone()
+                dev.ntt(d, modset, idx)
+                f = d.clone()
+                dev.ntt(d, modset, idx, inverse=True)
+                assert (d == src).all(), ("roundtrip", v)
+                outs.append(f)
+        finally:
+            _set_tuning(b"ntt_variant", 14)
+        assert (outs[0] == outs[1]).all() and (outs[0] == outs[2]).all()
+    # grouped inner product: group 0 = {v0, v1} (multi-vector: summed after the lift), group 1 = {v2 (shorter)}
+    T = 9
+    encs = ctx.random_enc(51, T)
+    v = [ctx.random_ring(52 + k, T) for k in range(2)] + [ctx.random_ring(55, T - 3)]
+    v[0][2] = 0
+    v[1][3, 0] = 0
+    kinds = np.zeros(T, dtype=np.uint8)
+    kinds[4] = O.KIND_ONE
+    vecs = [(dev.put(v[0]), kinds, 0), (dev.put(v[1]), None, 0), (dev.put(v[2]), None, 1)]
+    res = {}
+    try:
+        for mv, pv in ((5, 1), (3, 0), (5, 0), (3, 1)):
+            _set_tuning(b"mac_variant", mv)
+            _set_tuning(b"plain_variant", pv)
+            out, used = dev.msm([dev.put(encs)], vecs, 2, want_used=True)
+            res[(mv, pv)] = (host(out), used)
+    finally:
+        _set_tuning(b"mac_variant", 5)
+        _set_tuning(b"plain_variant", 1)
+    ref = res[(3, 0)]
+    for k, r in res.items():
+        assert r[1] == ref[1], k
+        assert (r[0] == ref[0]).all(), k
+    e0 = ctx.enc_add(ctx.inner_product(encs, v[0], kinds)[0], ctx.inner_product(encs, v[1])[0])
+    e1 = ctx.inner_product(encs[: T - 3], v[2])[0]
+    assert (ref[0][0, 0] == e0).all() and (ref[0][0, 1] == e1).all()
+
+
 @pytest.mark.parametrize("name,m,kind", [("toy", 1, "chain"), ("toy", 2, "chain"), ("toy", 3, "wide"), ("toy", 7, "wide"),
                                           ("toy", 16, "wide"), ("toy", 100, "wide"), ("toy", 100, "many_inputs"),
                                           ("toy", 600, "wide"),  # M = 1024: split Newton / in-place product-tree kernels

@@ -11,7 +11,7 @@ asg = dev.ring_empty(m + 2); dev.fill_uniform(asg[:2], 0, 7); dev.chain_assignme
 pk = dict(s_pows=dev.fill_uniform(dev.enc_empty(m + 1), 1, 3), alpha_s_pows=dev.fill_uniform(dev.enc_empty(m + 1), 1, 4),
           beta_prods=dev.fill_uniform(dev.enc_empty(m), 1, 5), beta_rv_ts=dev.fill_uniform(dev.enc_empty(), 1, 6),
           beta_rw_ts=dev.fill_uniform(dev.enc_empty(), 1, 7), beta_ry_ts=dev.fill_uniform(dev.enc_empty(), 1, 8))
-for variant in (2, 3):
+for variant in (2, 3, 5):
     _lib.check(lib.rs_set_tuning(b"mac_variant", variant))
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.time()

@@ -134,12 +134,13 @@ def rinocchio_key_ranges(plan: ShardPlan, m, n_aux):
 # ---------------------------------------------------------------------------------------------------
 # slot-sharded witness map -> term-sharded coefficient vectors
 # ---------------------------------------------------------------------------------------------------
-def _p2p(ops_send, ops_recv, group):
-    """One batch of point-to-point transfers inside `group`: (tensor, global peer rank) lists.  RCCL runs the
-    batch as one grouped all-to-all over the direct xGMI links; gloo (CPU tests, single-GPU rehearsals) moves
-    host tensors, so device tensors are staged through the host there."""
+def _p2p_start(ops_send, ops_recv, group):
+    """Launch one batch of point-to-point transfers inside `group`: (tensor, global peer rank) lists; returns a
+    function that waits for it.  RCCL runs the batch as one grouped exchange over the direct xGMI links, on its own
+    stream: whatever the caller launches before waiting overlaps the transfer.  gloo (CPU tests, single-GPU
+    rehearsals) moves host tensors, so device tensors are staged through the host there."""
     if not ops_send and not ops_recv:
-        return
+        return lambda: None
     stage = dist.get_backend(group) == "gloo" and any(t.is_cuda for t, _ in ops_send + ops_recv)
     if stage:
         send_h = [(t.cpu(), p) for t, p in ops_send]
@@ -147,23 +148,33 @@ def _p2p(ops_send, ops_recv, group):
     else:
         send_h, recv_h = ops_send, ops_recv
     ops = [dist.P2POp(dist.isend, t.contiguous(), p, group) for t, p in send_h] + [dist.P2POp(dist.irecv, t, p, group) for t, p in recv_h]
-    for r in dist.batch_isend_irecv(ops):
-        r.wait()
-    if stage:
-        for (dst, _), (src, _) in zip(ops_recv, recv_h):
-            dst.copy_(src)
+    works = dist.batch_isend_irecv(ops)
+
+    def wait():
+        for r in works:
+            r.wait()
+        if stage:
+            for (dst, _), (src, _) in zip(ops_recv, recv_h):
+                dst.copy_(src)
+    return wait
 
 
-def sharded_witness(backend, plan: ShardPlan, group, cs_local, assignment_local, want, ranges, ds=(None, None, None)):
+def _p2p(ops_send, ops_recv, group):
+    _p2p_start(ops_send, ops_recv, group)()
+
+
+def sharded_witness(backend, plan: ShardPlan, group, cs_local, assignment_local, want, ranges, ds=(None, None, None), defer=False):
     """The witness map of this rank's limbs, returned TERM-sharded: {k: rows [lo_k, hi_k) of vector k, all N
     slots}, plus "Z" (host array [L_local][m+1]).  ranges[k] = function shard -> (lo, hi) of vector k.
     With one rank per limb group this is the plain witness map; otherwise every rank maps its slot range
-    (rs_witness_map_slots) and one batch of point-to-point transfers re-shards slots -> terms."""
+    (rs_witness_map_slots) and one batch of point-to-point transfers re-shards slots -> terms.
+    defer=True: returns (out, finish); the vectors are complete only after finish() -- work that does not read them
+    (the inner product over the auxiliary inputs) goes in between and overlaps the exchange."""
     if plan.term_shards == 1:
         w = backend.witness(cs_local, assignment_local, want, ds)
         out = {k: w[k][ranges[k](0)[0]:ranges[k](0)[1]] for k in want}
         out["Z"] = w["Z"]
-        return out
+        return (out, lambda: None) if defer else out
     N = backend.N
     s0, ns = plan.slot_range(N)
     wc = backend.witness_slots(cs_local, assignment_local, s0, ns, want, ds)  # compact [rows][L][ns]
@@ -186,9 +197,15 @@ def sharded_witness(backend, plan: ShardPlan, group, cs_local, assignment_local,
                 buf = torch.empty((hi - lo,) + tuple(wc[k].shape[1:-1]) + (pns,), dtype=wc[k].dtype, device=wc[k].device)
                 recvs.append((buf, peer))
                 pending.append((full, ps0, pns, buf))
-    _p2p(sends, recvs, group)
-    for full, ps0, pns, buf in pending:
-        full[..., ps0:ps0 + pns] = buf
+    wait = _p2p_start(sends, recvs, group)
+
+    def finish():
+        wait()
+        for full, ps0, pns, buf in pending:
+            full[..., ps0:ps0 + pns] = buf
+    if defer:
+        return out, finish
+    finish()
     return out
 
 
@@ -212,20 +229,23 @@ def groth16_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_loc
     every rank."""
     rng_ab = lambda s: plan.term_range(m, s)
     rng_h = lambda s: plan.term_range(m + 1, s)
-    w = sharded_witness(backend, plan, term_group, cs_local, assignment_local, ("A_io", "A_mid", "B_io", "B_mid", "H"),
-                        {"A_io": rng_ab, "A_mid": rng_ab, "B_io": rng_ab, "B_mid": rng_ab, "H": rng_h})
+    w, finish = sharded_witness(backend, plan, term_group, cs_local, assignment_local, ("A_io", "A_mid", "B_io", "B_mid", "H"),
+                                {"A_io": rng_ab, "A_mid": rng_ab, "B_io": rng_ab, "B_mid": rng_ab, "H": rng_h}, defer=True)
     lead = plan.term_shard == 0  # exactly one shard per limb group adds alpha / beta
     ranges = groth16_key_ranges(plan, m, n_aux)
+    c2 = None
+    if n_aux:  # <delta_mid, aux> reads the assignment only: it runs while the coefficient rows are exchanged
+        lo, hi = ranges["delta_mid"]
+        aux = assignment_local[n_inputs:]
+        c2, _ = backend.msm([key_slice(pk_local["delta_mid"], lo, hi)], [(aux[lo:hi], None, 0)], 1)
+    finish()
     lo, hi = ranges["s_pows"]
     ab, _ = backend.msm([key_slice(pk_local["s_pows"], lo, hi)], [(w["A_io"], None, 0), (w["A_mid"], None, 0), (w["B_io"], None, 1), (w["B_mid"], None, 1)], 2,
                         addends=[pk_local["alpha"], pk_local["beta"]] if lead else None)
     lo, hi = ranges["delta_ts"]
     c, _ = backend.msm([key_slice(pk_local["delta_ts"], lo, hi)], [(w["H"], None, 0)], 1)
     ab, c = ab[0], c[0]
-    if n_aux:
-        lo, hi = ranges["delta_mid"]
-        aux = assignment_local[n_inputs:]
-        c2, _ = backend.msm([key_slice(pk_local["delta_mid"], lo, hi)], [(aux[lo:hi], None, 0)], 1)
+    if c2 is not None:
         c = backend.enc_add(c, c2[0])
     piece = torch.cat([ab.reshape((2,) + tuple(ab.shape[-4:])), c.reshape((1,) + tuple(c.shape[-4:]))], dim=0).contiguous()
     if plan.term_shards > 1:

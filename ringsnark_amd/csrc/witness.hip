@@ -1639,12 +1639,20 @@ h_top_kernel(uint64_t *__restrict__ top, const uint64_t *__restrict__ d1, const 
 struct TabPtrs {
   const void *t[RS_MAX_L];  // tables of the context's arithmetic (8-byte words)
 };
+#ifndef RS_WORKSPACE_NT
+#define RS_WORKSPACE_NT 1
+#endif
 template <class T>
 struct GlobalIOT {
   T *p;
   __device__ __forceinline__ int pbase(int) const { return 0; }
+#if RS_WORKSPACE_NT  // the multi-pass workspaces are streamed once per pass and are far larger than L2 and the Infinity Cache
+  __device__ __forceinline__ T load(int base, int, int eoff, int) const { return __builtin_nontemporal_load(p + base + eoff); }
+  __device__ __forceinline__ void store(int base, int, int eoff, int, T v) const { __builtin_nontemporal_store(v, p + base + eoff); }
+#else
   __device__ __forceinline__ T load(int base, int, int eoff, int) const { return p[base + eoff]; }
   __device__ __forceinline__ void store(int base, int, int eoff, int, T v) const { p[base + eoff] = v; }
+#endif
 };
 using GlobalF64IO = GlobalIOT<double>;
 

@@ -1013,7 +1013,7 @@ static void launch_mac(rs_ctx *ctx, const MacArgs &a, const MsmScratch &sc, hipS
   RS_HIP(hipGetLastError());
 }
 
-extern int g_mac_variant, g_mac_ablate, g_plain_variant;
+extern int g_mac_variant, g_mac_ablate, g_plain_variant, g_mac_chunk_units;
 static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, hipStream_t st) {
   const size_t lds = (padded_len((size_t)ctx->N_enc) + (size_t)ctx->N_enc) * sizeof(double);
   const int rows = a.n_chunks * ctx->L;
@@ -1082,6 +1082,7 @@ static void launch_mac_v3(rs_ctx *ctx, const MacArgs3 &a, const MsmScratch &sc, 
 }
 
 int g_mac_ablate = 0;
+int g_mac_chunk_units = 768;  // tuning knob "mac_chunk_units": (limb, prime, chunk) units per MAC launch (term chunks = units / (L K))
 int g_plain_variant = 1;  // 1: plain_center_wide_kernel at N_enc = 8192; 0: plain_center_kernel
 int g_mac_variant = 5;  // 5: half-spectrum wide kernel at N_enc = 8192 (else as 3); 3: streaming kernel, 1024-thread shape at N_enc = 8192 (else as 2); 2: 512-thread streaming kernel; 1: generic kernel
 
@@ -1157,7 +1158,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     RS_REQUIRE(crs_window % tile_terms == 0, "crs_window must be a multiple of the term tile (use a power of two)");
   }
   auto crs_at = [&](int c, size_t t0) { return d_crs[c] + (crs_window ? t0 % crs_window : t0) * enc_words; };
-  int n_chunks = (int)std::min<size_t>(tile_terms, (size_t)std::max(1, (768 + L * K - 1) / (L * K)));
+  int n_chunks = (int)std::min<size_t>(tile_terms, (size_t)std::max(1, (g_mac_chunk_units + L * K - 1) / (L * K)));
   if (Tmax == 0) n_chunks = 1;
   Lift *d_C = (Lift *)ws_get(ctx, 0, std::max<size_t>(256, tile_terms * c_bytes_per_term));
   uint64_t *d_partial = (uint64_t *)ws_get(ctx, 1, (size_t)n_chunks * n_sets * enc_words * sizeof(uint64_t));

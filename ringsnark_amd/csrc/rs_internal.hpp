@@ -244,7 +244,7 @@ inline hipStream_t S(rs_stream s) { return (hipStream_t)s; }
 
 // launch helpers implemented in the .hip files
 void msm_scratch_release(rs_ctx *ctx);  // msm.hip
-extern int g_mac_variant, g_mac_ablate, g_plain_variant;  // msm.hip tuning knobs
+extern int g_mac_variant, g_mac_ablate, g_plain_variant, g_mac_chunk_units;  // msm.hip tuning knobs
 extern int g_witness_force_bc;             // witness.hip: cap on the transform length (block-convolution path)
 extern int g_witness_sub_ct;              // witness.hip: compile-time-length sub-transform kernel
 extern int g_witness_tree_ct;             // witness.hip: level-unrolled product-tree kernel

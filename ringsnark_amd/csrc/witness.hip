@@ -1089,14 +1089,27 @@ tree_wide_kernel(double *__restrict__ cols, int logM, size_t col0, unsigned S, u
   const Mod mod = P.mod;
   const size_t M = (size_t)1 << logM;
   double *c = cols + col * M + pos0;
+  const int wave = t >> 6, lane = t & 63;
   {
+    // The tile enters and leaves through the LDS tile in wave-sized transposes: a wave's 64 threads own 2048
+    // consecutive coefficients, which it moves with fully coalesced 16-byte accesses (a thread reading or writing its
+    // own 256-byte run directly touches each 128-byte line with eight separate 16-byte accesses: measured 4.8x the
+    // written bytes at the memory interface).
+    {
+      const double2 *src = reinterpret_cast<const double2 *>(c + 2048 * wave) + lane;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const double2 v = src[64 * i];
+        const int pa = tw_addr(2048 * wave + 128 * i + 2 * lane);
+        s[pa] = v.x;
+        s[pa + 1] = v.y;
+      }
+    }
+    wave_sync();
     double r[32];
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-      const double2 v = reinterpret_cast<const double2 *>(c + 32 * t)[q];
-      r[2 * q] = v.x;
-      r[2 * q + 1] = v.y;
-    }
+    for (int e = 0; e < 32; e++) r[e] = s[33 * t + e];
+    wave_sync();
     // levels 1..4 (schoolbook) on the two 16-coefficient halves
     {
       double v[16];
@@ -1128,9 +1141,14 @@ tree_wide_kernel(double *__restrict__ cols, int logM, size_t col0, unsigned S, u
   tree_wide_level_big<11>(s, P, mod, P.dhat + (size_t)11 * M + pos0, t);
   tree_wide_level_big<12>(s, P, mod, P.dhat + (size_t)12 * M + pos0, t);
   tree_wide_level_big<13>(s, P, mod, P.dhat + (size_t)13 * M + pos0, t);
+  {  // level 13 ended with a workgroup barrier: every coefficient of the tile is final
+    double2 *dst = reinterpret_cast<double2 *>(c + 2048 * wave) + lane;
 #pragma unroll
-  for (int q = 0; q < 16; q++)
-    reinterpret_cast<double2 *>(c + 32 * t)[q] = make_double2(canon(s[33 * t + 2 * q], mod), canon(s[33 * t + 2 * q + 1], mod));
+    for (int i = 0; i < 16; i++) {
+      const int pa = tw_addr(2048 * wave + 128 * i + 2 * lane);
+      dst[64 * i] = make_double2(canon(s[pa], mod), canon(s[pa + 1], mod));
+    }
+  }
 }
 
 // H = quo(A*B, Z) per column + the ZK patch of r1cs_to_qrp.tcc:230-235.  The reference divides

@@ -896,9 +896,24 @@ __device__ __forceinline__ void tree_wide_mid_tw_inv(const ColPlan &P, int u, do
 }
 // The middle of a level on the consecutive layout: forward stages l-5..l-1, product with the spectrum of D_left,
 // inverse stages 0..4.  u = thread index inside the node (0 for l = 5), b = the thread's 32 coefficients.
+// dh_wave: the level's table at the first coefficient of the WAVE (2048 consecutive entries for its 64 threads); they are
+// fetched with coalesced 16-byte loads and handed to their owners through the wave's own (at this point free) region of
+// the tile -- a thread fetching its own 256-byte run touches 64 different lines per instruction.
 template <int LV, bool ZU>
-__device__ __forceinline__ void tree_wide_middle(double (&b)[32], const ColPlan &P, const Mod mod, const double *__restrict__ dh, int u) {
+__device__ __forceinline__ void tree_wide_middle(double (&b)[32], double *s, const ColPlan &P, const Mod mod,
+                                                 const double *__restrict__ dh_wave, int u) {
   constexpr int c = LV - 5;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  {
+    const double2 *src = reinterpret_cast<const double2 *>(dh_wave) + lane;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const double2 v = src[64 * i];
+      const int pa = tw_addr(2048 * wave + 128 * i + 2 * lane);
+      s[pa] = v.x;
+      s[pa + 1] = v.y;
+    }
+  }
   const uint32_t fmask = P.fmask[LV] >> c, imask = P.imask[LV];
   double w[31];
   tree_wide_mid_tw_fwd<LV>(P, u, w);
@@ -906,13 +921,9 @@ __device__ __forceinline__ void tree_wide_middle(double (&b)[32], const ColPlan 
     reg_fwd_stages_zu<5>(b, mod, fmask, [&](int k, int blk) { return w[(1 << k) - 1 + blk]; });
   else
     reg_fwd_stages<5, true>(b, mod, fmask, [&](int k, int blk) { return w[(1 << k) - 1 + blk]; });
+  wave_sync();
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    double d[8];
-    tw_run<8>(dh + 8 * q, d);
-#pragma unroll
-    for (int e = 0; e < 8; e++) b[8 * q + e] = mulmod(reduce(b[8 * q + e], mod), d[e], mod);
-  }
+  for (int e = 0; e < 32; e++) b[e] = mulmod(reduce(b[e], mod), s[33 * t + e], mod);
   tree_wide_mid_tw_inv<LV>(P, u, w);
   reg_inv_stages<5, true>(b, mod, imask, [&](int k, int i) { return w[32 - (32 >> k) + i]; });
 }
@@ -945,7 +956,7 @@ __device__ __forceinline__ void tree_wide_level(double *s, const ColPlan &P, con
     double b[32];
 #pragma unroll
     for (int e = 0; e < 32; e++) b[e] = s[33 * t + e];
-    tree_wide_middle<LV, false>(b, P, mod, dh_tile + 32 * t, u);
+    tree_wide_middle<LV, false>(b, s, P, mod, dh_tile + 2048 * (t >> 6), u);
 #pragma unroll
     for (int e = 0; e < 32; e++) s[33 * t + e] = b[e];
   }
@@ -1016,7 +1027,7 @@ __device__ __forceinline__ void tree_wide_level_big(double *s, const ColPlan &P,
     double b[32];
 #pragma unroll
     for (int e = 0; e < 32; e++) b[e] = s[33 * t + e];
-    tree_wide_middle<LV, false>(b, P, mod, dh_tile + 32 * t, a);
+    tree_wide_middle<LV, false>(b, s, P, mod, dh_tile + 2048 * (t >> 6), a);
 #pragma unroll
     for (int e = 0; e < 32; e++) s[33 * t + e] = b[e];
   }
@@ -1127,7 +1138,7 @@ tree_wide_kernel(double *__restrict__ cols, int logM, size_t col0, unsigned S, u
       double b[32];
 #pragma unroll
       for (int e = 0; e < 16; e++) b[e] = r[16 + e];
-      tree_wide_middle<5, true>(b, P, mod, P.dhat + (size_t)5 * M + pos0 + 32 * t, 0);
+      tree_wide_middle<5, true>(b, s, P, mod, P.dhat + (size_t)5 * M + pos0 + 2048 * wave, 0);
 #pragma unroll
       for (int e = 0; e < 32; e++) s[33 * t + e] = reduce(b[e] + (e < 16 ? r[e] : 0.0), mod);
     }

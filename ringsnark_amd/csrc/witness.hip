@@ -2015,15 +2015,32 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
         continue;
       }
       {
-        double tb[16];
+        // The table entries of the wave's 64 groups are 1024 consecutive words: fetched with coalesced 16-byte loads
+        // and handed to their owners through the wave's range of the tile, which is free once x has been read (a
+        // thread fetching its own 128-byte run touches 64 different lines per instruction).
+        const double *tab = (MODE == 2) ? static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * S::N
+                                        : static_cast<const double *>(tabs.t[0]) + blk * (size_t)S::N;
+        const int wave = t >> 6, lane = t & 63;
+        const int r0 = (j * 256 + wave * 64) * 16;
+        const int p0 = S::px(r0 + 2 * lane);
+        const double2 *t2 = reinterpret_cast<const double2 *>(tab + r0) + lane;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+#ifdef RS_SUBW_ABLATE_TW
+          const double2 v2 = make_double2(3.0 + i, 5.0 + lane);
+#else
+          const double2 v2 = t2[64 * i];
+#endif
+          s[p0 + S::px128(i)] = v2.x;
+          s[p0 + S::px128(i) + 1] = v2.y;
+        }
+        wave_sync();
         if (MODE == 2) {
-          SubTw::run<16>(static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * S::N + 16 * g, tb);
 #pragma unroll
-          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), tb[e], mod);
+          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), s[pb + e], mod);
         } else {
-          SubTw::run<16>(static_cast<const double *>(tabs.t[0]) + blk * (size_t)S::N + 16 * g, tb);
 #pragma unroll
-          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), reduce(tb[e], mod), mod);
+          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), reduce(s[pb + e], mod), mod);
         }
       }
       // inverse stage k of the block: twiddle itw[(n >> (k+1)) root + (position >> (k+1))]

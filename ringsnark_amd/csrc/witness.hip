@@ -23,6 +23,7 @@
 // Requires q_i = 1 mod 4M (cyclic NTT of length 2M) and M <= 8192 in this round.
 #include <algorithm>
 #include <cstring>
+#include <string>
 #include <type_traits>
 
 #include "ntt_core.hpp"
@@ -2281,6 +2282,17 @@ static double cross_words(const CrossArgs &a, bool special) {
   if (!INV) return n + (MODE == CS_FILL_RIGHT ? M / 2.0 : M);                  // source words + workspace written
   return n + (MODE == CD_COMBINE || MODE == CD_COMBINE_CANON ? 1.5 * M : M);  // workspace read + sink traffic
 }
+// profile name of one instantiation, as rocprofv3 prints it ("rs::cross_kernel<false, 4, 1, ..."): static storage
+static const char *cross_name(bool inv, int R, int mode) {
+  static std::mutex mu;
+  static std::map<int, std::string> names;
+  std::lock_guard<std::mutex> lk(mu);
+  const int key = (inv ? 1 : 0) | (R << 1) | (mode << 8);
+  auto it = names.find(key);
+  if (it == names.end())
+    it = names.emplace(key, std::string("cross_kernel<") + (inv ? "true" : "false") + ", " + std::to_string(R) + ", " + std::to_string(mode) + ",").first;
+  return it->second.c_str();
+}
 template <bool INV, int MODE, class M>
 static void launch_cross(rs_ctx *ctx, CrossArgs a, size_t ncols, int logB, const ColPlansT<M> &cp, hipStream_t st) {
   const int ncross = a.logsub - logB;
@@ -2292,7 +2304,7 @@ static void launch_cross(rs_ctx *ctx, CrossArgs a, size_t ncols, int logB, const
     const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>((groups >> R) / 256, 1024));
     const dim3 grid(gx, (unsigned)ncols);
     const bool special = INV ? (done + R >= ncross) : (done == 0);
-    ProfScope prof(ctx, st, "cross_kernel", (double)ncols * 8.0 * cross_words<INV, MODE>(a, special),
+    ProfScope prof(ctx, st, cross_name(INV, R, special ? MODE : 0), (double)ncols * 8.0 * cross_words<INV, MODE>(a, special),
                    (double)ncols * ntt_fp64((double)groups, R));
     if (special)
       launch_cross_pass<INV, MODE, M>(R, grid, a, cp, st);

@@ -1089,14 +1089,18 @@ __device__ __forceinline__ void tree_school16(double (&v)[16], int gpos, int log
   }
 }
 
-__global__ void __launch_bounds__(256, 2)
+// LOGT = 13: 256 threads, two workgroups per CU; LOGT = 14: 512 threads, one workgroup per CU (the same 8 waves per CU)
+// and one more level inside the tile -- one level less through the multi-pass transforms (two cross passes and a
+// sub-transform pass over the whole column workspace).
+template <int LOGT>
+__global__ void __launch_bounds__(1 << (LOGT - 5), 2)
 tree_wide_kernel(double *__restrict__ cols, int logM, size_t col0, unsigned S, unsigned slots_per_limb, ColPlans plans) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   const int t = threadIdx.x;
-  const unsigned nb = 1u << (logM - 13);
+  const unsigned nb = 1u << (logM - LOGT);
   const size_t col = blockIdx.x / nb;
-  const int pos0 = (int)(blockIdx.x % nb) << 13;
+  const int pos0 = (int)(blockIdx.x % nb) << LOGT;
   const ColPlan &P = plans.l[((col0 + col) % S) / slots_per_limb];
   const Mod mod = P.mod;
   const size_t M = (size_t)1 << logM;
@@ -1153,7 +1157,8 @@ tree_wide_kernel(double *__restrict__ cols, int logM, size_t col0, unsigned S, u
   tree_wide_level_big<11>(s, P, mod, P.dhat + (size_t)11 * M + pos0, t);
   tree_wide_level_big<12>(s, P, mod, P.dhat + (size_t)12 * M + pos0, t);
   tree_wide_level_big<13>(s, P, mod, P.dhat + (size_t)13 * M + pos0, t);
-  {  // level 13 ended with a workgroup barrier: every coefficient of the tile is final
+  if (LOGT >= 14) tree_wide_level_big<(LOGT >= 14 ? 14 : 13)>(s, P, mod, P.dhat + (size_t)14 * M + pos0, t);
+  {  // the last level ended with a workgroup barrier: every coefficient of the tile is final
     double2 *dst = reinterpret_cast<double2 *>(c + 2048 * wave) + lane;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -2166,6 +2171,7 @@ static ColPlansT<M> make_colplans(rs_ctx *ctx, const WitnessPlan *P, int limb0 =
 static int col_threads(size_t M) { return (int)std::max<size_t>(64, std::min<size_t>(1024, M / 8)); }
 
 int g_witness_lds_logM = 13;  // columns up to 2^13 run entirely inside one LDS tile
+int g_witness_tree_log = 14;  // largest tile of the wide product-tree kernel: 13 or 14 (tuning knob "witness_tree_log")
 int g_witness_tree_ct = 2;    // 2: wide product-tree kernel (tree_wide_kernel) for 2^13 tiles; 1: level-unrolled tree_columns_kernel; 0: level loop
 int g_witness_sub_ct = 2;     // 1: compile-time-length sub-transform kernel for 2^13 blocks of the multi-pass path
 
@@ -2187,14 +2193,15 @@ static void launch_tree_tiles(rs_ctx *ctx, double *cols, size_t ncols, size_t co
   const double newton_fp64 = newton ? 4.0 * ntt_fp64((double)T, logT) + 31.0 * (double)T : 0.0;
   // names as rocprofv3 prints them (a prefix of "rs::<name>") so that profiles/ and the live record can be joined
   const bool ct13 = logT == 13 && g_witness_tree_ct;
-  const char *pname = (ct13 && !newton && g_witness_tree_ct == 2) ? "tree_wide_kernel"
+  const bool wide = !newton && g_witness_tree_ct == 2 && (logT == 13 || logT == 14);
+  const char *pname = wide ? (logT == 14 ? "tree_wide_kernel<14>" : "tree_wide_kernel<13>")
                       : ct13 ? (newton ? "tree_columns_kernel<512, 13, true>" : "tree_columns_kernel<512, 13, false>")
                            : (newton ? "tree_columns_kernel<NEWTON>" : "tree_columns_kernel");
   ProfScope prof(ctx, st, pname, tiles * (double)T * 16.0, tiles * (tree_fp64((double)T, logT) + newton_fp64));
   const size_t lds1 = padded_len(T) * sizeof(double);
   const unsigned grid = (unsigned)(ncols << (logM - logT));
   const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, T / 16));  // 1024 only for a 2^14 tile (one workgroup per CU)
-  RS_REQUIRE(T / thr <= 16 && logT >= 6, "tree tile out of range");
+  RS_REQUIRE(wide || (T / thr <= 16 && logT >= 6), "tree tile out of range");
   RS_REQUIRE(!newton || logT == logM, "fused Newton conversion needs single-tile columns");
 #define RS_TREE_LAUNCH_K(KERN)                                                                                   \
   do {                                                                                                           \
@@ -2209,10 +2216,15 @@ static void launch_tree_tiles(rs_ctx *ctx, double *cols, size_t ncols, size_t co
     else                                                             \
       RS_TREE_LAUNCH_K((tree_columns_kernel<THR, 0, false>));        \
   } while (0)
-  if (logT == 13 && !newton && g_witness_tree_ct == 2) {
-    const int wl = (int)((8192 + 256) * sizeof(double));
-    RS_HIP(hipFuncSetAttribute((const void *)tree_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
-    hipLaunchKernelGGL(tree_wide_kernel, dim3(grid), dim3(256), wl, st, cols, logM, col0, (unsigned)S, (unsigned)slots_per_limb, cp);
+  if (wide) {
+    const int wl = (int)((T + T / 32) * sizeof(double));
+    if (logT == 14) {
+      RS_HIP(hipFuncSetAttribute((const void *)tree_wide_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+      hipLaunchKernelGGL(tree_wide_kernel<14>, dim3(grid), dim3(512), wl, st, cols, logM, col0, (unsigned)S, (unsigned)slots_per_limb, cp);
+    } else {
+      RS_HIP(hipFuncSetAttribute((const void *)tree_wide_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+      hipLaunchKernelGGL(tree_wide_kernel<13>, dim3(grid), dim3(256), wl, st, cols, logM, col0, (unsigned)S, (unsigned)slots_per_limb, cp);
+    }
   } else if (thr == 512 && logT == 13 && g_witness_tree_ct) {
     if (newton)
       RS_TREE_LAUNCH_K((tree_columns_kernel<512, 13, true>));
@@ -2511,14 +2523,17 @@ static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp
   for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_ehat;
   launch_sub<2, M>(ctx, W, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * Mlen) >> logB, S, spl, cp, st);
   launch_cross<true, CD_TAKE_LOW, M>(ctx, a, ncols, logB, cp, st);
-  // product tree: levels <= logB inside LDS tiles
-  if constexpr (FP)
-    launch_tree_tiles(ctx, X, ncols, col0, logM, logB, S, spl, cp, st);
-  else
+  // product tree: levels <= logTree inside LDS tiles (the wide kernel takes 2^14 tiles: one multi-pass level less)
+  int logTree = logB;
+  if constexpr (FP) {
+    if (logB == 13 && logM >= 15 && g_witness_tree_ct == 2 && g_witness_tree_log >= 14) logTree = 14;
+    launch_tree_tiles(ctx, X, ncols, col0, logM, logTree, S, spl, cp, st);
+  } else {
     launch_tree_tiles_generic<M>(ctx, X, ncols, col0, logM, logB, S, spl, cp, st);
+  }
   // levels above: F_node = F_left + D_left * F_right with multi-pass transforms of length 2^l
   a.logtot = logM;
-  for (int l = logB + 1; l <= logM; l++) {
+  for (int l = logTree + 1; l <= logM; l++) {
     a.l = l;
     a.logsub = l;
     launch_cross<false, CS_FILL_RIGHT, M>(ctx, a, ncols, logB, cp, st);

@@ -624,13 +624,15 @@ def test_multipass_tuned_sub_transform_kernel_equals_generic(m, zk):
     # the product-tree kernels of the 2^13 tiles: level loop not unrolled (0), wave-private radix-8 (1), wide (2)
     from ringsnark_amd.witness_knobs import TREE_CT_DEFAULT
     try:
-        for variant in (0, 1, 2):
+        for variant, tile in ((0, 13), (1, 13), (2, 13), (2, 14)):  # the wide kernel on 2^13 and on 2^14 tiles
             _set_tuning(b"witness_tree_ct", variant)
+            _set_tuning(b"witness_tree_log", tile)
             got = {k: host(v) for k, v in dev.witness_map(dcs, asg, *ds).items() if k in keys}
             for k in keys:
-                assert (got[k] == runs[0][k]).all(), ("tree", variant, k)
+                assert (got[k] == runs[0][k]).all(), ("tree", variant, tile, k)
     finally:
         _set_tuning(b"witness_tree_ct", TREE_CT_DEFAULT)
+        _set_tuning(b"witness_tree_log", 14)
 
 
 def test_multipass_production_tile_matches_oracle_on_a_few_slots():

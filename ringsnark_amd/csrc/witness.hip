@@ -1698,7 +1698,7 @@ using GlobalF64IO = GlobalIOT<double>;
 // extraction).  Every other pass works in place on the workspace.  This removes the separate
 // element-wise launches (and their HBM round trips) around every multi-pass transform.
 enum CrossSrc { CS_PLAIN = 0, CS_SCALE_PAD, CS_FILL_RIGHT, CS_PAD_CENTER, CS_REV_TRUNC };
-enum CrossDst { CD_PLAIN = 0, CD_TAKE_LOW, CD_COMBINE, CD_COMBINE_CANON, CD_H_FINISH };
+enum CrossDst { CD_PLAIN = 0, CD_TAKE_LOW, CD_COMBINE, CD_COMBINE_CANON, CD_H_FINISH, CD_H_FINISH_CANON };
 struct CrossArgs {
   void *W;          // workspace columns [ncols][2^logtot]   (8-byte words of the context's arithmetic)
   const void *src;  // source columns (CS_*): [ncols][M] (CS_REV_TRUNC: [ncols][2M])
@@ -1741,6 +1741,11 @@ struct CrossOut {
       p[k] = DST == CD_COMBINE_CANON ? canon(f, mod) : f;
     } else if (DST == CD_H_FINISH) {  // H_j = U_{m-2-j}; positions j > m-2 are cleared by h_patch_kernel
       if (k <= m - 2) p[m - 2 - k] = reduce(v, mod);
+    } else if (DST == CD_H_FINISH_CANON) {  // no ZK patch to add: the finished column, canonical, zero above m-2
+      if (k <= m - 2)
+        p[m - 2 - k] = canon(v, mod);
+      else if (k < M)
+        p[k] = T(0);
     } else {
       p[k] = v;
     }
@@ -2581,6 +2586,10 @@ static void big_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, con
   for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_shat;
   launch_sub<2, M>(ctx, W1, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * Mlen) >> logB, S, spl, cp, st);
   a.dst = H;
+  if (!d1) {  // d1 = d2 = d3 = 0 (groth16.tcc:82-84): nothing to patch, the last pass writes the finished column
+    launch_cross<true, CD_H_FINISH_CANON, M>(ctx, a, ncols, logB, cp, st);
+    return;
+  }
   launch_cross<true, CD_H_FINISH, M>(ctx, a, ncols, logB, cp, st);
   const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((ncols * Mlen + 255) / 256, 256 * 16));
   ProfScope prof(ctx, st, "h_patch_kernel", (double)ncols * (double)Mlen * (d1 ? 32.0 : 16.0), d1 ? 24.0 * (double)ncols * (double)Mlen : 0.0);

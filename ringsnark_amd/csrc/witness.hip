@@ -2115,6 +2115,174 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
   }
 }
 
+// sub_ntt_wide_kernel at FOUR waves per SIMD (g_witness_sub_ct == 3): 512 threads x 16 coefficients per block of 2^13,
+// <= 128 registers, two workgroups (16 waves) per CU.  Forward rounds of 4, 3 and 2 stages, then the same fused middle
+// as the 32-coefficient form on 16 consecutive points (forward stages 9..12, table product, inverse stages 0..3), then
+// the mirror image: six tile exchanges instead of four, twice the waves to hide them behind.  Same stages, reduction
+// points and products: identical stored values.
+template <int MODE>
+__global__ void __launch_bounds__(512, 4)
+sub_ntt_wide16_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab_period, unsigned blocks_per_col, size_t col0,
+                      unsigned S_, unsigned slots_per_limb, ColPlans plans, unsigned long long nblocks) {
+  using S = WideShape<13>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int pt = t + (t >> 4);  // px(t), t < 512
+  double pre[16];
+  auto issue_loads = [&](unsigned long long b) {
+    const double *src = X + b * (size_t)S::N + t;
+#pragma unroll
+    for (int e = 0; e < 16; e++) pre[e] = src[512 * e];
+  };
+  unsigned long long blk = blockIdx.x;
+  if (blk < nblocks) issue_loads(blk);
+  for (; blk < nblocks; blk += gridDim.x) {
+    const size_t col = blk / blocks_per_col;
+    const int limb = (int)(((col0 + col) % S_) / slots_per_limb);
+    const ColPlan &P = plans.l[limb];
+    const Mod mod = P.mod;
+    const int root = (1 << log_n1) + (int)(blk & ((1u << log_n1) - 1));
+    const int logn = 13 + log_n1;
+    const uint32_t fmask = P.fmask[logn] >> log_n1, imask = P.imask[logn];
+    const double *__restrict__ tw = P.tw;
+    const double *__restrict__ itw = P.itw;
+    double v[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      v[e] = pre[e];
+      pin(v[e]);
+    }
+    mem_fence();
+    const unsigned long long bn = blk + gridDim.x;
+    if (bn < nblocks) issue_loads(bn);
+    mem_fence();
+    // ---- forward round 1: stages 0..3 on elements t + 512 e (uniform twiddles)
+    reg_fwd_stages<4, true>(v, mod, fmask, [&](int k, int b) { return tw[(root << k) + b]; });
+    __syncthreads();  // the previous block's last-round reads of the tile are done
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[pt + S::SP * e] = v[e];
+    __syncthreads();
+    // ---- forward round 2: stages 4..6 on hi*512 + lo + 64 e; hi = wave + 8 j is wave-uniform
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int hi = __builtin_amdgcn_readfirstlane(wave + 8 * j);
+      const int pb = hi * S::SP + lane + (lane >> 4);
+      double x[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) x[e] = s[pb + 68 * e];
+      reg_fwd_stages<3, true>(x, mod, fmask >> 4, [&](int k, int b) { return tw[(root << (4 + k)) + (hi << k) + b]; });
+#pragma unroll
+      for (int e = 0; e < 8; e++) s[pb + 68 * e] = x[e];
+    }
+    __syncthreads();
+    // ---- forward round 3: stages 7..8 on hi*64 + lo + 16 e
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int g = t + 512 * j, lo = g & 15, hi = g >> 4;
+      const int pb = hi * 68 + (hi >> 3) * 16 + lo;
+      double x[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) x[e] = s[pb + 17 * e];
+      const double w0 = tw[(root << 7) + hi];
+      const double2 w12 = reinterpret_cast<const double2 *>(tw + (root << 8) + (hi << 1))[0];
+      reg_fwd_stages<2, true>(x, mod, fmask >> 7, [&](int k, int b) { return k == 0 ? w0 : (b == 0 ? w12.x : w12.y); });
+#pragma unroll
+      for (int e = 0; e < 4; e++) s[pb + 17 * e] = x[e];
+    }
+    __syncthreads();
+    // ---- the middle on the 16 consecutive points of group t: forward stages 9..12, table product, inverse stages 0..3
+    {
+      const int pb = 17 * t + (t >> 5) * 16;  // px(16 t)
+      double w[15];
+      SubTw::run<1>(tw + (root << 9) + t, w);
+      SubTw::run<2>(tw + (root << 10) + (t << 1), w + 1);
+      SubTw::run<4>(tw + (root << 11) + (t << 2), w + 3);
+      SubTw::run<8>(tw + (root << 12) + (t << 3), w + 7);
+      double x[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) x[e] = s[pb + e];
+      reg_fwd_stages<4, true>(x, mod, fmask >> 9, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
+      if (MODE != 0) {
+        // the wave's 64 groups are 1024 consecutive table words: coalesced loads, handed over through its (free) range
+        const double *tab = (MODE == 2) ? static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * S::N
+                                        : static_cast<const double *>(tabs.t[0]) + blk * (size_t)S::N;
+        const int r0 = wave * 1024;
+        const int p0 = S::px(r0 + 2 * lane);
+        const double2 *t2 = reinterpret_cast<const double2 *>(tab + r0) + lane;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const double2 v2 = t2[64 * i];
+          s[p0 + S::px128(i)] = v2.x;
+          s[p0 + S::px128(i) + 1] = v2.y;
+        }
+        wave_sync();
+        if (MODE == 2) {
+#pragma unroll
+          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), s[pb + e], mod);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), reduce(s[pb + e], mod), mod);
+        }
+        SubTw::run<8>(itw + ((size_t)root << 12) + (t << 3), w);
+        SubTw::run<4>(itw + ((size_t)root << 11) + (t << 2), w + 8);
+        SubTw::run<2>(itw + ((size_t)root << 10) + (t << 1), w + 12);
+        SubTw::run<1>(itw + ((size_t)root << 9) + t, w + 14);
+        reg_inv_stages<4, true>(x, mod, imask, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[pb + e] = x[e];
+    }
+    if (MODE == 0) {  // forward only: every wave streams out the 1024 points its own groups cover
+      wave_sync();
+      const int r0 = wave * 1024;
+      const int p0 = S::px(r0 + 2 * lane);
+      double2 *d2 = reinterpret_cast<double2 *>(X + blk * (size_t)S::N + r0) + lane;
+#pragma unroll
+      for (int i = 0; i < 8; i++) d2[64 * i] = make_double2(s[p0 + S::px128(i)], s[p0 + S::px128(i) + 1]);
+      continue;
+    }
+    __syncthreads();
+    // ---- inverse round 3: stages 4..5 on hi*64 + lo + 16 e; block of stage 4+k: (hi << (1-k)) + (e >> (k+1)) of 256 >> k
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int g = t + 512 * j, lo = g & 15, hi = g >> 4;
+      const int pb = hi * 68 + (hi >> 3) * 16 + lo;
+      double x[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) x[e] = s[pb + 17 * e];
+      const double2 w01 = reinterpret_cast<const double2 *>(itw + ((size_t)root << 8) + (hi << 1))[0];
+      const double w2 = itw[((size_t)root << 7) + hi];
+      reg_inv_stages<2, true>(x, mod, imask >> 4, [&](int k, int i) { return k == 0 ? (i == 0 ? w01.x : w01.y) : w2; });
+#pragma unroll
+      for (int e = 0; e < 4; e++) s[pb + 17 * e] = x[e];
+    }
+    __syncthreads();
+    // ---- inverse round 2: stages 6..8 on hi*512 + lo + 64 e; block of stage 6+k: (hi << (2-k)) + (e >> (k+1)) of 64 >> k
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int hi = __builtin_amdgcn_readfirstlane(wave + 8 * j);
+      const int pb = hi * S::SP + lane + (lane >> 4);
+      double x[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) x[e] = s[pb + 68 * e];
+      reg_inv_stages<3, true>(x, mod, imask >> 6, [&](int k, int i) { return itw[((size_t)root << (6 - k)) + (hi << (2 - k)) + i]; });
+#pragma unroll
+      for (int e = 0; e < 8; e++) s[pb + 68 * e] = x[e];
+    }
+    __syncthreads();
+    // ---- inverse round 1: stages 9..12 on elements t + 512 e; block of stage 9+k: e >> (k+1) of 8 >> k
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = s[pt + S::SP * e];
+    reg_inv_stages<4, true>(v, mod, imask >> 9, [&](int k, int i) { return itw[((8 >> k) * root) + i]; });
+    {
+      double *dst = X + blk * (size_t)S::N + t;
+#pragma unroll
+      for (int e = 0; e < 16; e++) dst[512 * e] = v[e];
+    }
+  }
+}
+
 // ZK patch of the multi-pass H: H += d2*A + d1*B + d1*d2*Z, H[0] -= d3; then canonical form.
 template <class CPS>
 __global__ void __launch_bounds__(256)
@@ -2343,11 +2511,21 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
   static const char *const names_wide[4] = {"sub_ntt_wide_kernel<0>", "sub_ntt_wide_kernel<1>", "sub_ntt_wide_kernel<2>", "sub_ntt_wide_kernel<3>"};
   const bool ct = FP && logB == 13 && MODE != 1 && g_witness_sub_ct;
   const double Bn = (double)((size_t)1 << logB), blocks = (double)(ncols * bpc);
-  ProfScope prof(ctx, st, ct ? (g_witness_sub_ct == 2 ? names_wide[MODE] : names_ct[MODE]) : names[MODE], blocks * Bn * (MODE == 3 ? 24.0 : 16.0),
+  static const char *const names_w16[4] = {"sub_ntt_wide16_kernel<0>", "sub_ntt_wide16_kernel<1>", "sub_ntt_wide16_kernel<2>", "sub_ntt_wide16_kernel<3>"};
+  ProfScope prof(ctx, st, ct ? (g_witness_sub_ct == 3 ? names_w16[MODE] : g_witness_sub_ct == 2 ? names_wide[MODE] : names_ct[MODE]) : names[MODE], blocks * Bn * (MODE == 3 ? 24.0 : 16.0),
                  blocks * ((MODE >= 2 ? 2.0 : 1.0) * ntt_fp64(Bn, logB) + (MODE >= 2 ? 7.0 * Bn : 0.0)));
   static TabPtrs none{};
   const TabPtrs &tp = tabs ? *tabs : none;
   if constexpr (FP) {
+    if (logB == 13 && MODE != 1 && g_witness_sub_ct == 3) {
+      const int wl = (int)(WideShape<13>::TILE * sizeof(double));
+      const unsigned long long nb = (unsigned long long)(ncols * bpc);
+      RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_wide16_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+      hipLaunchKernelGGL((sub_ntt_wide16_kernel<MODE>), dim3((unsigned)std::min<unsigned long long>(nb, 512)), dim3(512), wl, st, X,
+                         logsub - logB, tp, (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp, nb);
+      RS_HIP(hipGetLastError());
+      return;
+    }
     if (logB == 13 && MODE != 1 && g_witness_sub_ct == 2) {
       const int wl = (int)(WideShape<13>::TILE * sizeof(double));
       const unsigned long long nb = (unsigned long long)(ncols * bpc);

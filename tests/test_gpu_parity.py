@@ -613,12 +613,12 @@ def test_multipass_tuned_sub_transform_kernel_equals_generic(m, zk):
     from ringsnark_amd.witness_knobs import SUB_CT_DEFAULT
     runs = {}
     try:
-        for variant in (0, 1, 2):  # generic, wave-private tuned (sub_ntt_ct_kernel), wide (sub_ntt_wide_kernel)
+        for variant in (0, 1, 2, 3):  # generic, wave-private tuned (sub_ntt_ct_kernel), wide (sub_ntt_wide_kernel), wide16
             _set_tuning(b"witness_sub_ct", variant)
             runs[variant] = {k: host(v) for k, v in dev.witness_map(dcs, asg, *ds).items() if k in keys}
     finally:
         _set_tuning(b"witness_sub_ct", SUB_CT_DEFAULT)
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         for k in keys:
             assert (runs[variant][k] == runs[0][k]).all(), (variant, k)
     # the product-tree kernels of the 2^13 tiles: level loop not unrolled (0), wave-private radix-8 (1), wide (2)

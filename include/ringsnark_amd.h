@@ -187,8 +187,9 @@ int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, ui
 /* ---- a10-a13: r1cs_to_qrp_witness_map (reductions/r1cs_to_qrp/r1cs_to_qrp.tcc:149-259) ----
  * Outputs in ring layout: A_io..C_mid [m][L][N], H [m+1][L][N]; h_Z [L][m+1] slot-constant
  * scalars (coefficients_for_Z).  d1,d2,d3: ring elements [L][N] or all NULL (zero).  Any output
- * pointer may be NULL to skip it.  Uses an exact quasi-linear algorithm when every q_i has the
- * 2-adicity for it (q_i = 1 mod 4*next_pow2(m)) and otherwise returns RS_ERR_UNSUPPORTED. */
+ * pointer may be NULL to skip it.  Exact quasi-linear algorithm: cyclic transforms of length 2*next_pow2(m) when
+ * every q_i has the 2-adicity for them (q_i = 1 mod 4*next_pow2(m)), otherwise block convolutions over the largest
+ * transform the primes support (same results). */
 int rs_witness_map(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_assignment, const uint64_t *d_d1,
                    const uint64_t *d_d2, const uint64_t *d_d3, uint64_t *d_A_io, uint64_t *d_B_io,
                    uint64_t *d_C_io, uint64_t *d_A_mid, uint64_t *d_B_mid, uint64_t *d_C_mid, uint64_t *d_H,

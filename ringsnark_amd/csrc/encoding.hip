@@ -162,6 +162,148 @@ encode_kernel(const uint64_t *__restrict__ rings, const uint64_t *__restrict__ s
   }
 }
 
+// ---- the same three kernels on the integer (Montgomery) arithmetic of intmod.hpp: contexts with a modulus >= 2^50.
+// Values are canonical residues; table constants are in Montgomery form (mulmod = data x constant, mulmod_dd = data x data).
+__global__ void __launch_bounds__(1024)
+decrypt_dot_kernel_int(const uint64_t *__restrict__ enc, const uint64_t *__restrict__ sk, uint64_t *__restrict__ V, int K, int logn,
+                       const NttTableI *__restrict__ coeff_tabs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t *s = reinterpret_cast<uint64_t *>(smem);
+  const int n = 1 << logn;
+  const size_t el = blockIdx.x;
+  const int j = blockIdx.y;
+  const NttTableI tab = coeff_tabs[j];
+  const ModI mod = tab.mod;
+  const uint64_t *c0 = enc + (el * 2 * K + j) * (size_t)n, *c1 = c0 + (size_t)K * n;
+  const uint64_t *sj = sk + (size_t)j * n;
+  for (int x = threadIdx.x; x < n; x += blockDim.x) s[pidx(x)] = addm(c0[x], mulmod_dd(c1[x], sj[x], mod), mod);
+  __syncthreads();
+  lds_ntt_inv(s, logn, tab.d_itw, 1, mod, 0u);
+  uint64_t *dst = V + (el * K + j) * (size_t)n;
+  for (int x = threadIdx.x; x < n; x += blockDim.x) dst[x] = mulmod(s[pidx(x)], tab.ninv, mod);
+}
+
+struct CrtConstsI {
+  int K;
+  ModI Qmod[RS_MAX_K];
+  uint64_t half[RS_MAX_K];                 // mixed-radix digits of floor(Q/2)
+  uint64_t prod_inv[RS_MAX_K];             // (prod_{i<k} Q_i)^-1 mod Q_k, Montgomery form
+  uint64_t Qi_mod_Qk[RS_MAX_K][RS_MAX_K];  // [i][k] = Q_i mod Q_k, Montgomery form
+};
+struct CrtLimbI {
+  ModI tmod;
+  uint64_t Qk_mod_t[RS_MAX_K];  // Montgomery form
+  uint64_t Q_mod_t;             // value
+};
+
+__global__ void __launch_bounds__(1024)
+crt_decode_kernel_int(const uint64_t *__restrict__ V, uint64_t *__restrict__ rings, int N, int L, int logn, CrtConstsI cc,
+                      const CrtLimbI *__restrict__ limbs, const uint32_t *__restrict__ index_map,
+                      const NttTableI *__restrict__ plain_tabs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t *s = reinterpret_cast<uint64_t *>(smem);
+  const int n = 1 << logn, K = cc.K;
+  const size_t el = blockIdx.x;
+  const int limb = (int)(el % (size_t)L);
+  const CrtLimbI cl = limbs[limb];
+  const NttTableI tab = plain_tabs[limb];
+  const ModI tmod = cl.tmod;
+  const uint64_t *v = V + el * (size_t)K * n;
+  for (int x = threadIdx.x; x < n; x += blockDim.x) {
+    uint64_t d[RS_MAX_K];
+    d[0] = v[x];
+    for (int k = 1; k < K; k++) {  // value = d0 + Q0*(d1 + Q1*(d2 + ...))
+      const ModI mk = cc.Qmod[k];
+      uint64_t acc = 0;
+      for (int i = k - 1; i >= 0; i--) acc = addm(mulmod(acc, cc.Qi_mod_Qk[i][k], mk), d[i] % mk.p, mk);
+      d[k] = mulmod(subm(v[(size_t)k * n + x], acc, mk), cc.prod_inv[k], mk);
+    }
+    bool upper = false;  // value > floor(Q/2)?
+    for (int k = K - 1; k >= 0; k--)
+      if (d[k] != cc.half[k]) {
+        upper = d[k] > cc.half[k];
+        break;
+      }
+    uint64_t r = 0;
+    for (int k = K - 1; k >= 0; k--) r = addm(mulmod(r, cl.Qk_mod_t[k], tmod), d[k] % tmod.p, tmod);
+    if (upper) r = subm(r, cl.Q_mod_t, tmod);
+    s[pidx(x)] = r;
+  }
+  __syncthreads();
+  lds_ntt_fwd(s, logn, tab.d_tw, 1, tmod, 0u);  // BatchEncoder::decode
+  uint64_t *dst = rings + el * (size_t)N;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) dst[i] = s[pidx((int)index_map[i])];
+}
+
+__global__ void __launch_bounds__(1024)
+encode_kernel_int(const uint64_t *__restrict__ rings, const uint64_t *__restrict__ sk, uint64_t *__restrict__ enc, uint64_t seed0,
+                  int N, int L, int K, int logn, const uint32_t *__restrict__ index_map, const NttTableI *__restrict__ plain_tabs,
+                  const NttTableI *__restrict__ coeff_tabs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t *s = reinterpret_cast<uint64_t *>(smem);
+  const int n = 1 << logn;
+  const size_t el = blockIdx.x;
+  const size_t elem = el / (size_t)L;
+  const int limb = (int)(el % (size_t)L), j = blockIdx.y;
+  const NttTableI pt = plain_tabs[limb], ct = coeff_tabs[j];
+  const ModI tmod = pt.mod, mod = ct.mod;
+  const uint64_t t = tmod.p, Q = mod.p;
+  const uint64_t seed = (seed0 + elem) * 1315423911ull + (uint64_t)limb + 1;
+  for (int p = threadIdx.x; p < n; p += blockDim.x) s[pidx(p)] = 0;
+  __syncthreads();
+  const uint64_t *src = rings + el * (size_t)N;
+  for (int x = threadIdx.x; x < N; x += blockDim.x) s[pidx((int)index_map[x])] = src[x];
+  __syncthreads();
+  lds_ntt_inv(s, logn, pt.d_itw, 1, tmod, 0u);
+  for (int p = threadIdx.x; p < n; p += blockDim.x) {
+    const uint64_t c = mulmod(s[pidx(p)], pt.ninv, tmod);
+    s[pidx(p)] = lift_residue(lift_centered(c, tmod), mod);
+  }
+  __syncthreads();
+  lds_ntt_fwd(s, logn, ct.d_tw, 1, mod, 0u);
+  uint64_t P[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int p = threadIdx.x + k * blockDim.x;
+    if (p < n) P[k] = s[pidx(p)];
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < n; p += blockDim.x) {
+    const int e = (int)(splitmix_at(seed, (uint64_t)p + 1) % 3) - 1;
+    s[pidx(p)] = e < 0 ? Q - 1 : (uint64_t)e;
+  }
+  __syncthreads();
+  lds_ntt_fwd(s, logn, ct.d_tw, 1, mod, 0u);
+  const uint64_t tq = t % Q;
+  uint64_t *c0 = enc + (el * 2 * K + j) * (size_t)n, *c1 = c0 + (size_t)K * n;
+  const uint64_t *sj = sk + (size_t)j * n;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int p = threadIdx.x + k * blockDim.x;
+    if (p < n) {
+      const uint64_t a = splitmix_at(seed, (uint64_t)n + (uint64_t)j * n + (uint64_t)p + 1) % Q;
+      const uint64_t as = mulmod_dd(a, sj[p], mod);
+      const uint64_t te = mulmod_dd(tq, s[pidx(p)], mod);
+      c1[p] = a;
+      c0[p] = subm(subm(P[k], as, mod), te, mod);
+    }
+  }
+}
+
+struct TabCopiesI {
+  NttTableI *d_plain = nullptr, *d_coeff = nullptr;
+  explicit TabCopiesI(rs_ctx *ctx) {
+    RS_HIP(hipMalloc(&d_plain, sizeof(NttTableI) * ctx->L));
+    RS_HIP(hipMemcpy(d_plain, ctx->plain_i, sizeof(NttTableI) * ctx->L, hipMemcpyHostToDevice));
+    RS_HIP(hipMalloc(&d_coeff, sizeof(NttTableI) * ctx->K));
+    RS_HIP(hipMemcpy(d_coeff, ctx->coeff_i, sizeof(NttTableI) * ctx->K, hipMemcpyHostToDevice));
+  }
+  ~TabCopiesI() {
+    (void)hipFree(d_plain);
+    (void)hipFree(d_coeff);
+  }
+};
+
 static int enc_threads(int logn) { return (int)std::max(64, std::min(1024, (1 << logn) / 8)); }
 
 // small device copies of the tables (allocated per call: generator / verifier paths are not hot)
@@ -194,13 +336,62 @@ extern "C" {
 
 int rs_enc_decode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size_t count, uint64_t *d_rings, rs_stream stream) {
   RS_API_BEGIN_CTX(ctx)
-  if (ctx->use_int)
-    throw Error(RS_ERR_UNSUPPORTED, "rs_enc_decode: setup / verifier-side entry points (SURVEY.md 8(f) f2, f3) run on the FP64 arithmetic only (all moduli < 2^50)");
   RS_REQUIRE(ctx && d_sk && d_enc && d_rings, "null argument");
   if (count == 0) return RS_OK;
   WsScope ws_scope(ctx, S(stream));
   const int L = ctx->L, K = ctx->K, n = ctx->N_enc;
   hipStream_t st = S(stream);
+  if (ctx->use_int) {  // the same composition on the integer arithmetic
+    using namespace host;
+    CrtConstsI cc;
+    memset(&cc, 0, sizeof(cc));
+    cc.K = K;
+    {
+      uint64_t carry = 0;
+      for (int k = K - 1; k >= 0; k--) {
+        const unsigned __int128 cur = (unsigned __int128)(ctx->Q[k] - 1) + (unsigned __int128)carry * ctx->Q[k];
+        cc.half[k] = (uint64_t)(cur >> 1);
+        carry = (uint64_t)(cur & 1);
+      }
+    }
+    for (int k = 0; k < K; k++) {
+      const uint64_t Qk = ctx->Q[k];
+      cc.Qmod[k] = HostArith<ModI>::make(Qk);
+      uint64_t prod = 1 % Qk;
+      for (int i = 0; i < k; i++) prod = mulmod(prod, ctx->Q[i] % Qk, Qk);
+      cc.prod_inv[k] = HostArith<ModI>::konst(k ? invmod(prod, Qk) : 1, Qk);
+      for (int i = 0; i < K; i++) cc.Qi_mod_Qk[i][k] = HostArith<ModI>::konst(ctx->Q[i] % Qk, Qk);
+    }
+    std::vector<CrtLimbI> hl(L);
+    for (int i = 0; i < L; i++) {
+      const uint64_t t = ctx->q[i];
+      memset(&hl[i], 0, sizeof(CrtLimbI));
+      hl[i].tmod = HostArith<ModI>::make(t);
+      uint64_t Qm = 1 % t;
+      for (int k = 0; k < K; k++) {
+        hl[i].Qk_mod_t[k] = HostArith<ModI>::konst(ctx->Q[k] % t, t);
+        Qm = mulmod(Qm, ctx->Q[k] % t, t);
+      }
+      hl[i].Q_mod_t = Qm;
+    }
+    CrtLimbI *d_limbs = nullptr;
+    RS_HIP(hipMalloc(&d_limbs, sizeof(CrtLimbI) * L));
+    RS_HIP(hipMemcpyAsync(d_limbs, hl.data(), sizeof(CrtLimbI) * L, hipMemcpyHostToDevice, st));
+    TabCopiesI tabs(ctx);
+    uint64_t *V = (uint64_t *)ws_get(ctx, 14, count * (size_t)L * K * n * sizeof(uint64_t));
+    const size_t lds = padded_len((size_t)n) * sizeof(uint64_t);
+    const int thr = enc_threads(ctx->logN_enc);
+    RS_HIP(hipFuncSetAttribute((const void *)decrypt_dot_kernel_int, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RS_HIP(hipFuncSetAttribute((const void *)crt_decode_kernel_int, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(decrypt_dot_kernel_int, dim3((unsigned)(count * L), K), dim3(thr), lds, st, d_enc, d_sk, V, K, ctx->logN_enc,
+                       tabs.d_coeff);
+    hipLaunchKernelGGL(crt_decode_kernel_int, dim3((unsigned)(count * L)), dim3(thr), lds, st, V, d_rings, ctx->N, L, ctx->logN_enc,
+                       cc, d_limbs, ctx->d_index_map, tabs.d_plain);
+    RS_HIP(hipGetLastError());
+    RS_HIP(hipStreamSynchronize(st));
+    (void)hipFree(d_limbs);
+    return RS_OK;
+  }
   // host constants of the CRT composition
   CrtConsts cc;
   memset(&cc, 0, sizeof(cc));
@@ -255,13 +446,22 @@ int rs_enc_decode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size
 int rs_enc_encode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_rings, size_t count, uint64_t seed, uint64_t *d_enc,
                   rs_stream stream) {
   RS_API_BEGIN_CTX(ctx)
-  if (ctx->use_int)
-    throw Error(RS_ERR_UNSUPPORTED, "rs_enc_encode: setup / verifier-side entry points (SURVEY.md 8(f) f2, f3) run on the FP64 arithmetic only (all moduli < 2^50)");
   RS_REQUIRE(ctx && d_sk && d_rings && d_enc, "null argument");
   if (count == 0) return RS_OK;
   RS_REQUIRE(ctx->N_enc <= 16 * 1024, "encoding degree out of range");
   WsScope ws_scope(ctx, S(stream));
   hipStream_t st = S(stream);
+  if (ctx->use_int) {
+    TabCopiesI tabs(ctx);
+    const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(uint64_t);
+    const int thr = std::max(enc_threads(ctx->logN_enc), ctx->N_enc / 16);
+    RS_HIP(hipFuncSetAttribute((const void *)encode_kernel_int, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(encode_kernel_int, dim3((unsigned)(count * ctx->L), ctx->K), dim3(thr), lds, st, d_rings, d_sk, d_enc, seed,
+                       ctx->N, ctx->L, ctx->K, ctx->logN_enc, ctx->d_index_map, tabs.d_plain, tabs.d_coeff);
+    RS_HIP(hipGetLastError());
+    RS_HIP(hipStreamSynchronize(st));
+    return RS_OK;
+  }
   TabCopies tabs(ctx);
   const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(double);
   const int thr = std::max(enc_threads(ctx->logN_enc), ctx->N_enc / 16);
@@ -435,6 +635,37 @@ lagrange_kernel(const uint64_t *__restrict__ s, uint64_t *__restrict__ Ht, uint6
   atomicMin(&hit[0], my_hit);
   atomicMax(&hit[1], my_hit);
 }
+__global__ void __launch_bounds__(256)
+lagrange_kernel_int(const uint64_t *__restrict__ s, uint64_t *__restrict__ Ht, uint64_t *__restrict__ U, uint64_t *__restrict__ Zt,
+                    const uint64_t *__restrict__ c /* [L][m], Montgomery form */, unsigned *__restrict__ hit, size_t m, int N, int L,
+                    const ModI *__restrict__ qmod) {
+  const size_t S = (size_t)L * N, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S) return;
+  const int limb = (int)(i / (size_t)N);
+  const ModI mod = qmod[limb];
+  const uint64_t sv = s[i];
+  unsigned my_hit = 0xFFFFFFFFu;
+  uint64_t suf = 1;
+  for (size_t j = m; j-- > 0;) {
+    U[j * S + i] = suf;
+    const uint64_t d = subm(sv, small_val((uint64_t)j, mod), mod);
+    if (d == 0) my_hit = (unsigned)j;
+    suf = mulmod_dd(suf, d, mod);
+  }
+  Zt[i] = suf;
+  uint64_t pre = 1, pw = 1;
+  for (size_t j = 0; j <= m; j++) {
+    Ht[j * S + i] = pw;
+    pw = mulmod_dd(pw, sv, mod);
+    if (j < m) {
+      const uint64_t v = mulmod_dd(pre, U[j * S + i], mod);
+      U[j * S + i] = mulmod(v, c[(size_t)limb * m + j], mod);
+      pre = mulmod_dd(pre, subm(sv, small_val((uint64_t)j, mod), mod), mod);
+    }
+  }
+  atomicMin(&hit[0], my_hit);
+  atomicMax(&hit[1], my_hit);
+}
 }  // namespace rs
 
 extern "C" {
@@ -442,8 +673,6 @@ extern "C" {
 int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, uint64_t *d_At, uint64_t *d_Bt, uint64_t *d_Ct,
                          uint64_t *d_Ht, uint64_t *d_Zt, rs_stream stream) {
   RS_API_BEGIN_CTX(ctx)
-  if (ctx->use_int)
-    throw Error(RS_ERR_UNSUPPORTED, "rs_instance_map_eval: setup / verifier-side entry points (SURVEY.md 8(f) f2, f3) run on the FP64 arithmetic only (all moduli < 2^50)");
   RS_REQUIRE(ctx && cs && d_s && d_At && d_Bt && d_Ct && d_Ht && d_Zt, "null argument");
   const size_t m = cs->m, SW = ctx->ring_words();
   const int L = ctx->L;
@@ -461,6 +690,7 @@ int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, ui
   guard.p.push_back(D);
   // slot-constant factors c_j = 1 / prod_{i != j} (j - i) = (-1)^(m-1-j) / (j! (m-1-j)!)
   std::vector<double> hc((size_t)L * m);
+  std::vector<uint64_t> hci(ctx->use_int ? (size_t)L * m : 0);  // the same constants for the integer arithmetic
   for (int l = 0; l < L; l++) {
     const uint64_t q = ctx->q[l];
     RS_REQUIRE(q > m, "ring prime too small for the evaluation domain");
@@ -471,6 +701,7 @@ int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, ui
       uint64_t v = host::invmod(host::mulmod(fact[j], fact[m - 1 - j], q), q);
       if ((m - 1 - j) & 1) v = v ? q - v : 0;
       hc[(size_t)l * m + j] = host::balanced(v, q);
+      if (ctx->use_int) hci[(size_t)l * m + j] = HostArith<ModI>::konst(v, q);
     }
   }
   double *d_c = nullptr;
@@ -481,10 +712,16 @@ int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, ui
   guard.p.push_back(d_hit);
   const unsigned hit0[2] = {0xFFFFFFFFu, 0u};
   unsigned hit[2];
-  RS_HIP(hipMemcpyAsync(d_c, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  static_assert(sizeof(double) == sizeof(uint64_t), "constant buffers are shared between the arithmetics");
+  RS_HIP(hipMemcpyAsync(d_c, ctx->use_int ? (const void *)hci.data() : (const void *)hc.data(), hc.size() * sizeof(double),
+                        hipMemcpyHostToDevice, st));
   RS_HIP(hipMemcpyAsync(d_hit, hit0, sizeof(hit0), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(lagrange_kernel, dim3((unsigned)((SW + 255) / 256)), dim3(256), 0, st, d_s, d_Ht, D, d_Zt, d_c, d_hit, m,
-                     ctx->N, L, ctx->d_qmod);
+  if (ctx->use_int)
+    hipLaunchKernelGGL(lagrange_kernel_int, dim3((unsigned)((SW + 255) / 256)), dim3(256), 0, st, d_s, d_Ht, D, d_Zt,
+                       reinterpret_cast<const uint64_t *>(d_c), d_hit, m, ctx->N, L, ctx->d_qmod_i);
+  else
+    hipLaunchKernelGGL(lagrange_kernel, dim3((unsigned)((SW + 255) / 256)), dim3(256), 0, st, d_s, d_Ht, D, d_Zt, d_c, d_hit, m,
+                       ctx->N, L, ctx->d_qmod);
   RS_HIP(hipGetLastError());
   RS_HIP(hipMemcpyAsync(hit, d_hit, sizeof(hit), hipMemcpyDeviceToHost, st));
   RS_HIP(hipStreamSynchronize(st));  // hc, hit

@@ -49,7 +49,7 @@ def test_oracle_rinocchio_generator_verifier_accept_and_reject():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["toy", "toy49", "C2"])
+@pytest.mark.parametrize("name", ["toy", "toy49", "C2", "toy54", "toy60"])  # toy54 / toy60: the integer (Montgomery) arithmetic
 def test_enc_encode_decode_match_oracle(name):
     from ringsnark_amd.device import Device, to_host
     prm = P.preset(name)
@@ -189,7 +189,7 @@ def test_wire_format_roundtrip_and_validation():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,m,kind", [("toy", 6, "chain"), ("toy49", 11, "wide")])
+@pytest.mark.parametrize("name,m,kind", [("toy", 6, "chain"), ("toy49", 11, "wide"), ("toy54", 9, "wide"), ("toy60", 7, "chain")])
 def test_instance_map_with_evaluation_matches_restatement(name, m, kind):
     """At/Bt/Ct/Ht/Zt on the device against the O(m^2) restatement of
     r1cs_to_qrp.tcc:76-116 (tests/snark_ref.py), bit for bit; only a point that IS a domain element is refused."""
@@ -208,7 +208,7 @@ def test_instance_map_with_evaluation_matches_restatement(name, m, kind):
     # s hitting a node in SOME slots is legal in the reference (evaluation_domain.tcc:24-39
     # only rejects s == domain element as a ring element, and computes products without dividing)
     hit = s.copy()
-    hit[1, 3] = m - 1
+    hit[prm.L - 1, 3] = m - 1  # the last limb (toy54 has one)
     hit[0, 5] = 0
     e = S.instance_map_with_evaluation(Rg, cs, hit)
     got = dev.instance_map_eval(dev.r1cs(cs), dev.put(hit))

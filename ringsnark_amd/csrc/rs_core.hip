@@ -312,7 +312,7 @@ ntt_fwd_stream_kernel(uint64_t *__restrict__ data, unsigned long long batch, int
   for (int i = threadIdx.x; i < n; i += 1024) twl[i] = tw[i];
   const int q = n >> 2;  // gap of the first radix-4 round
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int logb = logn - 4, bsz = 1 << logb, off = wave << logb;
+  const int logb = logn - 4, off = wave << logb;
   const LdsIO lds{s};
   const LdsBlockIO blk{s + pidx(off)};
   const Lanes wl = wave_lanes(true);

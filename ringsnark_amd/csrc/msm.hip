@@ -45,6 +45,7 @@ struct PlainGroup {
   unsigned *nz[MAX_GROUP_VECS];
   unsigned long long T[MAX_GROUP_VECS];
   int n;
+  MsmLin lin;  // optional extra vector in linear form (count == 0: none); wide plaintext kernel only
 };
 struct PlainArgs {
   PlainGroup g[MAX_GROUPS];
@@ -164,7 +165,8 @@ plain_center_kernel(PlainArgs args, typename ArithOf<M>::Lift *__restrict__ C, u
 struct PlainTwPtrs {
   const double *itw[RS_MAX_L];  // inverse twiddle tables of the ring primes (kernel-argument pointers: global loads)
 };
-template <bool MULTI, bool PAIRED, int NE>  // NE = N / 512: 16-byte coefficient pairs per thread (16 at N = 8192)
+// LIN: groups may carry a vector in linear form (MsmLin): its plaintext is accumulated from the encoded ring elements.
+template <bool MULTI, bool PAIRED, int NE, bool LIN = false>  // NE = N / 512: 16-byte coefficient pairs per thread (16 at N = 8192)
 __global__ void __launch_bounds__(256, 2)
 plain_center_wide_kernel(PlainArgs args, double *__restrict__ C, unsigned long long t0, unsigned long long tile_terms,
                          unsigned long long tt_count, int n_groups, int N, int L, const uint32_t *__restrict__ index_map,
@@ -328,6 +330,37 @@ plain_center_wide_kernel(PlainArgs args, double *__restrict__ C, unsigned long l
           acc[c][e] += lift_centered(canon(mulmod(a + b, ninv, mod), mod), mod);
           acc[c][e + 8] += lift_centered(canon(mulmod(a - b, w_last, mod), mod), mod);
         }
+      }
+    }
+    if (LIN && G.lin.count && term < G.lin.T) {
+      // plaintext of the linear-form vector: sum_e lv_e[term] * P_{k_e}, coefficient by coefficient (positions 2t+c + 512 e)
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        double a[2][8];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) a[c][e] = 0.0;
+        for (int x = 0; x < G.lin.count; x++) {
+          const double lv = center(G.lin.Lcols[((size_t)G.lin.col[x] * L + limb) * G.lin.Mlen + term], mod);
+          const u64x2 *pp = reinterpret_cast<const u64x2 *>(G.lin.P + ((size_t)G.lin.k[x] * L + limb) * (size_t)S::N) + t;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const u64x2 pv = pp[256 * (8 * half + e)];
+            a[0][e] += mulmod(from_u64(pv.x), lv, mod);
+            a[1][e] += mulmod(from_u64(pv.y), lv, mod);
+          }
+          if ((x & 3) == 3) {
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+              for (int e = 0; e < 8; e++) a[c][e] = reduce(a[c][e], mod);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) acc[c][8 * half + e] += lift_centered(canon(a[c][e], mod), mod);
       }
     }
     double *dst = C + (((size_t)g * tile_terms + tt) * L + limb) * (size_t)S::N;
@@ -1093,7 +1126,7 @@ int g_mac_variant = 5;  // 5: half-spectrum wide kernel at N_enc = 8192 (else as
 template <class M>
 static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
                           int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st,
-                          size_t crs_window) {
+                          size_t crs_window, const MsmLin *lin) {
   using Lift = typename ArithOf<M>::Lift;
   constexpr bool FP = std::is_same<M, Mod>::value;
   RS_REQUIRE(n_crs >= 1 && n_crs <= 2, "n_crs must be 1 or 2");
@@ -1147,6 +1180,16 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     }
   }
 
+  bool has_lin = false;
+  if (lin)
+    for (int g = 0; g < n_groups; g++)
+      if (lin[g].count > 0) {
+        RS_REQUIRE(lin[g].T <= crs_len && !h_used, "linear-form vector: too long, or used-term counts requested");
+        pa.g[g].lin = lin[g];
+        has_lin = true;
+        Tmax = std::max<size_t>(Tmax, (size_t)lin[g].T);
+        group_T[g] = std::max<size_t>(group_T[g], (size_t)lin[g].T);
+      }
   const int n_sets = n_crs * n_groups;
   // tiling: C workspace <= ~2 GiB
   const size_t c_bytes_per_term = (size_t)n_groups * L * n * sizeof(double);
@@ -1174,6 +1217,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     v3 = g_mac_variant == 5 && n == 8192;
     plain_wide = g_plain_variant == 1 && n == 8192 && (ctx->N == 8192 || ctx->N == 4096);
   }
+  RS_REQUIRE(!has_lin || plain_wide, "linear-form vectors need the wide plaintext kernel");
   const bool paired = v3 && plain_wide;  // row layout of this call: written by the plaintext kernel, read by the MAC
   bool multi = false;
   for (int g = 0; g < n_groups; g++) multi = multi || pa.g[g].n > 1;
@@ -1205,18 +1249,23 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
         PlainTwPtrs twp;
         memset(&twp, 0, sizeof(twp));
         for (int i = 0; i < L; i++) twp.itw[i] = ctx->plain[i].d_itw;
-#define RS_PLAIN_WIDE_NE(MULTI_, PAIRED_, NE_)                                                                                \
+#define RS_PLAIN_WIDE_NE(MULTI_, PAIRED_, NE_, LIN_)                                                                          \
   do {                                                                                                                        \
-    RS_HIP(hipFuncSetAttribute((const void *)plain_center_wide_kernel<MULTI_, PAIRED_, NE_>,                                  \
+    RS_HIP(hipFuncSetAttribute((const void *)plain_center_wide_kernel<MULTI_, PAIRED_, NE_, LIN_>,                            \
                                hipFuncAttributeMaxDynamicSharedMemorySize, wl));                                              \
-    hipLaunchKernelGGL((plain_center_wide_kernel<MULTI_, PAIRED_, NE_>), grid, dim3(256), wl, st, pa,                         \
+    hipLaunchKernelGGL((plain_center_wide_kernel<MULTI_, PAIRED_, NE_, LIN_>), grid, dim3(256), wl, st, pa,                   \
                        reinterpret_cast<double *>(d_C), (unsigned long long)t0, (unsigned long long)tile_terms,               \
                        (unsigned long long)tt, n_groups, ctx->N, L, ctx->d_index_map, sc.plain<Mod>(), twp);                  \
   } while (0)
-#define RS_PLAIN_WIDE(MULTI_, PAIRED_)                     \
-  do {                                                     \
-    if (ctx->N == 8192) RS_PLAIN_WIDE_NE(MULTI_, PAIRED_, 16); \
-    else RS_PLAIN_WIDE_NE(MULTI_, PAIRED_, 8);             \
+#define RS_PLAIN_WIDE(MULTI_, PAIRED_)                                  \
+  do {                                                                  \
+    if (ctx->N == 8192) {                                               \
+      if (has_lin) RS_PLAIN_WIDE_NE(MULTI_, PAIRED_, 16, true);         \
+      else RS_PLAIN_WIDE_NE(MULTI_, PAIRED_, 16, false);                \
+    } else {                                                            \
+      if (has_lin) RS_PLAIN_WIDE_NE(MULTI_, PAIRED_, 8, true);          \
+      else RS_PLAIN_WIDE_NE(MULTI_, PAIRED_, 8, false);                 \
+    }                                                                   \
   } while (0)
         if (multi && paired) RS_PLAIN_WIDE(true, true);
         else if (multi) RS_PLAIN_WIDE(true, false);
@@ -1394,9 +1443,28 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
 
 void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
              int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st,
-             size_t crs_window) {
-  RS_DISPATCH_ARITH(ctx, (msm_run_arith<Mod>(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, addends, h_used, st, crs_window)),
-                    (msm_run_arith<ModI>(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, addends, h_used, st, crs_window)));
+             size_t crs_window, const MsmLin *lin = nullptr) {
+  RS_DISPATCH_ARITH(ctx, (msm_run_arith<Mod>(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, addends, h_used, st, crs_window, lin)),
+                    (msm_run_arith<ModI>(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, addends, h_used, st, crs_window, lin)));
+}
+// can a call with linear-form vectors be served? (FP64 context on the wide plaintext kernel)
+bool msm_supports_lin(const rs_ctx *ctx) {
+  return !ctx->use_int && g_plain_variant == 1 && ctx->N_enc == 8192 && (ctx->N == 8192 || ctx->N == 4096);
+}
+void batch_encode_run(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, size_t count, hipStream_t st) {
+  if (!count) return;
+  MsmScratch &sc = scratch_for(ctx);
+  const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(double);
+  if (ctx->use_int) {
+    RS_HIP(hipFuncSetAttribute((const void *)batch_encode_kernel<ModI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(batch_encode_kernel<ModI>, dim3((unsigned)count, ctx->L), dim3(tile_threads(ctx->logN_enc)), lds, st, d_rings, d_plain,
+                       ctx->N, ctx->L, ctx->logN_enc, ctx->d_index_map, sc.plain<ModI>());
+  } else {
+    RS_HIP(hipFuncSetAttribute((const void *)batch_encode_kernel<Mod>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(batch_encode_kernel<Mod>, dim3((unsigned)count, ctx->L), dim3(tile_threads(ctx->logN_enc)), lds, st, d_rings, d_plain,
+                       ctx->N, ctx->L, ctx->logN_enc, ctx->d_index_map, sc.plain<Mod>());
+  }
+  RS_HIP(hipGetLastError());
 }
 
 void enc_add_run(rs_ctx *ctx, uint64_t *dst, const uint64_t *x, const uint64_t *y, size_t count, hipStream_t st) {
@@ -1417,20 +1485,7 @@ extern "C" {
 int rs_batch_encode(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, size_t count, rs_stream stream) {
   RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_rings && d_plain, "null argument");
-  if (count) {
-    MsmScratch &sc = scratch_for(ctx);
-    const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(double);
-    if (ctx->use_int) {
-      RS_HIP(hipFuncSetAttribute((const void *)batch_encode_kernel<ModI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(batch_encode_kernel<ModI>, dim3((unsigned)count, ctx->L), dim3(tile_threads(ctx->logN_enc)), lds,
-                         S(stream), d_rings, d_plain, ctx->N, ctx->L, ctx->logN_enc, ctx->d_index_map, sc.plain<ModI>());
-    } else {
-      RS_HIP(hipFuncSetAttribute((const void *)batch_encode_kernel<Mod>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(batch_encode_kernel<Mod>, dim3((unsigned)count, ctx->L), dim3(tile_threads(ctx->logN_enc)), lds,
-                         S(stream), d_rings, d_plain, ctx->N, ctx->L, ctx->logN_enc, ctx->d_index_map, sc.plain<Mod>());
-    }
-    RS_HIP(hipGetLastError());
-  }
+  batch_encode_run(ctx, d_rings, d_plain, count, S(stream));
   RS_API_END
 }
 

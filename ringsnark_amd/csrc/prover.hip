@@ -8,12 +8,25 @@
 namespace rs {
 void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
              int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st,
-             size_t crs_window);
+             size_t crs_window, const MsmLin *lin = nullptr);
+bool msm_supports_lin(const rs_ctx *ctx);
+void batch_encode_run(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, size_t count, hipStream_t st);
+bool witness_io_shortcut(const rs_r1cs *cs);
 void enc_add_run(rs_ctx *ctx, uint64_t *dst, const uint64_t *x, const uint64_t *y, size_t count, hipStream_t st);
 void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const uint64_t *d1, const uint64_t *d2,
                  const uint64_t *d3, uint64_t *const outs[7], uint64_t *h_Z, hipStream_t st, int slot0 = 0, int nslots = -1,
                  bool compact = false);
 void msm_scratch_release(rs_ctx *ctx);
+
+int g_prover_lin_io = 1;  // tuning knob "prover_lin_io": io vectors of groth16::prover as linear forms (MsmLin)
+
+__global__ void __launch_bounds__(256) fill_ones_kernel(uint64_t *p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 1;
+}
+static void fill_ones(rs_ctx *, uint64_t *p, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
+}
 
 struct PhaseTimer {
   rs_ctx *ctx;
@@ -107,15 +120,40 @@ int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, co
   // witness map (groth16.tcc:82-84: d1 = d2 = d3 = 0); C_io / C_mid are not consumed by the prover
   uint64_t *wbuf = (uint64_t *)ws_get(ctx, 8, (5 * m + 1) * rw * sizeof(uint64_t));
   uint64_t *A_io = wbuf, *A_mid = wbuf + m * rw, *B_io = wbuf + 2 * m * rw, *B_mid = wbuf + 3 * m * rw, *H = wbuf + 4 * m * rw;
-  uint64_t *outs[7] = {A_io, B_io, nullptr, A_mid, B_mid, nullptr, H};
+  // The io vectors are linear forms of the primary inputs (witness.hip): when the inner product can take them in that
+  // form (MsmLin) they are neither written by the witness map nor read and transformed by the inner product.
+  const size_t nk = cs->n_inputs + 1;  // [1, x_1 .. x_n_inputs]; their encodings are staged in the (then unused) io rows
+  const bool lin = g_prover_lin_io && msm_supports_lin(ctx) && witness_io_shortcut(cs) &&
+                   nk * std::max<size_t>(rw, (size_t)ctx->L * ctx->N_enc) <= m * rw;
+  uint64_t *outs[7] = {lin ? nullptr : A_io, lin ? nullptr : B_io, nullptr, A_mid, B_mid, nullptr, H};
   witness_run(ctx, cs, d_assignment, nullptr, nullptr, nullptr, outs, nullptr, st);
   pt.mark(1);
   // A = <s_pows, A_io> + <s_pows, A_mid> + alpha ; B likewise with beta   (groth16.tcc:89-103)
   {
     const uint64_t *crs[1] = {pk->d_s_pows};
-    rs_msm_vec v[4] = {{A_io, nullptr, m, 0}, {A_mid, nullptr, m, 0}, {B_io, nullptr, m, 1}, {B_mid, nullptr, m, 1}};
     const uint64_t *add[2] = {pk->d_alpha, pk->d_beta};
-    msm_run(ctx, crs, 1, m + 1, v, 4, 2, d_proof, add, nullptr, st, pk->window);
+    if (lin) {
+      // plaintexts of [1, x_1 .. x_n_inputs]: (n_inputs + 1) batch encodings, staged in the (unused) A_io rows
+      uint64_t *rings = A_io, *P = B_io;  // [nk][L][N] and [nk][L][N_enc] words
+      fill_ones(ctx, rings, rw, st);
+      if (cs->n_inputs) RS_HIP(hipMemcpyAsync(rings + rw, d_assignment, cs->n_inputs * rw * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+      batch_encode_run(ctx, rings, P, nk, st);
+      MsmLin ln[2];
+      for (int w = 0; w < 2; w++) {
+        ln[w].k = cs->d_io_k[w];
+        ln[w].col = cs->d_io_c[w];
+        ln[w].count = cs->io_count[w];
+        ln[w].Lcols = cs->d_io_cols;
+        ln[w].Mlen = cs->io_M;
+        ln[w].P = P;
+        ln[w].T = m;
+      }
+      rs_msm_vec v[2] = {{A_mid, nullptr, m, 0}, {B_mid, nullptr, m, 1}};
+      msm_run(ctx, crs, 1, m + 1, v, 2, 2, d_proof, add, nullptr, st, pk->window, ln);
+    } else {
+      rs_msm_vec v[4] = {{A_io, nullptr, m, 0}, {A_mid, nullptr, m, 0}, {B_io, nullptr, m, 1}, {B_mid, nullptr, m, 1}};
+      msm_run(ctx, crs, 1, m + 1, v, 4, 2, d_proof, add, nullptr, st, pk->window);
+    }
   }
   // C = <delta_ts, H> (+ <delta_mid, aux>)                                 (groth16.tcc:105-112)
   size_t used_h = 1, used_aux = 0;

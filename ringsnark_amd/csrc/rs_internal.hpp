@@ -131,6 +131,7 @@ struct rs_r1cs {
   double *d_io_cols = nullptr;  // [ncols][L][M]
   int *d_io_k[3] = {nullptr, nullptr, nullptr}, *d_io_c[3] = {nullptr, nullptr, nullptr};
   int io_count[3] = {0, 0, 0}, io_const_col[3] = {-1, -1, -1};
+  size_t io_M = 0;  // column length M of d_io_cols
 };
 
 struct rs_ctx {
@@ -211,6 +212,20 @@ struct DeviceGuard {
   }
 };
 // Times ONE kernel launch when profiling is on (no-op otherwise):  { ProfScope p(...); launch; }
+// A coefficient vector of an inner product given as a linear form instead of rows: vector[t] = sum_e lv_e[t] * r_{k_e}
+// (slot-wise), lv_e[t] = Lcols[(col_e * L + limb) * Mlen + t] slot-constant scalars and r_0 = 1, r_k = k-th ring element of
+// `rings` -- the io vectors of the witness map (witness.hip, "io vectors without interpolation").  The plaintext of such a
+// vector is the same linear form of the PLAINTEXTS of the r_k (the inverse transform is linear over Z_q), so the inner
+// product never materialises the rows nor transforms them: P = batch-encoded [1, r_1, ..] as [(nk)][L][N_enc] canonical words.
+struct MsmLin {
+  const int *k = nullptr, *col = nullptr;  // device arrays [count]
+  int count = 0;
+  const double *Lcols = nullptr;
+  size_t Mlen = 0;
+  const uint64_t *P = nullptr;
+  unsigned long long T = 0;  // terms
+};
+
 struct ProfScope {
   rs_ctx *ctx;
   hipStream_t st;
@@ -246,6 +261,7 @@ inline hipStream_t S(rs_stream s) { return (hipStream_t)s; }
 void msm_scratch_release(rs_ctx *ctx);  // msm.hip
 extern int g_mac_variant, g_mac_ablate, g_plain_variant, g_mac_chunk_units;  // msm.hip tuning knobs
 extern int g_witness_force_bc;             // witness.hip: cap on the transform length (block-convolution path)
+extern int g_prover_lin_io;               // prover.hip: io vectors as linear forms in groth16::prover
 extern int g_witness_tree_log;            // witness.hip: tile of the wide product-tree kernel (13 or 14)
 extern int g_witness_sub_ct;              // witness.hip: compile-time-length sub-transform kernel
 extern int g_witness_tree_ct;             // witness.hip: level-unrolled product-tree kernel

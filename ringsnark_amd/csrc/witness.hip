@@ -3023,6 +3023,9 @@ void r1cs_evaluate_run(rs_ctx *ctx, const rs_r1cs *cs, int which, int mode, cons
 }
 
 constexpr size_t IO_SHORTCUT_MAX_INPUTS = 64;
+// does the witness map of this system compute the io vectors as linear forms of the primary inputs (cs->d_io_* hold them
+// after the first witness_run)?
+bool witness_io_shortcut(const rs_r1cs *cs) { return cs->n_inputs <= IO_SHORTCUT_MAX_INPUTS; }
 
 // Per-circuit cache for the io shortcut: L_k = interp(column k of X), k = 0 (constant) .. n_inputs.
 template <class M_>
@@ -3075,6 +3078,7 @@ static void build_io_cache(rs_ctx *ctx, const rs_r1cs *cs, const WitnessPlan *P,
       RS_HIP(hipMemcpy(mc->d_io_c[w], hc[w].data(), hc[w].size() * sizeof(int), hipMemcpyHostToDevice));
     }
   }
+  mc->io_M = M;
   mc->io_built = true;
 }
 

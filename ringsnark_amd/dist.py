@@ -227,6 +227,12 @@ def groth16_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_loc
 
     *_local hold only this rank's limbs.  Returns the full proof [3][L][2][K][N_enc] (int64) on
     every rank."""
+    if plan.term_shards == 1 and hasattr(backend, "groth16_prove_local"):
+        # limbs only: this rank's limbs of the proof are an ordinary proof over its own context (the fused device prover,
+        # rs_groth16_prove), and nothing is exchanged before the proof is assembled
+        piece = backend.groth16_prove_local(cs_local, pk_local, assignment_local)
+        if piece is not None:
+            return _gather_limbs(plan, piece.contiguous(), 3)
     rng_ab = lambda s: plan.term_range(m, s)
     rng_h = lambda s: plan.term_range(m + 1, s)
     w, finish = sharded_witness(backend, plan, term_group, cs_local, assignment_local, ("A_io", "A_mid", "B_io", "B_mid", "H"),
@@ -346,6 +352,25 @@ class DeviceBackend:
         if addends is not None:
             out = torch.stack([torch.stack([self.dev.enc_add(out[c][g], addends[g]) for g in range(n_groups)]) for c in range(len(crs_list))])
         return out, used
+
+    def groth16_prove_local(self, dcs, pk_local, assignment):
+        """The whole prover on this rank's context (rs_groth16_prove); None when the key vectors are not whole,
+        equally windowed vectors (then the caller runs the piecewise plan)."""
+        vecs = {k: pk_local.get(k) for k in ("s_pows", "delta_ts", "delta_mid")}
+        windows, stores = set(), {}
+        for k, v in vecs.items():
+            if isinstance(v, TiledKey):
+                if v.lo != 0 or v.hi != v.T:
+                    return None
+                windows.add(v.window)
+                stores[k] = v.store
+            else:
+                windows.add(0)
+                stores[k] = v
+        if len(windows) != 1:
+            return None
+        pk1 = dict(stores, alpha=pk_local["alpha"], beta=pk_local["beta"])
+        return self.dev.groth16_prove(dcs, pk1, assignment, want_empty=False, window=windows.pop())[0]
 
     def enc_add(self, a, b):
         return self.dev.enc_add(a.contiguous(), b.contiguous())

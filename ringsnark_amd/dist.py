@@ -20,6 +20,7 @@ Sharding:
 gloo with an oracle-backed stand-in to check the sharding and the collectives).
 """
 import math
+import os
 from collections import namedtuple
 from dataclasses import dataclass
 from typing import List
@@ -163,6 +164,17 @@ def _p2p(ops_send, ops_recv, group):
     _p2p_start(ops_send, ops_recv, group)()
 
 
+# How the ranks of one limb group (N > L: two ranks per limb at N = 8) share the witness map:
+#   "replicate" (default)  each runs it whole and keeps its term range: no exchange.  Per rank at the headline and N = 8:
+#                          134 ms of witness map + 24 ms of inner products.
+#   "slots"                each maps half the NTT slots (67 ms), then one batch of point-to-point transfers re-shards the
+#                          five coefficient vectors from slots to terms: 5.4 GiB per rank each way over ONE xGMI link
+#                          (>= 75 ms at the link's 76.8 GB/s per direction) -- it pays only if the exchange sustains
+#                          more than ~85 GB/s, which no measurement supports yet.
+WITNESS_SPLIT = os.environ.get("RINGSNARK_WITNESS_SPLIT", "replicate")
+assert WITNESS_SPLIT in ("replicate", "slots")
+
+
 def sharded_witness(backend, plan: ShardPlan, group, cs_local, assignment_local, want, ranges, ds=(None, None, None), defer=False):
     """The witness map of this rank's limbs, returned TERM-sharded: {k: rows [lo_k, hi_k) of vector k, all N
     slots}, plus "Z" (host array [L_local][m+1]).  ranges[k] = function shard -> (lo, hi) of vector k.
@@ -170,9 +182,11 @@ def sharded_witness(backend, plan: ShardPlan, group, cs_local, assignment_local,
     (rs_witness_map_slots) and one batch of point-to-point transfers re-shards slots -> terms.
     defer=True: returns (out, finish); the vectors are complete only after finish() -- work that does not read them
     (the inner product over the auxiliary inputs) goes in between and overlaps the exchange."""
-    if plan.term_shards == 1:
+    if plan.term_shards == 1 or WITNESS_SPLIT == "replicate":
+        # every rank of the limb group runs the whole witness map of its limbs and keeps the rows of its term range
         w = backend.witness(cs_local, assignment_local, want, ds)
-        out = {k: w[k][ranges[k](0)[0]:ranges[k](0)[1]] for k in want}
+        me = plan.term_shard
+        out = {k: w[k][ranges[k](me)[0]:ranges[k](me)[1]] for k in want}
         out["Z"] = w["Z"]
         return (out, lambda: None) if defer else out
     N = backend.N

@@ -108,8 +108,9 @@ def _rinocchio_key(ctx, m, n_aux, zk):
                 beta_rv_ts=ctx.random_enc(84), beta_rw_ts=ctx.random_enc(85), beta_ry_ts=ctx.random_enc(86))
 
 
-def _worker(rank, world, port, preset, m, q_override, tmp, prover="groth16", zk=False):
+def _worker(rank, world, port, preset, m, q_override, tmp, prover="groth16", zk=False, split="slots"):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    RD.WITNESS_SPLIT = split  # how the ranks of one limb group share the witness map (dist.py)
     try:
         prm = P.preset(preset)
         if q_override:
@@ -146,11 +147,13 @@ def _worker(rank, world, port, preset, m, q_override, tmp, prover="groth16", zk=
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("q_override,desc", [(None, "limb split: 2 limbs over 2 ranks"),
-                                             (1, "one limb on 2 ranks: slot-sharded witness map, row exchange, term-sharded MSM, all-reduce")])
-def test_sharded_groth16_equals_single_process(tmp_path, q_override, desc):
+@pytest.mark.parametrize("q_override,split,desc", [
+    (None, "slots", "limb split: 2 limbs over 2 ranks"),
+    (1, "slots", "one limb on 2 ranks: slot-sharded witness map, row exchange, term-sharded MSM, all-reduce"),
+    (1, "replicate", "one limb on 2 ranks: witness map on both, term-sharded MSM, all-reduce (the default plan)")])
+def test_sharded_groth16_equals_single_process(tmp_path, q_override, split, desc):
     out = str(tmp_path / "result.txt")
-    mp.spawn(_worker, args=(2, _free_port(), "toy", 7, q_override, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), "toy", 7, q_override, out, "groth16", False, split), nprocs=2, join=True)
     assert open(out).read() == "ok", desc
 
 
@@ -189,9 +192,10 @@ def test_shard_plans():
         assert (cover == 1).all()
 
 
-def _gpu_worker(rank, world, port, m, q_override, tmp, prover="groth16", zk=False):
+def _gpu_worker(rank, world, port, m, q_override, tmp, prover="groth16", zk=False, split="slots"):
     """Both ranks drive the REAL device backend on cuda:0 (gloo transports the collectives)."""
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    RD.WITNESS_SPLIT = split
     try:
         from ringsnark_amd.device import Device, to_host
         prm = P.preset("toy")
@@ -236,20 +240,21 @@ def _gpu_worker(rank, world, port, m, q_override, tmp, prover="groth16", zk=Fals
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q_override,m", [(None, 9), (1, 9), (1, 8)])  # m even and odd: the windows of s_pows (m of m+1 entries)
-def test_sharded_groth16_on_device_backend(tmp_path, q_override, m):
+@pytest.mark.parametrize("q_override,m,split", [(None, 9, "replicate"), (1, 9, "slots"), (1, 8, "slots"), (1, 9, "replicate")])
+def test_sharded_groth16_on_device_backend(tmp_path, q_override, m, split):
+    """m even and odd: the windows of s_pows (m of m+1 entries); both ways of sharing the witness map inside a limb group."""
     out = str(tmp_path / "result.txt")
-    mp.spawn(_gpu_worker, args=(2, _free_port(), m, q_override, out), nprocs=2, join=True)
+    mp.spawn(_gpu_worker, args=(2, _free_port(), m, q_override, out, "groth16", False, split), nprocs=2, join=True)
     assert open(out).read() == "ok"
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q_override,m,zk", [(None, 7, True), (1, 8, True), (1, 9, False)])
-def test_sharded_rinocchio_on_device_backend(tmp_path, q_override, m, zk):
+@pytest.mark.parametrize("q_override,m,zk,split", [(None, 7, True, "slots"), (1, 8, True, "slots"), (1, 9, False, "slots"), (1, 8, True, "replicate")])
+def test_sharded_rinocchio_on_device_backend(tmp_path, q_override, m, zk, split):
     """The sharded Rinocchio prover (limb split; slot-sharded witness map + row exchange + term-sharded MSM) with
     both ranks on the real device backend, against the single-process oracle."""
     out = str(tmp_path / "result.txt")
-    mp.spawn(_gpu_worker, args=(2, _free_port(), m, q_override, out, "rinocchio", zk), nprocs=2, join=True)
+    mp.spawn(_gpu_worker, args=(2, _free_port(), m, q_override, out, "rinocchio", zk, split), nprocs=2, join=True)
     assert open(out).read() == "ok"
 
 

@@ -7,13 +7,14 @@ Sharding:
     matching slice [:, limbs] of the key and of the assignment.  No exchange until the proof is
     assembled.
   * When there are more ranks than limbs, the G_t ranks sharing a limb set ("limb group") split
-      - the WITNESS MAP by NTT slots (it is column parallel: rank s takes slots [s N/G_t, (s+1) N/G_t)
-        of every limb it owns, rs_witness_map_slots), then ONE pairwise exchange (point-to-point
-        sends over xGMI, issued as one batch) turns the slot-sharded coefficient vectors into
-        term-sharded ones: rank s receives, from every peer, the rows of ITS term range;
       - the INNER PRODUCTS by terms (constraints): each rank multiplies its term range of the key,
         and the partial encoding sums are combined by ONE all-reduce(SUM) (residues < 2^50, so integer
-        sums of <= 2^13 partials cannot overflow int64) followed by a reduction mod Q_j.
+        sums of <= 2^13 partials cannot overflow int64) followed by a reduction mod Q_j;
+      - the WITNESS MAP not at all by default (every rank of the group runs it whole and keeps the rows of its
+        term range: WITNESS_SPLIT = "replicate"), or by NTT slots (it is column parallel: rank s takes slots
+        [s N/G_t, (s+1) N/G_t) of every limb it owns, rs_witness_map_slots) followed by ONE pairwise exchange
+        (point-to-point sends over xGMI, issued as one batch) that turns the slot-sharded coefficient vectors
+        into term-sharded ones -- see WITNESS_SPLIT below for the trade.
   * The proof is assembled by an all-gather over the limb axis.
 
 `backend` abstracts the arithmetic (DeviceBackend in production; the CPU tests drive the same code over

@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--logw", type=int, default=14, help="log2 of the key window (stored elements per key vector) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-ntt", action="store_true", help="skip the standalone NTT bandwidth leg (profiling passes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -261,7 +262,7 @@ def main():
 
     # ---- the standalone transform (row a4), HBM bound by design: 16 bytes per coefficient per transform, on 4 GiB
     ntt_roofline = None
-    if world == 1:
+    if world == 1 and not args.no_ntt:
         from ringsnark_amd import _lib
         batch = (4 << 30) // (prm.N_enc * 8)
         polys = torch.empty((batch, prm.N_enc), dtype=torch.int64, device=dev.device).random_(0, int(prm.Q[0]))

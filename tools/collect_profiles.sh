@@ -1,0 +1,37 @@
+#!/bin/bash
+# Collects, on the GPU box, every rocprofv3 record the bench line's rooflines are recomputed from:
+#   1. kernel trace + stats of the default bench command (NTT on 4 GiB included)
+#   2. SQ instruction-mix pass (FP64 opcode counters) and SQ stall pass of one headline proof
+#   3. FETCH_SIZE and WRITE_SIZE passes (separate: they do not fit one pass)
+# PMC passes run with --kernel-trace only (never with other trace domains).  Outputs land under gpurun_out/<tag>/;
+# tools/pmc_fp64.py and tools/pmc_summary.py turn them into the files kept under profiles/.
+#   usage: gpurun -- 'bash tools/collect_profiles.sh <tag> [preset] [stages]'    stages: subset of "kpst" (default all)
+set -u
+TAG=${1:-r03}
+PRESET=${2:-C3}
+STAGES=${3:-kpst}
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+PROBE="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-check --no-ntt --preset $PRESET"
+if [[ $STAGES == *k* ]]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check --preset "$PRESET" > "$OUT/bench_stats.json" 2> "$OUT/bench_stats.err"
+fi
+if [[ $STAGES == *p* ]]; then
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_mix" -o run \
+    --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS SQ_INSTS_SALU \
+    -- $PROBE > "$OUT/pmc_mix.json" 2> "$OUT/pmc_mix.err"
+fi
+if [[ $STAGES == *s* ]]; then
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_stall" -o run \
+    --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT \
+    -- $PROBE > "$OUT/pmc_stall.json" 2> "$OUT/pmc_stall.err"
+fi
+if [[ $STAGES == *t* ]]; then
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o run --pmc FETCH_SIZE -- $PROBE > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_write" -o run --pmc WRITE_SIZE -- $PROBE > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
+fi
+# keep what travels back small: the per-dispatch csv files are what the summarisers read
+find "$OUT" -name '*.db' -delete
+du -sh "$OUT"

@@ -1,0 +1,49 @@
+"""Summarise the SQ passes of tools/collect_profiles.sh into profiles/<name>.json, keyed by the kernel name rocprofv3
+prints (template arguments kept, parameter list dropped):
+
+  usage: tools/pmc_fp64.py <pmc_mix dir> <pmc_stall dir or -> <out.json>
+
+Per kernel: launches in the run, and PER-LAUNCH averages of every counter (wave-level instruction counts as
+rocprofv3 reports them), plus
+  fp64_lane_ops  = (SQ_INSTS_VALU_ADD_F64 + _MUL_F64 + _FMA_F64) x 64   -- counted FP64 arithmetic, lane operations
+  valu_lane_ops  = SQ_INSTS_VALU x 64                                   -- every vector instruction (v_rndne_f64,
+                   moves, integer address arithmetic included: v_rndne_f64 has no opcode counter of its own)
+bench.py divides these by the live per-launch time of the same kernel (`roofline.achieved_counted`)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+mix, stall, out = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def load(d):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.defaultdict(set)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            calls[k].add((f, r["Dispatch_Id"]))
+    return agg, {k: len(v) for k, v in calls.items()}
+
+
+res = {"units": "per launch, wave-level counts as reported by rocprofv3 (x64 = lane operations)", "kernels": {}}
+A, nA = load(mix)
+B, nB = load(stall) if stall != "-" else ({}, {})
+for k in sorted(A, key=lambda k: -A[k].get("SQ_INSTS_VALU", 0)):
+    n = nA[k]
+    e = {"launches": n}
+    for c, v in sorted(A[k].items()):
+        e[c] = v / n
+    if k in B:
+        for c, v in sorted(B[k].items()):
+            e[c] = v / nB[k]
+    e["fp64_lane_ops"] = 64.0 * (e.get("SQ_INSTS_VALU_ADD_F64", 0) + e.get("SQ_INSTS_VALU_MUL_F64", 0) + e.get("SQ_INSTS_VALU_FMA_F64", 0))
+    e["valu_lane_ops"] = 64.0 * e.get("SQ_INSTS_VALU", 0)
+    res["kernels"][k] = e
+json.dump(res, open(out, "w"), indent=1)
+for k, e in list(res["kernels"].items())[:12]:
+    print("%-52s launches %4d  fp64 %.4g  valu %.4g lane-ops/launch  fp64 share %.2f" % (
+        k[:52], e["launches"], e["fp64_lane_ops"], e["valu_lane_ops"], e["fp64_lane_ops"] / max(1.0, e["valu_lane_ops"])))

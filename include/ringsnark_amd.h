@@ -210,9 +210,11 @@ int rs_interpolate(rs_ctx *ctx, const uint64_t *d_y, uint64_t *d_out, size_t n, 
  * normalised the way Boost's polynomial is: *h_len (may be NULL) = length after stripping trailing coefficients equal
  * to RingT(0); rows at or beyond *h_len of the output are zero.  Synchronise.
  *   multiply: d_out [na+nb-1]     add: d_out [max(na,nb)]
- *   divide:   d_quot [nn-nd+1] (untouched if nn < nd: the quotient is the zero polynomial, *h_len = 0); the
+ *   divide:   d_quot [nn-nd+1] (nothing to write if nn < nd: the quotient is the zero polynomial, *h_len = 0); the
  *             divisor's leading coefficient must be a unit, else RS_ERR_NOT_INVERTIBLE ("element is not invertible
- *             in ring", what RingElem::operator/ throws inside Boost's division). */
+ *             in ring", what RingElem::operator/ throws inside Boost's division).  If the denominator has zero
+ *             leading coefficients that the numerator does not match, the quotient is longer than nn-nd+1 rows:
+ *             RS_ERR_INVALID -- pass the denominator's normalised length (ring.hpp's divide does). */
 int rs_poly_multiply(rs_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, size_t *h_len,
                      rs_stream stream);
 int rs_poly_add(rs_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb, uint64_t *d_out, size_t *h_len,

@@ -250,14 +250,26 @@ plain_center_wide_kernel(PlainArgs args, double *__restrict__ C, unsigned long l
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[c][e] = 0.0;
     const int nv = MULTI ? G.n : 1;
+    // MULTI == false: the next item's coefficients are requested during this item's transform -- or right here when this
+    // item has nothing to transform (vectors of different lengths, constant-1 terms): every path issues it exactly once
+    auto prefetch_next = [&]() {
+      if (!MULTI) {
+        const unsigned long long nxt = item + (unsigned long long)nslots;
+        if (nxt < items && loadable(nxt)) issue_loads(src_of(nxt, 0));
+      }
+    };
     for (int v = 0; v < nv; v++) {
-      if (term >= G.T[v]) continue;
+      if (term >= G.T[v]) {
+        prefetch_next();
+        continue;
+      }
       const int kind = G.kinds[v] ? (int)G.kinds[v][term] : RS_KIND_POLY;
       if (kind == RS_KIND_ONE) {  // Scalar 1: the plaintext is the constant polynomial 1
         if (t == 0) {
           acc[0][0] += 1.0;
           if (G.nz[v]) atomicOr(&G.nz[v][term], 1u);
         }
+        prefetch_next();
         continue;
       }
       double tw1[2][15];
@@ -276,10 +288,7 @@ plain_center_wide_kernel(PlainArgs args, double *__restrict__ C, unsigned long l
       }
       mem_fence();
       if (MULTI) load_tw1(tw1);  // after the scatter: the coefficient registers are free
-      if (!MULTI) {  // next item's coefficients: in flight during this transform
-        const unsigned long long nxt = item + (unsigned long long)nslots;
-        if (nxt < items && loadable(nxt)) issue_loads(src_of(nxt, 0));
-      }
+      prefetch_next();  // next item's coefficients: in flight during this transform
       mem_fence();
       const bool any = __syncthreads_or(nz);
       if (!any) continue;  // is_zero term (this limb): contributes nothing; nobody reads the tile

@@ -111,12 +111,13 @@ int rs_poly_multiply(rs_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t
   WsScope ws_scope(ctx, S(stream));
   hipStream_t st = S(stream);
   const size_t S_ = ctx->ring_words();
+  const size_t nominal = (na && nb) ? na + nb - 1 : 0;  // rows the caller allocated
   // operands are normalised first, as Boost's polynomial(vector) constructor does
   na = normalised_len(ctx, d_a, na, st);
   nb = normalised_len(ctx, d_b, nb, st);
-  size_t len = 0;
+  size_t len = 0, written = 0;
   if (na && nb) {
-    const size_t rows = na + nb - 1;
+    const size_t rows = written = na + nb - 1;
     const unsigned by = (unsigned)((S_ / 2 + 255) / 256);
     if (ctx->use_int)
       hipLaunchKernelGGL(poly_mul_kernel<ModI>, dim3((unsigned)rows, by), dim3(256), 0, st, d_a, na, d_b, nb, d_out, ctx->N, ctx->L, ctx->d_qmod_i);
@@ -125,6 +126,8 @@ int rs_poly_multiply(rs_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t
     RS_HIP(hipGetLastError());
     len = normalised_len(ctx, d_out, rows, st);
   }
+  // the header's contract: every row of the nominal output at or beyond the result's length is zero
+  if (nominal > written) RS_HIP(hipMemsetAsync(d_out + written * S_, 0, (nominal - written) * S_ * sizeof(uint64_t), st));
   if (h_len) *h_len = len;
   RS_API_END
 }
@@ -155,12 +158,18 @@ int rs_poly_divide(rs_ctx *ctx, const uint64_t *d_num, size_t nn, const uint64_t
   hipStream_t st = S(stream);
   const size_t S_ = ctx->ring_words();
   size_t len = 0;
+  const size_t nominal = nn >= nd ? nn - nd + 1 : 0;  // rows the caller allocated
   {
     WsScope ws_scope(ctx, st);
     nn = normalised_len(ctx, d_num, nn, st);
     nd = normalised_len(ctx, d_den, nd, st);
   }
   RS_REQUIRE(nd >= 1, "division by the zero polynomial");
+  // a denominator that loses more trailing zero coefficients than the numerator has a quotient LONGER than the
+  // nominal nn - nd + 1 rows: the caller must pass normalised lengths then (the C++ adapter does)
+  RS_REQUIRE(nn < nd || nn - nd + 1 <= nominal, "quotient exceeds nn - nd + 1 rows: strip the denominator's zero leading coefficients");
+  const size_t written = nn >= nd ? nn - nd + 1 : 0;
+  if (nominal > written) RS_HIP(hipMemsetAsync(d_quot + written * S_, 0, (nominal - written) * S_ * sizeof(uint64_t), st));
   if (nn >= nd) {
     // the leading coefficient must be a unit of the ring (Boost divides by it: RingElem::operator/ ->
     // invert_inplace -> "element is not invertible in ring", seal_ring.tcc:87-103)

@@ -319,24 +319,27 @@ class Device:
         return o
 
     # ---- a11: util/polynomials.tcc:62-81
-    def _poly(self, fn, a, b, rows):
+    def _poly(self, fn, a, b, rows, out=None):
+        """out: optional caller buffer of the nominal row count (the library zeroes the rows beyond the result)."""
         na, nb = self._count(a, self.ring_words), self._count(b, self.ring_words)
-        out = torch.zeros((max(rows(na, nb), 1), self.L, self.N), dtype=torch.int64, device=self.device)
+        if out is None:
+            out = torch.empty((max(rows(na, nb), 1), self.L, self.N), dtype=torch.int64, device=self.device)
+        assert out.shape[0] >= max(rows(na, nb), 0)
         n = C.c_size_t(0)
         _lib.check(fn(self.h, _ptr(a) if na else None, na, _ptr(b) if nb else None, nb, _ptr(out), C.byref(n), self.stream()))
         return out[:n.value]
 
-    def poly_multiply(self, a, b):
+    def poly_multiply(self, a, b, out=None):
         """multiply(x, y): coefficient vectors [n][L][N]; the result is normalised like Boost's polynomial."""
-        return self._poly(self.lib.rs_poly_multiply, a, b, lambda na, nb: na + nb - 1 if na and nb else 0)
+        return self._poly(self.lib.rs_poly_multiply, a, b, lambda na, nb: na + nb - 1 if na and nb else 0, out)
 
-    def poly_add(self, a, b):
-        return self._poly(self.lib.rs_poly_add, a, b, lambda na, nb: max(na, nb))
+    def poly_add(self, a, b, out=None):
+        return self._poly(self.lib.rs_poly_add, a, b, lambda na, nb: max(na, nb), out)
 
-    def poly_divide(self, num, den):
+    def poly_divide(self, num, den, out=None):
         """divide(numerator, denominator): the quotient; RsError(RS_ERR_NOT_INVERTIBLE) unless the divisor's leading
         coefficient is a unit."""
-        return self._poly(self.lib.rs_poly_divide, num, den, lambda nn, nd: nn - nd + 1)
+        return self._poly(self.lib.rs_poly_divide, num, den, lambda nn, nd: nn - nd + 1, out)
 
     # ---- a15 / a16
     def groth16_prove(self, dcs, pk, assignment, want_empty=True, window=0):

@@ -173,7 +173,8 @@ def _p2p(ops_send, ops_recv, group):
 #                          (>= 75 ms at the link's 76.8 GB/s per direction) -- it pays only if the exchange sustains
 #                          more than ~85 GB/s, which no measurement supports yet.
 WITNESS_SPLIT = os.environ.get("RINGSNARK_WITNESS_SPLIT", "replicate")
-assert WITNESS_SPLIT in ("replicate", "slots")
+if WITNESS_SPLIT not in ("replicate", "slots"):
+    raise ValueError("RINGSNARK_WITNESS_SPLIT must be 'replicate' or 'slots', not %r" % WITNESS_SPLIT)
 
 
 def sharded_witness(backend, plan: ShardPlan, group, cs_local, assignment_local, want, ranges, ds=(None, None, None), defer=False):
@@ -192,6 +193,9 @@ def sharded_witness(backend, plan: ShardPlan, group, cs_local, assignment_local,
         return (out, lambda: None) if defer else out
     N = backend.N
     s0, ns = plan.slot_range(N)
+    if ns < 2:  # rs_witness_map_slots takes even, non-empty slot ranges: every shard of the group needs a share
+        raise ValueError("slot split of N = %d slots over %d ranks leaves rank %d without a share; use "
+                         "RINGSNARK_WITNESS_SPLIT=replicate or fewer ranks per limb" % (N, plan.term_shards, plan.rank))
     wc = backend.witness_slots(cs_local, assignment_local, s0, ns, want, ds)  # compact [rows][L][ns]
     peers = plan.group_ranks()
     me = plan.term_shard
@@ -286,7 +290,9 @@ def rinocchio_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_l
     empty[9]) on every rank."""
     zk = d1 is not None
     assert (d1 is None) == (d2 is None) == (d3 is None)
-    rng_mid = lambda s: (plan.term_range(m + 1, s)[0], min(plan.term_range(m + 1, s)[1], m))
+    def rng_mid(s):  # the *_mid vectors have m rows: a late shard's range may be empty, never negative
+        lo, hi = plan.term_range(m + 1, s)
+        return min(lo, m), max(min(lo, m), min(hi, m))
     rng_h = lambda s: plan.term_range(m + 1, s)
     w = sharded_witness(backend, plan, term_group, cs_local, assignment_local, ("A_mid", "B_mid", "C_mid", "H"),
                         {"A_mid": rng_mid, "B_mid": rng_mid, "C_mid": rng_mid, "H": rng_h}, (d1, d2, d3))
@@ -345,6 +351,30 @@ def rinocchio_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_l
     return _gather_limbs(plan, out, 9), [int(e) for e in empty]
 
 
+def fused_groth16_key(pk_local, m, n_aux):
+    """Key of the fused device prover (rs_groth16_prove) from a rank's local key, or None when the rank does not hold
+    what that prover reads: s_pows on terms [0, m) (A and B have m coefficients, groth16.tcc:89-101; groth16_key_ranges
+    stores exactly those m of its m + 1 entries), delta_ts on [0, m], delta_mid on [0, n_aux); all three stored in full
+    or all three with the same window.  Returns {s_pows, delta_ts, delta_mid, alpha, beta, window}."""
+    need = {"s_pows": m, "delta_ts": m + 1, "delta_mid": n_aux}
+    windows, stores = set(), {}
+    for k, n in need.items():
+        v = pk_local.get(k)
+        if isinstance(v, TiledKey):
+            if v.lo != 0 or v.hi < n:
+                return None
+            windows.add(v.window)
+            stores[k] = v.store
+        else:
+            if v is None or len(v) < n:
+                return None
+            windows.add(0)
+            stores[k] = v
+    if len(windows) != 1:
+        return None
+    return dict(stores, alpha=pk_local["alpha"], beta=pk_local["beta"], window=windows.pop())
+
+
 class DeviceBackend:
     """Production backend: ringsnark_amd.device.Device over this rank's limb subset."""
 
@@ -369,23 +399,14 @@ class DeviceBackend:
         return out, used
 
     def groth16_prove_local(self, dcs, pk_local, assignment):
-        """The whole prover on this rank's context (rs_groth16_prove); None when the key vectors are not whole,
-        equally windowed vectors (then the caller runs the piecewise plan)."""
-        vecs = {k: pk_local.get(k) for k in ("s_pows", "delta_ts", "delta_mid")}
-        windows, stores = set(), {}
-        for k, v in vecs.items():
-            if isinstance(v, TiledKey):
-                if v.lo != 0 or v.hi != v.T:
-                    return None
-                windows.add(v.window)
-                stores[k] = v.store
-            else:
-                windows.add(0)
-                stores[k] = v
-        if len(windows) != 1:
+        """The whole prover on this rank's context (rs_groth16_prove); None when a key vector does not start at term 0
+        or stops short of what the fused prover reads, or the vectors are not equally windowed (then the caller runs
+        the piecewise plan)."""
+        pk1 = fused_groth16_key(pk_local, dcs.m, dcs.n_vars - dcs.n_inputs)
+        if pk1 is None:
             return None
-        pk1 = dict(stores, alpha=pk_local["alpha"], beta=pk_local["beta"])
-        return self.dev.groth16_prove(dcs, pk1, assignment, want_empty=False, window=windows.pop())[0]
+        window = pk1.pop("window")
+        return self.dev.groth16_prove(dcs, pk1, assignment, want_empty=False, window=window)[0]
 
     def enc_add(self, a, b):
         return self.dev.enc_add(a.contiguous(), b.contiguous())

@@ -69,6 +69,24 @@ int main(int argc, char **argv) {
   EXPECT(-(-z) == z);
   EXPECT(RingElem(5) * x == x + x + x + x + x);  // scalar promoted to a polynomial (seal_ring.tcc:265-277)
   EXPECT(RingElem::zero() * x == RingElem::zero() && (RingElem::zero() * x).is_zero());
+  {  // representation follows the reference (seal_ring.tcc:105-247): which results stay a Scalar
+    const size_t qb = 64 - __builtin_clzll(p.q[0]);
+    const RingElem s3(3), s4(4), big((uint64_t)1 << (qb - 2));
+    EXPECT((s3 + s4).is_scalar() && (s3 + s4).get_scalar() == 7);      // bit sizes 2, 3 -> 3 < |q_1|
+    EXPECT((s3 * s4).is_scalar() && (s3 * s4).get_scalar() == 12);     // 2 + 3 < |q_1|
+    EXPECT((big + big).is_poly());                                     // equal sizes: |q_1| - 1 + 1 is not < |q_1|
+    EXPECT(big + big == RingElem((uint64_t)1 << (qb - 1)));            // ... with the right value
+    EXPECT((big * s4).is_poly() && big * s4 == (big + big) + (big + big));
+    EXPECT((s4 - s3).is_poly() && s4 - s3 == RingElem::one());         // Scalar - Scalar is always promoted (:176-178)
+    EXPECT((s3 + RingElem::zero()).is_poly() && s3 + RingElem::zero() == s3);  // bit size of 0: promoted (see ring.hpp)
+    EXPECT((RingElem::zero() + s3).is_scalar());                       // Scalar 0 on the left copies the operand (:121-124)
+    EXPECT((x * RingElem::zero()).is_scalar() && (x * RingElem::zero()).get_scalar() == 0);  // :196-199
+    EXPECT((RingElem::one() * x).is_poly() && (RingElem::one() * s4).is_scalar());
+    EXPECT((x * RingElem::one()).is_poly() && x * RingElem::one() == x);
+    EXPECT((s3 * x).is_poly() && s3 * x == x + x + x && x * s3 == s3 * x);
+    EXPECT((s3 + x).is_poly() && s3 + x == x + s3 && (x + s3) - s3 == x);
+    EXPECT((x - RingElem::zero()).is_poly() && x - RingElem::zero() == x);
+  }
   {
     std::vector<uint64_t> w = x.get_poly();
     w[3] = 0;  // one zero slot: not invertible

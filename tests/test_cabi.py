@@ -92,6 +92,47 @@ int main() {
         assert r.returncode == 0, r.stderr
 
 
+def test_adapter_generator_is_chacha20_keyed_from_the_os(tmp_path):
+    """The adapters draw secrets (secret key, the point s, alpha/beta/delta, blinding, noise seeds) from a ChaCha20
+    keystream keyed with OS entropy: the block function against the RFC 8439 section 2.3.2 known answer, two
+    default-constructed generators differ, the test hook is reproducible."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    src = r"""
+#include <cstdio>
+#include <ringsnark_amd/ring.hpp>
+int main() {
+  using ringsnark::amd::ChaCha20Rng;
+  uint32_t in[16] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574, 0x03020100, 0x07060504, 0x0b0a0908, 0x0f0e0d0c,
+                     0x13121110, 0x17161514, 0x1b1a1918, 0x1f1e1d1c, 1, 0x09000000, 0x4a000000, 0}, out[16];
+  ChaCha20Rng::block(in, out);
+  for (int i = 0; i < 16; i++) std::printf("%08x%c", out[i], i == 15 ? '\n' : ' ');
+  ChaCha20Rng a, b, c, d;
+  c.seed_for_tests(5);
+  d.seed_for_tests(5);
+  std::uniform_int_distribution<int> tern(-1, 1);
+  int lo = 0, hi = 0;
+  for (int i = 0; i < 3000; i++) { int t = tern(a); lo += t == -1; hi += t == 1; }
+  std::printf("%d %d %d\n", a() != b(), c() == d() && c() == d(), lo > 800 && hi > 800);
+  return 0;
+}
+"""
+    f = tmp_path / "t.cpp"
+    f.write_text(src)
+    exe = str(tmp_path / "t")
+    r = subprocess.run([gxx, "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), str(f), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe], capture_output=True, text=True).stdout.splitlines()
+    assert out[0] == ("e4e7f110 15593bd1 1fdd0f50 c47120a3 c7f4d1c7 0368c033 9aaa2204 4e6cd4c3 "
+                      "466482d2 09aa9f07 05d7c214 a2028bd9 d19c12b5 b94e16de e883d0cb 4e3c50a2")
+    assert out[1] == "1 1 1"
+    hdr = open(os.path.join(ROOT, "include", "ringsnark_amd", "ring.hpp")).read()
+    assert "mt19937" not in hdr and "random_device" not in hdr
+
+
 @pytest.mark.gpu
 def test_cpp_adapters_run_against_the_library(tmp_path):
     """tests/cpp/adapter_run.cpp: the RingElem / EncodingElem adapters, compiled with plain g++ and

@@ -258,6 +258,61 @@ def test_sharded_rinocchio_on_device_backend(tmp_path, q_override, m, zk, split)
     assert open(out).read() == "ok"
 
 
+def test_limb_only_plans_take_the_fused_device_prover():
+    """A rank that owns whole limbs (N <= L) must run rs_groth16_prove on the key ranges bench.py / groth16_key_ranges
+    give it: s_pows is stored on m of its m + 1 entries, which the fused prover never reads beyond (the path
+    was dead because it demanded hi == T)."""
+    class Dcs:
+        m, n_vars, n_inputs = 9, 11, 2
+
+    class FakeDev:
+        calls = []
+
+        def groth16_prove(self, dcs, pk, asg, want_empty, window):
+            self.calls.append((sorted(pk), {k: len(v) for k, v in pk.items() if k in ("s_pows", "delta_ts", "delta_mid")}, window))
+            return ["proof"]
+
+    class Backend(RD.DeviceBackend):
+        def __init__(self, dev):
+            self.dev = dev
+
+    m, n_aux = Dcs.m, Dcs.n_vars - Dcs.n_inputs
+    for world, L in ((1, 2), (2, 2), (2, 4), (4, 4)):
+        for W in (None, 4):  # whole ranges, and windows of 4 elements
+            plan = RD.make_plan(world, 0, L)
+            assert plan.term_shards == 1
+            rg = RD.groth16_key_ranges(plan, m, n_aux)
+            T = {"s_pows": m + 1, "delta_ts": m + 1, "delta_mid": n_aux}
+            pk = {k: RD.TiledKey(list(range(min(hi - lo, W or hi - lo))), lo, hi, T[k]) for k, (lo, hi) in rg.items()}
+            pk.update(alpha="a", beta="b")
+            dev = FakeDev()
+            dev.calls = []
+            assert Backend(dev).groth16_prove_local(Dcs, pk, "asg") == "proof"
+            names, lens, window = dev.calls[0]
+            assert names == ["alpha", "beta", "delta_mid", "delta_ts", "s_pows"] and window == (W or 0)
+            assert lens == ({"s_pows": m, "delta_ts": m + 1, "delta_mid": n_aux} if W is None else {"s_pows": 4, "delta_ts": 4, "delta_mid": 4})
+    # a term-sharded rank (N > L) does not hold whole vectors: piecewise plan
+    plan = RD.make_plan(4, 3, 2)
+    rg = RD.groth16_key_ranges(plan, m, n_aux)
+    pk = {k: RD.TiledKey(list(range(max(1, hi - lo))), lo, hi, m + 1) for k, (lo, hi) in rg.items()}
+    assert RD.fused_groth16_key(dict(pk, alpha="a", beta="b"), m, n_aux) is None
+    # mixed windows: refused
+    pk = {"s_pows": RD.TiledKey(list(range(4)), 0, m, m + 1), "delta_ts": RD.TiledKey(list(range(m + 1)), 0, m + 1, m + 1),
+          "delta_mid": RD.TiledKey(list(range(n_aux)), 0, n_aux, n_aux), "alpha": "a", "beta": "b"}
+    assert RD.fused_groth16_key(pk, m, n_aux) is None
+
+
+def test_late_shards_get_empty_not_negative_ranges():
+    """rng_mid of rinocchio_prove_sharded and slot_range for shards beyond the data."""
+    plan = RD.make_plan(8, 7, 1)  # 8 ranks on one limb
+    for m in (1, 3, 6, 7, 8, 9):
+        for s in range(8):
+            lo, hi = plan.term_range(m + 1, s)
+            mlo, mhi = min(lo, m), max(min(lo, m), min(hi, m))
+            assert 0 <= mlo <= mhi <= m
+    assert plan.slot_range(6, 7) == (6, 0)
+
+
 def test_key_windows_cover_every_slice_the_sharded_prover_takes():
     """bench.py allocates only a window of each key vector per rank; the windows must be exactly the
     ranges groth16_prove_sharded reads (s_pows on m of its m+1 entries), for every plan shape."""

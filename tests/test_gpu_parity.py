@@ -142,6 +142,29 @@ def test_grouped_msm_equals_sum_of_inner_products():
         assert (got[c, 1] == ctx.inner_product(crs, v[2])[0]).all()
 
 
+@pytest.mark.parametrize("name", ["toy", "C2", "C3"])
+def test_grouped_msm_with_vectors_of_different_lengths(name):
+    """rs_msm lets every vector have its own length.  Three single-vector groups of lengths {4, T, T} and a constant-1
+    term in the middle: in the wide plaintext kernel (N_enc = 8192) a workgroup then meets items with nothing to load
+    between items it must load, which once left the next item computed from stale registers."""
+    dev = dev_for(name)
+    ctx = H.oracle_ctx(dev.prm)
+    T = 300  # > 2 x 128 slots per limb / 3 groups, so a slot of the persistent kernel sees skip -> load sequences
+    crs = ctx.random_enc(141, 16)  # tiled key: term t reads element t % 16
+    lens = [4, T, T - 7]
+    vs = [ctx.random_ring(143 + k, n) for k, n in enumerate(lens)]
+    kinds = [None, np.zeros(T, dtype=np.uint8), None]
+    kinds[1][5] = O.KIND_ONE
+    kinds[1][T - 1] = O.KIND_ONE
+    out, used = dev.msm([dev.put(crs)], [(dev.put(v), k, g) for g, (v, k) in enumerate(zip(vs, kinds))], 3, want_used=True,
+                        crs_len=T, window=16)
+    got = host(out)
+    assert used == lens
+    for g, (v, k) in enumerate(zip(vs, kinds)):
+        exp, _ = ctx.inner_product(crs, v, k, threads=0, window=16)
+        assert (got[0, g] == exp).all(), g
+
+
 @pytest.mark.parametrize("name", ["C2", "C3"])
 def test_wide_kernels_equal_their_predecessors_and_the_oracle(name):
     """N_enc = 8192: the wide NTT (ntt_variant 14), the half-spectrum MAC (mac_variant 5) and the wide plaintext kernel
@@ -680,6 +703,20 @@ def test_poly_multiply_add_divide_match_oracle(name):
     z = np.concatenate([a, np.zeros((3,) + a.shape[1:], dtype=np.uint64)])
     assert dev.poly_multiply(dev.put(z), dev.put(b)).shape[0] == na + nb - 1
     assert dev.poly_divide(dev.put(b), dev.put(a)).shape[0] == 0  # deg num < deg den: the zero polynomial
+    # C contract (ringsnark_amd.h): rows of the NOMINAL output beyond the result are zero, whatever the buffer held
+    import torch
+    buf = torch.full((na + 3 + nb - 1, prm.L, prm.N), -1, dtype=torch.int64, device=dev.device)
+    r = dev.poly_multiply(dev.put(z), dev.put(b), out=buf)
+    assert r.shape[0] == na + nb - 1 and not host(buf[na + nb - 1:]).any() and (host(r) == prod).all()
+    znum = np.concatenate([num, np.zeros((4,) + num.shape[1:], dtype=np.uint64)])
+    buf = torch.full((na + nb - 1 + 4 - nb + 1, prm.L, prm.N), -1, dtype=torch.int64, device=dev.device)
+    r = dev.poly_divide(dev.put(znum), dev.put(b), out=buf)
+    assert r.shape[0] == quo.shape[0] and not host(buf[quo.shape[0]:]).any() and (host(r) == quo).all()
+    # a denominator with zero leading coefficients has a longer quotient than nn - nd + 1 rows: refused, not overrun
+    zden = np.concatenate([b, np.zeros((2,) + b.shape[1:], dtype=np.uint64)])
+    with pytest.raises(_lib.RsError) as ei:
+        dev.poly_divide(dev.put(num), dev.put(zden))
+    assert ei.value.code == _lib.RS_ERR_INVALID
     # the divisor's leading coefficient must be a unit of the ring
     bad = b.copy()
     bad[-1, 0, 3] = 0

@@ -159,10 +159,21 @@ int rs_msm(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len,
 /* ---- a14: R1CS in CSR form + linear_combination::evaluate (relations/variable.tcc:246-254) -- */
 typedef struct rs_r1cs rs_r1cs;
 /* For M in {a,b,c}: h_row_ptr[M][m+1], h_col[M][nnz] (0 = constant one, k>=1 = variable k-1),
- * h_coeff[M][L][nnz] slot-constant residues. */
+ * h_coeff[M][L][nnz] slot-constant residues (what gadgetlib produces). */
 int rs_r1cs_create(rs_ctx *ctx, size_t m, size_t n_vars, size_t n_inputs, const uint32_t *const h_row_ptr[3],
                    const uint32_t *const h_col[3], const uint64_t *const h_coeff[3], const size_t nnz[3],
                    rs_r1cs **out);
+/* The same with coefficients that are GENERAL ring elements: linear_term<RingT>::coeff is a RingT
+ * (relations/variable.hpp), and linear_combination::evaluate multiplies by it whatever it holds
+ * (relations/variable.tcc:246-254) -- the DFT constraint of benchmarks/bench_ntt_SEAL.cpp:46-53 multiplies the
+ * variables by powers of a polynomial (`row * vars[i]`).  h_poly_idx[M][nnz] (an entry of the outer array may be
+ * NULL): -1 = the slot-constant scalar h_coeff[M][.][e] as above, k >= 0 = row k of h_poly_table [n_poly][L][N]
+ * (ring layout; h_coeff[M][.][e] is then ignored).  Slot-constant coefficients stay the fast case: the witness
+ * map's linear-form io vectors are used whenever no polynomial coefficient multiplies the
+ * constant one or a primary input. */
+int rs_r1cs_create_poly(rs_ctx *ctx, size_t m, size_t n_vars, size_t n_inputs, const uint32_t *const h_row_ptr[3],
+                        const uint32_t *const h_col[3], const uint64_t *const h_coeff[3], const size_t nnz[3],
+                        const int32_t *const h_poly_idx[3], const uint64_t *h_poly_table, size_t n_poly, rs_r1cs **out);
 void rs_r1cs_destroy(rs_r1cs *cs);
 #define RS_EVAL_FULL 0 /* full assignment                      (r1cs_to_qrp.tcc:216-220) */
 #define RS_EVAL_IO 1   /* primary || zeros                      (r1cs_to_qrp.tcc:189-201) */

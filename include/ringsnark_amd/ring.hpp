@@ -30,6 +30,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -571,7 +572,10 @@ inline EncodingElem operator*(const RingElem &r, EncodingElem a) { return a *= r
 struct R1csCsr {
   size_t m = 0, n_vars = 0, n_inputs = 0;
   std::vector<uint32_t> row_ptr[3], col[3];
-  std::vector<uint64_t> coeff[3];  // [L][nnz]
+  std::vector<uint64_t> coeff[3];    // [L][nnz] slot-constant scalars
+  std::vector<int32_t> poly_idx[3];  // [nnz]: -1 = the scalar, k = row k of poly_table (a general ring element)
+  std::vector<uint64_t> poly_table;  // [n_poly][L][N]
+  size_t n_poly() const { return poly_table.size() / Context::ring_words(); }
 };
 class DeviceR1cs {
  public:
@@ -580,7 +584,12 @@ class DeviceR1cs {
     const uint32_t *cl[3] = {c.col[0].data(), c.col[1].data(), c.col[2].data()};
     const uint64_t *cf[3] = {c.coeff[0].data(), c.coeff[1].data(), c.coeff[2].data()};
     const size_t nnz[3] = {c.col[0].size(), c.col[1].size(), c.col[2].size()};
-    check(rs_r1cs_create(Context::get_context(), m, n_vars, n_inputs, rp, cl, cf, nnz, &h_));
+    if (c.poly_table.empty()) {
+      check(rs_r1cs_create(Context::get_context(), m, n_vars, n_inputs, rp, cl, cf, nnz, &h_));
+    } else {
+      const int32_t *pi[3] = {c.poly_idx[0].data(), c.poly_idx[1].data(), c.poly_idx[2].data()};
+      check(rs_r1cs_create_poly(Context::get_context(), m, n_vars, n_inputs, rp, cl, cf, nnz, pi, c.poly_table.data(), c.n_poly(), &h_));
+    }
   }
   ~DeviceR1cs() { rs_r1cs_destroy(h_); }
   DeviceR1cs(const DeviceR1cs &) = delete;
@@ -614,8 +623,10 @@ inline std::vector<uint64_t> flatten(const std::vector<RingElem> &v) {
 // (relations/constraint_satisfaction_problems/r1cs/r1cs.hpp:118-123; linear_combination::terms of
 // linear_term{index, coeff}, relations/variable.hpp).  Duck-typed, so this header needs none of the
 // reference's: CS has constraints[i].{a,b,c}.terms, primary_input_size, auxiliary_input_size.
-// Coefficients must be slot-constant ring elements (Scalars, or polynomials equal in every slot of a limb) --
-// what gadgetlib produces; anything else is refused.
+// A coefficient is any RingElem (relations/variable.tcc:246-254 multiplies by it whatever it holds): Scalars and
+// polynomials that are equal in every slot of a limb -- what gadgetlib produces -- are exported as slot-constant
+// scalars (the fast case on the device); every other polynomial (benchmarks/bench_ntt_SEAL.cpp:46-53: `row * vars[i]`)
+// goes into the table of general ring elements, once per distinct value.
 template <class CS>
 R1csCsr export_csr(const CS &cs) {
   const Params &p = Context::get_params();
@@ -624,26 +635,38 @@ R1csCsr export_csr(const CS &cs) {
   out.n_inputs = cs.primary_input_size;
   out.n_vars = cs.primary_input_size + cs.auxiliary_input_size;
   std::vector<std::vector<uint64_t>> per_limb[3];
+  std::unordered_multimap<size_t, int32_t> seen;  // hash of a table row -> its index
+  const size_t rw = Context::ring_words();
   for (int w = 0; w < 3; w++) {
     out.row_ptr[w].assign(1, 0);
     per_limb[w].assign(p.L, {});
   }
+  auto table_row = [&](const RingElem &c) -> int32_t {
+    const size_t h = c.hash();
+    auto range = seen.equal_range(h);
+    for (auto it = range.first; it != range.second; ++it)
+      if (std::equal(c.get_poly().begin(), c.get_poly().end(), out.poly_table.begin() + (size_t)it->second * rw)) return it->second;
+    const int32_t k = (int32_t)(out.poly_table.size() / rw);
+    out.poly_table.insert(out.poly_table.end(), c.get_poly().begin(), c.get_poly().end());
+    seen.emplace(h, k);
+    return k;
+  };
   auto add = [&](int w, const auto &lc) {
     for (const auto &t : lc.terms) {
       if ((size_t)t.index > out.n_vars) throw std::invalid_argument("variable index out of range");
       out.col[w].push_back((uint32_t)t.index);
       const RingElem &c = t.coeff;
-      for (int i = 0; i < p.L; i++) {
-        uint64_t v;
-        if (c.is_scalar()) {
-          v = c.get_scalar() % p.q[i];
-        } else {
-          v = c.get_poly()[(size_t)i * p.N];
+      bool slot_constant = true;
+      if (c.is_poly())
+        for (int i = 0; i < p.L && slot_constant; i++)
           for (int x = 1; x < p.N; x++)
-            if (c.get_poly()[(size_t)i * p.N + x] != v) throw std::invalid_argument("R1CS coefficient is not slot constant");
-        }
-        per_limb[w][i].push_back(v);
-      }
+            if (c.get_poly()[(size_t)i * p.N + x] != c.get_poly()[(size_t)i * p.N]) {
+              slot_constant = false;
+              break;
+            }
+      out.poly_idx[w].push_back(slot_constant ? -1 : table_row(c));
+      for (int i = 0; i < p.L; i++)
+        per_limb[w][i].push_back(!slot_constant ? 0 : c.is_scalar() ? c.get_scalar() % p.q[i] : c.get_poly()[(size_t)i * p.N]);
     }
     out.row_ptr[w].push_back((uint32_t)out.col[w].size());
   };

@@ -36,6 +36,11 @@ class R1CS(C.Structure):
         ("col", u32p * 3),
         ("coeff", u64p * 3),
         ("nnz", C.c_size_t * 3),
+        ("pidx", C.POINTER(C.c_int32) * 3),
+        ("ptab", u64p),
+        ("ptab_L", C.c_size_t),
+        ("ptab_N", C.c_size_t),
+        ("ptab_slot0", C.c_size_t),
     ]
 
 
@@ -397,13 +402,16 @@ def vanishing(q, m):
 class R1CSHandle:
     """Keeps the numpy buffers behind an rso_r1cs alive.
 
-    mats: dict a/b/c -> (row_ptr uint32[m+1], col uint32[nnz], coeff uint64[L][nnz])."""
+    mats: dict a/b/c -> (row_ptr uint32[m+1], col uint32[nnz], coeff uint64[L][nnz]).
+    poly_idx / poly_table: coefficients that are general ring elements (rs_oracle.h): poly_idx[name] int32[nnz]
+    (-1 = the scalar of mats), poly_table uint64[n_poly][L][N]."""
 
-    def __init__(self, m, n_vars, n_inputs, mats):
+    def __init__(self, m, n_vars, n_inputs, mats, poly_idx=None, poly_table=None, slot0=0):
         self.m, self.n_vars, self.n_inputs = m, n_vars, n_inputs
         self.s = R1CS()
         self.s.m, self.s.n_vars, self.s.n_inputs = m, n_vars, n_inputs
         self._keep = []
+        self._args = (m, n_vars, n_inputs, mats, poly_idx, poly_table)
         for k, name in enumerate("abc"):
             rp, col, cf = mats[name]
             rp = np.ascontiguousarray(rp, dtype=np.uint32)
@@ -414,6 +422,21 @@ class R1CSHandle:
             self.s.col[k] = col.ctypes.data_as(u32p)
             self.s.coeff[k] = cf.ctypes.data_as(u64p)
             self.s.nnz[k] = col.shape[0]
+            if poly_table is not None and poly_idx is not None and poly_idx.get(name) is not None:
+                pi = np.ascontiguousarray(poly_idx[name], dtype=np.int32)
+                assert pi.shape == col.shape
+                self._keep.append(pi)
+                self.s.pidx[k] = pi.ctypes.data_as(C.POINTER(C.c_int32))
+        if poly_table is not None:
+            pt = np.ascontiguousarray(poly_table, dtype=np.uint64)
+            assert pt.ndim == 3
+            self._keep.append(pt)
+            self.s.ptab = pt.ctypes.data_as(u64p)
+            self.s.ptab_L, self.s.ptab_N, self.s.ptab_slot0 = pt.shape[1], pt.shape[2], slot0
+
+    def at_slots(self, slot0):
+        """The same system for calls whose arrays start at ring slot `slot0` of every limb."""
+        return self if slot0 == self.s.ptab_slot0 else R1CSHandle(*self._args, slot0=slot0)
 
     def ref(self):
         return C.byref(self.s)

@@ -13,7 +13,9 @@
 // Everything the Python side needs to recompute the proofs through ctypes is written as raw little-endian u64
 // files into <outdir>.  TEST INFRASTRUCTURE; the binary lands in oracle/_ref/ (git-ignored, travels to the GPU box).
 //
-// usage: ref_adapter_prove N L q.. N_enc K Q.. m outdir
+// usage: ref_adapter_prove N L q.. N_enc K Q.. m outdir [poly]
+// poly: the circuit's ring coefficients are general ring elements (random polynomials) instead of the Scalar 5 -- on a
+// primary input and on an auxiliary variable -- as in benchmarks/bench_ntt_SEAL.cpp:46-53 (`row * vars[i]`).
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -63,6 +65,7 @@ int main(int argc, char **argv) {
     for (int j = 0; j < p.K; j++) p.Q.push_back(strtoull(argv[a++], nullptr, 10));
     const size_t m = (size_t)atoi(argv[a++]);
     const std::string out = argv[a++];
+    const bool poly = a < argc && std::string(argv[a]) == "poly";
     Context::set_context(p);
     Context::seed_prng(20261002);
 
@@ -71,13 +74,14 @@ int main(int argc, char **argv) {
     ringsnark::pb_variable_array<R> x(m + 2, ringsnark::pb_variable<R>());
     x.allocate(pb, m + 2, "x");
     pb.set_input_sizes(2);
-    const R c(5);
+    // poly: u multiplies x_i (an auxiliary variable from i = 2 on), c multiplies the primary input x_0, k is the constant term
+    const R c = poly ? R::random_element() : R(5), u = poly ? R::random_element() : R(1), k = poly ? R::random_element() : R(2);
     for (size_t i = 0; i < m; i++)
-      pb.add_r1cs_constraint(ringsnark::r1cs_constraint<R>(x[i] + 3 * x[i + 1] + 2, x[i + 1] - c * x[0], x[i + 2]));
+      pb.add_r1cs_constraint(ringsnark::r1cs_constraint<R>(u * x[i] + 3 * x[i + 1] + k * ringsnark::variable<R>(0), x[i + 1] - c * x[0], x[i + 2]));
     pb.val(x[0]) = R::random_element();
     pb.val(x[1]) = R::random_element();
     for (size_t i = 0; i < m; i++)
-      pb.val(x[i + 2]) = (pb.val(x[i]) + R(3) * pb.val(x[i + 1]) + R(2)) * (pb.val(x[i + 1]) - c * pb.val(x[0]));
+      pb.val(x[i + 2]) = (u * pb.val(x[i]) + R(3) * pb.val(x[i + 1]) + k) * (pb.val(x[i + 1]) - c * pb.val(x[0]));
     if (!pb.is_satisfied()) throw std::runtime_error("reference is_satisfied() rejects a satisfying assignment");
     {
       ringsnark::protoboard<R> bad(pb);
@@ -136,7 +140,11 @@ int main(int argc, char **argv) {
       dump(out + "/row_ptr" + std::to_string(w) + ".bin", rp64);
       dump(out + "/col" + std::to_string(w) + ".bin", col64);
       dump(out + "/coeff" + std::to_string(w) + ".bin", csr.coeff[w]);
+      std::vector<uint64_t> pi64(csr.poly_idx[w].size());
+      for (size_t e = 0; e < pi64.size(); e++) pi64[e] = (uint64_t)(int64_t)csr.poly_idx[w][e];
+      dump(out + "/poly_idx" + std::to_string(w) + ".bin", pi64);
     }
+    dump(out + "/poly_table.bin", csr.poly_table);
     std::vector<R> full(primary);
     full.insert(full.end(), aux.begin(), aux.end());
     dump(out + "/assignment.bin", ringsnark::amd::flatten(full));

@@ -505,7 +505,9 @@ void rso_witness_map_mt(uint64_t q, size_t S, const rso_r1cs *cs, int limb, cons
     uint64_t *o[7];
     for (int e = 0; e < 7; e++) o[e] = (uint64_t *)malloc(sizeof(uint64_t) * (m + 1) * w);
     uint64_t *Zl = (uint64_t *)malloc(sizeof(uint64_t) * (m + 1));
-    rso_witness_map(q, w, cs, limb, asg, dd[0], dd[1], dd[2], o[0], o[1], o[2], o[3], o[4], o[5], Zl, o[6]);
+    rso_r1cs cs_at = *cs; /* this thread's slots start at ring slot ptab_slot0 + lo */
+    cs_at.ptab_slot0 += lo;
+    rso_witness_map(q, w, &cs_at, limb, asg, dd[0], dd[1], dd[2], o[0], o[1], o[2], o[3], o[4], o[5], Zl, o[6]);
     uint64_t *dst[7] = {A_io, B_io, C_io, A_mid, B_mid, C_mid, H};
     for (int e = 0; e < 7; e++) {
       const size_t rows = e == 6 ? m + 1 : m;
@@ -767,20 +769,27 @@ void rso_vanishing(uint64_t q, size_t m, uint64_t *Z) {
   }
 }
 
-/* relations/variable.tcc:246-254: acc += (index==0 ? one : assignment[index-1]) * coeff. */
+/* relations/variable.tcc:246-254: acc += (index==0 ? one : assignment[index-1]) * coeff.  coeff is a RingT: a
+ * slot-constant scalar (cf) or a general ring element (row of ptab: one residue per slot). */
 void rso_r1cs_evaluate(uint64_t q, size_t S, const rso_r1cs *cs, int which, int limb,
                        const uint64_t *assignment, uint64_t *out) {
   const uint32_t *rp = cs->row_ptr[which], *col = cs->col[which];
   const uint64_t *cf = cs->coeff[which] + (size_t)limb * cs->nnz[which];
+  const int32_t *pidx = cs->pidx[which];
   memset(out, 0, sizeof(uint64_t) * cs->m * S);
   for (size_t i = 0; i < cs->m; i++) {
     uint64_t *o = out + i * S;
     for (uint32_t e = rp[i]; e < rp[i + 1]; e++) {
+      const uint64_t *a = col[e] ? assignment + (size_t)(col[e] - 1) * S : NULL;
+      if (pidx && pidx[e] >= 0) {
+        const uint64_t *pc = cs->ptab + ((size_t)pidx[e] * cs->ptab_L + (size_t)limb) * cs->ptab_N + cs->ptab_slot0;
+        for (size_t v = 0; v < S; v++) o[v] = addmod(o[v], a ? rso_mulmod(a[v], pc[v] % q, q) : pc[v] % q, q);
+        continue;
+      }
       uint64_t cc = cf[e] % q;
-      if (col[e] == 0) {
+      if (!a) {
         for (size_t v = 0; v < S; v++) o[v] = addmod(o[v], cc, q);
       } else {
-        const uint64_t *a = assignment + (size_t)(col[e] - 1) * S;
         for (size_t v = 0; v < S; v++) o[v] = addmod(o[v], rso_mulmod(a[v], cc, q), q);
       }
     }

@@ -156,6 +156,14 @@ typedef struct rso_r1cs {
   const uint32_t *col[3];
   const uint64_t *coeff[3];
   size_t nnz[3];
+  /* Coefficients that are general ring elements (linear_term<RingT>::coeff is a RingT, relations/variable.hpp; the
+   * DFT constraint of benchmarks/bench_ntt_SEAL.cpp:46-53 multiplies variables by powers of a POLYNOMIAL):
+   * pidx[M][e] >= 0 selects row pidx of ptab [n_poly][ptab_L][ptab_N] instead of coeff[M][.][e]; pidx[M] == NULL or
+   * pidx[M][e] < 0: the slot-constant scalar.  ptab_slot0: the ring slot that slot 0 of the `assignment` / `out`
+   * arrays of a call corresponds to (calls on a slot sub-range of a limb). */
+  const int32_t *pidx[3];
+  const uint64_t *ptab;
+  size_t ptab_L, ptab_N, ptab_slot0;
 } rso_r1cs;
 /* linear_combination::evaluate for every constraint: out[m][S], assignment [n_vars][S]. */
 void rso_r1cs_evaluate(uint64_t q, size_t S, const rso_r1cs *cs, int which, int limb,

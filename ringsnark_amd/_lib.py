@@ -86,6 +86,9 @@ SIGNATURES = {
                          C.POINTER(C.c_size_t), vp]),
     "rs_r1cs_create": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(u32p), C.POINTER(u32p),
                                  C.POINTER(u64p), C.POINTER(C.c_size_t), C.POINTER(vp)]),
+    "rs_r1cs_create_poly": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(u32p), C.POINTER(u32p),
+                                      C.POINTER(u64p), C.POINTER(C.c_size_t), C.POINTER(C.POINTER(C.c_int32)), u64p, C.c_size_t,
+                                      C.POINTER(vp)]),
     "rs_r1cs_destroy": (None, [vp]),
     "rs_r1cs_evaluate": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "rs_witness_map": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64p, vp]),

@@ -733,8 +733,10 @@ int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, ui
   const size_t rows = cs->n_vars + 1;
   std::vector<uint32_t> rp[3], col[3];
   std::vector<uint64_t> cf[3];
+  std::vector<int32_t> pi[3];  // polynomial coefficients travel with their terms (same table)
   const uint32_t *rpp[3], *colp[3];
   const uint64_t *cfp[3];
+  const int32_t *pip[3];
   size_t nnz[3];
   for (int w = 0; w < 3; w++) {
     const size_t z = cs->nnz[w];
@@ -744,18 +746,23 @@ int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, ui
     for (size_t k = 0; k < rows; k++) rp[w][k + 1] += rp[w][k];
     col[w].resize(std::max<size_t>(z, 1));
     cf[w].resize(std::max<size_t>((size_t)L * z, 1));
+    pi[w].assign(std::max<size_t>(z, 1), -1);
     std::vector<uint32_t> fill(rp[w].begin(), rp[w].end() - 1);
     for (size_t i = 0; i < m; i++)
       for (uint32_t e = cs->h_row_ptr[w][i]; e < cs->h_row_ptr[w][i + 1]; e++) {
         const uint32_t dst = fill[cs->h_col[w][e]]++;
         col[w][dst] = (uint32_t)(i + 1);
         for (int l = 0; l < L; l++) cf[w][(size_t)l * z + dst] = cs->h_coeff[w][(size_t)l * z + e];
+        if (!cs->h_pidx[w].empty()) pi[w][dst] = cs->h_pidx[w][e];
       }
     rpp[w] = rp[w].data();
     colp[w] = col[w].data();
     cfp[w] = cf[w].data();
+    pip[w] = cs->h_pidx[w].empty() ? nullptr : pi[w].data();
   }
-  RS_REQUIRE(rs_r1cs_create(ctx, rows, m, 0, rpp, colp, cfp, nnz, &guard.tr) == RS_OK, rs_last_error());
+  RS_REQUIRE(rs_r1cs_create_poly(ctx, rows, m, 0, rpp, colp, cfp, nnz, pip, cs->n_poly ? cs->h_ptab.data() : nullptr, cs->n_poly,
+                                 &guard.tr) == RS_OK,
+             rs_last_error());
   uint64_t *outs[3] = {d_At, d_Bt, d_Ct};
   for (int w = 0; w < 3; w++) r1cs_evaluate_run(ctx, guard.tr, w, RS_EVAL_FULL, D, outs[w], st);
   RS_HIP(hipStreamSynchronize(st));

@@ -124,8 +124,17 @@ struct rs_r1cs {
   size_t nnz[3] = {0, 0, 0};
   std::vector<uint32_t> h_row_ptr[3], h_col[3];
   std::vector<uint64_t> h_coeff[3];
-  std::vector<uint64_t> h_const[3];  // [L][m] sum of the index-0 (constant-one) coefficients per row
+  std::vector<uint64_t> h_const[3];  // [L][m] sum of the SCALAR index-0 (constant-one) coefficients per row
   bool has_const[3] = {false, false, false};
+  // coefficients that are general ring elements (rs_r1cs_create_poly): per non-zero -1 (the scalar above) or a row of
+  // the table [n_poly][L][N] (device copy: table constants of the context's arithmetic, like d_coeff)
+  int32_t *d_pidx[3] = {nullptr, nullptr, nullptr};
+  double *d_ptab = nullptr;
+  std::vector<int32_t> h_pidx[3];
+  std::vector<uint64_t> h_ptab;
+  size_t n_poly = 0;
+  bool io_poly = false;                           // a polynomial coefficient multiplies the constant one or a primary input
+  bool const_poly[3] = {false, false, false};     // ... multiplies the constant one (index 0) in this matrix
   // io shortcut cache (witness.hip): interpolated columns of the constant and primary-input variables
   bool io_built = false;
   double *d_io_cols = nullptr;  // [ncols][L][M]

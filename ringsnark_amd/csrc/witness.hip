@@ -1543,7 +1543,7 @@ template <class CPS>
 __global__ void __launch_bounds__(256)
 mid_kernel(typename CPS::T *__restrict__ full, const typename CPS::T *__restrict__ io,
            const typename CPS::T *__restrict__ cst /* [Ltot][M] or null */, size_t M, size_t S, unsigned slots_per_limb, CPS plans,
-           int limb0) {
+           int limb0, const typename CPS::T *__restrict__ cst_cols /* [S][M] or null: a constant part that differs per slot */) {
   using T = typename CPS::T;
   const size_t total = S * M, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -1552,32 +1552,44 @@ mid_kernel(typename CPS::T *__restrict__ full, const typename CPS::T *__restrict
     const typename CPS::M mod = plans.l[limb].mod;
     T v = subm(full[i], io[i], mod);
     if (cst) v = addm(v, cst[(size_t)(limb0 + limb) * M + k], mod);
+    if (cst_cols) v = addm(v, cst_cols[i], mod);
     full[i] = canon(v, mod);
   }
 }
 
-// one row of linear_combination::evaluate for a slot pair: sum_e coeff_e * x_{col_e} (index 0 = the constant one)
+// one row of linear_combination::evaluate for a slot pair: sum_e coeff_e * x_{col_e} (index 0 = the constant one).
+// coeff_e is a slot-constant scalar, or -- pidx[e] >= 0 -- a general ring element: row pidx[e] of the table, whose two
+// residues for this slot pair sit at ptab_pair + pidx[e] * Si (the table has the assignment's [L][N] layout).
+#define RS_EVAL_CONST 3 /* internal mode: the index-0 terms only (the constant part of a mid vector) */
 template <class M>
 __device__ __forceinline__ void eval_row_pair(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
                                               const typename ArithOf<M>::T *__restrict__ coeff_limb, size_t row,
                                               const uint64_t *__restrict__ asg, size_t Si, size_t pair, int mode, unsigned n_inputs,
-                                              const M mod, typename ArithOf<M>::T &o0, typename ArithOf<M>::T &o1) {
+                                              const M mod, typename ArithOf<M>::T &o0, typename ArithOf<M>::T &o1,
+                                              const int32_t *__restrict__ pidx, const typename ArithOf<M>::T *__restrict__ ptab) {
   using T = typename ArithOf<M>::T;
   T a0 = T(0), a1 = T(0);
   int since = 0;
   for (uint32_t e = row_ptr[row]; e < row_ptr[row + 1]; e++) {
     const uint32_t cv = col[e];
-    const T cf = coeff_limb[e];  // a table constant
+    T cf0 = coeff_limb[e], cf1 = cf0;  // table constants
+    if (pidx) {
+      const int32_t pk = pidx[e];
+      if (pk >= 0) {
+        const T *pc = ptab + (size_t)pk * Si + 2 * pair;
+        cf0 = pc[0];
+        cf1 = pc[1];
+      }
+    }
     if (cv == 0) {
-      const T one_times = konst_value(cf, mod);
-      a0 = addm(a0, one_times, mod);
-      a1 = addm(a1, one_times, mod);
+      a0 = addm(a0, konst_value(cf0, mod), mod);
+      a1 = addm(a1, konst_value(cf1, mod), mod);
     } else {
       const bool is_input = (cv - 1) < n_inputs;
-      if ((mode == RS_EVAL_IO && !is_input) || (mode == RS_EVAL_MID && is_input)) continue;
+      if ((mode == RS_EVAL_IO && !is_input) || (mode == RS_EVAL_MID && is_input) || mode == RS_EVAL_CONST) continue;
       const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(cv - 1) * Si)[pair];
-      a0 = addm(a0, mulmod(from_res<T>(v.x), cf, mod), mod);
-      a1 = addm(a1, mulmod(from_res<T>(v.y), cf, mod), mod);
+      a0 = addm(a0, mulmod(from_res<T>(v.x), cf0, mod), mod);
+      a1 = addm(a1, mulmod(from_res<T>(v.y), cf1, mod), mod);
     }
     if (++since == 4) {
       since = 0;
@@ -1595,7 +1607,8 @@ template <class M>
 __global__ void __launch_bounds__(256)
 r1cs_eval_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
                  const typename ArithOf<M>::T *__restrict__ coeff, size_t nnz, const uint64_t *__restrict__ asg,
-                 uint64_t *__restrict__ out, int N, int L, int mode, unsigned n_inputs, const M *__restrict__ qmod) {
+                 uint64_t *__restrict__ out, int N, int L, int mode, unsigned n_inputs, const M *__restrict__ qmod,
+                 const int32_t *__restrict__ pidx, const typename ArithOf<M>::T *__restrict__ ptab) {
   using T = typename ArithOf<M>::T;
   const size_t row = blockIdx.x;
   const size_t S = (size_t)L * N;
@@ -1603,7 +1616,7 @@ r1cs_eval_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restric
   if (2 * pair >= S) return;
   const int limb = (int)((2 * pair) / (size_t)N);
   T a0, a1;
-  eval_row_pair<M>(row_ptr, col, coeff + (size_t)limb * nnz, row, asg, S, pair, mode, n_inputs, qmod[limb], a0, a1);
+  eval_row_pair<M>(row_ptr, col, coeff + (size_t)limb * nnz, row, asg, S, pair, mode, n_inputs, qmod[limb], a0, a1, pidx, ptab);
   ulonglong2 o;
   o.x = to_res(a0);
   o.y = to_res(a1);
@@ -1618,7 +1631,8 @@ __global__ void __launch_bounds__(256)
 r1cs_eval_cols_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
                       const typename ArithOf<M>::T *__restrict__ coeff, size_t nnz, const uint64_t *__restrict__ asg,
                       typename ArithOf<M>::T *__restrict__ cols, size_t m, size_t C, size_t Mlen, int mode, unsigned n_inputs,
-                      const M *__restrict__ qmod, ColMap cm) {
+                      const M *__restrict__ qmod, ColMap cm, const int32_t *__restrict__ pidx,
+                      const typename ArithOf<M>::T *__restrict__ ptab) {
   using T = typename ArithOf<M>::T;
   __shared__ T tile[64][33];  // [column][row]
   const size_t s0 = (size_t)blockIdx.x * 64, r0 = (size_t)blockIdx.y * 32;
@@ -1632,7 +1646,7 @@ r1cs_eval_cols_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__re
     for (int k = ty; k < 32; k += 8) {
       const size_t row = r0 + k;
       T a0 = T(0), a1 = T(0);
-      if (row < m) eval_row_pair<M>(row_ptr, col, coeff + (size_t)limb * nnz, row, asg, Si, pair, mode, n_inputs, mod, a0, a1);
+      if (row < m) eval_row_pair<M>(row_ptr, col, coeff + (size_t)limb * nnz, row, asg, Si, pair, mode, n_inputs, mod, a0, a1, pidx, ptab);
       tile[2 * tx][k] = a0;
       tile[2 * tx + 1][k] = a1;
     }
@@ -3015,17 +3029,19 @@ void r1cs_evaluate_run(rs_ctx *ctx, const rs_r1cs *cs, int which, int mode, cons
   if (ctx->use_int)
     hipLaunchKernelGGL(r1cs_eval_kernel<ModI>, dim3((unsigned)cs->m, by), dim3(256), 0, st, cs->d_row_ptr[which], cs->d_col[which],
                        reinterpret_cast<const uint64_t *>(cs->d_coeff[which]), cs->nnz[which], d_asg, d_out, ctx->N, ctx->L, mode,
-                       (unsigned)cs->n_inputs, ctx->d_qmod_i);
+                       (unsigned)cs->n_inputs, ctx->d_qmod_i, cs->d_pidx[which], reinterpret_cast<const uint64_t *>(cs->d_ptab));
   else
     hipLaunchKernelGGL(r1cs_eval_kernel<Mod>, dim3((unsigned)cs->m, by), dim3(256), 0, st, cs->d_row_ptr[which], cs->d_col[which],
-                       cs->d_coeff[which], cs->nnz[which], d_asg, d_out, ctx->N, ctx->L, mode, (unsigned)cs->n_inputs, ctx->d_qmod);
+                       cs->d_coeff[which], cs->nnz[which], d_asg, d_out, ctx->N, ctx->L, mode, (unsigned)cs->n_inputs, ctx->d_qmod,
+                       cs->d_pidx[which], cs->d_ptab);
   RS_HIP(hipGetLastError());
 }
 
 constexpr size_t IO_SHORTCUT_MAX_INPUTS = 64;
 // does the witness map of this system compute the io vectors as linear forms of the primary inputs (cs->d_io_* hold them
 // after the first witness_run)?
-bool witness_io_shortcut(const rs_r1cs *cs) { return cs->n_inputs <= IO_SHORTCUT_MAX_INPUTS; }
+// The shortcut needs slot-constant coefficients on the constant one and on the primary inputs (the L_k are slot constant).
+bool witness_io_shortcut(const rs_r1cs *cs) { return cs->n_inputs <= IO_SHORTCUT_MAX_INPUTS && !cs->io_poly; }
 
 // Per-circuit cache for the io shortcut: L_k = interp(column k of X), k = 0 (constant) .. n_inputs.
 template <class M_>
@@ -3100,36 +3116,46 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
   const size_t C = (size_t)nl * cm.ns;  // columns in this chunk
   const CPS cp = make_colplans<M_>(ctx, P, cm.limb0);
   const bool needH = outs[6] != nullptr;
-  const bool shortcut = cs->n_inputs <= IO_SHORTCUT_MAX_INPUTS;
-  bool need_io[3], need_full[3];
+  const bool shortcut = witness_io_shortcut(cs);
+  bool need_io[3], need_full[3], need_cst[3];
   for (int w = 0; w < 3; w++) {
     need_io[w] = outs[w] != nullptr || outs[3 + w] != nullptr;
     need_full[w] = outs[3 + w] != nullptr || (needH && w < 2);  // H needs A and B only
+    // a constant part that differs per slot (polynomial coefficients on the constant one) is evaluated and
+    // interpolated column by column like the other vectors; the shortcut never sees such a system
+    need_cst[w] = cs->const_poly[w] && outs[3 + w] != nullptr;
   }
-  // column-major workspace, only the vectors this call needs: io (fallback path only), full, H
-  auto needed = [&](int k) { return k < 3 ? (need_io[k] && !shortcut) : (k < 6 ? need_full[k - 3] : needH); };
-  int slot_of[7], nvec = 0;
-  for (int k = 0; k < 7; k++) slot_of[k] = needed(k) ? nvec++ : -1;
+  // column-major workspace, only the vectors this call needs: io (fallback path only), full, per-slot constant parts, H
+  auto needed = [&](int k) {
+    return k < 3 ? (need_io[k] && !shortcut) : (k < 6 ? need_full[k - 3] : (k == 6 ? needH : need_cst[k - 7]));
+  };
+  static const int order[10] = {0, 1, 2, 3, 4, 5, 7, 8, 9, 6};  // the interpolated vectors adjacent, H last
+  int slot_of[10], nvec = 0;
+  for (int k = 0; k < 10; k++) slot_of[k] = -1;
+  for (int o = 0; o < 10; o++)
+    if (needed(order[o])) slot_of[order[o]] = nvec++;
   const size_t vec = C * M;
   T *colbuf = (T *)ws_get(ctx, 5, std::max<size_t>(1, (size_t)nvec * vec) * sizeof(T));
   auto colv = [&](int k) { return colbuf + (size_t)slot_of[k] * vec; };
   const dim3 tgrid((unsigned)((C + 31) / 32), (unsigned)((M + 31) / 32));
   const dim3 tgrid64((unsigned)((C + 63) / 64), (unsigned)((M + 31) / 32));
+  const T *ptab = reinterpret_cast<const T *>(cs->d_ptab);
   for (int w = 0; w < 3; w++)
-    for (int full = 0; full < 2; full++) {
-      if (!needed(3 * full + w)) continue;
+    for (int kind = 0; kind < 3; kind++) {  // io, full, constant part
+      const int k = kind == 2 ? 7 + w : 3 * kind + w;
+      if (!needed(k)) continue;
       // per (row, slot): 8 bytes of assignment per non-zero + 8 bytes of column written
       ProfScope prof(ctx, st, "r1cs_eval_cols_kernel", (double)C * 8.0 * ((double)cs->nnz[w] + (double)M), 7.0 * (double)C * (double)cs->nnz[w]);
       hipLaunchKernelGGL(r1cs_eval_cols_kernel<M_>, tgrid64, dim3(256), 0, st, cs->d_row_ptr[w], cs->d_col[w], coeff[w],
-                         cs->nnz[w], d_asg, colv(3 * full + w), m, C, M, full ? (int)RS_EVAL_FULL : (int)RS_EVAL_IO,
-                         (unsigned)cs->n_inputs, qmod, cm);
+                         cs->nnz[w], d_asg, colv(k), m, C, M, kind == 2 ? (int)RS_EVAL_CONST : (kind ? (int)RS_EVAL_FULL : (int)RS_EVAL_IO),
+                         (unsigned)cs->n_inputs, qmod, cm, cs->d_pidx[w], ptab);
     }
   RS_HIP(hipGetLastError());
-  // one batched interpolation: the needed io / full vectors are adjacent in the workspace
+  // one batched interpolation: the needed io / full / constant vectors are adjacent in the workspace
   {
-    int n6 = 0;
-    for (int k = 0; k < 6; k++) n6 += needed(k);
-    if (n6) launch_interp<M_>(ctx, P, cp, colbuf, (size_t)n6 * C, C, (size_t)cm.ns, cm.limb0, st);
+    int n9 = 0;
+    for (int k = 0; k < 10; k++) n9 += (k != 6) && needed(k);
+    if (n9) launch_interp<M_>(ctx, P, cp, colbuf, (size_t)n9 * C, C, (size_t)cm.ns, cm.limb0, st);
   }
   if (needH) launch_h<M_>(ctx, P, cp, colv(3), colv(4), colv(6), C, (size_t)cm.ns, d1, d2, d3, cm, st);
   const unsigned eb = (unsigned)std::min<size_t>((vec + 255) / 256, 256 * 16);
@@ -3137,9 +3163,12 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
     // fallback: X_mid = interp(full) - interp(io) + interp(constant part), combined in column-major form
     for (int w = 0; w < 3; w++) {
       if (!outs[3 + w]) continue;
-      const T *cst = (d_const && cs->has_const[w]) ? d_const + (size_t)w * ctx->L * M : nullptr;
+      // the constant part: slot constant (interpolated once per call), or per slot when polynomial coefficients
+      // multiply the constant one (then the column holds EVERY index-0 term, scalar ones included)
+      const T *cst = (!need_cst[w] && d_const && cs->has_const[w]) ? d_const + (size_t)w * ctx->L * M : nullptr;
       ProfScope prof(ctx, st, "mid_kernel", (double)vec * 24.0, 3.0 * (double)vec);
-      hipLaunchKernelGGL(mid_kernel<CPS>, dim3(eb), dim3(256), 0, st, colv(3 + w), colv(w), cst, M, C, (unsigned)cm.ns, cp, cm.limb0);
+      hipLaunchKernelGGL(mid_kernel<CPS>, dim3(eb), dim3(256), 0, st, colv(3 + w), colv(w), cst, M, C, (unsigned)cm.ns, cp, cm.limb0,
+                         need_cst[w] ? colv(7 + w) : (const T *)nullptr);
     }
     RS_HIP(hipGetLastError());
     for (int k = 0; k < 6; k++)
@@ -3198,7 +3227,7 @@ static void witness_run_arith(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_
   const int L = ctx->L;
   if (h_Z)
     for (int i = 0; i < L; i++) memcpy(h_Z + (size_t)i * (m + 1), P->limb[i].Z.data(), sizeof(uint64_t) * (m + 1));
-  const bool shortcut = cs->n_inputs <= IO_SHORTCUT_MAX_INPUTS;
+  const bool shortcut = witness_io_shortcut(cs);
   if (shortcut) build_io_cache<M_>(ctx, cs, P, make_colplans<M_>(ctx, P), st);
   // fallback path: interpolated constant parts [3][L][M], once per call
   T *d_const = nullptr;
@@ -3218,7 +3247,7 @@ static void witness_run_arith(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_
     const bool needH = outs[6] != nullptr;
     for (int w = 0; w < 3; w++) {
       const bool need_io = outs[w] || outs[3 + w], need_full = outs[3 + w] || (needH && w < 2);
-      nvec += (need_io && !shortcut) + need_full;
+      nvec += (need_io && !shortcut) + need_full + (cs->const_poly[w] && outs[3 + w]);
     }
     nvec += needH;
   }
@@ -3277,9 +3306,16 @@ void rs_witness_plans_destroy(rs_ctx *ctx) {
 
 int rs_r1cs_create(rs_ctx *ctx, size_t m, size_t n_vars, size_t n_inputs, const uint32_t *const h_row_ptr[3],
                    const uint32_t *const h_col[3], const uint64_t *const h_coeff[3], const size_t nnz[3], rs_r1cs **out) {
+  return rs_r1cs_create_poly(ctx, m, n_vars, n_inputs, h_row_ptr, h_col, h_coeff, nnz, nullptr, nullptr, 0, out);
+}
+
+int rs_r1cs_create_poly(rs_ctx *ctx, size_t m, size_t n_vars, size_t n_inputs, const uint32_t *const h_row_ptr[3],
+                        const uint32_t *const h_col[3], const uint64_t *const h_coeff[3], const size_t nnz[3],
+                        const int32_t *const h_poly_idx[3], const uint64_t *h_poly_table, size_t n_poly, rs_r1cs **out) {
   RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && out && h_row_ptr && h_col && h_coeff && nnz, "null argument");
   RS_REQUIRE(m >= 1 && n_inputs <= n_vars, "bad R1CS shape");
+  RS_REQUIRE(n_poly == 0 || (h_poly_idx && h_poly_table), "polynomial coefficient table without indices");
   struct Holder {  // frees a partly built object when a check below throws
     rs_r1cs *p;
     ~Holder() { rs_r1cs_destroy(p); }
@@ -3289,6 +3325,21 @@ int rs_r1cs_create(rs_ctx *ctx, size_t m, size_t n_vars, size_t n_inputs, const 
   cs->n_vars = n_vars;
   cs->n_inputs = n_inputs;
   cs->L = ctx->L;
+  cs->n_poly = n_poly;
+  const size_t rw = ctx->ring_words();
+  if (n_poly) {  // the table as constants of the context's arithmetic, in the ring layout [n_poly][L][N]
+    cs->h_ptab.assign(h_poly_table, h_poly_table + n_poly * rw);
+    std::vector<uint64_t> pt(n_poly * rw);
+    for (size_t k = 0; k < n_poly; k++)
+      for (int i = 0; i < ctx->L; i++)
+        for (int x = 0; x < ctx->N; x++) {
+          const size_t at = (k * ctx->L + i) * (size_t)ctx->N + x;
+          cs->h_ptab[at] %= ctx->q[i];
+          pt[at] = konst_word(ctx, cs->h_ptab[at], ctx->q[i]);
+        }
+    RS_HIP(hipMalloc(&cs->d_ptab, sizeof(double) * pt.size()));
+    RS_HIP(hipMemcpy(cs->d_ptab, pt.data(), sizeof(double) * pt.size(), hipMemcpyHostToDevice));
+  }
   for (int w = 0; w < 3; w++) {
     const size_t z = nnz[w];
     cs->nnz[w] = z;
@@ -3300,12 +3351,23 @@ int rs_r1cs_create(rs_ctx *ctx, size_t m, size_t n_vars, size_t n_inputs, const 
     cs->h_coeff[w].assign(h_coeff[w], h_coeff[w] + (size_t)ctx->L * z);
     cs->h_const[w].assign((size_t)ctx->L * m, 0);
     cs->has_const[w] = false;
+    const int32_t *pidx = (n_poly && h_poly_idx[w]) ? h_poly_idx[w] : nullptr;
+    bool any_poly = false;
+    for (size_t e = 0; pidx && e < z; e++) {
+      RS_REQUIRE(pidx[e] < 0 || (size_t)pidx[e] < n_poly, "polynomial coefficient index out of range");
+      if (pidx[e] < 0) continue;
+      any_poly = true;
+      if (h_col[w][e] <= n_inputs) cs->io_poly = true;
+      if (h_col[w][e] == 0) cs->const_poly[w] = true;
+    }
     std::vector<uint64_t> cf((size_t)ctx->L * std::max<size_t>(z, 1), 0);  // table constants of the context's arithmetic
     for (size_t r = 0; r < m; r++)
       for (uint32_t e = h_row_ptr[w][r]; e < h_row_ptr[w][r + 1]; e++) {
         RS_REQUIRE(h_col[w][e] <= n_vars, "column index out of range");
+        const bool is_poly = pidx && pidx[e] >= 0;
         for (int i = 0; i < ctx->L; i++) {
-          const uint64_t c = h_coeff[w][(size_t)i * z + e] % ctx->q[i];
+          const uint64_t c = is_poly ? 0 : h_coeff[w][(size_t)i * z + e] % ctx->q[i];  // the scalar slot of a polynomial term is unused
+          cs->h_coeff[w][(size_t)i * z + e] = c;
           cf[(size_t)i * z + e] = konst_word(ctx, c, ctx->q[i]);
           if (h_col[w][e] == 0) {
             cs->h_const[w][(size_t)i * m + r] = host::addmod(cs->h_const[w][(size_t)i * m + r], c, ctx->q[i]);
@@ -3319,6 +3381,11 @@ int rs_r1cs_create(rs_ctx *ctx, size_t m, size_t n_vars, size_t n_inputs, const 
     if (z) RS_HIP(hipMemcpy(cs->d_col[w], h_col[w], sizeof(uint32_t) * z, hipMemcpyHostToDevice));
     RS_HIP(hipMalloc(&cs->d_coeff[w], sizeof(double) * cf.size()));
     RS_HIP(hipMemcpy(cs->d_coeff[w], cf.data(), sizeof(double) * cf.size(), hipMemcpyHostToDevice));
+    if (any_poly) {
+      cs->h_pidx[w].assign(pidx, pidx + z);
+      RS_HIP(hipMalloc(&cs->d_pidx[w], sizeof(int32_t) * z));
+      RS_HIP(hipMemcpy(cs->d_pidx[w], pidx, sizeof(int32_t) * z, hipMemcpyHostToDevice));
+    }
   }
   holder.p = nullptr;
   *out = cs;
@@ -3333,8 +3400,10 @@ void rs_r1cs_destroy(rs_r1cs *cs) {
     if (cs->d_coeff[w]) (void)hipFree(cs->d_coeff[w]);
     if (cs->d_io_k[w]) (void)hipFree(cs->d_io_k[w]);
     if (cs->d_io_c[w]) (void)hipFree(cs->d_io_c[w]);
+    if (cs->d_pidx[w]) (void)hipFree(cs->d_pidx[w]);
   }
   if (cs->d_io_cols) (void)hipFree(cs->d_io_cols);
+  if (cs->d_ptab) (void)hipFree(cs->d_ptab);
   delete cs;
 }
 

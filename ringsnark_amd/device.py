@@ -51,7 +51,20 @@ class DeviceR1CS:
             cf[k] = f.ctypes.data_as(_lib.u64p)
             nnz[k] = c.shape[0]
         h = C.c_void_p()
-        _lib.check(dev.lib.rs_r1cs_create(dev.h, cs.m, cs.n_vars, cs.n_inputs, rp, col, cf, nnz, C.byref(h)))
+        if cs.poly_table is None:
+            _lib.check(dev.lib.rs_r1cs_create(dev.h, cs.m, cs.n_vars, cs.n_inputs, rp, col, cf, nnz, C.byref(h)))
+        else:  # coefficients that are general ring elements (relations/variable.tcc:246-254)
+            i32p = C.POINTER(C.c_int32)
+            pidx = (i32p * 3)()
+            for k, name in enumerate("abc"):
+                pi = np.ascontiguousarray(cs.poly_idx[name], dtype=np.int32)
+                assert pi.shape[0] == nnz[k]
+                keep.append(pi)
+                pidx[k] = pi.ctypes.data_as(i32p)
+            tab = np.ascontiguousarray(cs.poly_table, dtype=np.uint64)
+            assert tab.shape[1:] == (dev.L, dev.N)
+            _lib.check(dev.lib.rs_r1cs_create_poly(dev.h, cs.m, cs.n_vars, cs.n_inputs, rp, col, cf, nnz, pidx,
+                                                   tab.ctypes.data_as(_lib.u64p), tab.shape[0], C.byref(h)))
         self.h = h
 
     def __del__(self):

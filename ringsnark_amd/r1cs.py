@@ -3,12 +3,14 @@
 Mirrors what the hot path reads from the reference's r1cs_constraint_system<RingT>
 (relations/constraint_satisfaction_problems/r1cs/r1cs.hpp:118-123): for every constraint i the
 three linear combinations a, b, c as lists of (index, coeff) with index 0 = the constant one
-(relations/variable.tcc:246-254).  Coefficients are slot-constant ring scalars, stored reduced
-per RNS limb as uint64[L][nnz] (a signed literal c < 0 is -c's negation mod q_i, i.e.
--RingT::one()*|c|; SURVEY.md Appendix E-4).
+(relations/variable.tcc:246-254).  A coefficient is a RingT: either a slot-constant ring scalar, stored
+reduced per RNS limb as uint64[L][nnz] (a signed literal c < 0 is -c's negation mod q_i, i.e.
+-RingT::one()*|c|; SURVEY.md Appendix E-4), or a general ring element (one residue per NTT slot: the DFT
+constraint of benchmarks/bench_ntt_SEAL.cpp:46-53 multiplies variables by powers of a polynomial), kept
+once in `poly_table` [n_poly][L][N] and referenced per non-zero by `poly_idx` (-1 = the scalar).
 """
 from dataclasses import dataclass
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -19,6 +21,8 @@ class R1CS:
     n_vars: int  # variables, excluding the constant one
     n_inputs: int  # primary inputs (the first n_inputs variables)
     mats: Dict[str, Tuple[np.ndarray, np.ndarray, np.ndarray]]  # a/b/c -> (row_ptr, col, coeff[L][nnz])
+    poly_idx: Optional[Dict[str, np.ndarray]] = None  # a/b/c -> int32[nnz], -1 = scalar coefficient of mats
+    poly_table: Optional[np.ndarray] = None  # uint64 [n_poly][L][N]: coefficients that are general ring elements
 
     @property
     def n_aux(self):
@@ -28,21 +32,32 @@ class R1CS:
         return int(self.mats[name][1].shape[0])
 
 
-def from_rows(m, n_vars, n_inputs, rows: Dict[str, List[List[Tuple[int, int]]]], q: List[int]) -> R1CS:
-    """rows[name][i] = [(index, signed_int_coeff), ...]."""
-    mats = {}
+def from_rows(m, n_vars, n_inputs, rows: Dict[str, List[List[Tuple[int, object]]]], q: List[int]) -> R1CS:
+    """rows[name][i] = [(index, coeff), ...]; coeff: a signed int (slot-constant scalar) or a uint64 array [L][N]
+    (a general ring element)."""
+    mats, pidx, table = {}, {}, []
     for name in "abc":
         rp = np.zeros(m + 1, dtype=np.uint32)
-        col, cf = [], []
+        col, cf, pi = [], [], []
         for i, terms in enumerate(rows[name]):
             for idx, c in terms:
                 assert 0 <= idx <= n_vars
                 col.append(idx)
-                cf.append(c)
+                if isinstance(c, np.ndarray):
+                    assert c.ndim == 2 and c.shape[0] == len(q)
+                    pi.append(len(table))
+                    table.append(np.ascontiguousarray(c, dtype=np.uint64))
+                    cf.append(0)
+                else:
+                    pi.append(-1)
+                    cf.append(c)
             rp[i + 1] = len(col)
         coeff = np.array([[c % p for c in cf] for p in q], dtype=np.uint64).reshape(len(q), len(cf))
         mats[name] = (rp, np.array(col, dtype=np.uint32), coeff)
-    return R1CS(m, n_vars, n_inputs, mats)
+        pidx[name] = np.array(pi, dtype=np.int32)
+    if not table:
+        return R1CS(m, n_vars, n_inputs, mats)
+    return R1CS(m, n_vars, n_inputs, mats, pidx, np.stack(table))
 
 
 def chain_r1cs(m: int, q: List[int]) -> R1CS:
@@ -67,16 +82,57 @@ def wide_r1cs(m: int, q: List[int], seed: int = 11, width: int = 8, n_inputs: in
     return from_rows(m, m + 2, n_inputs, rows, q)
 
 
+def wide_poly_r1cs(m: int, q: List[int], N: int, seed: int = 17, width: int = 4, n_inputs: int = 2, aux_only: bool = False,
+                   constants: bool = True) -> R1CS:
+    """wide_r1cs with general ring elements among the coefficients: in `a` one polynomial coefficient per row on an
+    arbitrary earlier variable (primary inputs included) and, on every third row, on the constant one; in `b` a
+    polynomial coefficient on x_{i+1} on every other row:  <a_i, x> * (u_i x_{i+1}) = x_{i+2}.  Exercises every place
+    a coefficient is read (evaluate in its three modes, the constant part of the mid vectors, the instance map).
+    aux_only: polynomial coefficients multiply auxiliary variables only (the constant one and the primary inputs keep
+    slot-constant scalars, so the device keeps its linear-form io vectors).  constants = False: no term on the constant
+    one (the reference's witness map counts such terms in BOTH its io and its mid pass, r1cs_to_qrp.tcc:175-201, so a
+    circuit with constants does not pass the reference's own verifier; end-to-end tests use circuits without them)."""
+    rng = np.random.RandomState(seed)
+    rand_ring = lambda: np.stack([rng.randint(0, p, N, dtype=np.int64).astype(np.uint64) for p in q])
+    rows = {"a": [], "b": [], "c": []}
+    for i in range(m):
+        terms = [(0, rand_ring() if i % 3 == 0 and not aux_only else int(rng.randint(1, 5)))] if constants else []
+        for k in range(width):
+            idx = int(rng.randint(1, i + 3))
+            poly = k == 0 and not (aux_only and idx <= n_inputs)
+            terms.append((idx, rand_ring() if poly else (int(rng.randint(-3, 4)) or 1)))
+        rows["a"].append(terms)
+        rows["b"].append([(i + 2, rand_ring() if i % 2 == 0 and not (aux_only and i + 2 <= n_inputs) else 1)])
+        rows["c"].append([(i + 3, 1)])
+    return from_rows(m, m + 2, n_inputs, rows, q)
+
+
+def dft_r1cs(q: List[int], N: int, root_pows: np.ndarray) -> R1CS:
+    """The ONE-constraint circuit of the reference's benchmarks/bench_ntt_SEAL.cpp:28-55 (BASELINE.json configs[0]):
+    N + 1 variables, all of them primary inputs (:28-29,37);  (x_1 + sum_{i=1}^{N-1} row^i * x_{i+1}) * 1 = x_{N+1}
+    with row^i the i-th slot-wise power of the ring element `rs` whose residues are root_pows (:40-53).  root_pows:
+    uint64 [L][N] (the reference fills it with the powers of the first prime's minimal 2N-th root of unity)."""
+    rs = np.ascontiguousarray(root_pows, dtype=np.uint64)
+    assert rs.shape == (len(q), N)
+    qa = [int(p) for p in q]
+    terms = [(1, 1)]
+    row = rs.copy()
+    for i in range(1, N):
+        terms.append((i + 1, row.copy()))
+        row = np.stack([(row[l].astype(object) * rs[l].astype(object) % qa[l]).astype(np.uint64) for l in range(len(q))])
+    rows = {"a": [terms], "b": [[(0, 1)]], "c": [[(N + 1, 1)]]}
+    return from_rows(1, N + 1, N + 1, rows, q)
+
+
 def solve_forward(cs: R1CS, x0, x1, ring_mul, ring_lincomb):
-    """Fill the assignment of chain/wide circuits: x_{i+2} = <a_i, x> * x_{i+1}.
+    """Fill the assignment of chain/wide circuits: x_{i+2} = <a_i, x> * <b_i, x>  (b_i = x_{i+1}, possibly scaled).
 
     ring_lincomb(terms, assignment_list) and ring_mul(a, b) are supplied by the caller (CPU
     oracle in tests, device ring ops in the bench)."""
     asg = [x0, x1]
     rp, col, _ = cs.mats["a"]
     for i in range(cs.m):
-        a_val = ring_lincomb("a", i, asg)
-        asg.append(ring_mul(a_val, asg[i + 1]))
+        asg.append(ring_mul(ring_lincomb("a", i, asg), ring_lincomb("b", i, asg)))
     return asg
 
 

@@ -72,6 +72,43 @@ def probe_case(kind, m, q, seed, slots=4):
     return case
 
 
+def probe_case_poly(m, q, seed, S=8):
+    """Coefficients that are general ring elements (relations/variable.tcc:246-254 multiplies by any RingT; the DFT
+    constraint of benchmarks/bench_ntt_SEAL.cpp:46-53): the reference's headers instantiated over Z_q^S with
+    slot-wise operations (the probe's "vec" form).  The LAST slot of the last variable is tampered."""
+    probe = os.path.join(ROOT, "oracle", "_ref", "ref_r1cs_probe")
+    cs = R.wide_poly_r1cs(m, [q], S, seed=seed)
+    rng = np.random.RandomState(seed)
+    coeff = lambda name, e: [int(x) for x in cs.poly_table[cs.poly_idx[name][e], 0]] if cs.poly_idx[name][e] >= 0 else [int(cs.mats[name][2][0, e])] * S
+    vals = [[int(rng.randint(1, 2**31)) for _ in range(S)] for _ in range(2)]  # [variable][slot]
+    for i in range(m):
+        def lc(name, s):
+            rp, col, _ = cs.mats[name]
+            return sum(coeff(name, e)[s] * (1 if col[e] == 0 else vals[col[e] - 1][s]) for e in range(rp[i], rp[i + 1])) % q
+        vals.append([lc("a", s) * lc("b", s) % q for s in range(S)])
+    case = {"kind": "wide_poly", "q": q, "S": S, "m": m, "n_vars": cs.n_vars, "n_inputs": cs.n_inputs, "mats": {}, "runs": []}
+    for name in "abc":
+        rp, col, _ = cs.mats[name]
+        case["mats"][name] = {"row_ptr": [int(x) for x in rp], "col": [int(x) for x in col],
+                              "coeff": [coeff(name, e) for e in range(len(col))],  # S residues per non-zero
+                              "is_poly": [int(cs.poly_idx[name][e] >= 0) for e in range(len(col))]}
+    for tamper in (False, True):
+        v = [list(x) for x in vals]
+        if tamper:
+            v[-1][-1] = (v[-1][-1] + 1) % q
+        lines = ["vec %d %d %d %d %d" % (q, S, m, cs.n_vars, cs.n_inputs)]
+        for name in "abc":
+            rp, col, _ = cs.mats[name]
+            for i in range(m):
+                terms = ["%d %s" % (col[e], " ".join(str(x) for x in coeff(name, e))) for e in range(rp[i], rp[i + 1])]
+                lines.append("%d %s" % (len(terms), " ".join(terms)))
+        lines.append(" ".join(str(x) for var in v for x in var))
+        out = subprocess.run([probe], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.split("\n")
+        case["runs"].append({"assignment": v, "satisfied": int(out[0].split()[1]),
+                             "rows": [[[int(x) for x in tok.split(",")] for tok in out[1 + i].split()] for i in range(m)]})
+    return case
+
+
 # ---- 2. the reference's own test data ----------------------------------------------------------
 def horner(coeffs, x, q):
     acc = 0
@@ -163,7 +200,8 @@ def oracle_vectors():
 
 def main():
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_r1cs_probe")):
-        cases = [probe_case("wide", 9, 0xFFFFEE001, 5), probe_case("chain", 6, 0xFFFFEE001, 6), probe_case("wide", 17, 0xFFFFC4001, 8)]
+        cases = [probe_case("wide", 9, 0xFFFFEE001, 5), probe_case("chain", 6, 0xFFFFEE001, 6), probe_case("wide", 17, 0xFFFFC4001, 8),
+                 probe_case_poly(7, 0xFFFFEE001, 21), probe_case_poly(12, 0xFFFFC4001, 22, S=4)]
         json.dump({"generator": "oracle/_ref/ref_r1cs_probe (reference relations/ headers, compiled as they lie)", "cases": cases},
                   open(os.path.join(HERE, "ref_r1cs_probe.json"), "w"), indent=0)
     else:

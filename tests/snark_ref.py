@@ -71,10 +71,14 @@ def instance_map_with_evaluation(R, cs, s):
     out = {}
     for name in "abc":
         rp, col, cf = cs.mats[name]
+        pidx = cs.poly_idx[name] if cs.poly_idx is not None else None
         vals = [R.scalar(0) for _ in range(cs.n_vars + 1)]
         for i in range(m):
             for e in range(rp[i], rp[i + 1]):
-                coeff = np.stack([np.full(R.ctx.N, cf[l, e], dtype=np.uint64) for l in range(R.ctx.L)])
+                if pidx is not None and pidx[e] >= 0:  # a coefficient that is a general ring element
+                    coeff = cs.poly_table[pidx[e]]
+                else:
+                    coeff = np.stack([np.full(R.ctx.N, cf[l, e], dtype=np.uint64) for l in range(R.ctx.L)])
                 vals[col[e]] = R.add(vals[col[e]], R.mul(u[i], coeff))
         out[name] = vals
     Ht = [R.scalar(1)]

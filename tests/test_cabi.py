@@ -174,11 +174,14 @@ def test_reference_templates_compile_on_the_adapters():
 
 
 @pytest.mark.gpu
-def test_reference_gadgetlib_drives_the_device_provers(tmp_path):
+@pytest.mark.parametrize("poly", [False, True])
+def test_reference_gadgetlib_drives_the_device_provers(tmp_path, poly):
     """oracle/_ref/ref_adapter_prove (built in the container from the reference's headers + the C++ adapters + librs_hip.so):
     a circuit assembled with the reference's protoboard, checked by the reference's is_satisfied() on device ring
     arithmetic, proven by ringsnark::amd::groth16::prover and rinocchio::prover FROM C++.  The proofs must equal what
-    the ctypes host obtains from the same key and assignment, and the ringGroth16 one must equal the CPU oracle's."""
+    the ctypes host obtains from the same key and assignment, and the ringGroth16 one must equal the CPU oracle's.
+    poly: the circuit's ring coefficients are general ring elements (on the constant one, a primary input and an
+    auxiliary variable; benchmarks/bench_ntt_SEAL.cpp:46-53) -- export_csr puts them into the coefficient table."""
     import subprocess
 
     import numpy as np
@@ -191,7 +194,7 @@ def test_reference_gadgetlib_drives_the_device_provers(tmp_path):
         pytest.skip("oracle/_ref/ref_adapter_prove not built (needs /root/reference at build time)")
     prm = P.preset("toy")
     m = 6
-    args = [str(prm.N), str(prm.L)] + [str(x) for x in prm.q] + [str(prm.N_enc), str(prm.K)] + [str(x) for x in prm.Q] + [str(m), str(tmp_path)]
+    args = [str(prm.N), str(prm.L)] + [str(x) for x in prm.q] + [str(prm.N_enc), str(prm.K)] + [str(x) for x in prm.Q] + [str(m), str(tmp_path)] + (["poly"] if poly else [])
     r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ref_adapter_prove: OK" in r.stdout, r.stdout + r.stderr
     rd = lambda name, shape=None: (lambda a: a if shape is None else a.reshape(shape))(np.fromfile(str(tmp_path / name), dtype=np.uint64))
@@ -203,7 +206,15 @@ def test_reference_gadgetlib_drives_the_device_provers(tmp_path):
         mats[name] = (rd("row_ptr%d.bin" % w).astype(np.uint32), col, rd("coeff%d.bin" % w, (prm.L, col.shape[0])))
     # the CSR export holds what the reference's gadgetlib produced: a-rows have 3 terms (x_i, 3 x_{i+1}, the constant 2)
     assert mats["a"][1].shape[0] == 3 * m and (mats["a"][1] == 0).sum() == m
-    cs = R.R1CS(m, n_vars, n_inputs, mats)
+    pidx = {name: rd("poly_idx%d.bin" % w).astype(np.int64).astype(np.int32) for w, name in enumerate("abc")}
+    table = rd("poly_table.bin")
+    if poly:  # u (on x_i), c (on x_0) and k (on the constant one): three distinct table rows, shared by the m constraints
+        table = table.reshape((-1, prm.L, prm.N))
+        assert table.shape[0] == 3 and (pidx["a"] >= 0).sum() == 2 * m and (pidx["b"] >= 0).sum() == m and (pidx["c"] >= 0).sum() == 0
+        cs = R.R1CS(m, n_vars, n_inputs, mats, pidx, table)
+    else:
+        assert table.size == 0 and all((p == -1).all() for p in pidx.values())
+        cs = R.R1CS(m, n_vars, n_inputs, mats)
     dev = Device(prm)
     ctx = H.oracle_ctx(prm)
     asg = rd("assignment.bin", (n_vars,) + ctx.ring_shape())

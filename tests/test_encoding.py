@@ -101,6 +101,30 @@ def test_device_proof_verifies_under_reference_equation(name, m):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("aux_only", [False, True])
+def test_device_proof_with_polynomial_coefficients_verifies(aux_only):
+    """A circuit whose coefficients are general ring elements (relations/variable.tcc:246-254; the DFT constraint of
+    benchmarks/bench_ntt_SEAL.cpp:46-53), end to end on the device: instance map with evaluation, encryption, the
+    ringGroth16 prover, decryption, the reference's verification equation; a tampered input is rejected."""
+    from ringsnark_amd.device import Device, to_host
+    prm = P.preset("toy49")
+    dev, ctx = Device(prm), H.oracle_ctx(prm)
+    m = 10
+    cs = R.wide_poly_r1cs(m, prm.q, prm.N, aux_only=aux_only, constants=False)
+    asg = H.make_assignment(ctx, cs)
+    dcs = dev.r1cs(cs)
+    pk, vk = S.groth16_generator(ctx, cs, 23, lambda sk, r, seed: to_host(dev.enc_encode(dev.put(sk), dev.put(r), seed)),
+                                 lambda s: [to_host(x) for x in dev.instance_map_eval(dcs, dev.put(s))])
+    got, empty = dev.groth16_prove(dcs, {k: dev.put(v) for k, v in pk.items()}, dev.put(asg))
+    assert [int(e) for e in empty] == [0, 0, 0]
+    dec = to_host(dev.enc_decode(dev.put(vk["sk"]), got))
+    assert S.groth16_verifier(ctx, cs, vk, asg[: cs.n_inputs], dec[0], dec[1], dec[2])
+    bad = asg[: cs.n_inputs].copy()
+    bad[0, 1, 7] = (int(bad[0, 1, 7]) + 1) % prm.q[1]
+    assert not S.groth16_verifier(ctx, cs, vk, bad, dec[0], dec[1], dec[2])
+
+
+@pytest.mark.gpu
 def test_device_rinocchio_proof_passes_reference_checks():
     from ringsnark_amd.device import Device, to_host
     prm = P.preset("toy49")
@@ -189,7 +213,8 @@ def test_wire_format_roundtrip_and_validation():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,m,kind", [("toy", 6, "chain"), ("toy49", 11, "wide"), ("toy54", 9, "wide"), ("toy60", 7, "chain")])
+@pytest.mark.parametrize("name,m,kind", [("toy", 6, "chain"), ("toy49", 11, "wide"), ("toy54", 9, "wide"), ("toy60", 7, "chain"),
+                                         ("toy", 9, "wide_poly"), ("toy60", 7, "wide_poly")])
 def test_instance_map_with_evaluation_matches_restatement(name, m, kind):
     """At/Bt/Ct/Ht/Zt on the device against the O(m^2) restatement of
     r1cs_to_qrp.tcc:76-116 (tests/snark_ref.py), bit for bit; only a point that IS a domain element is refused."""
@@ -197,7 +222,8 @@ def test_instance_map_with_evaluation_matches_restatement(name, m, kind):
     from ringsnark_amd.device import Device, to_host
     prm = P.preset(name)
     dev, ctx = Device(prm), H.oracle_ctx(prm)
-    cs = R.chain_r1cs(m, prm.q) if kind == "chain" else R.wide_r1cs(m, prm.q)
+    cs = {"chain": lambda: R.chain_r1cs(m, prm.q), "wide": lambda: R.wide_r1cs(m, prm.q),
+          "wide_poly": lambda: R.wide_poly_r1cs(m, prm.q, prm.N)}[kind]()  # wide_poly: coefficients that are general ring elements
     Rg = S.Ring(ctx)
     s = Rg.random_exceptional(np.random.RandomState(4), m)
     At, Bt, Ct, Ht, Zt = S.instance_map_with_evaluation(Rg, cs, s)

@@ -260,6 +260,89 @@ def test_witness_map_matches_oracle(name, m, kind):
             assert (w["Z"][limb] == exp["Z"]).all()
 
 
+@pytest.mark.parametrize("name,m,aux_only,zk,lds", [("toy", 9, False, True, 13), ("toy", 12, True, True, 13), ("toy60", 9, False, False, 13),
+                                                     ("toy+int", 12, True, True, 13), ("toy49", 150, False, True, 6), ("toy", 150, True, False, 6),
+                                                     ("toy54", 70, False, True, 6)])
+def test_polynomial_coefficients_match_oracle(name, m, aux_only, zk, lds):
+    """Row a14 with coefficients that are general ring elements (rs_r1cs_create_poly; relations/variable.tcc:246-254,
+    benchmarks/bench_ntt_SEAL.cpp:46-53): evaluate in its three modes, the whole witness map and both provers against
+    the oracle.  aux_only keeps the linear-form io vectors (no polynomial on the constant one or an input); otherwise
+    the generic io path and the per-slot constant part of the mid vectors run.  lds = 6 forces the multi-pass columns."""
+    from ringsnark_amd import _lib
+    dev = dev_for(name)
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    cs = R.wide_poly_r1cs(m, prm.q, prm.N, aux_only=aux_only)
+    assert cs.poly_table is not None and (cs.poly_idx["a"] >= 0).sum() >= m // 2
+    asg = H.make_assignment(ctx, cs)
+    ocs = H.oracle_cs(cs)
+    dcs, dasg = dev.r1cs(cs), dev.put(asg)
+    for which in range(3):
+        for mode, zero in ((_lib.RS_EVAL_FULL, None), (_lib.RS_EVAL_IO, slice(cs.n_inputs, None)), (_lib.RS_EVAL_MID, slice(0, cs.n_inputs))):
+            part = asg.copy()
+            if zero is not None:
+                part[zero] = 0
+            got = host(dev.r1cs_evaluate(dcs, which, mode, dasg))
+            for limb in range(prm.L):
+                assert (got[:, limb, :] == O.r1cs_evaluate(prm.q[limb], ocs, which, limb, np.ascontiguousarray(part[:, limb, :]))).all(), (which, mode)
+    ds = [ctx.random_ring(60 + k) for k in range(3)] if zk else [None] * 3
+    dds = [dev.put(d) if d is not None else None for d in ds]
+    _set_tuning(b"witness_lds_logM", lds)
+    try:
+        w = dev.witness_map(dcs, dasg, *dds)
+        got = {k: host(v) if k != "Z" else v for k, v in w.items()}
+        pk = dict(s_pows=ctx.random_enc(71, m + 1), delta_ts=ctx.random_enc(72, m + 1), delta_mid=ctx.random_enc(73, cs.n_aux),
+                  alpha=ctx.random_enc(74), beta=ctx.random_enc(75))
+        gp, gempty = dev.groth16_prove(dcs, {k: dev.put(v) for k, v in pk.items()}, dasg)
+        gp = host(gp)
+        rk = dict(s_pows=ctx.random_enc(81, m + 1), alpha_s_pows=ctx.random_enc(82, m + 1), beta_prods=ctx.random_enc(83, cs.n_aux),
+                  beta_rv_ts=ctx.random_enc(84), beta_rw_ts=ctx.random_enc(85), beta_ry_ts=ctx.random_enc(86))
+        rp, rempty = dev.rinocchio_prove(dcs, {k: dev.put(v) for k, v in rk.items()}, dasg, *dds)
+        rp = host(rp)
+    finally:
+        _set_tuning(b"witness_lds_logM", 13)
+    for limb in range(prm.L):
+        dl = [np.ascontiguousarray(d[limb]) if d is not None else None for d in ds]
+        exp = O.witness_map(prm.q[limb], ocs, limb, np.ascontiguousarray(asg[:, limb, :]), *dl)
+        for k in ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H"):
+            assert (got[k][:, limb, :] == exp[k]).all(), (k, limb)
+    if m <= 20:  # the oracle provers are O(m^2) per slot plus the inner products
+        exp, exp_empty = O.groth16_prove(ctx, ocs, pk, asg)
+        assert gempty == exp_empty and (gp == exp).all()
+        exp, exp_empty = O.rinocchio_prove(ctx, ocs, rk, asg, *ds)
+        assert rempty == exp_empty and (rp == exp).all()
+
+
+def test_bench_ntt_seal_circuit_proven_bit_exact():
+    """BASELINE.json configs[0] is the reference's benchmarks/bench_ntt_SEAL.cpp: Rinocchio Setup / Prove / Verify of ONE
+    constraint over N + 1 = 4097 variables, all public, whose coefficients are the powers of a POLYNOMIAL ring element
+    (:28-55), on N = 4096 with BFVDefault(4096) = preset C2's ring.  rs_rinocchio_prove on it, bit for bit against the
+    oracle (the non-ZK branch: no auxiliary inputs, rinocchio.tcc:81-87), and the witness map against the oracle."""
+    dev = dev_for("C2")
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    cs, asg = H.dft_circuit(prm, ctx)
+    assert (cs.m, cs.n_vars, cs.n_inputs, cs.n_aux) == (1, 4097, 4097, 0) and cs.poly_table.shape == (4095, prm.L, prm.N)
+    ocs = H.oracle_cs(cs)
+    dcs, dasg = dev.r1cs(cs), dev.put(asg)
+    # the assignment satisfies the constraint: <a, x> * 1 = x_{N+1}
+    ev = [host(dev.r1cs_evaluate(dcs, k, 0, dasg)) for k in range(3)]
+    assert (ctx.ring_mul(ev[0][0], ev[1][0]) == ev[2][0]).all() and (ev[2][0] == asg[-1]).all() and ev[0][0].any()
+    w = dev.witness_map(dcs, dasg)
+    for limb in range(prm.L):
+        exp = O.witness_map(prm.q[limb], ocs, limb, np.ascontiguousarray(asg[:, limb, :]))
+        for k in ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H"):
+            assert (host(w[k])[:, limb, :] == exp[k]).all(), (k, limb)
+    m = 1
+    pk = dict(s_pows=ctx.random_enc(81, m + 1), alpha_s_pows=ctx.random_enc(82, m + 1), beta_prods=None,
+              beta_rv_ts=ctx.random_enc(84), beta_rw_ts=ctx.random_enc(85), beta_ry_ts=ctx.random_enc(86))
+    got, empty = dev.rinocchio_prove(dcs, {k: (dev.put(v) if v is not None else None) for k, v in pk.items()}, dasg)
+    opk = dict(pk, beta_prods=np.zeros((0,) + ctx.enc_shape(), dtype=np.uint64))
+    exp, exp_empty = O.rinocchio_prove(ctx, ocs, opk, asg)
+    assert empty == exp_empty == [1, 1, 0, 0, 1, 1, 1, 1, 1]  # only <s_pows, b_mid> = the constant 1 has a non-zero term
+    assert (host(got) == exp).all()
+
+
 def test_interpolate_known_answer_on_device():
     # util/interpolation_test.cpp:29-55 through the device path
     dev = dev_for("toy")

@@ -143,7 +143,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--preset", default="C3")
     ap.add_argument("--logm", type=int, default=16, help="log2 of the constraints of the statement (all GPUs together)")
-    ap.add_argument("--logw", type=int, default=14, help="log2 of the key window (stored elements per key vector) per GPU")
+    ap.add_argument("--logw", type=int, default=None,
+                    help="log2 of the key window (stored elements per key vector) per GPU; default: every rank stores its WHOLE "
+                         "term range of the key when that fits beside the prover's workspaces (N >= 4 at the headline), else 2^14")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-ntt", action="store_true", help="skip the standalone NTT bandwidth leg (profiling passes)")
@@ -186,7 +188,14 @@ def main():
     # Key: every rank stores, per key vector, a window of at most 2^logw elements of its limbs; a rank whose
     # term range is shorter than the window stores exactly its range (TiledKey maps a logical term to storage).
     ranges = RD.groth16_key_ranges(plan, m, n_aux)
-    W = 1 << args.logw
+    if args.logw is not None:
+        W = 1 << args.logw
+    else:
+        # bytes of this rank's real key share: its limbs of the terms it reads; the prover's own buffers (assignment,
+        # five coefficient vectors, column chunk, multi-pass workspaces, MSM scratch) take up to ~125 GiB per rank
+        share = sum(hi - lo for lo, hi in ([(0, m + 1), (0, m + 1), (0, n_aux)] if world == 1 else ranges.values()))
+        whole_fits = share * prm_local.enc_words * 8 <= 140 * 2**30
+        W = (1 << 40) if whole_fits else (1 << 14)
 
     def key_vector(name, T, seed):
         lo, hi = (0, T) if world == 1 else ranges[name]
@@ -306,9 +315,9 @@ def main():
                                    "encodings N_enc=%d K=%d; %s; real m=%d witness map"
                                    % (m, prm.N, prm.L, prm.N_enc, prm.K,
                                       ("tiled synthetic CRS: %.0f GiB key stood in for by a resident window of 2^%d elements per key vector "
-                                       "(%.0f GiB in HBM), term index wrapped" % (key_gib, args.logw, stored_gib)) if tiled else
+                                       "(%.0f GiB in HBM per GPU), term index wrapped" % (key_gib, W.bit_length() - 1, stored_gib)) if tiled else
                                       ("synthetic CRS %.0f GiB, %.0f GiB resident per GPU" % (key_gib, stored_gib)), m),
-                       "preset": prm.name, "constraints": m, "key_window": (W if tiled else None),
+                       "preset": prm.name, "constraints": m, "key_window": (min(W, m + 1) if tiled else None),
                        "parallelism": "limbs%d x shards%d" % (plan.limb_groups, plan.term_shards)},
         }
         if timings:

@@ -926,6 +926,8 @@ int rs_set_tuning(const char *key, int value) {
   else if (std::string(key) == "witness_force_bc") {
     RS_REQUIRE(value == 0 || (value >= 5 && value <= 20), "witness_force_bc must be 0 or in [5, 20]");
     g_witness_force_bc = value;  // takes effect for plans built afterwards (plans are cached per context and size)
+  } else if (std::string(key) == "witness_bc2") {
+    g_witness_bc2 = value ? 1 : 0;  // takes effect for plans built afterwards, like witness_force_bc
   } else if (std::string(key) == "witness_tree_log") {
     RS_REQUIRE(value == 13 || value == 14, "witness_tree_log must be 13 or 14");
     g_witness_tree_log = value;

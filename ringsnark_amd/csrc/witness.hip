@@ -50,6 +50,10 @@ struct LimbPlan {
   void *d_bc_e = nullptr;                  // [M/B][2B] blocks of (-1)^k/k!
   void *d_bc_s = nullptr;                  // [M/B][2B] blocks of rev(Z)^-1 mod x^(m-1)
   void *d_bc_d = nullptr;                  // [logM - bcLog][M] per level l > bcLog: [node][block][2B] blocks of D_left's low part
+  // two-dimensional form of the same tables (WitnessPlan::bc2): per spectrum point, the Y-point transform ACROSS the
+  // zero-padded sequence of blocks (Y = 2 x blocks of the operand), scaled by 1/(2B Y):
+  void *d_b2_e = nullptr, *d_b2_s = nullptr;  // [Y][2B], Y = 2M/B
+  void *d_b2_d = nullptr;                     // [logM - bcLog][2M]: per level l, [node][Y_l][2B], Y_l = 2^l / B
   uint32_t fwd_mask2 = 0, inv_mask2 = 0;     // reduce masks for length 2M
   std::vector<uint64_t> Z;                   // m+1 coefficients of the vanishing polynomial
 };
@@ -63,6 +67,9 @@ struct WitnessPlan {
   // what makes the witness map work for the primes the reference's own recipe produces, which only guarantee
   // q = 1 mod 2*N_inner (seal/seal_util.hpp:20-32).
   int bcLog = 0;
+  // Block convolutions as TWO-DIMENSIONAL transforms (FP64 arithmetic, primes with 2-adicity >= 14, M >= 2^15; see
+  // "two-dimensional block convolutions" below): blocks of B = 2^13 coefficients, bcLog = 14.
+  bool bc2 = false;
   std::vector<LimbPlan> limb;
 };
 
@@ -202,6 +209,7 @@ static uint64_t plain_word(const rs_ctx *ctx, uint64_t v, uint64_t p) {
 }
 
 int g_witness_force_bc = 0;  // tuning knob "witness_force_bc": pretend the ring primes have only this 2-adicity (tests)
+int g_witness_bc2 = 1;       // tuning knob "witness_bc2": two-dimensional block convolutions where they apply (0: the pairwise form)
 
 static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
   using namespace hostw;
@@ -219,7 +227,8 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
   for (int li = 0; li < ctx->L; li++) vmin = std::min(vmin, host::two_adicity(ctx->q[li]));
   if (g_witness_force_bc > 0) vmin = std::min(vmin, g_witness_force_bc);  // tests: the block path on well-endowed primes
   const bool blocked = vmin < logM + 1;
-  P->bcLog = blocked ? std::min(vmin, 13) : 0;
+  P->bc2 = blocked && g_witness_bc2 && !ctx->use_int && vmin >= 14 && logM >= 15;
+  P->bcLog = blocked ? (P->bc2 ? 14 : std::min(vmin, 13)) : 0;
   // every context prime is 1 mod 2*N_enc with N_enc >= 16, so the 2-adicity is at least 5
   RS_REQUIRE(!blocked || P->bcLog > SCHOOL_LEVELS, "ring prime with too little 2-adicity for the witness map");
   const int tabLog = blocked ? P->bcLog : logM + 1;  // longest transform the device tables serve
@@ -239,16 +248,30 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
       lp.d_itw = up(itw);
     }
     // spectra (scaled by 1/(2 Bc)) of the Bc-coefficient blocks of a polynomial: [blocks][2 Bc]
-    auto block_spectra = [&](const std::vector<uint64_t> &poly, size_t blocks) {
+    auto block_spectra = [&](const std::vector<uint64_t> &poly, size_t blocks, bool raw = false) {
       std::vector<uint64_t> out(blocks * 2 * Bc, 0);
       const uint64_t sc = invmod((uint64_t)(2 * Bc) % p, p);
       for (size_t b = 0; b < blocks; b++) {
         std::vector<uint64_t> f(2 * Bc, 0);
         for (size_t k = 0; k < Bc && b * Bc + k < poly.size(); k++) f[k] = poly[b * Bc + k];
         ntt_fwd(f, P->bcLog, T);
-        for (size_t k = 0; k < 2 * Bc; k++) out[b * 2 * Bc + k] = bal(mulmod(f[k], sc, p));
+        for (size_t k = 0; k < 2 * Bc; k++) out[b * 2 * Bc + k] = raw ? mulmod(f[k], sc, p) : bal(mulmod(f[k], sc, p));
       }
       return out;
+    };
+    // bc2: the Y-point transform across the (zero-padded) blocks of such spectra, point by point, scaled by 1/Y; output
+    // [Y][2 Bc] in the order the device's forward transform across blocks leaves its results (host ntt_fwd order)
+    auto across_blocks = [&](const std::vector<uint64_t> &poly, size_t blocks, uint64_t *dst) {
+      const std::vector<uint64_t> sp = block_spectra(poly, blocks, true);
+      const size_t Y = 2 * blocks;
+      const int logY = clog2(Y);
+      const uint64_t sc = invmod((uint64_t)Y % p, p);
+      std::vector<uint64_t> v(Y);
+      for (size_t k = 0; k < 2 * Bc; k++) {
+        for (size_t y = 0; y < Y; y++) v[y] = y < blocks ? sp[y * 2 * Bc + k] : 0;
+        ntt_fwd(v, logY, T);
+        for (size_t y = 0; y < Y; y++) dst[y * 2 * Bc + k] = bal(mulmod(v[y], sc, p));
+      }
     };
     lp.fwd_mask2 = fwd_reduce_mask(p, logM + 1);
     lp.inv_mask2 = inv_reduce_mask(p, logM + 1);
@@ -267,6 +290,11 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
       if (blocked) {
         e.resize(M);
         lp.d_bc_e = up(block_spectra(e, nblk));
+        if (P->bc2) {
+          std::vector<uint64_t> t2(2 * nblk * 2 * Bc);
+          across_blocks(e, nblk, t2.data());
+          lp.d_b2_e = up(t2);
+        }
       } else {
         ntt_fwd(e, logM + 1, T);
         const uint64_t s2 = invmod((uint64_t)(2 * M) % p, p);
@@ -295,6 +323,7 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
     {
       std::vector<uint64_t> dhat((size_t)(logM + 1) * M, 0), dlow((size_t)(SCHOOL_LEVELS + 1) * (M / 2 + 1), 0);
       std::vector<uint64_t> bcd(blocked && logM > P->bcLog ? (size_t)(logM - P->bcLog) * M : 0, 0);
+      std::vector<uint64_t> b2d(P->bc2 && logM > P->bcLog ? (size_t)(logM - P->bcLog) * 2 * M : 0, 0);
       for (int l = 1; l <= logM; l++) {
         const size_t n = (size_t)1 << l, h = n >> 1;
         for (size_t i = 0; i < (M >> l); i++) {
@@ -305,6 +334,7 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
             // node i of level l: the h / Bc blocks of D_left's low part (the monic x^h term is added by the sink)
             const std::vector<uint64_t> sp = block_spectra(dl, h / Bc);
             std::copy(sp.begin(), sp.end(), bcd.begin() + (size_t)(l - P->bcLog - 1) * M + i * n);
+            if (P->bc2) across_blocks(dl, h / Bc, b2d.data() + (size_t)(l - P->bcLog - 1) * 2 * M + i * 2 * n);
           } else {
             std::vector<uint64_t> f(n, 0);
             for (size_t k = 0; k < h; k++) f[k] = dl[k];
@@ -318,6 +348,7 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
       lp.d_dhat = up(dhat);
       lp.d_dlow = up(dlow);
       if (!bcd.empty()) lp.d_bc_d = up(bcd);
+      if (!b2d.empty()) lp.d_b2_d = up(b2d);
     }
     // Z = prod_{j<m} (x - j): product of the maximal aligned blocks of [0, m)
     {
@@ -365,6 +396,11 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
       if (blocked) {
         shat.resize(M);  // S itself, m - 1 <= M coefficients
         lp.d_bc_s = up(block_spectra(shat, nblk));
+        if (P->bc2) {
+          std::vector<uint64_t> t2(2 * nblk * 2 * Bc);
+          across_blocks(shat, nblk, t2.data());
+          lp.d_b2_s = up(t2);
+        }
       } else {
         std::vector<uint64_t> sh(2 * M);
         for (size_t k = 0; k < 2 * M; k++) sh[k] = bal(shat[k]);
@@ -377,7 +413,8 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
 
 static void free_plan(WitnessPlan *P) {
   for (auto &lp : P->limb) {
-    void *ptrs[] = {lp.d_tw, lp.d_itw, lp.d_invfact, lp.d_ehat, lp.d_dhat, lp.d_dlow, lp.d_shat, lp.d_ztab, lp.d_bc_e, lp.d_bc_s, lp.d_bc_d};
+    void *ptrs[] = {lp.d_tw, lp.d_itw, lp.d_invfact, lp.d_ehat, lp.d_dhat, lp.d_dlow, lp.d_shat, lp.d_ztab, lp.d_bc_e, lp.d_bc_s, lp.d_bc_d,
+                    lp.d_b2_e, lp.d_b2_s, lp.d_b2_d};
     for (void *q : ptrs)
       if (q) (void)hipFree(q);
   }
@@ -403,7 +440,9 @@ struct ColPlanT {
   M mod;
   const T *tw, *itw, *invfact, *ehat, *dhat, *dlow, *shat, *ztab;
   const T *bc_e, *bc_s, *bc_d;  // block-convolution path (LimbPlan)
+  const T *b2_e, *b2_s, *b2_d;  // ... in its two-dimensional form
   T bc_inv2b;                   // 1 / (2B) as a table constant
+  T b2_inv;                     // 1 / (2B * 2M/B) = 1 / (4M): both unscaled inverse transforms of a two-dimensional data x data product
   uint32_t fwd_mask2, inv_mask2;
   uint32_t fmask[24], imask[24];  // reduce masks for transforms of length 2^l (FP64 arithmetic)
 };
@@ -1953,14 +1992,16 @@ struct SubTw {  // twiddle fetch: 2^k consecutive table entries, 16-byte loads w
 template <int MODE>
 __global__ void __launch_bounds__(256, 2)
 sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab_period, unsigned blocks_per_col, size_t col0,
-                    unsigned S_, unsigned slots_per_limb, ColPlans plans, unsigned long long nblocks) {
+                    unsigned S_, unsigned slots_per_limb, ColPlans plans, unsigned long long nblocks,
+                    const double *__restrict__ Xsrc /* null: in place.  Else block b reads block b >> 1 of Xsrc: the two
+                    sub-transforms (roots 2 and 3) of ONE zero-padded block of 2^13 coefficients (two-dimensional block convolutions) */) {
   using S = WideShape<13>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   const int t = threadIdx.x;
   u64x2 pre[16];
   auto issue_loads = [&](unsigned long long b) {
-    const u64x2 *src = reinterpret_cast<const u64x2 *>(X + b * (size_t)S::N) + t;
+    const u64x2 *src = reinterpret_cast<const u64x2 *>(Xsrc ? Xsrc + (b >> 1) * (size_t)S::N : X + b * (size_t)S::N) + t;
 #pragma unroll
     for (int e = 0; e < 16; e++) pre[e] = src[(S::S / 2) * e];
   };
@@ -2344,7 +2385,11 @@ static ColPlansT<M> make_colplans(rs_ctx *ctx, const WitnessPlan *P, int limb0 =
     c.bc_e = static_cast<const T *>(lp.d_bc_e);
     c.bc_s = static_cast<const T *>(lp.d_bc_s);
     c.bc_d = static_cast<const T *>(lp.d_bc_d);
+    c.b2_e = static_cast<const T *>(lp.d_b2_e);
+    c.b2_s = static_cast<const T *>(lp.d_b2_s);
+    c.b2_d = static_cast<const T *>(lp.d_b2_d);
     c.bc_inv2b = P->bcLog ? HostArith<M>::konst(host::invmod(((uint64_t)1 << P->bcLog) % lp.p, lp.p), lp.p) : T(0);
+    c.b2_inv = P->bc2 ? HostArith<M>::konst(host::invmod((uint64_t)(4 * P->M) % lp.p, lp.p), lp.p) : T(0);
     c.fwd_mask2 = lp.fwd_mask2;
     c.inv_mask2 = lp.inv_mask2;
     for (int l = 0; l < 24; l++) {
@@ -2545,7 +2590,8 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
       const unsigned long long nb = (unsigned long long)(ncols * bpc);
       RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_wide_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
       hipLaunchKernelGGL((sub_ntt_wide_kernel<MODE>), dim3((unsigned)std::min<unsigned long long>(nb, 512)), dim3(256), wl, st, X,
-                         logsub - logB, tp, (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp, nb);
+                         logsub - logB, tp, (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp, nb,
+                         (const double *)nullptr);
       RS_HIP(hipGetLastError());
       return;
     }
@@ -2695,6 +2741,177 @@ __global__ void __launch_bounds__(256) bc_out_kernel(BcArgs a, CPS plans, size_t
   }
 }
 
+// =============================================================================================
+// Two-dimensional block convolutions (WitnessPlan::bc2; FP64, ring primes with 2-adicity >= 14, M >= 2^15).
+// A polynomial of n B-coefficient blocks, B = 2^13, is the bivariate  F(x, y) = sum_i f_i(x) y^i  at y = x^B.  The product
+// of two such polynomials has degree < 2B in x and < 2n in y, so it IS the two-dimensional cyclic convolution of size
+// 2B x Y, Y = 2n, of the zero-padded operands -- and a two-dimensional transform only needs a 2B-th and a Y-th root of
+// unity (there are no twiddles between the dimensions, unlike the one-dimensional transform of length 2B*Y that the
+// primes of the reference's recipe do not support).  Per convolution:
+//     bc2_yfwd_kernel   the step's source functor, then the Y-point transform ACROSS the blocks (half of them zero), per
+//                       coefficient position: [Y][B] words out
+//     sub_ntt_wide_kernel  per block: the 2B-point transform of the zero-padded block = the two B-point sub-transforms
+//                       rooted at nodes 2 and 3 of the SAME input (Xsrc), the product with the two-dimensional spectrum
+//                       of the other operand, the inverse sub-transforms -- the tuned kernel of the multi-pass path
+//     bc2_yinv_kernel   the last inverse stage of the 2B-point transforms (u +- v), the inverse Y-point transform across
+//                       blocks, the overlap-add (coefficient k B + r = low half of block k + high half of block k-1: both in
+//                       this thread's registers) and the step's sink functor
+// against the pairwise form above: (blocks)^2 block products re-read from memory become Y log Y butterflies in registers.
+// Exact, hence bit-identical.
+// =============================================================================================
+struct Bc2Args {
+  const double *src;  // source columns
+  double *Wy;         // [ncols * units][Y][B]
+  double *Ws;         // [ncols * units][Y][2][B]
+  double *dst;
+  int logM, m, l, units;
+  size_t col0;
+  unsigned S, slots_per_limb;
+};
+constexpr int BC2_LOGB = 13, BC2_B = 1 << BC2_LOGB;
+
+template <int SRC, int LOGY>
+__global__ void __launch_bounds__(256) bc2_yfwd_kernel(Bc2Args a, ColPlans plans) {
+  constexpr int Y = 1 << LOGY, NX = Y / 2, B = BC2_B;
+  const int r = 2 * (int)(blockIdx.x * 256 + threadIdx.x);
+  const size_t cu = blockIdx.y, unit = cu % (size_t)a.units, col = cu / (size_t)a.units, M = (size_t)1 << a.logM;
+  const ColPlan &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const Mod mod = P.mod;
+  double v0[Y], v1[Y];
+#pragma unroll
+  for (int i = 0; i < NX; i++) {
+    const size_t k = (size_t)i * B + r;  // position inside the operand (pairs k, k + 1 never straddle a limit: all are even)
+    double x0 = 0.0, x1 = 0.0;
+    if (SRC == BS_SCALE) {
+      if (k < M) {
+        const double2 d = *reinterpret_cast<const double2 *>(a.src + col * M + k), f = *reinterpret_cast<const double2 *>(P.invfact + k);
+        x0 = mulmod(d.x, f.x, mod);
+        x1 = mulmod(d.y, f.y, mod);
+      }
+    } else if (SRC == BS_CENTER) {
+      if (k < M) {
+        const double2 d = *reinterpret_cast<const double2 *>(a.src + col * M + k);
+        x0 = center(d.x, mod);
+        x1 = center(d.y, mod);
+      }
+    } else if (SRC == BS_REVTRUNC) {  // T_k = P_{2m-2-k}, k < m-1, from a [ncols][2M] buffer
+      const long long lim = (long long)a.m - 1;
+      if ((long long)k < lim) x0 = reduce(a.src[col * 2 * M + (size_t)(2 * a.m - 2) - k], mod);
+      if ((long long)k + 1 < lim) x1 = reduce(a.src[col * 2 * M + (size_t)(2 * a.m - 2) - k - 1], mod);
+    } else {  // BS_RIGHT: F_right of node `unit` at level l
+      const size_t n = (size_t)1 << a.l, h = n >> 1;
+      const double2 d = *reinterpret_cast<const double2 *>(a.src + col * M + unit * n + h + k);
+      x0 = d.x;
+      x1 = d.y;
+    }
+    v0[i] = x0;
+    v1[i] = x1;
+  }
+  const double *__restrict__ tw = P.tw;
+  reg_fwd_stages_zu<LOGY>(v0, mod, P.fmask[LOGY], [&](int st, int blk) { return tw[(1 << st) + blk]; });
+  reg_fwd_stages_zu<LOGY>(v1, mod, P.fmask[LOGY], [&](int st, int blk) { return tw[(1 << st) + blk]; });
+  double *out = a.Wy + cu * (size_t)Y * B + r;
+#pragma unroll
+  for (int y = 0; y < Y; y++) *reinterpret_cast<double2 *>(out + (size_t)y * B) = make_double2(reduce(v0[y], mod), reduce(v1[y], mod));
+}
+
+template <int DST, int LOGY>
+__global__ void __launch_bounds__(256) bc2_yinv_kernel(Bc2Args a, ColPlans plans) {
+  constexpr int Y = 1 << LOGY, B = BC2_B;
+  const int r = 2 * (int)(blockIdx.x * 256 + threadIdx.x);
+  const size_t cu = blockIdx.y, unit = cu % (size_t)a.units, col = cu / (size_t)a.units, M = (size_t)1 << a.logM;
+  const ColPlan &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const Mod mod = P.mod;
+  const double *__restrict__ itw = P.itw;
+  // lo / hi: coefficients r (+1) and B + r (+1) of the 2B-point blocks; [c]: the two adjacent positions of this thread
+  double lo[2][Y], hi[2][Y];
+  const double *in = a.Ws + cu * (size_t)Y * 2 * B + r;
+#pragma unroll
+  for (int y = 0; y < Y; y++) {
+    const double2 u = *reinterpret_cast<const double2 *>(in + (size_t)(2 * y) * B), w = *reinterpret_cast<const double2 *>(in + (size_t)(2 * y + 1) * B);
+    lo[0][y] = reduce(u.x + w.x, mod);  // last inverse stage of the 2B-point transform: its twiddle is 1
+    hi[0][y] = reduce(u.x - w.x, mod);
+    lo[1][y] = reduce(u.y + w.y, mod);
+    hi[1][y] = reduce(u.y - w.y, mod);
+  }
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    reg_inv_stages<LOGY, true>(lo[c], mod, P.imask[LOGY], [&](int k, int i) { return itw[(Y >> (k + 1)) + i]; });
+    reg_inv_stages<LOGY, true>(hi[c], mod, P.imask[LOGY], [&](int k, int i) { return itw[(Y >> (k + 1)) + i]; });
+  }
+#pragma unroll
+  for (int k = 0; k < Y; k++) {
+    const size_t t = (size_t)k * B + r;  // output coefficient (and t + 1)
+    double o0 = lo[0][k], o1 = lo[1][k];
+    if (k >= 1) {
+      o0 += hi[0][k - 1];
+      o1 += hi[1][k - 1];
+    }
+    if (DST == BD_NEWTON) {  // Newton coefficients: the low M terms, zero beyond m
+      if (t < M) {
+        const double2 f = *reinterpret_cast<const double2 *>(P.invfact + t);
+        *reinterpret_cast<double2 *>(a.dst + col * M + t) = make_double2(f.x != 0.0 ? reduce(o0, mod) : 0.0, f.y != 0.0 ? reduce(o1, mod) : 0.0);
+      }
+    } else if (DST == BD_PLAIN_SCALED) {  // data x data product: the scale of both inverse transforms is applied here
+      *reinterpret_cast<double2 *>(a.dst + col * 2 * M + t) = make_double2(mulmod(reduce(o0, mod), P.b2_inv, mod), mulmod(reduce(o1, mod), P.b2_inv, mod));
+    } else if (DST == BD_HFIN) {  // H_j = U_{m-2-j}
+      const long long top = (long long)a.m - 2;
+      if ((long long)t <= top) a.dst[col * M + (size_t)(top - (long long)t)] = reduce(o0, mod);
+      if ((long long)t + 1 <= top) a.dst[col * M + (size_t)(top - (long long)t - 1)] = reduce(o1, mod);
+    } else {  // F_node = (F_left, 0) + x^h F_right + d * F_right: both extra terms sit at this very position
+      double2 *p = reinterpret_cast<double2 *>(a.dst + col * M + unit * ((size_t)1 << a.l) + t);
+      const double2 d = *p;
+      const double f0 = reduce(o0 + d.x, mod), f1 = reduce(o1 + d.y, mod);
+      *p = DST == BD_COMBINE_CANON ? make_double2(canon(f0, mod), canon(f1, mod)) : make_double2(f0, f1);
+    }
+  }
+}
+
+// one two-dimensional block convolution of `ncols * units` operands of Y/2 blocks each.  MODE 2: against the table
+// `tab` ([units][Y][2B] per limb, limbs from limb0 on); MODE 3: against the data spectra `other` ([ncols*units][Y][2][B], same
+// layout as Ws); MODE 0: forward only (Ws receives the spectra; no sink).
+template <int SRC, int DST, int MODE>
+static void bc2_conv(rs_ctx *ctx, Bc2Args a, int logY, size_t ncols, const TabPtrs *tab, const double *other, const ColPlans &cp,
+                     hipStream_t st) {
+  const size_t Y = (size_t)1 << logY, cu = ncols * (size_t)a.units;
+  const dim3 grid((unsigned)(BC2_B / 2 / 256), (unsigned)cu);
+  RS_REQUIRE(cu <= 65535 && logY >= 2 && logY <= 5, "two-dimensional block convolution out of range");
+  {
+    ProfScope prof(ctx, st, "bc2_yfwd_kernel", (double)cu * (double)Y * BC2_B * 12.0, (double)cu * BC2_B * ntt_fp64((double)Y, logY));
+    switch (logY) {
+      case 2: hipLaunchKernelGGL((bc2_yfwd_kernel<SRC, 2>), grid, dim3(256), 0, st, a, cp); break;
+      case 3: hipLaunchKernelGGL((bc2_yfwd_kernel<SRC, 3>), grid, dim3(256), 0, st, a, cp); break;
+      case 4: hipLaunchKernelGGL((bc2_yfwd_kernel<SRC, 4>), grid, dim3(256), 0, st, a, cp); break;
+      default: hipLaunchKernelGGL((bc2_yfwd_kernel<SRC, 5>), grid, dim3(256), 0, st, a, cp); break;
+    }
+  }
+  {
+    const unsigned long long nb = (unsigned long long)(cu * Y * 2);
+    const double Bn = (double)BC2_B;
+    static const char *const names[4] = {"sub_ntt_wide_kernel<0>", "sub_ntt_wide_kernel<1>", "sub_ntt_wide_kernel<2>", "sub_ntt_wide_kernel<3>"};
+    ProfScope prof(ctx, st, names[MODE], (double)nb * Bn * (MODE == 3 ? 24.0 : 16.0),
+                   (double)nb * ((MODE >= 2 ? 2.0 : 1.0) * ntt_fp64(Bn, BC2_LOGB) + (MODE >= 2 ? 7.0 * Bn : 0.0)));
+    TabPtrs tp{};
+    if (MODE == 2) tp = *tab;
+    if (MODE == 3) tp.t[0] = other;
+    const int wl = (int)(WideShape<13>::TILE * sizeof(double));
+    RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_wide_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+    hipLaunchKernelGGL((sub_ntt_wide_kernel<MODE>), dim3((unsigned)std::min<unsigned long long>(nb, 512)), dim3(256), wl, st, a.Ws, 1, tp,
+                       (unsigned)((size_t)a.units * Y * 2), (unsigned)((size_t)a.units * Y * 2), a.col0, a.S, a.slots_per_limb, cp, nb,
+                       (const double *)a.Wy);
+  }
+  if (MODE != 0) {
+    ProfScope prof(ctx, st, "bc2_yinv_kernel", (double)cu * (double)Y * BC2_B * 24.0, (double)cu * 2.0 * BC2_B * ntt_fp64((double)Y, logY));
+    switch (logY) {
+      case 2: hipLaunchKernelGGL((bc2_yinv_kernel<DST, 2>), grid, dim3(256), 0, st, a, cp); break;
+      case 3: hipLaunchKernelGGL((bc2_yinv_kernel<DST, 3>), grid, dim3(256), 0, st, a, cp); break;
+      case 4: hipLaunchKernelGGL((bc2_yinv_kernel<DST, 4>), grid, dim3(256), 0, st, a, cp); break;
+      default: hipLaunchKernelGGL((bc2_yinv_kernel<DST, 5>), grid, dim3(256), 0, st, a, cp); break;
+    }
+  }
+  RS_HIP(hipGetLastError());
+}
+
 // multi-pass interpolation of `ncols` columns X[ncols][M] in place; W: workspace [ncols][2M]
 template <class M>
 static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, typename ArithOf<M>::T *X, typename ArithOf<M>::T *W,
@@ -2834,7 +3051,9 @@ static void bc_conv(rs_ctx *ctx, BcArgs a, size_t ncols, size_t per_unit, const 
 }
 
 // columns per chunk such that the block workspaces (spectra + pair products, up to ~8M words per column) stay within ~6 GiB
-static size_t bc_chunk_cols(const WitnessPlan *P) { return std::max<size_t>(1, ((size_t)6 << 30) / (10 * P->M * sizeof(double))); }
+static size_t bc_chunk_cols(const WitnessPlan *P) {
+  return std::max<size_t>(1, ((size_t)6 << 30) / ((P->bc2 ? 12 : 10) * P->M * sizeof(double)));
+}
 
 template <class M>
 static void bc_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, typename ArithOf<M>::T *X, size_t ncols, size_t col0,
@@ -2860,7 +3079,16 @@ static void bc_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp,
   a.nxb = a.nyb = a.nk = (int)(Mlen / B);
   bc_conv<BS_SCALE, BY_E, BD_NEWTON, M>(ctx, a, ncols, Mlen, cp, st);
   // product tree: levels <= bc inside LDS tiles (transforms of length <= 2^bc) ...
-  launch_tree_tiles_generic<M>(ctx, X, ncols, col0, logM, bc, S, spl, cp, st);
+  if constexpr (std::is_same<M, Mod>::value) {
+    // ... through the wide tile kernel where it exists (2^13 / 2^14 tiles: the recipe primes of the headline shape have
+    // 2-adicity 14, so the whole 2^14 tile of tree_wide_kernel<14> is available to them)
+    if ((bc == 13 || bc == 14) && g_witness_tree_ct == 2 && (bc == 13 || g_witness_tree_log >= 14))
+      launch_tree_tiles(ctx, X, ncols, col0, logM, bc, S, spl, cp, st);
+    else
+      launch_tree_tiles_generic<M>(ctx, X, ncols, col0, logM, bc, S, spl, cp, st);
+  } else {
+    launch_tree_tiles_generic<M>(ctx, X, ncols, col0, logM, bc, S, spl, cp, st);
+  }
   // ... and above: F_node = F_left + (x^h + d) * F_right with d * F_right as a block convolution
   for (int l = bc + 1; l <= logM; l++) {
     a.l = l;
@@ -2925,6 +3153,82 @@ static void bc_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, cons
   RS_HIP(hipGetLastError());
 }
 
+// ---- two-dimensional block convolutions: host side ----------------------------------------------------------
+// workspaces: Wy [ncols][2M] and Ws [ncols][4M] words per convolution in flight (+ the same again and a [ncols][2M]
+// product buffer for H); bc_chunk_cols keeps a chunk of columns within ~6 GiB
+static void bc2_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, double *X, size_t ncols, size_t col0, size_t S, size_t spl,
+                       int limb0, hipStream_t st) {
+  const int logM = P->logM;
+  const size_t Mlen = P->M;
+  Bc2Args a{};
+  a.src = X;
+  a.dst = X;
+  a.Wy = (double *)ws_get(ctx, 12, ncols * 2 * Mlen * sizeof(double));
+  a.Ws = (double *)ws_get(ctx, 13, ncols * 4 * Mlen * sizeof(double));
+  a.logM = logM;
+  a.m = (int)P->m;
+  a.col0 = col0;
+  a.S = (unsigned)S;
+  a.slots_per_limb = (unsigned)spl;
+  TabPtrs tp{};
+  // values -> Newton coefficients: low M terms of (y_k / k!) * ((-1)^k / k!)
+  a.units = 1;
+  for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_b2_e;
+  bc2_conv<BS_SCALE, BD_NEWTON, 2>(ctx, a, logM + 1 - BC2_LOGB, ncols, &tp, nullptr, cp, st);
+  // product tree: levels <= 14 inside LDS tiles, the levels above as block convolutions F_node = F_left + (x^h + d) * F_right
+  launch_tree_tiles(ctx, X, ncols, col0, logM, (g_witness_tree_ct == 2 && g_witness_tree_log >= 14) ? 14 : 13, S, spl, cp, st);
+  const int first = (g_witness_tree_ct == 2 && g_witness_tree_log >= 14) ? 15 : 14;
+  for (int l = first; l <= logM; l++) {
+    a.l = l;
+    a.units = (int)(Mlen >> l);
+    for (int i = limb0; i < ctx->L; i++)
+      tp.t[i - limb0] = static_cast<const double *>(P->limb[i].d_b2_d) + (size_t)(l - P->bcLog - 1) * 2 * Mlen;
+    if (l == logM)
+      bc2_conv<BS_RIGHT, BD_COMBINE_CANON, 2>(ctx, a, l - BC2_LOGB, ncols, &tp, nullptr, cp, st);
+    else
+      bc2_conv<BS_RIGHT, BD_COMBINE, 2>(ctx, a, l - BC2_LOGB, ncols, &tp, nullptr, cp, st);
+  }
+}
+
+static void bc2_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const double *A, const double *Bc, double *H, size_t ncols,
+                  size_t col0, size_t S, size_t spl, const uint64_t *d1, const uint64_t *d2, const uint64_t *d3, const ColMap &cm, int limb0,
+                  hipStream_t st) {
+  const int logM = P->logM, logY = logM + 1 - BC2_LOGB;
+  const size_t Mlen = P->M;
+  double *Wy = (double *)ws_get(ctx, 12, ncols * 2 * Mlen * sizeof(double));
+  double *Ws = (double *)ws_get(ctx, 13, ncols * 4 * Mlen * sizeof(double));
+  double *WsA = (double *)ws_get(ctx, 6, ncols * 4 * Mlen * sizeof(double));
+  double *Pbuf = (double *)ws_get(ctx, 15, ncols * 2 * Mlen * sizeof(double));
+  Bc2Args a{};
+  a.logM = logM;
+  a.m = (int)P->m;
+  a.col0 = col0;
+  a.S = (unsigned)S;
+  a.slots_per_limb = (unsigned)spl;
+  a.units = 1;
+  a.Wy = Wy;
+  // the two-dimensional spectrum of A ...
+  a.src = A;
+  a.Ws = WsA;
+  bc2_conv<BS_CENTER, BD_PLAIN_SCALED, 0>(ctx, a, logY, ncols, nullptr, nullptr, cp, st);
+  // ... P = A * B, 2M coefficients
+  a.src = Bc;
+  a.Ws = Ws;
+  a.dst = Pbuf;
+  bc2_conv<BS_CENTER, BD_PLAIN_SCALED, 3>(ctx, a, logY, ncols, nullptr, WsA, cp, st);
+  // U = rev(P) * rev(Z)^-1 mod x^(m-1);  H_j = U_{m-2-j}
+  TabPtrs tp{};
+  for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_b2_s;
+  a.src = Pbuf;
+  a.dst = H;
+  bc2_conv<BS_REVTRUNC, BD_HFIN, 2>(ctx, a, logY, ncols, &tp, nullptr, cp, st);
+  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((ncols * Mlen + 255) / 256, 256 * 16));
+  ProfScope prof(ctx, st, "h_patch_kernel", (double)ncols * (double)Mlen * (d1 ? 32.0 : 16.0), d1 ? 24.0 * (double)ncols * (double)Mlen : 0.0);
+  hipLaunchKernelGGL(h_patch_kernel<ColPlans>, dim3(blocks), dim3(256), 0, st, H, A, Bc, logM, (int)P->m, ncols, col0, (unsigned)S, (unsigned)spl, cp,
+                     d1, d2, d3, cm);
+  RS_HIP(hipGetLastError());
+}
+
 // Interpolate `ncols` columns in place.  Column c belongs to chunk-local limb (c % S) / slots_per_limb
 // (several vectors of S columns are batched); cp is shifted so that entry 0 is limb0.
 template <class M>
@@ -2934,8 +3238,15 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> 
   constexpr bool FP = std::is_same<M, Mod>::value;
   if (P->bcLog) {  // a ring prime without a 2M-th root of unity: block convolutions
     const size_t chunk = std::min(ncols, bc_chunk_cols(P));
-    for (size_t c0 = 0; c0 < ncols; c0 += chunk)
+    for (size_t c0 = 0; c0 < ncols; c0 += chunk) {
+      if constexpr (FP) {
+        if (P->bc2) {
+          bc2_interp(ctx, P, cp, cols + c0 * P->M, std::min(chunk, ncols - c0), c0, S, slots_per_limb, limb0, st);
+          continue;
+        }
+      }
       bc_interp<M>(ctx, P, cp, cols + c0 * P->M, std::min(chunk, ncols - c0), c0, S, slots_per_limb, st);
+    }
     return;
   }
   if constexpr (FP) {
@@ -2975,8 +3286,15 @@ static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, 
   const size_t Mlen = P->M;
   if (P->bcLog) {
     const size_t chunk = std::min(S, bc_chunk_cols(P));
-    for (size_t c0 = 0; c0 < S; c0 += chunk)
+    for (size_t c0 = 0; c0 < S; c0 += chunk) {
+      if constexpr (FP) {
+        if (P->bc2) {
+          bc2_h(ctx, P, cp, A + c0 * Mlen, B + c0 * Mlen, H + c0 * Mlen, std::min(chunk, S - c0), c0, S, spl, d1, d2, d3, cm, cm.limb0, st);
+          continue;
+        }
+      }
       bc_h<M>(ctx, P, cp, A + c0 * Mlen, B + c0 * Mlen, H + c0 * Mlen, std::min(chunk, S - c0), c0, S, spl, d1, d2, d3, cm, st);
+    }
     return;
   }
   if constexpr (FP) {

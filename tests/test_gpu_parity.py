@@ -741,6 +741,43 @@ def test_multipass_tuned_sub_transform_kernel_equals_generic(m, zk):
         _set_tuning(b"witness_tree_log", 14)
 
 
+@pytest.mark.parametrize("m,zk", [(20000, True), (40000, False), (65536, True)])
+def test_two_dimensional_block_convolutions_equal_the_other_paths(m, zk):
+    """Ring primes with 2-adicity 14 (what the reference's recipe gives the headline ring, seal_util.hpp:20-32) and
+    M >= 2^15: the witness map runs its long products as TWO-DIMENSIONAL block convolutions (blocks of 2^13 coefficients,
+    a 2^14-point transform inside a block x a small transform across blocks; sub_ntt_wide_kernel does the heavy part).
+    Forced here on well-endowed primes (witness_force_bc = 14), it must reproduce, bit for bit, the full-length
+    transforms those primes also allow AND the pairwise block convolutions (witness_bc2 = 0); every path is exact."""
+    from ringsnark_amd.device import Device
+    prm = P.preset("toy44")
+    ctx = H.oracle_ctx(prm)
+    cs = R.chain_r1cs(m, prm.q)
+    keys = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
+    runs = {}
+    for label, force, bc2 in (("full-length", 0, 1), ("two-dimensional", 14, 1), ("pairwise", 14, 0)):
+        _set_tuning(b"witness_force_bc", force)
+        _set_tuning(b"witness_bc2", bc2)
+        try:
+            dev = Device(prm)  # fresh context: plans are cached per context
+            asg = dev.ring_empty(m + 2)
+            dev.fill_uniform(asg[:2], 0, 9)
+            dev.chain_assignment(asg, m)
+            ds = [dev.put(ctx.random_ring(60 + k)) for k in range(3)] if zk else [None] * 3
+            dev.set_profiling(True)
+            runs[label] = {k: host(v) for k, v in dev.witness_map(dev.r1cs(cs), asg, *ds).items() if k in keys}
+            names = {k["name"] for k in dev.profile_read()}
+            dev.set_profiling(False)
+            assert ("bc2_yfwd_kernel" in names) == (label == "two-dimensional"), (label, names)
+            assert ("bc_mac_kernel" in names) == (label == "pairwise"), (label, names)
+            del dev, asg
+        finally:
+            _set_tuning(b"witness_force_bc", 0)
+            _set_tuning(b"witness_bc2", 1)
+    for label in ("two-dimensional", "pairwise"):
+        for k in keys:
+            assert (runs[label][k] == runs["full-length"][k]).all(), (label, k)
+
+
 def test_multipass_production_tile_matches_oracle_on_a_few_slots():
     """The multi-pass path at its production tile (2^13) against the oracle's O(m^2) map: m = 16400 (M = 2^15), four
     slots per limb (rs_witness_map_slots), oracle spread over the host cores."""

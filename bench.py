@@ -79,30 +79,84 @@ def kernel_roofline(k, pmc):
 from tests.proof_check import groth16_check as post_run_check  # noqa: E402
 
 
+PRIME_CLASS = {
+    "C3": "ring primes q_i = 1 mod 2^20 (a custom coeff_modulus, valid in the reference: the fields have roots of unity of order 2M "
+          "and the witness map runs full-length transforms)",
+    "C3R": "ring primes exactly as the reference's recipe yields them (default_double_batching_modulus, seal/seal_util.hpp:20-32: "
+           "q_i = 1 mod 2N = 2^14 only), i.e. what a SEAL-produced headline key has; the witness map runs two-dimensional block convolutions",
+}
+
+
+def single_gpu_leg(preset, m, logw, steps, warmup, check):
+    """The same headline statement on another preset (one GPU): time, phases, top kernels and the post-run oracle check."""
+    from ringsnark_amd.device import Device
+    prm = P.preset(preset)
+    dev = Device(prm, 0)
+    cs = R.chain_r1cs(m, prm.q)
+    dcs = dev.r1cs(cs)
+    asg = dev.ring_empty(m + 2)
+    dev.fill_uniform(asg[:2], 0, 1007)
+    dev.chain_assignment(asg, m)
+    W = 1 << logw
+    pk = {k: dev.fill_uniform(dev.enc_empty(min(W, T)), 1, 1013 + i)
+          for i, (k, T) in enumerate((("s_pows", m + 1), ("delta_ts", m + 1), ("delta_mid", cs.n_aux)))}
+    pk["alpha"], pk["beta"] = dev.fill_uniform(dev.enc_empty(), 1, 1016), dev.fill_uniform(dev.enc_empty(), 1, 1017)
+    window = W if W < m else 0
+    proof = None
+    for _ in range(warmup):
+        proof = dev.groth16_prove(dcs, pk, asg, want_empty=False, window=window)[0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = dev.groth16_prove(dcs, pk, asg, want_empty=False, window=window)[0]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev.set_profiling(True)
+    dev.profile_read()
+    proof = dev.groth16_prove(dcs, pk, asg, want_empty=False, window=window)[0]
+    torch.cuda.synchronize()
+    timings, stats = dev.last_timings(), dev.profile_read()
+    dev.set_profiling(False)
+    out = {"preset": prm.name, "primes": PRIME_CLASS.get(prm.name, prm.notes), "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed / steps * 1e3, 3), "value": round(m * steps / elapsed, 1), "unit": "constraints/s",
+           "phase_ms": {"witness_map": round(timings["witness_ms"], 3), "msm": round(timings["msm_ms"], 3)},
+           "kernels": [{"name": k["name"], "ms": round(k["total_ms"], 2), "launches": k["launches"]} for k in stats[:6]]}
+    if check:
+        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk, proof, m, window or None)
+        out["check"] = dict(info, ok=ok)
+    del proof, asg, pk, dcs, dev
+    torch.cuda.empty_cache()
+    return out
+
+
+
 # ---------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (a port of the reference's algorithm) on a bounded sample
 # ---------------------------------------------------------------------------------------------------
 def cpu_baseline(prm, m, n_aux):
-    """oracle/rs_oracle.c timed on this box's host cores: 1 thread (what groth16::prover uses -- no OpenMP in
-    groth16.tcc:70-115) and all cores (OpenMP over terms / slots).  MSM: inner-product terms at
-    full ring shape.  Witness map: the reference's O(m^2) algorithm measured at a small m_s on a few slots and
-    scaled by (m/m_s)^2 x (N L / slots): its cost is exactly quadratic in m and linear in slots."""
+    """The CPU restatement of the reference's algorithm timed on this box's host cores with the arithmetic Microsoft SEAL
+    publishes for it (oracle/librs_oracle_fast.so: Harvey lazy NTT with Shoup quotients, Barrett products -- NOT the
+    `%`-based checker, which would understate a SEAL build; tests/test_oracle.py holds the two bit-identical):
+    1 thread (what groth16::prover uses -- no OpenMP in groth16.tcc:70-115) and all cores (OpenMP over terms / slots,
+    SURVEY.md 8(d)).  MSM: inner-product terms at full ring shape, >= 64 terms per thread.  Witness map: the reference's
+    O(m^2) algorithm measured at a small m_s on a few slots and scaled by (m/m_s)^2 x (N L / slots): its cost is exactly
+    quadratic in m and linear in slots."""
+    from oracle import fastcpu as F
     from oracle import oracle as O
     from tests import helpers as H
 
-    ctx = H.oracle_ctx(prm)
-    nthr = O.max_threads()
+    ctx = H.oracle_ctx(prm)  # input generators only
+    fast = F.FastCtx(prm.N, prm.q, prm.N_enc, prm.Q)
+    nthr = F.max_threads()
     terms_total = 4 * m + (m + 1) + n_aux  # groth16.tcc:89-112
     win = 16
     encs = ctx.random_enc(1, win)
+    T1, TN = 256, max(1024, 64 * nthr)
 
     def msm_rate(threads, T):
         rings = ctx.random_ring(2, T)
         t0 = time.perf_counter()
-        if threads == 1:
-            ctx.inner_product(np.ascontiguousarray(np.concatenate([encs] * ((T + win - 1) // win))[:T]), rings)
-        else:
-            ctx.inner_product(encs, rings, threads=threads, window=win)
+        fast.inner_product(encs, rings, threads=threads, window=win)
         return (time.perf_counter() - t0) / T  # seconds per term
 
     def witness_time(threads, m_s, slots):
@@ -115,20 +169,23 @@ def cpu_baseline(prm, m, n_aux):
         for i in range(m_s):
             asg[i + 2] = (asg[i].astype(object) * asg[i + 1].astype(object) % q).astype(np.uint64)
         t0 = time.perf_counter()
-        O.witness_map(q, H.oracle_cs(cs), 0, asg, threads=threads)
+        F.witness_map(q, H.oracle_cs(cs), 0, asg, threads=threads)
         return (time.perf_counter() - t0) * (m / m_s) ** 2 * (prm.N * prm.L / slots)
 
-    t1_term = msm_rate(1, 48)
-    tN_term = msm_rate(0, max(64, 8 * nthr))
+    t1_term = msm_rate(1, T1)
+    tN_term = msm_rate(0, TN)
+    slots_n = max(256, 32 * nthr)
     w1 = witness_time(1, 128, 256)
-    wN = witness_time(0, 128, max(256, 32 * nthr))
+    wN = witness_time(0, 128, slots_n)
     one = m / (w1 + terms_total * t1_term)
     allc = m / (wN + terms_total * tN_term)
     return {
-        "value": allc, "unit": "constraints/s", "cores": nthr, "kind": "port",
-        "sample": "oracle/rs_oracle.c (-O3 -fopenmp): inner_product on %d terms (1 thread) / %d terms (%d threads) at full "
-                  "ring shape, scaled to the %d terms of one proof; the reference's O(m^2) witness map at m=128 on 256 / %d slots, "
-                  "scaled x(m/128)^2 x(N L/slots)" % (48, max(64, 8 * nthr), nthr, terms_total, max(256, 32 * nthr)),
+        "value": allc, "unit": "constraints/s", "cores": nthr, "kind": "port", "nproc": os.cpu_count(),
+        "arithmetic": "SEAL-style: Harvey lazy NTT with Shoup quotients, Barrett 128-bit products (oracle/rs_fastcpu.c, "
+                      "rs_oracle.c -DRSO_FAST_MULMOD); gcc -O3 -march=native -fopenmp",
+        "sample": "inner_product on %d terms (1 thread) / %d terms (%d threads, %d per thread) at full ring shape, scaled to the %d "
+                  "terms of one proof; the reference's O(m^2) witness map at m=128 on 256 / %d slots, scaled x(m/128)^2 x(N L/slots)"
+                  % (T1, TN, nthr, TN // max(1, nthr), terms_total, slots_n),
         "one_thread": {"value": one, "cores": 1, "msm_s_per_proof": terms_total * t1_term, "witness_s_per_proof": w1},
         "all_cores": {"value": allc, "cores": nthr, "msm_s_per_proof": terms_total * tN_term, "witness_s_per_proof": wN},
         "msm_only": {"one_thread": m / (terms_total * t1_term), "all_cores": m / (terms_total * tN_term), "unit": "constraints/s"},
@@ -149,6 +206,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-ntt", action="store_true", help="skip the standalone NTT bandwidth leg (profiling passes)")
+    ap.add_argument("--no-recipe-primes", action="store_true", help="skip the second leg on preset C3R (the reference recipe's ring primes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -304,6 +362,17 @@ def main():
         ok, info = post_run_check(dev, prm, cs, dcs, asg, pk1, proof[0], m, window1 or pk1["s_pows"].shape[0])
         check = dict(info, ok=ok)
 
+    # ---- the same statement on the ring primes the reference's own recipe yields (preset C3R), one GPU
+    recipe = None
+    if world == 1 and prm.name == "C3" and not args.no_recipe_primes:
+        del proof[0]
+        proof.append(None)
+        pk.clear()
+        pk1.clear()
+        del asg, dcs, dev, backend
+        torch.cuda.empty_cache()
+        recipe = single_gpu_leg("C3R", m, min(14, W.bit_length() - 1), max(1, min(args.steps, 5)), 1, not args.no_check)
+
     if rank == 0:
         key_gib = (3 * m + 2) * prm.enc_words * 8 / 2**30
         out = {
@@ -317,7 +386,8 @@ def main():
                                       ("tiled synthetic CRS: %.0f GiB key stood in for by a resident window of 2^%d elements per key vector "
                                        "(%.0f GiB in HBM per GPU), term index wrapped" % (key_gib, W.bit_length() - 1, stored_gib)) if tiled else
                                       ("synthetic CRS %.0f GiB, %.0f GiB resident per GPU" % (key_gib, stored_gib)), m),
-                       "preset": prm.name, "constraints": m, "key_window": (min(W, m + 1) if tiled else None),
+                       "preset": prm.name, "primes": PRIME_CLASS.get(prm.name, prm.notes), "constraints": m,
+                       "key_window": (min(W, m + 1) if tiled else None),
                        "parallelism": "limbs%d x shards%d" % (plan.limb_groups, plan.term_shards)},
         }
         if timings:
@@ -332,12 +402,14 @@ def main():
             out["ntt_roofline"] = ntt_roofline
         if check is not None:
             out["check"] = check
+        if recipe is not None:
+            out["recipe_primes"] = recipe
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prm, m, n_aux)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    if check is not None and not check["ok"]:
+    if (check is not None and not check["ok"]) or (recipe is not None and "check" in recipe and not recipe["check"]["ok"]):
         sys.exit(3)
 
 

@@ -16,7 +16,31 @@ typedef unsigned __int128 u128;
  * modular arithmetic (SEAL util/uintarithsmallmod.h: multiply_uint_mod, exponentiate_uint_mod,
  * try_invert_uint_mod).  Results are canonical residues, so the reduction method is free.
  * ---------------------------------------------------------------------------------------- */
+#ifndef RSO_FAST_MULMOD
 uint64_t rso_mulmod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)(((u128)a * b) % q); }
+#else
+/* librs_oracle_fast.so (the TIMED cpu_baseline leg of bench.py, never the checker): the same function with SEAL's
+ * Barrett reduction (util/uintarithsmallmod.h barrett_reduce_128) instead of a hardware divide per product; the
+ * ratio floor(2^128 / q) of the last modulus is cached per thread.  Same canonical results (tests/test_oracle.py). */
+static __thread uint64_t tl_q, tl_hi, tl_lo;
+uint64_t rso_mulmod(uint64_t a, uint64_t b, uint64_t q) {
+  if (q != tl_q) {
+    u128 ratio = ((((u128)1) << 127) / q) << 1;
+    if ((u128)0 - ratio * q >= q) ratio += 1;
+    tl_q = q;
+    tl_hi = (uint64_t)(ratio >> 64);
+    tl_lo = (uint64_t)ratio;
+  }
+  const u128 z = (u128)a * b;
+  const uint64_t z0 = (uint64_t)z, z1 = (uint64_t)(z >> 64);
+  const uint64_t carry = (uint64_t)(((u128)z0 * tl_lo) >> 64);
+  const u128 mid1 = (u128)z0 * tl_hi + carry;
+  const u128 mid2 = (u128)z1 * tl_lo + (uint64_t)mid1;
+  const uint64_t quo = z1 * tl_hi + (uint64_t)(mid1 >> 64) + (uint64_t)(mid2 >> 64);
+  const uint64_t r = z0 - quo * q;
+  return r >= q ? r - q : r;
+}
+#endif
 static inline uint64_t addmod(uint64_t a, uint64_t b, uint64_t q) {
   uint64_t s = a + b;
   return s >= q ? s - q : s;

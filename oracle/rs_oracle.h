@@ -205,6 +205,16 @@ void rso_rinocchio_prove(const rso_ctx *c, const rso_r1cs *cs, const rso_rinocch
                          const uint64_t *assignment, const uint64_t *d1, const uint64_t *d2,
                          const uint64_t *d3, uint64_t *proof /* [9] */, int *empty /* [9] */);
 
+/* ---- rs_fastcpu.c (librs_oracle_fast.so only): the timed CPU-baseline leg -- EncodingElem::inner_product with SEAL's
+ * published arithmetic (Harvey lazy NTT with Shoup quotients, Barrett dyadic products).  Same results as above. ---- */
+typedef struct rsf_ctx rsf_ctx;
+rsf_ctx *rsf_ctx_create(const rso_ctx *base);
+void rsf_ctx_destroy(rsf_ctx *c);
+void rsf_ntt_fwd(const rsf_ctx *c, int modset /*0 plain q_i, 1 coeff Q_j*/, int index, uint64_t *a);
+void rsf_ntt_inv(const rsf_ctx *c, int modset, int index, uint64_t *a);
+size_t rsf_inner_product_mt(const rsf_ctx *c, const uint64_t *encs, size_t window, const uint64_t *rings,
+                            const uint8_t *kinds, size_t T, uint64_t *out, int threads);
+
 /* deterministic PRNG shared with the test-suite (splitmix64) */
 uint64_t rso_splitmix64(uint64_t *state);
 void rso_fill_uniform(uint64_t seed, uint64_t q, size_t n, uint64_t *out);

@@ -249,3 +249,39 @@ def test_r1cs_evaluate_matches_reference_headers():
         ev = [O.r1cs_evaluate(q, ocs, k, 0, asg) for k in range(3)]
         for i in range(m):
             assert [int(x) for x in out[1 + i].split()] == [int(ev[k][i, 0]) for k in range(3)]
+
+
+@pytest.mark.parametrize("name,T", [("toy", 21), ("toy49", 12), ("toy60", 9), ("C2", 3)])
+def test_seal_style_timing_library_equals_the_checker(name, T):
+    """oracle/librs_oracle_fast.so -- the TIMED leg of bench.py's cpu_baseline (Harvey lazy NTT with Shoup quotients,
+    Barrett products: the arithmetic SEAL publishes) -- must give the checker's results bit for bit: transforms, the
+    inner product (zero term, Scalar-1 term, tiled window, threads) and the O(m^2) witness map."""
+    from oracle import fastcpu as F
+    prm = P.preset(name)
+    ctx = H.oracle_ctx(prm)
+    f = F.FastCtx(prm.N, prm.q, prm.N_enc, prm.Q)
+    logn = prm.N_enc.bit_length() - 1
+    for modset, primes in ((0, prm.q), (1, prm.Q)):
+        for idx, p in enumerate(primes):
+            x = np.random.RandomState(idx).randint(0, p, prm.N_enc, dtype=np.int64).astype(np.uint64)
+            t = O.NTT(logn, p)
+            assert (f.ntt(modset, idx, x) == t.fwd(x.copy())).all() and (f.ntt(modset, idx, x, True) == t.inv(x.copy())).all()
+    encs, rings = ctx.random_enc(31, T), ctx.random_ring(32, T)
+    kinds = np.zeros(T, dtype=np.uint8)
+    rings[1] = 0
+    kinds[2] = O.KIND_ONE
+    exp, used = ctx.inner_product(encs, rings, kinds)
+    for threads in (1, 3):
+        got, u = f.inner_product(encs, rings, kinds, threads=threads)
+        assert u == used and (got == exp).all()
+    exp, used = ctx.inner_product(encs[:2], rings, kinds, threads=0, window=2)
+    got, u = f.inner_product(encs[:2], rings, kinds, threads=0, window=2)
+    assert u == used and (got == exp).all()
+    if prm.N <= 64:
+        cs = R.wide_r1cs(25, prm.q)
+        asg = H.make_assignment(ctx, cs)
+        ds = [ctx.random_ring(60 + k) for k in range(3)]
+        limb = prm.L - 1
+        args = (prm.q[limb], H.oracle_cs(cs), limb, np.ascontiguousarray(asg[:, limb, :])) + tuple(np.ascontiguousarray(d[limb]) for d in ds)
+        w0, w1 = O.witness_map(*args), F.witness_map(*args, threads=2)
+        assert all((w0[k] == w1[k]).all() for k in w0)

@@ -156,6 +156,17 @@ int rs_msm(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len,
            const rs_msm_vec *vecs, int n_vecs, int n_groups, uint64_t *d_out /* [n_crs][n_groups] enc elems */,
            size_t *h_used /* [n_vecs] or NULL */, rs_stream stream);
 
+/* rs_msm with the CRS vectors in HOST memory (h_crs[c]: host pointers, pinned memory recommended -- rs_host_alloc): how a
+ * proving key larger than HBM is used on one GPU (the 384 GiB key of the 2^16-constraint headline,
+ * zk_proof_systems/groth16/groth16.hpp:34-37; SURVEY.md section 7 "host-pinned streaming").  The term tiles are
+ * streamed through two device staging buffers, the copy of tile k+1 on its own stream under the kernels of tile k;
+ * throughput is bounded by the host link (PCIe), not by HBM.  Same results as rs_msm.  Synchronises. */
+int rs_msm_hostkey(rs_ctx *ctx, const uint64_t *const *h_crs, int n_crs, size_t crs_len, size_t crs_window,
+                   const rs_msm_vec *vecs, int n_vecs, int n_groups, uint64_t *d_out, size_t *h_used, rs_stream stream);
+/* page-locked host memory for such keys (hipHostMalloc / hipHostFree) */
+int rs_host_alloc(rs_ctx *ctx, size_t bytes, void **h_ptr);
+int rs_host_free(rs_ctx *ctx, void *h_ptr);
+
 /* ---- a14: R1CS in CSR form + linear_combination::evaluate (relations/variable.tcc:246-254) -- */
 typedef struct rs_r1cs rs_r1cs;
 /* For M in {a,b,c}: h_row_ptr[M][m+1], h_col[M][nnz] (0 = constant one, k>=1 = variable k-1),
@@ -243,6 +254,7 @@ typedef struct rs_groth16_pk {
   const uint64_t *d_delta_mid; /* [n_aux] */
   const uint64_t *d_alpha, *d_beta;
   size_t window; /* 0 = vectors stored in full; else see crs_window of rs_msm */
+  int host_key;  /* 1: d_s_pows, d_delta_ts, d_delta_mid are HOST pointers (see rs_msm_hostkey); alpha / beta stay on the device */
 } rs_groth16_pk;
 int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, const uint64_t *d_assignment,
                      uint64_t *d_proof, int *h_empty /* [3] or NULL */, rs_stream stream);
@@ -255,6 +267,7 @@ typedef struct rs_rinocchio_pk {
   const uint64_t *d_beta_prods;              /* [n_aux] */
   const uint64_t *d_beta_rv_ts, *d_beta_rw_ts, *d_beta_ry_ts;
   size_t window; /* 0 = vectors stored in full; else see crs_window of rs_msm */
+  int host_key;  /* 1: d_s_pows, d_alpha_s_pows, d_beta_prods are HOST pointers (see rs_msm_hostkey) */
 } rs_rinocchio_pk;
 int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk, const uint64_t *d_assignment,
                        const uint64_t *d_d1, const uint64_t *d_d2, const uint64_t *d_d3, uint64_t *d_proof,
@@ -281,7 +294,7 @@ int rs_profile_read(rs_ctx *ctx, rs_kernel_stat *out, int capacity, int *n_out);
 /* process-wide kernel-shape knobs; results are identical for every accepted value:
  *   "ntt_variant" (14: wide kernels of ntt_wide.hpp, default), "ntt_wide_grid", "mac_variant" (5: mac_kernel_v3),
  *   "plain_variant" (1: plain_center_wide_kernel), "witness_lds_logM", "witness_sub_ct" (2: sub_ntt_wide_kernel),
- *   "witness_tree_ct" (2: tree_wide_kernel), "witness_tree_log" (14), "mac_chunk_units", "prover_lin_io" (1), "witness_col_budget_mib", "witness_force_bc", "witness_bc2" (1), "force_int_arith".
+ *   "witness_tree_ct" (2: tree_wide_kernel), "witness_tree_log" (14), "mac_chunk_units", "prover_lin_io" (1), "witness_col_budget_mib", "witness_force_bc", "witness_bc2" (1), "msm_host_tile" (1024 terms per staging buffer), "force_int_arith".
  * (Variants that alter results -- timing ablations -- exist only as compile-time macros / the separate experiments
  * build, `make -C ringsnark_amd/csrc experiments`; never in the release library.) */
 int rs_set_tuning(const char *key, int value);

@@ -763,7 +763,7 @@ inline proof prover(const proving_key_device &pk, const std::vector<RingElem> &p
   full.insert(full.end(), auxiliary_input.begin(), auxiliary_input.end());
   const std::vector<uint64_t> asg = flatten(full);
   DeviceWords dasg(asg.data(), asg.size()), dproof(3 * Context::enc_words());
-  rs_groth16_pk k{pk.s_pows_.get(), pk.delta_ts_.get(), pk.delta_mid_.get(), pk.alpha_.get(), pk.beta_.get(), 0};
+  rs_groth16_pk k{pk.s_pows_.get(), pk.delta_ts_.get(), pk.delta_mid_.get(), pk.alpha_.get(), pk.beta_.get(), 0, 0};
   int empty[3] = {0, 0, 0};
   check(rs_groth16_prove(Context::get_context(), pk.cs.get(), &k, dasg.get(), dproof.get(), empty, nullptr));
   std::vector<uint64_t> w(3 * Context::enc_words());
@@ -831,7 +831,7 @@ inline proof prover(const proving_key_device &pk, const std::vector<RingElem> &p
     }
   }
   rs_rinocchio_pk k{pk.s_pows_.get(), pk.alpha_s_pows_.get(), pk.beta_prods_.get(), pk.beta_rv_ts_.get(),
-                    pk.beta_rw_ts_.get(), pk.beta_ry_ts_.get(), 0};
+                    pk.beta_rw_ts_.get(), pk.beta_ry_ts_.get(), 0, 0};
   int empty[9] = {0};
   check(rs_rinocchio_prove(Context::get_context(), pk.cs.get(), &k, dasg.get(), dp[0], dp[1], dp[2], dproof.get(), empty, nullptr));
   std::vector<uint64_t> w(9 * Context::enc_words());

@@ -33,12 +33,12 @@ class MsmVec(C.Structure):
 
 class Groth16PK(C.Structure):
     _fields_ = [("d_s_pows", vp), ("d_delta_ts", vp), ("d_delta_mid", vp), ("d_alpha", vp), ("d_beta", vp),
-                ("window", C.c_size_t)]
+                ("window", C.c_size_t), ("host_key", C.c_int)]
 
 
 class RinocchioPK(C.Structure):
     _fields_ = [("d_s_pows", vp), ("d_alpha_s_pows", vp), ("d_beta_prods", vp), ("d_beta_rv_ts", vp),
-                ("d_beta_rw_ts", vp), ("d_beta_ry_ts", vp), ("window", C.c_size_t)]
+                ("d_beta_rw_ts", vp), ("d_beta_ry_ts", vp), ("window", C.c_size_t), ("host_key", C.c_int)]
 
 
 class Timings(C.Structure):
@@ -84,6 +84,10 @@ SIGNATURES = {
     "rs_inner_product": (C.c_int, [vp, vp, vp, u8p, C.c_size_t, vp, C.POINTER(C.c_size_t), vp]),
     "rs_msm": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_size_t, C.c_size_t, C.POINTER(MsmVec), C.c_int, C.c_int, vp,
                          C.POINTER(C.c_size_t), vp]),
+    "rs_msm_hostkey": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_size_t, C.c_size_t, C.POINTER(MsmVec), C.c_int, C.c_int, vp,
+                                 C.POINTER(C.c_size_t), vp]),
+    "rs_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "rs_host_free": (C.c_int, [vp, vp]),
     "rs_r1cs_create": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(u32p), C.POINTER(u32p),
                                  C.POINTER(u64p), C.POINTER(C.c_size_t), C.POINTER(vp)]),
     "rs_r1cs_create_poly": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(u32p), C.POINTER(u32p),

@@ -998,6 +998,9 @@ static int tile_threads(int logn) { return std::max(64, std::min(1024, (1 << log
 struct MsmScratch {
   void *d_plain_tabs = nullptr, *d_coeff_tabs = nullptr;  // device copies of the context's tables (NttTable or NttTableI)
   uint64_t *d_Qint = nullptr;
+  // host-resident keys: copy stream and the events of the two staging buffers (copied: data landed; freed: its readers ran)
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_freed[2] = {nullptr, nullptr};
   template <class M>
   const NttTableT<typename ArithOf<M>::T, M> *plain() const {
     return static_cast<const NttTableT<typename ArithOf<M>::T, M> *>(d_plain_tabs);
@@ -1041,6 +1044,13 @@ void msm_scratch_release(rs_ctx *ctx) {
   (void)hipFree(it->second.d_plain_tabs);
   (void)hipFree(it->second.d_coeff_tabs);
   (void)hipFree(it->second.d_Qint);
+  if (it->second.copy_stream) {
+    (void)hipStreamDestroy(it->second.copy_stream);
+    for (int b = 0; b < 2; b++) {
+      (void)hipEventDestroy(it->second.ev_copied[b]);
+      (void)hipEventDestroy(it->second.ev_freed[b]);
+    }
+  }
   g_scratch.erase(it);
 }
 
@@ -1124,6 +1134,7 @@ static void launch_mac_v3(rs_ctx *ctx, const MacArgs3 &a, const MsmScratch &sc, 
 }
 
 int g_mac_ablate = 0;
+int g_msm_host_tile = 1024;  // tuning knob "msm_host_tile": terms per staging buffer of a host-resident key
 int g_mac_chunk_units = 768;  // tuning knob "mac_chunk_units": (limb, prime, chunk) units per MAC launch (term chunks = units / (L K))
 int g_plain_variant = 1;  // 1: plain_center_wide_kernel at N_enc = 8192; 0: plain_center_kernel
 int g_mac_variant = 5;  // 5: half-spectrum wide kernel at N_enc = 8192 (else as 3); 3: streaming kernel, 1024-thread shape at N_enc = 8192 (else as 2); 2: 512-thread streaming kernel; 1: generic kernel
@@ -1135,7 +1146,7 @@ int g_mac_variant = 5;  // 5: half-spectrum wide kernel at N_enc = 8192 (else as
 template <class M>
 static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
                           int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st,
-                          size_t crs_window, const MsmLin *lin) {
+                          size_t crs_window, const MsmLin *lin, bool crs_on_host) {
   using Lift = typename ArithOf<M>::Lift;
   constexpr bool FP = std::is_same<M, Mod>::value;
   RS_REQUIRE(n_crs >= 1 && n_crs <= 2, "n_crs must be 1 or 2");
@@ -1209,7 +1220,46 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     tile_terms = std::min(p2, crs_window);
     RS_REQUIRE(crs_window % tile_terms == 0, "crs_window must be a multiple of the term tile (use a power of two)");
   }
-  auto crs_at = [&](int c, size_t t0) { return d_crs[c] + (crs_window ? t0 % crs_window : t0) * enc_words; };
+  // Host-resident key (crs_on_host: d_crs are HOST pointers -- a proving key larger than HBM, e.g. the 384 GiB key of the
+  // 2^16-constraint headline on one GPU): the term tiles are streamed through two device staging buffers; the copy of
+  // tile k+1 runs on its own stream under the kernels of tile k (pinned host memory, rs_host_alloc, for real overlap).
+  uint64_t *stage = nullptr;
+  size_t stage_words = 0;
+  if (crs_on_host) {
+    tile_terms = std::min<size_t>(tile_terms, (size_t)std::max(1, g_msm_host_tile));
+    if (crs_window) {
+      size_t p2 = 1;
+      while (p2 * 2 <= tile_terms) p2 *= 2;
+      tile_terms = std::min(p2, crs_window);
+    }
+    stage_words = tile_terms * enc_words;
+    stage = (uint64_t *)ws_get(ctx, 7, (size_t)2 * n_crs * stage_words * sizeof(uint64_t));
+    if (!sc.copy_stream) {
+      RS_HIP(hipStreamCreateWithFlags(&sc.copy_stream, hipStreamNonBlocking));
+      for (int b = 0; b < 2; b++) {
+        RS_HIP(hipEventCreateWithFlags(&sc.ev_copied[b], hipEventDisableTiming));
+        RS_HIP(hipEventCreateWithFlags(&sc.ev_freed[b], hipEventDisableTiming));
+      }
+    }
+    // the staging buffers may still be read by an earlier call on another stream: order the copy stream after `st`
+    RS_HIP(hipEventRecord(sc.ev_freed[0], st));
+    RS_HIP(hipEventRecord(sc.ev_freed[1], st));
+  }
+  auto stage_at = [&](int buf, int c) { return stage + ((size_t)buf * n_crs + c) * stage_words; };
+  auto issue_copy = [&](int tile, size_t t0) {  // tile -> staging buffer tile % 2, on the copy stream
+    const int buf = tile & 1;
+    const size_t tt = std::min(tile_terms, Tmax - t0);
+    RS_HIP(hipStreamWaitEvent(sc.copy_stream, sc.ev_freed[buf], 0));
+    for (int c = 0; c < n_crs; c++)
+      RS_HIP(hipMemcpyAsync(stage_at(buf, c), d_crs[c] + (crs_window ? t0 % crs_window : t0) * enc_words, tt * enc_words * sizeof(uint64_t),
+                            hipMemcpyHostToDevice, sc.copy_stream));
+    RS_HIP(hipEventRecord(sc.ev_copied[buf], sc.copy_stream));
+  };
+  int cur_tile = 0;
+  auto crs_at = [&](int c, size_t t0) -> const uint64_t * {
+    if (crs_on_host) return stage_at(cur_tile & 1, c);
+    return d_crs[c] + (crs_window ? t0 % crs_window : t0) * enc_words;
+  };
   int n_chunks = (int)std::min<size_t>(tile_terms, (size_t)std::max(1, (g_mac_chunk_units + L * K - 1) / (L * K)));
   if (Tmax == 0) n_chunks = 1;
   Lift *d_C = (Lift *)ws_get(ctx, 0, std::max<size_t>(256, tile_terms * c_bytes_per_term));
@@ -1242,8 +1292,14 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
   if (Tmax == 0) RS_HIP(hipMemsetAsync(d_partial, 0, (size_t)n_chunks * n_sets * enc_words * sizeof(uint64_t), st));
 
   int tile_idx = 0;
+  if (crs_on_host && Tmax) issue_copy(0, 0);
   for (size_t t0 = 0; t0 < Tmax; t0 += tile_terms, tile_idx++) {
     const size_t tt = std::min(tile_terms, Tmax - t0);
+    cur_tile = tile_idx;
+    if (crs_on_host) {
+      if (t0 + tile_terms < Tmax) issue_copy(tile_idx + 1, t0 + tile_terms);  // under this tile's kernels
+      RS_HIP(hipStreamWaitEvent(st, sc.ev_copied[tile_idx & 1], 0));
+    }
     double rows_in = 0;  // coefficient rows (term, limb) read by this tile
     for (int v = 0; v < n_vecs; v++) rows_in += (double)(vecs[v].T > t0 ? std::min(tt, vecs[v].T - t0) : 0) * L;
     {
@@ -1424,6 +1480,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
         run(1, 2, gs, cs);
       }
     }
+    if (crs_on_host) RS_HIP(hipEventRecord(sc.ev_freed[tile_idx & 1], st));  // its readers are enqueued: the buffer may be refilled after them
   }
   ReduceArgs ra;
   memset(&ra, 0, sizeof(ra));
@@ -1452,9 +1509,9 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
 
 void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
              int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st,
-             size_t crs_window, const MsmLin *lin = nullptr) {
-  RS_DISPATCH_ARITH(ctx, (msm_run_arith<Mod>(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, addends, h_used, st, crs_window, lin)),
-                    (msm_run_arith<ModI>(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, addends, h_used, st, crs_window, lin)));
+             size_t crs_window, const MsmLin *lin = nullptr, bool crs_on_host = false) {
+  RS_DISPATCH_ARITH(ctx, (msm_run_arith<Mod>(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, addends, h_used, st, crs_window, lin, crs_on_host)),
+                    (msm_run_arith<ModI>(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, addends, h_used, st, crs_window, lin, crs_on_host)));
 }
 // can a call with linear-form vectors be served? (FP64 context on the wide plaintext kernel)
 bool msm_supports_lin(const rs_ctx *ctx) {
@@ -1504,6 +1561,28 @@ int rs_msm(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len,
   RS_REQUIRE(ctx && d_crs && vecs && d_out && n_vecs >= 1, "null argument");
   WsScope ws_scope(ctx, S(stream));
   msm_run(ctx, d_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, nullptr, h_used, S(stream), crs_window);
+  RS_API_END
+}
+
+int rs_msm_hostkey(rs_ctx *ctx, const uint64_t *const *h_crs, int n_crs, size_t crs_len, size_t crs_window, const rs_msm_vec *vecs,
+                   int n_vecs, int n_groups, uint64_t *d_out, size_t *h_used, rs_stream stream) {
+  RS_API_BEGIN_CTX(ctx)
+  RS_REQUIRE(ctx && h_crs && vecs && d_out && n_vecs >= 1, "null argument");
+  WsScope ws_scope(ctx, S(stream));
+  msm_run(ctx, h_crs, n_crs, crs_len, vecs, n_vecs, n_groups, d_out, nullptr, h_used, S(stream), crs_window, nullptr, true);
+  RS_HIP(hipStreamSynchronize(S(stream)));  // the caller may release or rewrite the host key on return
+  RS_API_END
+}
+
+int rs_host_alloc(rs_ctx *ctx, size_t bytes, void **h_ptr) {
+  RS_API_BEGIN_CTX(ctx)
+  RS_REQUIRE(h_ptr && bytes, "null argument");
+  RS_HIP(hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
+  RS_API_END
+}
+int rs_host_free(rs_ctx *ctx, void *h_ptr) {
+  RS_API_BEGIN_CTX(ctx)
+  if (h_ptr) RS_HIP(hipHostFree(h_ptr));
   RS_API_END
 }
 

@@ -8,7 +8,7 @@
 namespace rs {
 void msm_run(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, size_t crs_len, const rs_msm_vec *vecs, int n_vecs,
              int n_groups, uint64_t *d_out, const uint64_t *const *addends, size_t *h_used, hipStream_t st,
-             size_t crs_window, const MsmLin *lin = nullptr);
+             size_t crs_window, const MsmLin *lin = nullptr, bool crs_on_host = false);
 bool msm_supports_lin(const rs_ctx *ctx);
 void batch_encode_run(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, size_t count, hipStream_t st);
 bool witness_io_shortcut(const rs_r1cs *cs);
@@ -114,6 +114,7 @@ int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, co
   const size_t m = cs->m, rw = ctx->ring_words(), ew = ctx->enc_words();
   const size_t n_aux = cs->n_vars - cs->n_inputs;
   RS_REQUIRE(n_aux == 0 || pk->d_delta_mid, "delta_mid missing");
+  const bool host_key = pk->host_key != 0;
   memset(&ctx->timings, 0, sizeof(ctx->timings));
   PhaseTimer pt(ctx, st);
   pt.mark(0);
@@ -149,10 +150,10 @@ int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, co
         ln[w].T = m;
       }
       rs_msm_vec v[2] = {{A_mid, nullptr, m, 0}, {B_mid, nullptr, m, 1}};
-      msm_run(ctx, crs, 1, m + 1, v, 2, 2, d_proof, add, nullptr, st, pk->window, ln);
+      msm_run(ctx, crs, 1, m + 1, v, 2, 2, d_proof, add, nullptr, st, pk->window, ln, host_key);
     } else {
       rs_msm_vec v[4] = {{A_io, nullptr, m, 0}, {A_mid, nullptr, m, 0}, {B_io, nullptr, m, 1}, {B_mid, nullptr, m, 1}};
-      msm_run(ctx, crs, 1, m + 1, v, 4, 2, d_proof, add, nullptr, st, pk->window);
+      msm_run(ctx, crs, 1, m + 1, v, 4, 2, d_proof, add, nullptr, st, pk->window, nullptr, host_key);
     }
   }
   // C = <delta_ts, H> (+ <delta_mid, aux>)                                 (groth16.tcc:105-112)
@@ -161,16 +162,17 @@ int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, co
   if (n_aux) {
     const uint64_t *crs[1] = {pk->d_delta_mid};
     rs_msm_vec v{d_assignment + cs->n_inputs * rw, nullptr, n_aux, 0};
-    msm_run(ctx, crs, 1, n_aux, &v, 1, 1, C, nullptr, h_empty ? &used_aux : nullptr, st, pk->window);
+    msm_run(ctx, crs, 1, n_aux, &v, 1, 1, C, nullptr, h_empty ? &used_aux : nullptr, st, pk->window, nullptr, host_key);
   }
   {
     const uint64_t *crs[1] = {pk->d_delta_ts};
     rs_msm_vec v{H, nullptr, m + 1, 0};
     const uint64_t *add[1] = {n_aux ? C : nullptr};
-    msm_run(ctx, crs, 1, m + 1, &v, 1, 1, C, add, h_empty ? &used_h : nullptr, st, pk->window);
+    msm_run(ctx, crs, 1, m + 1, &v, 1, 1, C, add, h_empty ? &used_h : nullptr, st, pk->window, nullptr, host_key);
   }
   pt.mark(2);
   pt.finish();
+  if (host_key) RS_HIP(hipStreamSynchronize(st));  // the caller may release or rewrite the host key on return
   if (h_empty) {
     h_empty[0] = h_empty[1] = 0;  // alpha / beta are always added
     h_empty[2] = (used_h == 0 && used_aux == 0) ? 1 : 0;
@@ -220,7 +222,7 @@ int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk
     const uint64_t *crs[2] = {pk->d_s_pows, pk->d_alpha_s_pows};
     rs_msm_vec v[5] = {{A_mid, nullptr, m, 0}, {B_mid, nullptr, m, 1}, {C_mid, nullptr, m, 2}, {H, nullptr, m + 1, 3},
                        {Zr, zkinds.data(), m + 1, 4}};
-    msm_run(ctx, crs, 2, m + 1, v, 5, 5, mo, nullptr, used, st, pk->window);
+    msm_run(ctx, crs, 2, m + 1, v, 5, 5, mo, nullptr, used, st, pk->window, nullptr, pk->host_key != 0);
   }
   auto slot = [&](int c, int g) { return mo + ((size_t)c * 5 + g) * ew; };
   int empty[9];
@@ -254,7 +256,7 @@ int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk
     size_t used_f = 0;
     const uint64_t *crs[1] = {pk->d_beta_prods};
     rs_msm_vec v{d_assignment + cs->n_inputs * rw, nullptr, n_aux, 0};
-    msm_run(ctx, crs, 1, n_aux, &v, 1, 1, F, nullptr, &used_f, st, pk->window);
+    msm_run(ctx, crs, 1, n_aux, &v, 1, 1, F, nullptr, &used_f, st, pk->window, nullptr, pk->host_key != 0);
     empty[8] = used_f == 0;
     if (zk) {
       add_scaled(F, &empty[8], pk->d_beta_rv_ts, d_d1);

@@ -919,6 +919,8 @@ int rs_set_tuning(const char *key, int value) {
     g_plain_variant = value;
   else if (std::string(key) == "prover_lin_io")
     g_prover_lin_io = value;
+  else if (std::string(key) == "msm_host_tile")
+    g_msm_host_tile = std::max(1, value);
   else if (std::string(key) == "mac_chunk_units")
     g_mac_chunk_units = std::max(1, value);
   else if (std::string(key) == "ntt_wide_grid")

@@ -30,6 +30,30 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+class HostWords:
+    """Page-locked host buffer of uint64 words (rs_host_alloc); `array` is a numpy view of it."""
+
+    def __init__(self, dev, words):
+        self.dev, self.words = dev, int(words)
+        p = C.c_void_p()
+        _lib.check(dev.lib.rs_host_alloc(dev.h, self.words * 8, C.byref(p)))
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array((C.c_uint64 * self.words).from_address(self.ptr))
+
+    def fill_from(self, tensor, offset_words=0):
+        """device tensor (int64) -> this buffer at offset_words (rs_download)."""
+        t = tensor.contiguous()
+        assert offset_words + t.numel() <= self.words
+        _lib.check(self.dev.lib.rs_download(self.dev.h, C.c_void_p(self.ptr + 8 * offset_words), C.c_void_p(t.data_ptr()), t.numel() * 8, self.dev.stream()))
+        self.dev.sync()
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and self.dev.lib is not None and getattr(self.dev, "h", None):
+            self.array = None
+            self.dev.lib.rs_host_free(self.dev.h, C.c_void_p(self.ptr))
+            self.ptr = None
+
+
 class DeviceR1CS:
     def __init__(self, dev, cs: R1CS):
         self.dev, self.cs = dev, cs
@@ -265,11 +289,14 @@ class Device:
 
     def msm(self, crs_list, vecs, n_groups, want_used=False, crs_len=None, window=0):
         """vecs: list of (coeff tensor [T][L][N], kinds or None, group).  window != 0: the CRS tensors hold
-        `window` elements and logical element t is read from t % window (crs_len = logical length)."""
+        `window` elements and logical element t is read from t % window (crs_len = logical length).
+        CRS vectors given as HostWords (host_alloc) are streamed from host memory (rs_msm_hostkey)."""
         n_crs = len(crs_list)
+        on_host = isinstance(crs_list[0], HostWords)
+        assert all(isinstance(c, HostWords) == on_host for c in crs_list)
         if crs_len is None:
-            crs_len = self._count(crs_list[0], self.enc_words)
-        crs = (C.c_void_p * n_crs)(*[c.data_ptr() for c in crs_list])
+            crs_len = crs_list[0].words // self.enc_words if on_host else self._count(crs_list[0], self.enc_words)
+        crs = (C.c_void_p * n_crs)(*[(c.ptr if on_host else c.data_ptr()) for c in crs_list])
         mv = (_lib.MsmVec * len(vecs))()
         keep = []
         for k, (coeff, kinds, group) in enumerate(vecs):
@@ -282,8 +309,8 @@ class Device:
                 mv[k].h_kinds = kk.ctypes.data_as(_lib.u8p)
         out = self.enc_empty(n_crs, n_groups)
         used = (C.c_size_t * len(vecs))()
-        _lib.check(self.lib.rs_msm(self.h, crs, n_crs, crs_len, window, mv, len(vecs), n_groups, _ptr(out),
-                                   used if want_used else None, self.stream()))
+        fn = self.lib.rs_msm_hostkey if on_host else self.lib.rs_msm
+        _lib.check(fn(self.h, crs, n_crs, crs_len, window, mv, len(vecs), n_groups, _ptr(out), used if want_used else None, self.stream()))
         return out, [int(u) for u in used]
 
     # ---- a10-a14
@@ -355,12 +382,19 @@ class Device:
         return self._poly(self.lib.rs_poly_divide, num, den, lambda nn, nd: nn - nd + 1, out)
 
     # ---- a15 / a16
+    def host_alloc(self, words):
+        """Page-locked host memory of `words` uint64 (rs_host_alloc): where a proving key larger than HBM lives."""
+        return HostWords(self, words)
+
     def groth16_prove(self, dcs, pk, assignment, want_empty=True, window=0):
         """pk: dict s_pows, delta_ts, delta_mid, alpha, beta (CUDA tensors).  window != 0: the key vectors hold
-        `window` elements each, element t read from t % window (tiled synthetic key, ringsnark_amd.h)."""
-        s = _lib.Groth16PK(pk["s_pows"].data_ptr(), pk["delta_ts"].data_ptr(),
-                           pk["delta_mid"].data_ptr() if pk.get("delta_mid") is not None else None,
-                           pk["alpha"].data_ptr(), pk["beta"].data_ptr(), window)
+        `window` elements each, element t read from t % window (tiled synthetic key, ringsnark_amd.h).
+        Key VECTORS given as HostWords: a host-resident key, streamed tile by tile (rs_groth16_pk.host_key)."""
+        host_key = isinstance(pk["s_pows"], HostWords)
+        addr = lambda v: None if v is None else (v.ptr if isinstance(v, HostWords) else v.data_ptr())
+        assert all(isinstance(pk[k], HostWords) == host_key for k in ("s_pows", "delta_ts") + (("delta_mid",) if pk.get("delta_mid") is not None else ()))
+        s = _lib.Groth16PK(addr(pk["s_pows"]), addr(pk["delta_ts"]), addr(pk.get("delta_mid")),
+                           pk["alpha"].data_ptr(), pk["beta"].data_ptr(), window, 1 if host_key else 0)
         proof = self.enc_empty(3)
         empty = (C.c_int * 3)()
         _lib.check(self.lib.rs_groth16_prove(self.h, dcs.h, C.byref(s), _ptr(assignment), _ptr(proof),
@@ -368,9 +402,10 @@ class Device:
         return proof, [int(e) for e in empty]
 
     def rinocchio_prove(self, dcs, pk, assignment, d1=None, d2=None, d3=None, window=0):
-        g = lambda k: pk[k].data_ptr() if pk.get(k) is not None else None
+        host_key = isinstance(pk.get("s_pows"), HostWords)
+        g = lambda k: None if pk.get(k) is None else (pk[k].ptr if isinstance(pk[k], HostWords) else pk[k].data_ptr())
         s = _lib.RinocchioPK(g("s_pows"), g("alpha_s_pows"), g("beta_prods"), g("beta_rv_ts"), g("beta_rw_ts"), g("beta_ry_ts"),
-                             window)
+                             window, 1 if host_key else 0)
         proof = self.enc_empty(9)
         empty = (C.c_int * 9)()
         _lib.check(self.lib.rs_rinocchio_prove(self.h, dcs.h, C.byref(s), _ptr(assignment), _ptr(d1), _ptr(d2), _ptr(d3),

@@ -701,6 +701,54 @@ def test_msm_with_a_tiled_key_equals_the_explicit_key():
     assert (host(got) == host(exp)).all()
 
 
+@pytest.mark.parametrize("name,tile", [("toy", 3), ("toy", 8), ("C2", 64), ("toy60", 5)])
+def test_host_resident_key_equals_the_device_resident_one(name, tile):
+    """A proving key kept in (page-locked) HOST memory and streamed tile by tile through two device staging buffers
+    (rs_msm_hostkey, rs_groth16_pk.host_key: how a key larger than HBM is used on one GPU) gives the same inner
+    products and the same proofs as the device-resident key -- with the oracle as the judge of both.  Small staging
+    tiles (msm_host_tile) force many copy / compute hand-overs; a tiled (windowed) host key as well."""
+    dev = dev_for(name)
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    m = 37 if prm.N_enc <= 128 else 300
+    cs = R.wide_r1cs(m, prm.q) if prm.N_enc <= 128 else R.chain_r1cs(m, prm.q)
+    asg = H.make_assignment(ctx, cs)
+    pk = dict(s_pows=ctx.random_enc(71, m + 1), delta_ts=ctx.random_enc(72, m + 1), delta_mid=ctx.random_enc(73, cs.n_aux),
+              alpha=ctx.random_enc(74), beta=ctx.random_enc(75))
+
+    def on_host(a):
+        hw = dev.host_alloc(a.size)
+        hw.array[:] = a.reshape(-1)
+        return hw
+
+    hk = {k: (on_host(v) if v.ndim == 5 else dev.put(v)) for k, v in pk.items()}
+    dk = {k: dev.put(v) for k, v in pk.items()}
+    dcs, dasg = dev.r1cs(cs), dev.put(asg)
+    _set_tuning(b"msm_host_tile", tile)
+    try:
+        got_h, empty_h = dev.groth16_prove(dcs, hk, dasg)
+        rings = ctx.random_ring(32, m + 1)
+        kinds = np.zeros(m + 1, dtype=np.uint8)
+        rings[2] = 0
+        kinds[4] = O.KIND_ONE
+        ip_h, used_h = dev.msm([hk["s_pows"], hk["delta_ts"]], [(dev.put(rings), kinds, 0)], 1, want_used=True)
+        # a tiled host key: window of 8 stored elements, logical length m + 1
+        w8 = on_host(pk["s_pows"][:8])
+        ip_w, _ = dev.msm([w8], [(dev.put(rings), None, 0)], 1, crs_len=m + 1, window=8)
+    finally:
+        _set_tuning(b"msm_host_tile", 1024)
+    got_d, empty_d = dev.groth16_prove(dcs, dk, dasg)
+    assert empty_h == empty_d and (host(got_h) == host(got_d)).all()
+    if prm.N_enc <= 128:
+        exp, exp_empty = O.groth16_prove(ctx, H.oracle_cs(cs), pk, asg)
+        assert exp_empty == empty_h and (host(got_h) == exp).all()
+    for c, key in enumerate(("s_pows", "delta_ts")):
+        exp, used = ctx.inner_product(pk[key], rings, kinds, threads=0)
+        assert used_h[0] == used and (host(ip_h)[c, 0] == exp).all()
+    exp, _ = ctx.inner_product(pk["s_pows"][:8], rings, None, threads=0, window=8)
+    assert (host(ip_w)[0, 0] == exp).all()
+
+
 @pytest.mark.parametrize("m,zk", [(20000, True), (40000, False)])
 def test_multipass_tuned_sub_transform_kernel_equals_generic(m, zk):
     """M >= 2^15: the multi-pass path runs its 2^13-point sub-transforms through sub_ntt_wide_kernel (32 coefficients

@@ -729,10 +729,15 @@ struct MacArgs3 {
   int paired;                // rows in plain_center_wide_kernel's paired layout
   uint32_t red_mask[RS_MAX_K];  // bit s: reduce before stage s of the forward transform mod Q_j (start bound = max |C|)
 };
-template <bool PAIRED>
+// LOGN = 14 (N_enc = 16384: the shapes of BASELINE configs[3] / [4] and of the reference's microbench.cpp:13-14): a
+// workgroup owns a QUARTER of the spectrum -- the first TWO stages (gaps 8192 and 4096) are applied while the row is
+// loaded, the other 12 are the 4096-point sub-transform rooted at node 4 + quarter; everything after the load is the
+// LOGN = 13 kernel.  Rows are in natural order (PAIRED = false).
+template <bool PAIRED, int LOGN = 13>
 __global__ void __launch_bounds__(256, 2)
 mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs) {
-  constexpr int n = 8192, H = 4096;
+  constexpr int n = 1 << LOGN, H = 4096, LOGP = LOGN - 12, PARTS = 1 << LOGP;
+  static_assert(LOGN == 13 || (LOGN == 14 && !PAIRED), "half spectrum at 8192 points, quarter spectrum at 16384");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -743,15 +748,15 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
   unsigned q = b >> 3;
   const int g = (int)(q % (unsigned)a.n_groups);
   q /= (unsigned)a.n_groups;
-  const unsigned hj = q % (2u * (unsigned)K);
-  const unsigned rr = (q / (2u * (unsigned)K)) * 8u + x;  // (chunk, limb)
-  const int h = (int)(hj & 1u), j = (int)(hj >> 1);
+  const unsigned hj = q % ((unsigned)PARTS * (unsigned)K);
+  const unsigned rr = (q / ((unsigned)PARTS * (unsigned)K)) * 8u + x;  // (chunk, limb)
+  const int h = (int)(hj & (unsigned)(PARTS - 1)), j = (int)(hj >> LOGP);
   const int limb = (int)(rr % (unsigned)L), chunk = (int)(rr / (unsigned)L);
   if (chunk >= a.n_chunks) return;
   const Mod mod = coeff_tabs[j].mod;
   const double *__restrict__ tw = coeff_tabs[j].d_tw;
   const uint32_t red_mask = a.red_mask[j];
-  const int root = 2 + h;
+  const int root = PARTS + h;
   // per-lane twiddles of rounds 2 and 3, fixed for the whole chunk
   const int lo = t & 15, hi = t >> 4;
   // round-2 twiddles tw[(root << (4+k)) + (hi << k) + b] (16 lanes share each) come from an LDS copy of the table's
@@ -769,6 +774,7 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
   // wave-uniform twiddles of stage 0 and round 1, as scalar registers: fetched through the table pointer inside the
   // term loop they would be vector loads, and waiting for the youngest vector load drains the ciphertext stream
   const double w0 = uniform_f64(tw[1]);
+  const double w1 = uniform_f64(tw[2 + (h >> 1)]);  // LOGN = 14: stage 1 of this quarter's half
   double tw1[15];
 #pragma unroll
   for (int k = 0; k < 4; k++)
@@ -878,28 +884,82 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
   constexpr int TILE = H + H / 16;
   for (unsigned long long tt = tbeg; tt < tend; tt++) {
     double *tile = s + (int)((tt - tbeg) & 1) * TILE;
-    load_row_a();
-    mem_fence();
-    if (tt > tbeg) mac(s + (int)((tt - tbeg + 1) & 1) * TILE);  // term tt - 1
-    mem_fence();
-    load_row_b();
-    crow += (size_t)L * n;
-    mem_fence();
     double v[16];
-    // stage 0 (gap 4096): this half's operand of the 4096-point sub-transform
+    if (LOGN == 13) {
+      load_row_a();
+      mem_fence();
+      if (tt > tbeg) mac(s + (int)((tt - tbeg + 1) & 1) * TILE);  // term tt - 1
+      mem_fence();
+      load_row_b();
+      crow += (size_t)L * n;
+      mem_fence();
+      // stage 0 (gap 4096): this half's operand of the 4096-point sub-transform
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-      double bq = ch[e];
-      if (red_mask & 1u) bq = reduce(bq, mod);
-      ch[e] = mulmod(bq, w0, mod);
-      pin(ch[e]);
-    }
+      for (int e = 0; e < 16; e++) {
+        double bq = ch[e];
+        if (red_mask & 1u) bq = reduce(bq, mod);
+        ch[e] = mulmod(bq, w0, mod);
+        pin(ch[e]);
+      }
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-      double aq = cl[e];
-      if (red_mask & 1u) aq = reduce(aq, mod);
-      v[e] = h ? aq - ch[e] : aq + ch[e];
-      pin(v[e]);
+      for (int e = 0; e < 16; e++) {
+        double aq = cl[e];
+        if (red_mask & 1u) aq = reduce(aq, mod);
+        v[e] = h ? aq - ch[e] : aq + ch[e];
+        pin(v[e]);
+      }
+    } else {
+      // stages 0 (gap 8192) and 1 (gap 4096) on x[n'], x[n' + 4096], x[n' + 8192], x[n' + 12288], n' = t + 256 e: the two
+      // operands multiplied by stage 0's twiddle are requested before the previous term's multiply-accumulate, the
+      // other two after it, one at a time (all 64 words at once do not fit beside the accumulators)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        cl[e] = crow[256 * e + 2 * H];
+        ch[e] = crow[256 * e + 3 * H];
+      }
+      mem_fence();
+      if (tt > tbeg) mac(s + (int)((tt - tbeg + 1) & 1) * TILE);  // term tt - 1
+      mem_fence();
+#pragma unroll
+      for (int e = 0; e < 16; e++) v[e] = crow[256 * e];
+      mem_fence();
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        double x2 = cl[e], x3 = ch[e];
+        if (red_mask & 1u) {
+          x2 = reduce(x2, mod);
+          x3 = reduce(x3, mod);
+        }
+        cl[e] = mulmod(x2, w0, mod);
+        ch[e] = mulmod(x3, w0, mod);
+        pin(cl[e]);
+        pin(ch[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) {  // u0 = x0 +- w0 x2 (this quarter's half of stage 0)
+        double x0 = v[e];
+        if (red_mask & 1u) x0 = reduce(x0, mod);
+        cl[e] = (h & 2) ? x0 - cl[e] : x0 + cl[e];
+        pin(cl[e]);
+      }
+      mem_fence();
+#pragma unroll
+      for (int e = 0; e < 16; e++) v[e] = crow[256 * e + H];
+      crow += (size_t)L * n;
+      mem_fence();
+#pragma unroll
+      for (int e = 0; e < 16; e++) {  // u1 = x1 +- w0 x3, then stage 1: v = u0 +- w1 u1
+        double x1 = v[e];
+        if (red_mask & 1u) x1 = reduce(x1, mod);
+        double u1 = (h & 2) ? x1 - ch[e] : x1 + ch[e];
+        if (red_mask & 2u) {
+          u1 = reduce(u1, mod);
+          cl[e] = reduce(cl[e], mod);
+        }
+        u1 = mulmod(u1, w1, mod);
+        v[e] = (h & 1) ? cl[e] - u1 : cl[e] + u1;
+        pin(v[e]);
+      }
     }
     mem_fence();
     issue_ct();  // after the row registers are dead: the two never overlap
@@ -909,8 +969,8 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
     wave_sync();
     continue;
 #endif
-    // round 1: stages 1..4 on elements t + 256 e (uniform twiddles)
-    reg_fwd_stages<4, true>(v, mod, red_mask >> 1, [&](int k, int bk) { return tw1[(1 << k) - 1 + bk]; });
+    // round 1: stages LOGP..LOGP+3 on elements t + 256 e (uniform twiddles)
+    reg_fwd_stages<4, true>(v, mod, red_mask >> LOGP, [&](int k, int bk) { return tw1[(1 << k) - 1 + bk]; });
     {  // tile tt % 2 was last read by the multiply-accumulate of term tt - 2, two barriers ago
       const int pb = t + (t >> 4);
 #pragma unroll
@@ -921,7 +981,7 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
       const int pb = hi * 272 + lo;
 #pragma unroll
       for (int e = 0; e < 16; e++) v[e] = tile[pb + 17 * e];
-      reg_fwd_stages<4, true>(v, mod, red_mask >> 5, [&](int k, int bk) { return twl[(root << (4 + k)) + (hi << k) + bk]; });
+      reg_fwd_stages<4, true>(v, mod, red_mask >> (LOGP + 4), [&](int k, int bk) { return twl[(root << (4 + k)) + (hi << k) + bk]; });
 #pragma unroll
       for (int e = 0; e < 16; e++) tile[pb + 17 * e] = v[e];
     }
@@ -930,7 +990,7 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
       const int pb = 17 * t;
 #pragma unroll
       for (int e = 0; e < 16; e++) v[e] = tile[pb + e];
-      reg_fwd_stages<4, true>(v, mod, red_mask >> 9, [&](int k, int bk) { return tw3[(1 << k) - 1 + bk]; });
+      reg_fwd_stages<4, true>(v, mod, red_mask >> (LOGP + 8), [&](int k, int bk) { return tw3[(1 << k) - 1 + bk]; });
 #pragma unroll
       for (int e = 0; e < 16; e++) tile[pb + e] = a.reduce_u ? reduce(v[e], mod) : v[e];
     }
@@ -1122,8 +1182,12 @@ static uint32_t fwd_reduce_mask_from(uint64_t p, int logn, double b0, double *en
 static void launch_mac_v3(rs_ctx *ctx, const MacArgs3 &a, const MsmScratch &sc, hipStream_t st) {
   const size_t lds = (size_t)(2 * (4096 + 256) + 1024) * sizeof(double);  // two tiles + round-2 twiddles
   const unsigned rows = (unsigned)ctx->L * (unsigned)a.n_chunks;  // (chunk, limb), spread over the XCDs
-  const unsigned blocks = ((rows + 7) / 8) * 8 * 2u * (unsigned)ctx->K * (unsigned)a.n_groups;
-  if (a.paired) {
+  const unsigned parts = (unsigned)ctx->N_enc / 4096u;  // workgroups per (limb, prime): halves at 8192 points, quarters at 16384
+  const unsigned blocks = ((rows + 7) / 8) * 8 * parts * (unsigned)ctx->K * (unsigned)a.n_groups;
+  if (ctx->N_enc == 16384) {
+    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v3<false, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((mac_kernel_v3<false, 14>), dim3(blocks), dim3(256), lds, st, a, ctx->L, ctx->K, sc.coeff<Mod>());
+  } else if (a.paired) {
     RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(mac_kernel_v3<true>, dim3(blocks), dim3(256), lds, st, a, ctx->L, ctx->K, sc.coeff<Mod>());
   } else {
@@ -1273,7 +1337,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
   (void)plain13;
   bool v3 = false, plain_wide = false;
   if constexpr (FP) {
-    v3 = g_mac_variant == 5 && n == 8192;
+    v3 = g_mac_variant == 5 && (n == 8192 || n == 16384);
     plain_wide = g_plain_variant == 1 && n == 8192 && (ctx->N == 8192 || ctx->N == 4096);
   }
   RS_REQUIRE(!has_lin || plain_wide, "linear-form vectors need the wide plaintext kernel");
@@ -1430,7 +1494,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
             for (int gi = 0; gi < ng; gi++) terms += (double)a3.terms[gi];
             // ciphertext words once per launch (the second group's read is served on-die), every plaintext row once,
             // the accumulator sets written once
-            ProfScope prof(ctx, st, "mac_kernel_v3", (double)tmax * (double)enc_words * 8.0 + terms * (double)L * nd * 8.0 + ng * (double)enc_words * 8.0,
+            ProfScope prof(ctx, st, n == 16384 ? "mac_kernel_v3<false, 14>" : "mac_kernel_v3", (double)tmax * (double)enc_words * 8.0 + terms * (double)L * nd * 8.0 + ng * (double)enc_words * 8.0,
                            terms * L * K * (ntt_fp64(nd, logn_d) + 8.0 * nd / 2.0 + 15.0 * nd));
             launch_mac_v3(ctx, a3, sc, st);
           }

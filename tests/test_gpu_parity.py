@@ -100,7 +100,7 @@ def test_batch_encode_and_enc_ops(name):
 
 
 @pytest.mark.parametrize("name,T", [("toy", 1), ("toy", 37), ("toy49", 50), ("C2", 5), ("toy54", 37), ("toy60", 50), ("C5", 3),
-                                    ("toy+int", 37), ("toy49+int", 20)])
+                                    ("toy+int", 37), ("toy49+int", 20), ("C4", 5), ("C5s", 40)])
 def test_inner_product_matches_oracle(name, T):
     dev = dev_for(name)
     ctx = H.oracle_ctx(dev.prm)
@@ -140,6 +140,40 @@ def test_grouped_msm_equals_sum_of_inner_products():
     for c, crs in enumerate((crs0, crs1)):
         assert (got[c, 0] == ctx.inner_product(crs, v[0])[0]).all()
         assert (got[c, 1] == ctx.inner_product(crs, v[2])[0]).all()
+
+
+@pytest.mark.parametrize("name", ["C5s", "C4"])
+def test_quarter_spectrum_mac_at_16384_points(name):
+    """N_enc = 16384 on the FP64 arithmetic (the shapes of BASELINE configs[3] / [4], microbench.cpp:13-14): the inner
+    products run through mac_kernel_v3<false, 14> (a workgroup per quarter of the spectrum, two stages applied while the
+    row is loaded).  Two groups sharing a key vector, a second key vector, enough terms for several per chunk and an
+    accumulating second tile (tiled key), against the oracle; and against the generic kernel (mac_variant = 1)."""
+    dev = dev_for(name)
+    prm = dev.prm
+    assert prm.N_enc == 16384
+    ctx = H.oracle_ctx(prm)
+    T = 70 if name == "C5s" else 24
+    crs0, crs1 = ctx.random_enc(41, 8), ctx.random_enc(42, 8)  # windows of 8 elements
+    v = [ctx.random_ring(43 + k, T) for k in range(3)]
+    v[1][3] = 0
+    dv = [dev.put(x) for x in v]
+    dev.set_profiling(True)
+    out, used = dev.msm([dev.put(crs0)], [(dv[0], None, 0), (dv[1], None, 1), (dv[2], None, 1)], 2, want_used=True, crs_len=T, window=8)
+    names = {k["name"] for k in dev.profile_read()}
+    dev.set_profiling(False)
+    assert "mac_kernel_v3<false, 14>" in names, names
+    got = host(out)
+    e0, _ = ctx.inner_product(crs0, v[0], threads=0, window=8)
+    e1 = ctx.enc_add(ctx.inner_product(crs0, v[1], threads=0, window=8)[0], ctx.inner_product(crs0, v[2], threads=0, window=8)[0])
+    assert used == [T, T - 1, T] and (got[0, 0] == e0).all() and (got[0, 1] == e1).all()
+    out2, _ = dev.msm([dev.put(crs0), dev.put(crs1)], [(dv[0], None, 0)], 1, crs_len=T, window=8)
+    assert (host(out2)[0, 0] == e0).all() and (host(out2)[1, 0] == ctx.inner_product(crs1, v[0], threads=0, window=8)[0]).all()
+    _set_tuning(b"mac_variant", 1)
+    try:
+        ref, _ = dev.msm([dev.put(crs0)], [(dv[0], None, 0), (dv[1], None, 1), (dv[2], None, 1)], 2, crs_len=T, window=8)
+    finally:
+        _set_tuning(b"mac_variant", 5)
+    assert (host(ref) == got).all()
 
 
 @pytest.mark.parametrize("name", ["toy", "C2", "C3"])

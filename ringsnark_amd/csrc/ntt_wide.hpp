@@ -34,16 +34,25 @@ struct WideShape {
   static constexpr int N = 1 << LOGN;
   static constexpr int T = N / 32;      // threads per polynomial, 32 elements each
   static constexpr int S = N / 16;      // element stride of round 1's radix-16 groups
-  static constexpr int R2 = LOGN - 8;   // stages of round 2
+  // Round shapes: 4096 / 8192 points run 4 | LOGN-8 | 4 stages, the last round on two groups of 16 consecutive elements
+  // per thread; 16384 points (512 threads, one workgroup per CU) run 4 | 5 | 5, the last round on ONE group of 32
+  // consecutive elements per thread.
+  static constexpr int R3 = LOGN == 14 ? 5 : 4;   // stages of the round on consecutive elements
+  static constexpr int R2 = LOGN - 4 - R3;        // stages of the middle round
   static constexpr int E2 = 1 << R2;    // its radix
-  static constexpr int G2 = 32 / E2;    // round-2 groups per thread
+  static constexpr int G2 = 32 / E2;    // middle-round groups per thread
+  static constexpr int E3 = 1 << R3;    // consecutive elements per group of the last round
+  static constexpr int G3 = 32 / E3;    // its groups per thread (thread t: groups t + T*j)
+  static constexpr int ST2 = E3;        // element stride inside a middle-round group
   static constexpr int TWL = 1 << (4 + R2);  // LDS twiddle table: entries [0, n/16)
-  static_assert(LOGN == 12 || LOGN == 13, "shapes: 4096 and 8192 points");
+  static_assert(LOGN == 12 || LOGN == 13 || LOGN == 14, "shapes: 4096, 8192 and 16384 points");
   // LDS address map: one pad slot per 16 elements (round 3: lane stride 17), plus 16 slots per S elements when
   // S + S/16 would otherwise be a multiple of the 32 bank pairs (round 2 reads 16-lane runs that are S apart)
   static constexpr int PAD2 = ((S + S / 16) % 32 == 0) ? 16 : 0;
   static constexpr int SP = S + S / 16 + PAD2;  // mapped distance of elements S apart
   __host__ __device__ static constexpr int px(int i) { return i + (i >> 4) + (i / S) * PAD2; }
+  // mapped offset of element base + ST2*e from element base, base = (multiple of S) + (less than ST2)
+  __host__ __device__ static constexpr int px2(int e) { return ST2 * e + ((ST2 * e) >> 4); }
   // mapped offset of element r + 128*i from element r, r = (multiple of 1024) + (less than 128)
   __host__ __device__ static constexpr int px128(int i) { return 136 * i + ((128 * i) / S) * PAD2; }
   static constexpr int TILE = N + N / 16 + 16 * PAD2;
@@ -143,6 +152,14 @@ __device__ __forceinline__ uint64_t double_bits_as_u64(double d) {
 __device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void mem_fence() { asm volatile("" ::: "memory"); }
 
+// First element of the j-th (j = 0, 1) 1024-element range covered by the consecutive-element groups of wave `wave`:
+// two groups of 16 per thread (groups t and t + T), or one group of 32 (16384 points).
+template <int LOGN>
+__device__ __forceinline__ int wide_wave_range(int wave, int j) {
+  using S = WideShape<LOGN>;
+  return S::G3 == 2 ? (j * S::T + wave * 64) * 16 : (2 * wave + j) * 1024;
+}
+
 // ---- forward ------------------------------------------------------------------------------------------------
 // Output of a polynomial (canonical u64 bit patterns parked in the tile by round 3): every wave streams out the
 // two 1024-element ranges its own round-3 groups cover, 16 bytes per lane.
@@ -152,7 +169,7 @@ __device__ __forceinline__ void wide_fwd_flush(const double *s, uint64_t *__rest
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < 2; j++) {
-    const int r0 = (j * S::T + wave * 64) * 16;
+    const int r0 = wide_wave_range<LOGN>(wave, j);
     const int p0 = S::px(r0 + 2 * lane);
     u64x2 *d2 = reinterpret_cast<u64x2 *>(dst + r0) + lane;
 #pragma unroll
@@ -166,8 +183,8 @@ __device__ __forceinline__ void wide_fwd_flush(const double *s, uint64_t *__rest
 }
 
 template <int LOGN, bool RED>
-__device__ __forceinline__ void wide_fwd_body(double *s, const double *twl, const double (&tw3)[2][15], double (&v)[2][16],
-                                              const double *__restrict__ tw, const Mod mod, uint32_t red_mask) {
+__device__ __forceinline__ void wide_fwd_body(double *s, const double *twl, const double (&tw3)[WideShape<LOGN>::G3][WideShape<LOGN>::E3 - 1],
+                                              double (&v)[2][16], const double *__restrict__ tw, const Mod mod, uint32_t red_mask) {
   using S = WideShape<LOGN>;
   const int t = threadIdx.x;
   // round 1: stages 0..3 on elements 2t+c + S*e, twiddles tw[2^k + blk] (the same for every thread)
@@ -184,30 +201,30 @@ __device__ __forceinline__ void wide_fwd_body(double *s, const double *twl, cons
     }
   }
   __syncthreads();
-  // round 2: stages 4..4+R2-1 on groups base + 16*e, base = hi*S + lo
+  // round 2: stages 4..4+R2-1 on groups base + ST2*e, base = hi*S + lo
 #pragma unroll
   for (int j = 0; j < S::G2; j++) {
-    const int g = t + S::T * j, lo = g & 15, hi = g >> 4;
-    const int pb = hi * S::SP + lo;
+    const int g = t + S::T * j, lo = g & (S::ST2 - 1), hi = g / S::ST2;
+    const int pb = hi * S::SP + S::px(lo);
     double x[S::E2];
 #pragma unroll
-    for (int e = 0; e < S::E2; e++) x[e] = s[pb + 17 * e];
+    for (int e = 0; e < S::E2; e++) x[e] = s[pb + S::px2(e)];
     reg_fwd_stages<S::R2, RED>(x, mod, red_mask >> 4, [&](int k, int blk) { return twl[(16 << k) + (hi << k) + blk]; });
 #pragma unroll
-    for (int e = 0; e < S::E2; e++) s[pb + 17 * e] = x[e];
+    for (int e = 0; e < S::E2; e++) s[pb + S::px2(e)] = x[e];
   }
   __syncthreads();
-  // round 3: stages LOGN-4..LOGN-1 on 16 consecutive elements; results parked canonical for the flush
+  // round 3: stages LOGN-R3..LOGN-1 on E3 consecutive elements; results parked canonical for the flush
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j = 0; j < S::G3; j++) {
     const int g = t + S::T * j;
-    const int pb = S::px(16 * g);
-    double x[16];
+    const int pb = S::px(S::E3 * g);
+    double x[S::E3];
 #pragma unroll
-    for (int e = 0; e < 16; e++) x[e] = s[pb + e];
-    reg_fwd_stages<4, RED>(x, mod, red_mask >> (LOGN - 4), [&](int k, int blk) { return tw3[j][(1 << k) - 1 + blk]; });
+    for (int e = 0; e < S::E3; e++) x[e] = s[pb + e + (e >> 4)];
+    reg_fwd_stages<S::R3, RED>(x, mod, red_mask >> (LOGN - S::R3), [&](int k, int blk) { return tw3[j][(1 << k) - 1 + blk]; });
 #pragma unroll
-    for (int e = 0; e < 16; e++) s[pb + e] = u64_bits_as_double(to_u64(canon(x[e], mod)));
+    for (int e = 0; e < S::E3; e++) s[pb + e + (e >> 4)] = u64_bits_as_double(to_u64(canon(x[e], mod)));
   }
   wave_sync();
 }
@@ -223,21 +240,21 @@ ntt_fwd_wide_kernel(uint64_t *__restrict__ data, unsigned long long batch, const
   double *twl = s + S::TILE;
   const int t = threadIdx.x;
   for (int i = t; i < S::TWL; i += S::T) twl[i] = tw[i];
-  double tw3[2][15];
+  double tw3[S::G3][S::E3 - 1];
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j = 0; j < S::G3; j++) {
     const int g = t + S::T * j;
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < S::R3; k++)
 #pragma unroll
-      for (int blk = 0; blk < (1 << k); blk++) tw3[j][(1 << k) - 1 + blk] = tw[(1 << (LOGN - 4 + k)) + (g << k) + blk];
+      for (int blk = 0; blk < (1 << k); blk++) tw3[j][(1 << k) - 1 + blk] = tw[(1 << (LOGN - S::R3 + k)) + (g << k) + blk];
   }
   // the loop must not inherit these loads as "possibly still in flight" (it would wait for ALL memory traffic,
   // prefetch included, at their first use in every iteration)
 #pragma unroll
-  for (int j = 0; j < 2; j++)
+  for (int j = 0; j < S::G3; j++)
 #pragma unroll
-    for (int i = 0; i < 15; i++) pin(tw3[j][i]);
+    for (int i = 0; i < S::E3 - 1; i++) pin(tw3[j][i]);
   u64x2 pre[16];
   auto issue_loads = [&](unsigned long long q) {
     const u64x2 *src = reinterpret_cast<const u64x2 *>(data + q * (size_t)S::N) + t;
@@ -283,19 +300,19 @@ ntt_inv_wide_kernel(uint64_t *__restrict__ data, unsigned long long batch, const
   for (int i = t; i < S::TWL; i += S::T) twl[i] = itw[i];
   // round 1 (inverse stages 0..3 on 16 consecutive elements): block i of stage k of group g is
   // (16 g + e) >> (k+1) = (g << (3-k)) + (e >> (k+1)) among the n >> (k+1) blocks of that stage
-  double tw1[2][15];
+  double tw1[S::G3][S::E3 - 1];
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j = 0; j < S::G3; j++) {
     const int g = t + S::T * j;
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < S::R3; k++)
 #pragma unroll
-      for (int i = 0; i < (8 >> k); i++) tw1[j][16 - (16 >> k) + i] = itw[(S::N >> (k + 1)) + (g << (3 - k)) + i];
+      for (int i = 0; i < (S::E3 >> (k + 1)); i++) tw1[j][S::E3 - (S::E3 >> k) + i] = itw[(S::N >> (k + 1)) + (g << (S::R3 - 1 - k)) + i];
   }
 #pragma unroll
-  for (int j = 0; j < 2; j++)
+  for (int j = 0; j < S::G3; j++)
 #pragma unroll
-    for (int i = 0; i < 15; i++) pin(tw1[j][i]);
+    for (int i = 0; i < S::E3 - 1; i++) pin(tw1[j][i]);
   // n^-1 folded into the last stage: (a + b) * ninv and (a - b) * (w * ninv)
   const double w_last = mulmod(itw[1], ninv, mod);
   u64x2 pre[16];
@@ -303,7 +320,7 @@ ntt_inv_wide_kernel(uint64_t *__restrict__ data, unsigned long long batch, const
     const uint64_t *src = data + q * (size_t)S::N;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-      const int r0 = (j * S::T + wave * 64) * 16;
+      const int r0 = wide_wave_range<LOGN>(wave, j);
       const u64x2 *s2 = reinterpret_cast<const u64x2 *>(src + r0) + lane;
 #pragma unroll
       for (int i = 0; i < 8; i++) pre[j * 8 + i] = stream_load(s2 + 64 * i);
@@ -327,7 +344,7 @@ ntt_inv_wide_kernel(uint64_t *__restrict__ data, unsigned long long batch, const
     // the tile is free: every wave passed the barrier that follows its round-3 reads of the previous polynomial
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-      const int r0 = (j * S::T + wave * 64) * 16;
+      const int r0 = wide_wave_range<LOGN>(wave, j);
       const int p0 = S::px(r0 + 2 * lane);
 #pragma unroll
       for (int i = 0; i < 8; i++) {
@@ -342,31 +359,31 @@ ntt_inv_wide_kernel(uint64_t *__restrict__ data, unsigned long long batch, const
     if (pn < batch) issue_loads(pn);
     mem_fence();
     wave_sync();
-    // round 1: inverse stages 0..3
+    // round 1: inverse stages 0..R3-1 on E3 consecutive elements
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < S::G3; j++) {
       const int g = t + S::T * j;
-      const int pb = S::px(16 * g);
-      double x[16];
+      const int pb = S::px(S::E3 * g);
+      double x[S::E3];
 #pragma unroll
-      for (int e = 0; e < 16; e++) x[e] = s[pb + e];
-      reg_inv_stages<4, RED>(x, mod, red_mask, [&](int k, int i) { return tw1[j][16 - (16 >> k) + i]; });
+      for (int e = 0; e < S::E3; e++) x[e] = s[pb + e + (e >> 4)];
+      reg_inv_stages<S::R3, RED>(x, mod, red_mask, [&](int k, int i) { return tw1[j][S::E3 - (S::E3 >> k) + i]; });
 #pragma unroll
-      for (int e = 0; e < 16; e++) s[pb + e] = x[e];
+      for (int e = 0; e < S::E3; e++) s[pb + e + (e >> 4)] = x[e];
     }
     __syncthreads();
-    // round 2: inverse stages 4..4+R2-1 on groups hi*S + lo + 16*e; block of stage 4+k: (hi << (R2-1-k)) + (e >> (k+1))
+    // round 2: inverse stages R3..R3+R2-1 on groups hi*S + lo + ST2*e; block of stage R3+k: (hi << (R2-1-k)) + (e >> (k+1))
 #pragma unroll
     for (int j = 0; j < S::G2; j++) {
-      const int g = t + S::T * j, lo = g & 15, hi = g >> 4;
-      const int pb = hi * S::SP + lo;
+      const int g = t + S::T * j, lo = g & (S::ST2 - 1), hi = g / S::ST2;
+      const int pb = hi * S::SP + S::px(lo);
       double x[S::E2];
 #pragma unroll
-      for (int e = 0; e < S::E2; e++) x[e] = s[pb + 17 * e];
-      reg_inv_stages<S::R2, RED>(x, mod, red_mask >> 4,
-                                 [&](int k, int i) { return twl[(S::N >> (5 + k)) + (hi << (S::R2 - 1 - k)) + i]; });
+      for (int e = 0; e < S::E2; e++) x[e] = s[pb + S::px2(e)];
+      reg_inv_stages<S::R2, RED>(x, mod, red_mask >> S::R3,
+                                 [&](int k, int i) { return twl[(S::N >> (S::R3 + 1 + k)) + (hi << (S::R2 - 1 - k)) + i]; });
 #pragma unroll
-      for (int e = 0; e < S::E2; e++) s[pb + 17 * e] = x[e];
+      for (int e = 0; e < S::E2; e++) s[pb + S::px2(e)] = x[e];
     }
     __syncthreads();
     // round 3: inverse stages LOGN-4..LOGN-1 on elements 2t+c + S*e; block of stage LOGN-4+k is e >> (k+1) of 8 >> k

@@ -440,7 +440,7 @@ static void launch_ntt_variant(const NttTable &t, uint64_t *d_data, size_t batch
   RS_HIP(hipGetLastError());
 }
 
-// ntt_wide.hpp kernels: persistent, two workgroups of 256 threads per CU
+// ntt_wide.hpp kernels: persistent, two workgroups of 256 threads per CU (16384 points: one of 512)
 int g_ntt_wide_grid = 256;  // tuning knob "ntt_wide_grid": CUs to fill (workgroups = this x what fits one CU)
 template <int LOGN, bool RED>
 static void launch_ntt_wide_shape(const NttTable &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st) {
@@ -462,7 +462,9 @@ static void launch_ntt_wide_shape(const NttTable &t, uint64_t *d_data, size_t ba
 }
 static bool launch_ntt_wide(const NttTable &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st) {
   const bool red = (inverse ? t.inv_red_mask : t.fwd_red_mask) != 0;
-  if (t.logn == 13)
+  if (t.logn == 14)
+    red ? launch_ntt_wide_shape<14, true>(t, d_data, batch, inverse, st) : launch_ntt_wide_shape<14, false>(t, d_data, batch, inverse, st);
+  else if (t.logn == 13)
     red ? launch_ntt_wide_shape<13, true>(t, d_data, batch, inverse, st) : launch_ntt_wide_shape<13, false>(t, d_data, batch, inverse, st);
   else if (t.logn == 12)
     red ? launch_ntt_wide_shape<12, true>(t, d_data, batch, inverse, st) : launch_ntt_wide_shape<12, false>(t, d_data, batch, inverse, st);

@@ -35,7 +35,7 @@ def host(t):
     return to_host(t)
 
 
-@pytest.mark.parametrize("name", ["toy", "toy49", "C2", "C3", "C5s", "toy54", "toy60", "micro60", "C5", "toy+int", "toy49+int"])
+@pytest.mark.parametrize("name", ["toy", "toy49", "C2", "C3", "C5s", "C4", "toy54", "toy60", "micro60", "C5", "toy+int", "toy49+int"])
 def test_ntt_matches_oracle(name):
     from ringsnark_amd import _lib
     dev = dev_for(name)
@@ -45,7 +45,7 @@ def test_ntt_matches_oracle(name):
     for modset, primes in ((_lib.RS_MOD_PLAIN, prm.q), (_lib.RS_MOD_COEFF, prm.Q)):
         for idx, p in enumerate(primes):
             t = O.NTT(logn, p)
-            batch = 3
+            batch = 3 if prm.N_enc < 16384 else 5  # the persistent wide kernels: more polynomials than one per workgroup slot is tested by the bandwidth runs
             a = (rng.randint(0, 2**62, size=(batch, prm.N_enc), dtype=np.int64).astype(np.uint64)) % np.uint64(p)
             a[0, :4] = [0, 1, p - 1, p // 2]
             d = dev.put(a)

@@ -49,8 +49,10 @@ def rocprof_name(name):
     return "rs::" + name
 
 
-def kernel_roofline(k, pmc):
-    """Roofline object of one per-kernel record from rs_profile_read (live HIP events on the launch stream)."""
+def kernel_roofline(k, pmc, fp64_pmc=None):
+    """Roofline object of one per-kernel record from rs_profile_read (live HIP events on the launch stream).
+    pmc: profiles/*_pmc_traffic_*.json (HBM bytes per kernel); fp64_pmc: profiles/*_pmc_fp64_*.json (SQ opcode counters per
+    launch, tools/pmc_fp64.py) -- both from rocprofv3 passes of this very command, joined by the kernel name rocprofv3 prints."""
     sec = k["total_ms"] * 1e-3
     fp64 = any(k["name"].startswith(p) for p in FP64_KERNELS)
     out = {"kernel": k["name"], "launches": k["launches"], "avg_launch_ms": round(k["total_ms"] / max(1, k["launches"]), 4)}
@@ -58,7 +60,22 @@ def kernel_roofline(k, pmc):
         ach = k["fp64_ops"] / sec / 1e12
         out.update({"bound": "fp64-issue", "achieved": round(ach, 2), "peak": FP64_PEAK_T, "unit": "T lane-op/s",
                     "frac": round(ach / FP64_PEAK_T, 4), "fp64_ops_per_launch": int(k["fp64_ops"] / max(1, k["launches"])),
+                    "numerator": "model count of the library (8 FP64 instructions per lazy butterfly, 7 per pointwise modular multiply, "
+                                 "v_rndne_f64 included; DESIGN.md section 3)",
                     "hbm_frac": round(k["alg_bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4)})
+        if fp64_pmc:
+            fam = [v for n, v in fp64_pmc.get("kernels", {}).items() if n.startswith(rocprof_name(k["name"]))]
+            if fam:
+                # per-launch averages of the full-size launches (the counters file averages over all launches of the run)
+                cnt = max(v["fp64_lane_ops"] for v in fam)
+                valu = max(v["valu_lane_ops"] for v in fam)
+                per_launch_s = sec / max(1, k["launches"])
+                out["counted"] = {
+                    "source": "SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 per launch (rocprofv3 --pmc, profiles/); v_rndne_f64 has no opcode counter and is "
+                              "NOT in this figure (one per modular multiply: the model count minus ~1/8)",
+                    "fp64_lane_ops_per_launch": int(cnt), "valu_lane_ops_per_launch": int(valu),
+                    "achieved": round(cnt / per_launch_s / 1e12, 2), "frac": round(cnt / per_launch_s / 1e12 / FP64_PEAK_T, 4),
+                    "valu_issue_frac": round(valu / per_launch_s / 1e12 / FP64_PEAK_T, 4)}
     else:
         ach = k["alg_bytes"] / sec / 1e9
         out.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)})
@@ -122,7 +139,7 @@ def single_gpu_leg(preset, m, logw, steps, warmup, check):
            "phase_ms": {"witness_map": round(timings["witness_ms"], 3), "msm": round(timings["msm_ms"], 3)},
            "kernels": [{"name": k["name"], "ms": round(k["total_ms"], 2), "launches": k["launches"]} for k in stats[:6]]}
     if check:
-        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk, proof, m, window or None)
+        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk, proof, m, window or None, n_cols=10)
         out["check"] = dict(info, ok=ok)
     del proof, asg, pk, dcs, dev
     torch.cuda.empty_cache()
@@ -307,10 +324,13 @@ def main():
     # ---- per-kernel device time of one more (untimed) step: HIP events on the launch stream inside the library
     roofline = mac_roofline = timings = kernels = None
     if world == 1:
-        pmc = None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_%s_m%d.json" % (prm.name, m))
+        pmc = fp64_pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_%s_m%d.json" % (prm.name, m))
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
+        fp64_path = os.path.join(ROOT, "profiles", "r03_pmc_fp64_%s_m%d.json" % (prm.name, m))
+        if os.path.exists(fp64_path):
+            fp64_pmc = json.load(open(fp64_path))
         dev.set_profiling(True)
         dev.profile_read()
         step()
@@ -322,44 +342,54 @@ def main():
         kernels = [{"name": k["name"], "ms": round(k["total_ms"], 2), "share": round(k["total_ms"] / tot, 4),
                     "launches": k["launches"]} for k in stats[:10]]
         if stats:
-            roofline = kernel_roofline(stats[0], pmc)  # the dominant kernel by time
+            roofline = kernel_roofline(stats[0], pmc, fp64_pmc)  # the dominant kernel by time
         mac = [k for k in stats if k["name"].startswith("mac_kernel")]
         if mac:
-            mac_roofline = kernel_roofline(mac[0], pmc)
+            mac_roofline = kernel_roofline(mac[0], pmc, fp64_pmc)
 
     # ---- the standalone transform (row a4), HBM bound by design: 16 bytes per coefficient per transform, on 4 GiB
     ntt_roofline = None
     if world == 1 and not args.no_ntt:
         from ringsnark_amd import _lib
-        batch = (4 << 30) // (prm.N_enc * 8)
-        polys = torch.empty((batch, prm.N_enc), dtype=torch.int64, device=dev.device).random_(0, int(prm.Q[0]))
         reps, blocks = 10, 5
 
-        def ntt_gbs(inverse):
-            for _ in range(10):  # steady state: the first launches after an idle stretch run at a lower clock
-                dev.ntt(polys, _lib.RS_MOD_COEFF, 0, inverse=inverse)
-            rates = []
-            for _ in range(blocks):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()  # the library launches on torch's current stream (device.py passes it down)
-                for _ in range(reps):
-                    dev.ntt(polys, _lib.RS_MOD_COEFF, 0, inverse=inverse)
-                e1.record()
-                torch.cuda.synchronize()
-                rates.append(batch * prm.N_enc * 16 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9)
-            return sorted(rates)[len(rates) // 2]  # median of the blocks
+        def ntt_leg(d, p):
+            """forward / inverse GB/s of the standalone transform of context d on a 4 GiB batch (algorithmic 16 B / coefficient)"""
+            batch = (4 << 30) // (p.N_enc * 8)
+            polys = torch.empty((batch, p.N_enc), dtype=torch.int64, device=d.device).random_(0, int(p.Q[0]))
+            res = []
+            for inverse in (False, True):
+                for _ in range(10):  # steady state: the first launches after an idle stretch run at a lower clock
+                    d.ntt(polys, _lib.RS_MOD_COEFF, 0, inverse=inverse)
+                rates = []
+                for _ in range(blocks):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()  # the library launches on torch's current stream (device.py passes it down)
+                    for _ in range(reps):
+                        d.ntt(polys, _lib.RS_MOD_COEFF, 0, inverse=inverse)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    rates.append(batch * p.N_enc * 16 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+                res.append(sorted(rates)[len(rates) // 2])  # median of the blocks
+            del polys
+            return {"bound": "hbm", "kernel": "forward NTT, %d transforms of %d points per launch (4 GiB in place, preset %s), median of %d blocks of %d launches"
+                                              % (batch, p.N_enc, p.name, blocks, reps),
+                    "achieved": round(res[0], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(res[0] / HBM_PEAK_GBS, 4),
+                    "inverse": {"achieved": round(res[1], 1), "frac": round(res[1] / HBM_PEAK_GBS, 4)}}
 
-        gbs, gbs_inv = ntt_gbs(False), ntt_gbs(True)
-        ntt_roofline = {"bound": "hbm", "kernel": "forward NTT, %d transforms of %d points per launch (4 GiB in place), median of %d blocks of %d launches" % (batch, prm.N_enc, blocks, reps),
-                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                        "inverse": {"achieved": round(gbs_inv, 1), "frac": round(gbs_inv / HBM_PEAK_GBS, 4)}}
-        del polys
+        ntt_roofline = ntt_leg(dev, prm)
+        # the same at 16384 points (the reference's micro-benchmark length, microbench.cpp:13-14; the encoding degree of
+        # BASELINE configs[3] / [4]) on preset C4's 48-bit data primes: a second, small context
+        p16 = P.preset("C4")
+        d16 = Device(p16, local_rank)
+        ntt_roofline["at_16384_points"] = ntt_leg(d16, p16)
+        del d16
 
     # ---- untimed post-run check of the timed proof against the CPU oracle
     check = None
     if world == 1 and not args.no_check:
         pk.clear()  # the check releases the key (pk1 holds the last references) before it re-runs the witness map
-        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk1, proof[0], m, window1 or pk1["s_pows"].shape[0])
+        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk1, proof[0], m, window1 or pk1["s_pows"].shape[0], n_cols=10)
         check = dict(info, ok=ok)
 
     # ---- the same statement on the ring primes the reference's own recipe yields (preset C3R), one GPU

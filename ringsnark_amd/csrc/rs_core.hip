@@ -935,8 +935,14 @@ int rs_set_tuning(const char *key, int value) {
   } else if (std::string(key) == "witness_tree_log") {
     RS_REQUIRE(value == 13 || value == 14, "witness_tree_log must be 13 or 14");
     g_witness_tree_log = value;
-  } else if (std::string(key) == "witness_sub_ct")
+  } else if (std::string(key) == "witness_sub_ct") {
+#ifndef RS_EXPERIMENTS
+    // 0: generic kernel, 2: sub_ntt_wide_kernel (default).  The superseded A/B variants 1 (sub_ntt_ct_kernel) and 3
+    // (sub_ntt_wide16_kernel) are compiled into the experiments build only (make -C ringsnark_amd/csrc experiments)
+    if (value != 0 && value != 2) throw Error(RS_ERR_UNSUPPORTED, "witness_sub_ct 1 and 3 exist in the experiments build only");
+#endif
     g_witness_sub_ct = value;
+  }
   else if (std::string(key) == "witness_tree_ct")
     g_witness_tree_ct = value;
   else if (std::string(key) == "witness_col_budget_mib") {

@@ -1917,6 +1917,7 @@ struct SubMulLazyFactory {
 #ifndef RS_SUB_MAXR
 #define RS_SUB_MAXR 4  // radix of the wave-private rounds of sub_ntt_ct_kernel
 #endif
+#ifdef RS_EXPERIMENTS  // superseded A/B variant (witness_sub_ct = 1): experiments build only
 // sub_ntt_kernel for the production tile (Bn = 2^LOGB, compile time; 512 threads, two workgroups per CU):
 //   * the cross-wave round of the forward transform reads the block straight from global memory and the
 //     cross-wave round of the inverse writes it straight back (no staging pass, no extra barriers);
@@ -1961,6 +1962,8 @@ sub_ntt_ct_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab
   }
   lds_ntt_inv_wp<RS_SUB_MAXR, ColBlockFactory, GlobalF64IO, 3>(s, bf, gio, LOGB, LOGW, P.itw, mod, imask, root);
 }
+
+#endif  // RS_EXPERIMENTS
 
 // sub_ntt_ct_kernel in the wide form of ntt_wide.hpp (g_witness_sub_ct == 2): 256 threads x 32 coefficients per block of
 // 2^13, persistent, two workgroups per CU.  Forward rounds (4, 5, 4 stages); round 3 leaves every thread with 16
@@ -2170,6 +2173,7 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
   }
 }
 
+#ifdef RS_EXPERIMENTS  // superseded A/B variant (witness_sub_ct = 3, measured 11 % slower): experiments build only
 // sub_ntt_wide_kernel at FOUR waves per SIMD (g_witness_sub_ct == 3): 512 threads x 16 coefficients per block of 2^13,
 // <= 128 registers, two workgroups (16 waves) per CU.  Forward rounds of 4, 3 and 2 stages, then the same fused middle
 // as the 32-coefficient form on 16 consecutive points (forward stages 9..12, table product, inverse stages 0..3), then
@@ -2337,6 +2341,7 @@ sub_ntt_wide16_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned
     }
   }
 }
+#endif  // RS_EXPERIMENTS
 
 // ZK patch of the multi-pass H: H += d2*A + d1*B + d1*d2*Z, H[0] -= d3; then canonical form.
 template <class CPS>
@@ -2568,7 +2573,11 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
   static const char *const names[4] = {"sub_ntt_kernel<0", "sub_ntt_kernel<1", "sub_ntt_kernel<2", "sub_ntt_kernel<3"};
   static const char *const names_ct[4] = {"sub_ntt_ct_kernel<0, 13>", "sub_ntt_ct_kernel<1, 13>", "sub_ntt_ct_kernel<2, 13>", "sub_ntt_ct_kernel<3, 13>"};
   static const char *const names_wide[4] = {"sub_ntt_wide_kernel<0>", "sub_ntt_wide_kernel<1>", "sub_ntt_wide_kernel<2>", "sub_ntt_wide_kernel<3>"};
+#ifdef RS_EXPERIMENTS
   const bool ct = FP && logB == 13 && MODE != 1 && g_witness_sub_ct;
+#else
+  const bool ct = FP && logB == 13 && MODE != 1 && g_witness_sub_ct == 2;  // 0: the generic kernel; 1 and 3 exist in the experiments build only
+#endif
   const double Bn = (double)((size_t)1 << logB), blocks = (double)(ncols * bpc);
   static const char *const names_w16[4] = {"sub_ntt_wide16_kernel<0>", "sub_ntt_wide16_kernel<1>", "sub_ntt_wide16_kernel<2>", "sub_ntt_wide16_kernel<3>"};
   ProfScope prof(ctx, st, ct ? (g_witness_sub_ct == 3 ? names_w16[MODE] : g_witness_sub_ct == 2 ? names_wide[MODE] : names_ct[MODE]) : names[MODE], blocks * Bn * (MODE == 3 ? 24.0 : 16.0),
@@ -2576,6 +2585,7 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
   static TabPtrs none{};
   const TabPtrs &tp = tabs ? *tabs : none;
   if constexpr (FP) {
+#ifdef RS_EXPERIMENTS
     if (logB == 13 && MODE != 1 && g_witness_sub_ct == 3) {
       const int wl = (int)(WideShape<13>::TILE * sizeof(double));
       const unsigned long long nb = (unsigned long long)(ncols * bpc);
@@ -2585,6 +2595,7 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
       RS_HIP(hipGetLastError());
       return;
     }
+#endif
     if (logB == 13 && MODE != 1 && g_witness_sub_ct == 2) {
       const int wl = (int)(WideShape<13>::TILE * sizeof(double));
       const unsigned long long nb = (unsigned long long)(ncols * bpc);
@@ -2595,6 +2606,7 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
       RS_HIP(hipGetLastError());
       return;
     }
+#ifdef RS_EXPERIMENTS
     if (logB == 13 && MODE != 1 && g_witness_sub_ct) {
       RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_ct_kernel<MODE, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((sub_ntt_ct_kernel<MODE, 13>), dim3((unsigned)(ncols * bpc)), dim3(512), lds, st, X, logsub - logB, tp,
@@ -2602,6 +2614,7 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
       RS_HIP(hipGetLastError());
       return;
     }
+#endif
   }
   RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_kernel<MODE, ColPlansT<M>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, ((size_t)1 << logB) / 16));

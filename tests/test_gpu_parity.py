@@ -800,13 +800,19 @@ def test_multipass_tuned_sub_transform_kernel_equals_generic(m, zk):
     keys = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
     from ringsnark_amd.witness_knobs import SUB_CT_DEFAULT
     runs = {}
+    from ringsnark_amd import _lib
     try:
         for variant in (0, 1, 2, 3):  # generic, wave-private tuned (sub_ntt_ct_kernel), wide (sub_ntt_wide_kernel), wide16
-            _set_tuning(b"witness_sub_ct", variant)
+            try:
+                _set_tuning(b"witness_sub_ct", variant)
+            except _lib.RsError as e:  # 1 and 3 are superseded A/B variants: experiments build only
+                assert variant in (1, 3) and e.code == _lib.RS_ERR_UNSUPPORTED
+                continue
             runs[variant] = {k: host(v) for k, v in dev.witness_map(dcs, asg, *ds).items() if k in keys}
     finally:
         _set_tuning(b"witness_sub_ct", SUB_CT_DEFAULT)
-    for variant in (1, 2, 3):
+    assert 0 in runs and 2 in runs
+    for variant in runs:
         for k in keys:
             assert (runs[variant][k] == runs[0][k]).all(), (variant, k)
     # the product-tree kernels of the 2^13 tiles: level loop not unrolled (0), wave-private radix-8 (1), wide (2)

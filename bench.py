@@ -65,17 +65,16 @@ def kernel_roofline(k, pmc, fp64_pmc=None):
                     "hbm_frac": round(k["alg_bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4)})
         if fp64_pmc:
             fam = [v for n, v in fp64_pmc.get("kernels", {}).items() if n.startswith(rocprof_name(k["name"]))]
-            if fam:
-                # per-launch averages of the full-size launches (the counters file averages over all launches of the run)
-                cnt = max(v["fp64_lane_ops"] for v in fam)
-                valu = max(v["valu_lane_ops"] for v in fam)
-                per_launch_s = sec / max(1, k["launches"])
+            if fam:  # per-proof totals of the counters over the live per-proof time of the same kernel (this step = one proof)
+                cnt = sum(v["fp64_lane_ops"] for v in fam)
+                valu = sum(v["valu_lane_ops"] for v in fam)
                 out["counted"] = {
-                    "source": "SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 per launch (rocprofv3 --pmc, profiles/); v_rndne_f64 has no opcode counter and is "
-                              "NOT in this figure (one per modular multiply: the model count minus ~1/8)",
-                    "fp64_lane_ops_per_launch": int(cnt), "valu_lane_ops_per_launch": int(valu),
-                    "achieved": round(cnt / per_launch_s / 1e12, 2), "frac": round(cnt / per_launch_s / 1e12 / FP64_PEAK_T, 4),
-                    "valu_issue_frac": round(valu / per_launch_s / 1e12 / FP64_PEAK_T, 4)}
+                    "source": "SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 per proof (rocprofv3 --pmc, profiles/r03_pmc_fp64_*.json) over this run's time; "
+                              "v_rndne_f64 has no opcode counter and is NOT in this figure (one per modular multiply: the model count minus ~1/8)",
+                    "fp64_lane_ops_per_proof": int(cnt), "valu_lane_ops_per_proof": int(valu),
+                    "launches_per_proof": round(sum(v["launches_per_proof"] for v in fam), 1),
+                    "achieved": round(cnt / sec / 1e12, 2), "frac": round(cnt / sec / 1e12 / FP64_PEAK_T, 4),
+                    "valu_issue_frac": round(valu / sec / 1e12 / FP64_PEAK_T, 4)}
     else:
         ach = k["alg_bytes"] / sec / 1e9
         out.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)})

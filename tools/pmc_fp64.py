@@ -1,21 +1,21 @@
 """Summarise the SQ passes of tools/collect_profiles.sh into profiles/<name>.json, keyed by the kernel name rocprofv3
 prints (template arguments kept, parameter list dropped):
 
-  usage: tools/pmc_fp64.py <pmc_mix dir> <pmc_stall dir or -> <out.json>
+  usage: tools/pmc_fp64.py <pmc_mix dir> <pmc_stall dir or -> <out.json> <proofs in the run>
 
-Per kernel: launches in the run, and PER-LAUNCH averages of every counter (wave-level instruction counts as
-rocprofv3 reports them), plus
+Per kernel, PER PROOF (the run's sums divided by the number of prover calls it made: 3 for the collection script's
+command): launches, every counter (wave-level instruction counts as rocprofv3 reports them), plus
   fp64_lane_ops  = (SQ_INSTS_VALU_ADD_F64 + _MUL_F64 + _FMA_F64) x 64   -- counted FP64 arithmetic, lane operations
   valu_lane_ops  = SQ_INSTS_VALU x 64                                   -- every vector instruction (v_rndne_f64,
                    moves, integer address arithmetic included: v_rndne_f64 has no opcode counter of its own)
-bench.py divides these by the live per-launch time of the same kernel (`roofline.achieved_counted`)."""
+bench.py divides these by the live per-proof time of the same kernel (`roofline.counted`)."""
 import collections
 import csv
 import glob
 import json
 import sys
 
-mix, stall, out = sys.argv[1], sys.argv[2], sys.argv[3]
+mix, stall, out, proofs = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 
 
 def load(d):
@@ -29,21 +29,22 @@ def load(d):
     return agg, {k: len(v) for k, v in calls.items()}
 
 
-res = {"units": "per launch, wave-level counts as reported by rocprofv3 (x64 = lane operations)", "kernels": {}}
+res = {"units": "per proof (one prover call): wave-level counts as reported by rocprofv3; *_lane_ops = x64", "proofs_in_run": proofs, "kernels": {}}
 A, nA = load(mix)
 B, nB = load(stall) if stall != "-" else ({}, {})
 for k in sorted(A, key=lambda k: -A[k].get("SQ_INSTS_VALU", 0)):
-    n = nA[k]
-    e = {"launches": n}
+    e = {"launches_per_proof": nA[k] / proofs}
     for c, v in sorted(A[k].items()):
-        e[c] = v / n
+        e[c] = v / proofs
     if k in B:
         for c, v in sorted(B[k].items()):
-            e[c] = v / nB[k]
+            e[c] = v / proofs
     e["fp64_lane_ops"] = 64.0 * (e.get("SQ_INSTS_VALU_ADD_F64", 0) + e.get("SQ_INSTS_VALU_MUL_F64", 0) + e.get("SQ_INSTS_VALU_FMA_F64", 0))
     e["valu_lane_ops"] = 64.0 * e.get("SQ_INSTS_VALU", 0)
     res["kernels"][k] = e
 json.dump(res, open(out, "w"), indent=1)
 for k, e in list(res["kernels"].items())[:12]:
-    print("%-52s launches %4d  fp64 %.4g  valu %.4g lane-ops/launch  fp64 share %.2f" % (
-        k[:52], e["launches"], e["fp64_lane_ops"], e["valu_lane_ops"], e["fp64_lane_ops"] / max(1.0, e["valu_lane_ops"])))
+    w = e.get("SQ_WAVE_CYCLES", 0) or 1.0
+    print("%-52s %6.1f launches/proof  fp64 %.4g  valu %.4g lane-ops/proof  fp64 share %.2f  wait_any %.2f wait_inst %.2f active_valu %.2f" % (
+        k[:52], e["launches_per_proof"], e["fp64_lane_ops"], e["valu_lane_ops"], e["fp64_lane_ops"] / max(1.0, e["valu_lane_ops"]),
+        e.get("SQ_WAIT_ANY", 0) / w, e.get("SQ_WAIT_INST_ANY", 0) / w, e.get("SQ_ACTIVE_INST_VALU", 0) / w))

@@ -62,7 +62,7 @@ template <int EPT, int LOGN_CT = 0, class M = Mod>  // LOGN_CT != 0: transform l
 __global__ void __launch_bounds__(1024)
 plain_center_kernel(PlainArgs args, typename ArithOf<M>::Lift *__restrict__ C, unsigned long long t0, unsigned long long tile_terms,
                     int N, int L, int logn_arg, const uint32_t *__restrict__ index_map,
-                    const NttTableT<typename ArithOf<M>::T, M> *__restrict__ plain_tabs) {
+                    const NttTableT<typename ArithOf<M>::T, M> *__restrict__ plain_tabs, int out_f64) {
   using T = typename ArithOf<M>::T;
   using Lift = typename ArithOf<M>::Lift;
   constexpr bool FP = std::is_same<M, Mod>::value;
@@ -149,7 +149,18 @@ plain_center_kernel(PlainArgs args, typename ArithOf<M>::Lift *__restrict__ C, u
 #pragma unroll
   for (int k = 0; k < EPT; k++) {
     const int p = threadIdx.x + k * blockDim.x;
-    if (p < n) dst[p] = acc[k];
+    if (p < n) {
+      if constexpr (!FP) {
+        // hybrid contexts (integer ring side, FP64 encoding side): the row goes to the FP64 multiply-accumulate as a
+        // double -- exact, the host checked that the group's sum of lifts stays below 2^53
+        if (out_f64) {
+          const double d = (double)acc[k];
+          dst[p] = (Lift)__double_as_longlong(d);
+          continue;
+        }
+      }
+      dst[p] = acc[k];
+    }
   }
 }
 
@@ -1058,6 +1069,7 @@ static int tile_threads(int logn) { return std::max(64, std::min(1024, (1 << log
 struct MsmScratch {
   void *d_plain_tabs = nullptr, *d_coeff_tabs = nullptr;  // device copies of the context's tables (NttTable or NttTableI)
   uint64_t *d_Qint = nullptr;
+  void *d_coeff_tabs_f64 = nullptr;  // hybrid contexts: FP64 tables of the data primes beside the integer ones
   // host-resident keys: copy stream and the events of the two staging buffers (copied: data landed; freed: its readers ran)
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_freed[2] = {nullptr, nullptr};
@@ -1089,6 +1101,7 @@ static MsmScratch &scratch_for(rs_ctx *ctx) {
   if (ctx->use_int) {
     sc.d_plain_tabs = copy_tables(ctx->plain_i, ctx->L);
     sc.d_coeff_tabs = copy_tables(ctx->coeff_i, ctx->K);
+    if (ctx->hybrid) sc.d_coeff_tabs_f64 = copy_tables(ctx->coeff, ctx->K);
   } else {
     sc.d_plain_tabs = copy_tables(ctx->plain, ctx->L);
     sc.d_coeff_tabs = copy_tables(ctx->coeff, ctx->K);
@@ -1104,6 +1117,7 @@ void msm_scratch_release(rs_ctx *ctx) {
   (void)hipFree(it->second.d_plain_tabs);
   (void)hipFree(it->second.d_coeff_tabs);
   (void)hipFree(it->second.d_Qint);
+  if (it->second.d_coeff_tabs_f64) (void)hipFree(it->second.d_coeff_tabs_f64);
   if (it->second.copy_stream) {
     (void)hipStreamDestroy(it->second.copy_stream);
     for (int b = 0; b < 2; b++) {
@@ -1182,17 +1196,19 @@ static uint32_t fwd_reduce_mask_from(uint64_t p, int logn, double b0, double *en
 static void launch_mac_v3(rs_ctx *ctx, const MacArgs3 &a, const MsmScratch &sc, hipStream_t st) {
   const size_t lds = (size_t)(2 * (4096 + 256) + 1024) * sizeof(double);  // two tiles + round-2 twiddles
   const unsigned rows = (unsigned)ctx->L * (unsigned)a.n_chunks;  // (chunk, limb), spread over the XCDs
+  // FP64 tables of the data primes: the context's own, or -- hybrid context -- the copies kept beside the integer tables
+  const NttTable *tabs = ctx->use_int ? static_cast<const NttTable *>(sc.d_coeff_tabs_f64) : sc.coeff<Mod>();
   const unsigned parts = (unsigned)ctx->N_enc / 4096u;  // workgroups per (limb, prime): halves at 8192 points, quarters at 16384
   const unsigned blocks = ((rows + 7) / 8) * 8 * parts * (unsigned)ctx->K * (unsigned)a.n_groups;
   if (ctx->N_enc == 16384) {
     RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v3<false, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((mac_kernel_v3<false, 14>), dim3(blocks), dim3(256), lds, st, a, ctx->L, ctx->K, sc.coeff<Mod>());
+    hipLaunchKernelGGL((mac_kernel_v3<false, 14>), dim3(blocks), dim3(256), lds, st, a, ctx->L, ctx->K, tabs);
   } else if (a.paired) {
     RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(mac_kernel_v3<true>, dim3(blocks), dim3(256), lds, st, a, ctx->L, ctx->K, sc.coeff<Mod>());
+    hipLaunchKernelGGL(mac_kernel_v3<true>, dim3(blocks), dim3(256), lds, st, a, ctx->L, ctx->K, tabs);
   } else {
     RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(mac_kernel_v3<false>, dim3(blocks), dim3(256), lds, st, a, ctx->L, ctx->K, sc.coeff<Mod>());
+    hipLaunchKernelGGL(mac_kernel_v3<false>, dim3(blocks), dim3(256), lds, st, a, ctx->L, ctx->K, tabs);
   }
   RS_HIP(hipGetLastError());
 }
@@ -1335,10 +1351,21 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
   const int plain_thr = plain16 ? n / 16 : thr;
   const bool plain13 = false;  // measured: no gain from a compile-time length here
   (void)plain13;
-  bool v3 = false, plain_wide = false;
+  bool v3 = false, plain_wide = false, hybrid = false;
   if constexpr (FP) {
     v3 = g_mac_variant == 5 && (n == 8192 || n == 16384);
     plain_wide = g_plain_variant == 1 && n == 8192 && (ctx->N == 8192 || ctx->N == 4096);
+  } else {
+    // Hybrid context: ring primes beyond 2^50 (SEAL's 54-bit BFVDefault(2048) prime of the reference's logistic-regression
+    // benchmark) on the integer arithmetic, data primes below 2^50: the plaintext row is produced by the integer kernel and
+    // handed, as exact doubles, to the FP64 multiply-accumulate of the data primes.  Needs |sum of a group's lifts| < 2^53.
+    uint64_t maxq = 0;
+    for (int i = 0; i < L; i++) maxq = std::max(maxq, ctx->q[i]);
+    int max_vecs = 1;
+    for (int g = 0; g < n_groups; g++) max_vecs = std::max(max_vecs, pa.g[g].n);
+    hybrid = ctx->hybrid && g_mac_variant == 5 && (n == 8192 || n == 16384) &&
+             (double)max_vecs * (0.5 * (double)maxq + 1.0) < 9007199254740992.0;
+    v3 = hybrid;
   }
   RS_REQUIRE(!has_lin || plain_wide, "linear-form vectors need the wide plaintext kernel");
   const bool paired = v3 && plain_wide;  // row layout of this call: written by the plaintext kernel, read by the MAC
@@ -1406,11 +1433,11 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     } else if (plain16)
       hipLaunchKernelGGL((plain_center_kernel<16, 0, M>), dim3((unsigned)tt, L, n_groups), dim3(plain_thr), lds, st, pa, d_C,
                          (unsigned long long)t0, (unsigned long long)tile_terms, ctx->N, L, ctx->logN_enc,
-                         ctx->d_index_map, sc.template plain<M>());
+                         ctx->d_index_map, sc.template plain<M>(), hybrid ? 1 : 0);
     else
       hipLaunchKernelGGL((plain_center_kernel<8, 0, M>), dim3((unsigned)tt, L, n_groups), dim3(thr), lds, st, pa, d_C,
                          (unsigned long long)t0, (unsigned long long)tile_terms, ctx->N, L, ctx->logN_enc,
-                         ctx->d_index_map, sc.template plain<M>());
+                         ctx->d_index_map, sc.template plain<M>(), hybrid ? 1 : 0);
     }
     RS_HIP(hipGetLastError());
     MacArgs base;
@@ -1458,7 +1485,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     // measured faster than the generic kernel that shares it (g_mac_variant == 2: generic for n_crs == 2).
     const bool v2 = FP && g_mac_variant >= 2 && (n_crs == 1 || g_mac_variant != 2) && n >= 2048 && n <= 8192;
     if (v3) {
-      if constexpr (FP) {
+      {
         // bound of a plaintext row: the sum of the centred lifts of the group's vectors
         uint64_t maxq = 0;
         for (int i = 0; i < L; i++) maxq = std::max(maxq, ctx->q[i]);

@@ -713,6 +713,14 @@ int rs_ctx_create(int device, int N, int L, const uint64_t *q, int N_enc, int K,
     RS_HIP(hipMemcpy(c->d_qmod_i, qm.data(), sizeof(ModI) * L, hipMemcpyHostToDevice));
     RS_HIP(hipMalloc(&c->d_Qmod_i, sizeof(ModI) * K));
     RS_HIP(hipMemcpy(c->d_Qmod_i, Qm.data(), sizeof(ModI) * K, hipMemcpyHostToDevice));
+    // Hybrid: only ring primes are beyond 2^50 (the 54-bit BFVDefault(2048) prime of bench_logistic_regression_inference.cpp
+    // :20-27 under 48/49-bit data primes): the inner products -- everything mod Q_j -- keep the FP64 kernels (msm.hip)
+    bool small_Q = !g_force_int;
+    for (int j = 0; j < K; j++) small_Q = small_Q && Q[j] < (1ull << 50);
+    for (int i = 0; i < L; i++) small_Q = small_Q && q[i] < (1ull << 54);
+    c->hybrid = small_Q;
+    if (c->hybrid)
+      for (int j = 0; j < K; j++) c->coeff[j] = make_negacyclic_table<Mod>(Q[j], c->logN_enc);
   } else {
     std::vector<Mod> qm(L), Qm(K);
     for (int i = 0; i < L; i++) {

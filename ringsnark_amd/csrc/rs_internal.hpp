@@ -151,6 +151,9 @@ struct rs_ctx {
   // (one choice per context: a plaintext lifted from a 54-bit q_i does not fit the FP64 operand bounds of a
   // 49-bit Q_j either).  Exactly one of the two table sets below is populated.
   bool use_int = false;
+  // use_int with every DATA prime below 2^50 and every ring prime below 2^54: the FP64 tables `coeff` are built as well and
+  // the inner products run their mod-Q_j work on the FP64 kernels (msm.hip, "hybrid")
+  bool hybrid = false;
   rs::NttTable plain[RS_MAX_L];  // mod q_i, length N_enc
   rs::NttTable coeff[RS_MAX_K];  // mod Q_j, length N_enc
   rs::NttTableI plain_i[RS_MAX_L], coeff_i[RS_MAX_K];

@@ -142,9 +142,11 @@ def test_grouped_msm_equals_sum_of_inner_products():
         assert (got[c, 1] == ctx.inner_product(crs, v[2])[0]).all()
 
 
-@pytest.mark.parametrize("name", ["C5s", "C4"])
+@pytest.mark.parametrize("name", ["C5s", "C4", "C5"])
 def test_quarter_spectrum_mac_at_16384_points(name):
-    """N_enc = 16384 on the FP64 arithmetic (the shapes of BASELINE configs[3] / [4], microbench.cpp:13-14): the inner
+    """C5: the HYBRID case -- the 54-bit ring prime of the reference's logistic-regression benchmark keeps the ring side
+    on the integer arithmetic, the 48 / 49-bit data primes keep the FP64 multiply-accumulate (rows handed over as exact
+    doubles).  N_enc = 16384 on the FP64 arithmetic (the shapes of BASELINE configs[3] / [4], microbench.cpp:13-14): the inner
     products run through mac_kernel_v3<false, 14> (a workgroup per quarter of the spectrum, two stages applied while the
     row is loaded).  Two groups sharing a key vector, a second key vector, enough terms for several per chunk and an
     accumulating second tile (tiled key), against the oracle; and against the generic kernel (mac_variant = 1)."""
@@ -152,28 +154,42 @@ def test_quarter_spectrum_mac_at_16384_points(name):
     prm = dev.prm
     assert prm.N_enc == 16384
     ctx = H.oracle_ctx(prm)
-    T = 70 if name == "C5s" else 24
+    T = 24 if name == "C4" else 70
     crs0, crs1 = ctx.random_enc(41, 8), ctx.random_enc(42, 8)  # windows of 8 elements
     v = [ctx.random_ring(43 + k, T) for k in range(3)]
     v[1][3] = 0
     dv = [dev.put(x) for x in v]
+    # C5: one vector per group -- two lifts of a 54-bit prime do not add up inside 2^53, and such a group keeps the
+    # integer multiply-accumulate (checked at the end)
+    groups = [(dv[0], None, 0), (dv[1], None, 1), (dv[2], None, 2 if name == "C5" else 1)]
+    ng = 3 if name == "C5" else 2
     dev.set_profiling(True)
-    out, used = dev.msm([dev.put(crs0)], [(dv[0], None, 0), (dv[1], None, 1), (dv[2], None, 1)], 2, want_used=True, crs_len=T, window=8)
+    out, used = dev.msm([dev.put(crs0)], groups, ng, want_used=True, crs_len=T, window=8)
     names = {k["name"] for k in dev.profile_read()}
     dev.set_profiling(False)
     assert "mac_kernel_v3<false, 14>" in names, names
     got = host(out)
-    e0, _ = ctx.inner_product(crs0, v[0], threads=0, window=8)
-    e1 = ctx.enc_add(ctx.inner_product(crs0, v[1], threads=0, window=8)[0], ctx.inner_product(crs0, v[2], threads=0, window=8)[0])
-    assert used == [T, T - 1, T] and (got[0, 0] == e0).all() and (got[0, 1] == e1).all()
+    e = [ctx.inner_product(crs0, v[k], threads=0, window=8)[0] for k in range(3)]
+    assert used == [T, T - 1, T] and (got[0, 0] == e[0]).all()
+    if name == "C5":
+        assert (got[0, 1] == e[1]).all() and (got[0, 2] == e[2]).all()
+    else:
+        assert (got[0, 1] == ctx.enc_add(e[1], e[2])).all()
     out2, _ = dev.msm([dev.put(crs0), dev.put(crs1)], [(dv[0], None, 0)], 1, crs_len=T, window=8)
-    assert (host(out2)[0, 0] == e0).all() and (host(out2)[1, 0] == ctx.inner_product(crs1, v[0], threads=0, window=8)[0]).all()
+    assert (host(out2)[0, 0] == e[0]).all() and (host(out2)[1, 0] == ctx.inner_product(crs1, v[0], threads=0, window=8)[0]).all()
     _set_tuning(b"mac_variant", 1)
     try:
-        ref, _ = dev.msm([dev.put(crs0)], [(dv[0], None, 0), (dv[1], None, 1), (dv[2], None, 1)], 2, crs_len=T, window=8)
+        ref, _ = dev.msm([dev.put(crs0)], groups, ng, crs_len=T, window=8)
     finally:
         _set_tuning(b"mac_variant", 5)
     assert (host(ref) == got).all()
+    if name == "C5":  # a two-vector group on the 54-bit prime: refused by the hybrid path, served by the integer kernel
+        dev.set_profiling(True)
+        out3, _ = dev.msm([dev.put(crs0)], [(dv[1], None, 0), (dv[2], None, 0)], 1, crs_len=T, window=8)
+        names = {k["name"] for k in dev.profile_read()}
+        dev.set_profiling(False)
+        assert "mac_kernel" in names and "mac_kernel_v3<false, 14>" not in names, names
+        assert (host(out3)[0, 0] == ctx.enc_add(e[1], e[2])).all()
 
 
 @pytest.mark.parametrize("name", ["toy", "C2", "C3"])

@@ -47,5 +47,5 @@ stats = dev.profile_read()
 print(json.dumps({
     "metric": "Rinocchio prover, logistic-regression inference circuit (configs[4])", "value": round(cs.m / dt, 1), "unit": "constraints/s",
     "ms_per_proof": round(dt * 1e3, 3), "constraints": cs.m, "variables": cs.n_vars, "public": cs.n_inputs, "preset": "C5",
-    "arithmetic": "u64 Montgomery (54-bit ring prime)", "phase_ms": {"witness_map": round(tm["witness_ms"], 3), "msm": round(tm["msm_ms"], 3)},
+    "arithmetic": "hybrid: u64 Montgomery on the ring side (54-bit ring prime), exact FP64 on the encoding side (48/49-bit data primes)", "phase_ms": {"witness_map": round(tm["witness_ms"], 3), "msm": round(tm["msm_ms"], 3)},
     "kernels": [{"name": k["name"], "ms": round(k["total_ms"], 3)} for k in stats[:6]], "data": "synthetic"}))

@@ -22,7 +22,9 @@ uint64_t rso_mulmod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)(((u1
 /* librs_oracle_fast.so (the TIMED cpu_baseline leg of bench.py, never the checker): the same function with SEAL's
  * Barrett reduction (util/uintarithsmallmod.h barrett_reduce_128) instead of a hardware divide per product; the
  * ratio floor(2^128 / q) of the last modulus is cached per thread.  Same canonical results (tests/test_oracle.py). */
-static __thread uint64_t tl_q, tl_hi, tl_lo;
+/* initial-exec: a plain %fs-relative load (the default dynamic TLS model of a shared object calls __tls_get_addr per use) */
+static __thread uint64_t tl_q __attribute__((tls_model("initial-exec"))), tl_hi __attribute__((tls_model("initial-exec"))),
+    tl_lo __attribute__((tls_model("initial-exec")));
 uint64_t rso_mulmod(uint64_t a, uint64_t b, uint64_t q) {
   if (q != tl_q) {
     u128 ratio = ((((u128)1) << 127) / q) << 1;

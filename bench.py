@@ -184,9 +184,13 @@ def cpu_baseline(prm, m, n_aux):
         asg[1] = rng.randint(1, 2**31, slots)
         for i in range(m_s):
             asg[i + 2] = (asg[i].astype(object) * asg[i + 1].astype(object) % q).astype(np.uint64)
-        t0 = time.perf_counter()
-        F.witness_map(q, H.oracle_cs(cs), 0, asg, threads=threads)
-        return (time.perf_counter() - t0) * (m / m_s) ** 2 * (prm.N * prm.L / slots)
+        best = None
+        for fn in (F.witness_map, O.witness_map):  # Barrett build and `%` build (128-by-64-bit hardware divide): whichever this host runs faster
+            t0 = time.perf_counter()
+            fn(q, H.oracle_cs(cs), 0, asg, threads=threads)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best * (m / m_s) ** 2 * (prm.N * prm.L / slots)
 
     t1_term = msm_rate(1, T1)
     tN_term = msm_rate(0, TN)
@@ -200,7 +204,8 @@ def cpu_baseline(prm, m, n_aux):
         "arithmetic": "SEAL-style: Harvey lazy NTT with Shoup quotients, Barrett 128-bit products (oracle/rs_fastcpu.c, "
                       "rs_oracle.c -DRSO_FAST_MULMOD); gcc -O3 -march=native -fopenmp",
         "sample": "inner_product on %d terms (1 thread) / %d terms (%d threads, %d per thread) at full ring shape, scaled to the %d "
-                  "terms of one proof; the reference's O(m^2) witness map at m=128 on 256 / %d slots, scaled x(m/128)^2 x(N L/slots)"
+                  "terms of one proof; the reference's O(m^2) witness map at m=128 on 256 / %d slots (the faster of the Barrett and the "
+                  "hardware-divide builds), scaled x(m/128)^2 x(N L/slots)"
                   % (T1, TN, nthr, TN // max(1, nthr), terms_total, slots_n),
         "one_thread": {"value": one, "cores": 1, "msm_s_per_proof": terms_total * t1_term, "witness_s_per_proof": w1},
         "all_cores": {"value": allc, "cores": nthr, "msm_s_per_proof": terms_total * tN_term, "witness_s_per_proof": wN},

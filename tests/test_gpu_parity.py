@@ -363,6 +363,37 @@ def test_polynomial_coefficients_match_oracle(name, m, aux_only, zk, lds):
         assert rempty == exp_empty and (rp == exp).all()
 
 
+@pytest.mark.parametrize("name,m", [("toy", 40), ("toyR", 300), ("toy60", 33)])
+def test_polynomial_coefficients_on_slot_ranges_chunks_and_recipe_primes(name, m):
+    """Polynomial R1CS coefficients through the other ways the witness map is driven: a slot range of every limb with
+    compact outputs (rs_witness_map_slots: the coefficient table is indexed by the ABSOLUTE slot), column chunks smaller
+    than a limb, and ring primes that need the block-convolution path (toyR at m = 300)."""
+    dev = dev_for(name)
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    cs = R.wide_poly_r1cs(m, prm.q, prm.N)
+    asg = H.make_assignment(ctx, cs)
+    ds = [ctx.random_ring(60 + k) for k in range(3)]
+    dcs, dasg, dds = dev.r1cs(cs), dev.put(asg), [dev.put(d) for d in ds]
+    ocs = H.oracle_cs(cs)
+    keys = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
+    exp = [O.witness_map(prm.q[limb], ocs, limb, np.ascontiguousarray(asg[:, limb, :]), *[np.ascontiguousarray(d[limb]) for d in ds])
+           for limb in range(prm.L)]
+    s0, ns = 6, 10
+    w = dev.witness_map_slots(dcs, dasg, s0, ns, *dds)
+    for limb in range(prm.L):
+        for k in keys:
+            assert (host(w[k])[:, limb, :] == exp[limb][k][:, s0:s0 + ns]).all(), (k, limb)
+    _set_tuning(b"witness_col_budget_mib", 1)  # chunks of at most 64 columns
+    try:
+        w = dev.witness_map(dcs, dasg, *dds)
+    finally:
+        _set_tuning(b"witness_col_budget_mib", 16 * 1024)
+    for limb in range(prm.L):
+        for k in keys:
+            assert (host(w[k])[:, limb, :] == exp[limb][k]).all(), (k, limb)
+
+
 def test_bench_ntt_seal_circuit_proven_bit_exact():
     """BASELINE.json configs[0] is the reference's benchmarks/bench_ntt_SEAL.cpp: Rinocchio Setup / Prove / Verify of ONE
     constraint over N + 1 = 4097 variables, all public, whose coefficients are the powers of a POLYNOMIAL ring element

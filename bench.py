@@ -146,6 +146,54 @@ def single_gpu_leg(preset, m, logw, steps, warmup, check):
 
 
 
+def rinocchio_leg(preset, steps=3, logm=None, logw=None, logreg=False):
+    """Rinocchio prover (rinocchio.tcc:75-190) on another BASELINE configuration's shape, one GPU: configs[3]'s ring shape
+    (preset C4: N = 16384, 6 ring primes, N_enc = 16384, K = 8) on a chain circuit of 2^logm constraints with a tiled key
+    -- the configuration's 2^18 constraints need a 9 TiB key -- or configs[4] exactly as the reference's
+    benchmarks/bench_logistic_regression_inference.cpp has it (preset C5, 1031 constraints, whole key).  ZK blinding on."""
+    from ringsnark_amd.device import Device
+    prm = P.preset(preset)
+    dev = Device(prm, 0)
+    if logreg:
+        cs = R.logreg_r1cs(prm.q, 256)
+        inputs = dev.fill_uniform(dev.ring_empty(4 * 256), 0, 41)
+        asg = R.logreg_assignment(256, inputs, dev.ring_mul, dev.ring_add, dev.ring_mul_scalar)
+        W = 0
+    else:
+        cs = R.chain_r1cs(1 << logm, prm.q)
+        asg = dev.ring_empty(cs.m + 2)
+        dev.fill_uniform(asg[:2], 0, 7)
+        dev.chain_assignment(asg, cs.m)
+        W = 1 << logw
+    nk = (lambda T: min(T, W) if W else T)
+    pk = {"s_pows": dev.fill_uniform(dev.enc_empty(nk(cs.m + 1)), 1, 22), "alpha_s_pows": dev.fill_uniform(dev.enc_empty(nk(cs.m + 1)), 1, 23),
+          "beta_prods": dev.fill_uniform(dev.enc_empty(nk(cs.n_aux)), 1, 24)}
+    for i, k in enumerate(("beta_rv_ts", "beta_rw_ts", "beta_ry_ts")):
+        pk[k] = dev.fill_uniform(dev.enc_empty(), 1, 25 + i)
+    ds = [dev.fill_uniform(dev.ring_empty(), 0, 30 + k) for k in range(3)]
+    dcs = dev.r1cs(cs)
+    for _ in range(2):
+        dev.rinocchio_prove(dcs, pk, asg, *ds, window=W)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dev.rinocchio_prove(dcs, pk, asg, *ds, window=W)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    dev.set_profiling(True)
+    dev.profile_read()
+    dev.rinocchio_prove(dcs, pk, asg, *ds, window=W)
+    torch.cuda.synchronize()
+    tm, stats = dev.last_timings(), dev.profile_read()
+    out = {"preset": prm.name, "shape": "ring N=%d L=%d, encodings N_enc=%d K=%d" % (prm.N, prm.L, prm.N_enc, prm.K), "constraints": cs.m,
+           "key_window": W or None, "ms_per_proof": round(dt * 1e3, 3), "value": round(cs.m / dt, 1), "unit": "constraints/s",
+           "phase_ms": {"witness_map": round(tm["witness_ms"], 3), "msm": round(tm["msm_ms"], 3)},
+           "kernels": [{"name": k["name"], "ms": round(k["total_ms"], 2)} for k in stats[:4]]}
+    del asg, pk, dcs, dev
+    torch.cuda.empty_cache()
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (a port of the reference's algorithm) on a bounded sample
 # ---------------------------------------------------------------------------------------------------
@@ -228,6 +276,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-ntt", action="store_true", help="skip the standalone NTT bandwidth leg (profiling passes)")
     ap.add_argument("--no-recipe-primes", action="store_true", help="skip the second leg on preset C3R (the reference recipe's ring primes)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short Rinocchio legs at the shapes of BASELINE configs[3] / configs[4]")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -407,6 +456,12 @@ def main():
         torch.cuda.empty_cache()
         recipe = single_gpu_leg("C3R", m, min(14, W.bit_length() - 1), max(1, min(args.steps, 5)), 1, not args.no_check)
 
+    # ---- the other BASELINE configurations' shapes, a few seconds each (extra keys, not the metric)
+    other = None
+    if world == 1 and prm.name == "C3" and recipe is not None and not args.no_other_configs:
+        other = {"configs[3] shape (Rinocchio, N=16384, 6 ring primes, K=8; 2^12 constraints, key window 2^9)": rinocchio_leg("C4", logm=12, logw=9),
+                 "configs[4] (Rinocchio, the reference's logistic-regression circuit and parameters)": rinocchio_leg("C5", steps=10, logreg=True)}
+
     if rank == 0:
         key_gib = (3 * m + 2) * prm.enc_words * 8 / 2**30
         out = {
@@ -438,6 +493,8 @@ def main():
             out["check"] = check
         if recipe is not None:
             out["recipe_primes"] = recipe
+        if other is not None:
+            out["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prm, m, n_aux)
         print(json.dumps(out), flush=True)

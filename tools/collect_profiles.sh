@@ -14,9 +14,9 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-PROBE="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-check --no-ntt --no-recipe-primes --preset $PRESET"  # exactly 3 proofs: warm-up, timed, profiled
+PROBE="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-check --no-ntt --no-recipe-primes --no-other-configs --preset $PRESET"  # exactly 3 proofs: warm-up, timed, profiled
 if [[ $STAGES == *k* ]]; then
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-recipe-primes --preset "$PRESET" > "$OUT/bench_stats.json" 2> "$OUT/bench_stats.err"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-recipe-primes --no-other-configs --preset "$PRESET" > "$OUT/bench_stats.json" 2> "$OUT/bench_stats.err"
 fi
 if [[ $STAGES == *p* ]]; then
   rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_mix" -o run \

@@ -996,7 +996,7 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
 #pragma unroll
       for (int e = 0; e < 16; e++) tile[pb + 17 * e] = v[e];
     }
-    __syncthreads();
+    wave_sync();  // a round-2 group (256 elements) is 16 consecutive threads, who also own it in round 3: no workgroup barrier
     {  // round 3: stages 9..12 on 16 consecutive points, parked for the wave-private transposition
       const int pb = 17 * t;
 #pragma unroll

@@ -1019,6 +1019,233 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
     }
 }
 
+// mac_kernel_v4 (N_enc = 16384, FP64, TWO key vectors): Rinocchio multiplies every coefficient vector into BOTH s_pows and
+// alpha_s_pows (rinocchio.tcc:106-160: a, b, c, h, z against each), so the plaintext spectrum -- 82 % of mac_kernel_v3's
+// arithmetic -- is wanted twice.  Four accumulator sets (2 keys x 2 components) of a spectrum quarter do not fit the
+// registers of 256 threads next to a 16-coefficient-per-thread transform; here 512 threads (one workgroup per CU, the same
+// 8 waves) own the quarter with EIGHT points each: the accumulators of both keys take the registers one key took, the
+// ciphertext streams of both keys the registers one stream took, and the transform runs once per term.
+//   stages 0, 1       while the row is loaded (as mac_kernel_v3<false, 14>), on elements t + 512 e
+//   round 1           sub-stages 0..2 on t + 512 e           wave-uniform twiddles        -> tile, WORKGROUP barrier
+//   round 2           sub-stages 3..5 on 512 w + lane + 64 e  wave w's own 512 elements:
+//   round 3           sub-stages 6..8 on 64 (t/8) + t%8 + 8 e   every later exchange is wave-private
+//   round 4           sub-stages 9..11 on 8 t + e             the lane's own twiddles, in registers for the whole chunk
+// One workgroup barrier per term; the spectrum of term t is multiplied into the accumulators during iteration t + 1 (tiles
+// alternate), under the row loads of that term.  Tile position of element i: i + i/8.
+// Up to RS_MAC4_GROUPS coefficient vectors (groups) run in one launch as neighbouring workgroups of one XCD, so that one of
+// them fetches a ciphertext word from memory and the others find it in that XCD's L2.
+constexpr int RS_MAC4_GROUPS = 6;
+struct MacArgs4 {
+  const double *C[RS_MAC4_GROUPS];        // [tile_terms][L][n] plaintext rows per group
+  uint64_t *partial[2][RS_MAC4_GROUPS];   // accumulator set per (key, group): [n_chunks] stride part_stride
+  unsigned long long terms[RS_MAC4_GROUPS];
+  const uint64_t *crs[2];                 // first ciphertext of the tile, per key vector
+  size_t part_stride;
+  int n_groups, terms_per_chunk, n_chunks, accumulate, acc_period, reduce_u;
+  uint32_t red_mask[RS_MAX_K];
+};
+__global__ void __launch_bounds__(512, 2)
+mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs) {
+  constexpr int n = 16384, H = 4096, LOGP = 2, PARTS = 4, TILE = H + H / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const unsigned b = blockIdx.x, x = b & 7u;  // XCD slot and position in its sequence, as mac_kernel_v3
+  unsigned q = b >> 3;
+  const int g = (int)(q % (unsigned)a.n_groups);
+  q /= (unsigned)a.n_groups;
+  const unsigned hj = q % ((unsigned)PARTS * (unsigned)K);
+  const unsigned rr = (q / ((unsigned)PARTS * (unsigned)K)) * 8u + x;  // (chunk, limb)
+  const int h = (int)(hj & (unsigned)(PARTS - 1)), j = (int)(hj >> LOGP);
+  const int limb = (int)(rr % (unsigned)L), chunk = (int)(rr / (unsigned)L);
+  if (chunk >= a.n_chunks) return;
+  const Mod mod = coeff_tabs[j].mod;
+  const double *__restrict__ tw = coeff_tabs[j].d_tw;
+  const uint32_t red_mask = a.red_mask[j];
+  const int root = PARTS + h;
+  const double w0 = uniform_f64(tw[1]);
+  const double w1 = uniform_f64(tw[2 + (h >> 1)]);
+  double tw1[7], tw2[7], tw3[7], tw4[7];
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int bk = 0; bk < (1 << k); bk++) {
+      tw1[(1 << k) - 1 + bk] = uniform_f64(tw[(root << k) + bk]);
+      tw2[(1 << k) - 1 + bk] = uniform_f64(tw[(root << (3 + k)) + (wave << k) + bk]);
+      tw3[(1 << k) - 1 + bk] = tw[(root << (6 + k)) + ((t >> 3) << k) + bk];
+      tw4[(1 << k) - 1 + bk] = tw[(root << (9 + k)) + (t << k) + bk];
+    }
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    pin(tw3[i]);
+    pin(tw4[i]);
+  }
+  const size_t enc_words = (size_t)L * 2 * K * n;
+  const size_t slab = (((size_t)limb * 2) * K + j) * (size_t)n + (size_t)h * H;  // component 0; component 1 is + K*n
+  const size_t comp = (size_t)K * n;
+  const int r0 = wave * 512;  // the wave's range of the quarter: its 64 round-4 groups
+  uint64_t *part[2];
+  double acc[2][2][8];
+#pragma unroll
+  for (int kx = 0; kx < 2; kx++) {
+    part[kx] = a.partial[kx][g] + (size_t)chunk * a.part_stride + slab + r0;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        acc[kx][c][2 * i] = acc[kx][c][2 * i + 1] = 0.0;
+        if (a.accumulate) {
+          const u64x2 v = reinterpret_cast<const u64x2 *>(part[kx] + c * comp)[lane + 64 * i];
+          acc[kx][c][2 * i] = from_u64(v.x);
+          acc[kx][c][2 * i + 1] = from_u64(v.y);
+        }
+      }
+  }
+  const unsigned long long tbeg = (unsigned long long)chunk * a.terms_per_chunk;
+  const unsigned long long tend = min(tbeg + (unsigned long long)a.terms_per_chunk, a.terms[g]);
+  const double *crow = a.C[g] + ((size_t)tbeg * L + limb) * (size_t)n + t;
+  const uint64_t *ctp0 = a.crs[0] + (size_t)tbeg * enc_words + slab + r0;
+  const uint64_t *ctp1 = a.crs[1] + (size_t)tbeg * enc_words + slab + r0;
+  u64x2 ct[2][2][4];
+  auto issue_ct = [&]() {
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        ct[0][c][i] = stream_load(reinterpret_cast<const u64x2 *>(ctp0 + c * comp) + lane + 64 * i);
+        ct[1][c][i] = stream_load(reinterpret_cast<const u64x2 *>(ctp1 + c * comp) + lane + 64 * i);
+      }
+    ctp0 += enc_words;
+    ctp1 += enc_words;
+  };
+  int since = 0;
+  auto mac = [&](const double *tile) {
+    const int p0 = r0 + (r0 >> 3) + 2 * lane + (lane >> 2);  // position of element r0 + 2 lane
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const double u0 = tile[p0 + 144 * i], u1 = tile[p0 + 144 * i + 1];
+#pragma unroll
+      for (int kx = 0; kx < 2; kx++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          acc[kx][c][2 * i] += mulmod(from_u64(ct[kx][c][i].x), u0, mod);
+          acc[kx][c][2 * i + 1] += mulmod(from_u64(ct[kx][c][i].y), u1, mod);
+        }
+    }
+    if (++since >= a.acc_period) {
+      since = 0;
+#pragma unroll
+      for (int kx = 0; kx < 2; kx++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+          for (int i = 0; i < 8; i++) acc[kx][c][i] = reduce(acc[kx][c][i], mod);
+    }
+  };
+  for (unsigned long long tt = tbeg; tt < tend; tt++) {
+    double *tile = s + (int)((tt - tbeg) & 1) * TILE;
+    double v[8], c2[8], c3[8];
+    // stages 0 (gap 8192) and 1 (gap 4096) on x[n'], x[n' + 4096], x[n' + 8192], x[n' + 12288], n' = t + 512 e
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      c2[e] = crow[512 * e + 2 * H];
+      c3[e] = crow[512 * e + 3 * H];
+    }
+    mem_fence();
+    if (tt > tbeg) mac(s + (int)((tt - tbeg + 1) & 1) * TILE);  // term tt - 1, under the row loads
+    mem_fence();
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = crow[512 * e];
+    mem_fence();
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      double x2 = c2[e], x3 = c3[e];
+      if (red_mask & 1u) {
+        x2 = reduce(x2, mod);
+        x3 = reduce(x3, mod);
+      }
+      c2[e] = mulmod(x2, w0, mod);
+      c3[e] = mulmod(x3, w0, mod);
+      pin(c2[e]);
+      pin(c3[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {  // u0 = x0 +- w0 x2 (this quarter's half of stage 0)
+      double x0 = v[e];
+      if (red_mask & 1u) x0 = reduce(x0, mod);
+      c2[e] = (h & 2) ? x0 - c2[e] : x0 + c2[e];
+      pin(c2[e]);
+    }
+    mem_fence();
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = crow[512 * e + H];
+    crow += (size_t)L * n;
+    mem_fence();
+#pragma unroll
+    for (int e = 0; e < 8; e++) {  // u1 = x1 +- w0 x3, then stage 1: v = u0 +- w1 u1
+      double x1 = v[e];
+      if (red_mask & 1u) x1 = reduce(x1, mod);
+      double u1 = (h & 2) ? x1 - c3[e] : x1 + c3[e];
+      if (red_mask & 2u) {
+        u1 = reduce(u1, mod);
+        c2[e] = reduce(c2[e], mod);
+      }
+      u1 = mulmod(u1, w1, mod);
+      v[e] = (h & 1) ? c2[e] - u1 : c2[e] + u1;
+      pin(v[e]);
+    }
+    mem_fence();
+    issue_ct();  // both keys' words of this term: a whole transform to land
+    mem_fence();
+    reg_fwd_stages<3, true>(v, mod, red_mask >> LOGP, [&](int k, int bk) { return tw1[(1 << k) - 1 + bk]; });
+    {  // tile tt % 2 was last read by the multiply-accumulate of term tt - 2, before the previous barrier
+      const int pb = t + (t >> 3);
+#pragma unroll
+      for (int e = 0; e < 8; e++) tile[pb + 576 * e] = v[e];
+    }
+    __syncthreads();
+    {  // round 2: the wave's own 512 elements
+      const int pb = wave * 576 + lane + (lane >> 3);
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = tile[pb + 72 * e];
+      reg_fwd_stages<3, true>(v, mod, red_mask >> (LOGP + 3), [&](int k, int bk) { return tw2[(1 << k) - 1 + bk]; });
+#pragma unroll
+      for (int e = 0; e < 8; e++) tile[pb + 72 * e] = v[e];
+    }
+    wave_sync();
+    {  // round 3: 64-element groups of 8 consecutive threads
+      const int pb = (t >> 3) * 72 + (t & 7);
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = tile[pb + 9 * e];
+      reg_fwd_stages<3, true>(v, mod, red_mask >> (LOGP + 6), [&](int k, int bk) { return tw3[(1 << k) - 1 + bk]; });
+#pragma unroll
+      for (int e = 0; e < 8; e++) tile[pb + 9 * e] = v[e];
+    }
+    wave_sync();
+    {  // round 4: 8 consecutive points
+      const int pb = 9 * t;
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = tile[pb + e];
+      reg_fwd_stages<3, true>(v, mod, red_mask >> (LOGP + 9), [&](int k, int bk) { return tw4[(1 << k) - 1 + bk]; });
+#pragma unroll
+      for (int e = 0; e < 8; e++) tile[pb + e] = a.reduce_u ? reduce(v[e], mod) : v[e];
+    }
+    wave_sync();
+  }
+  if (tend > tbeg) mac(s + (int)((tend - tbeg + 1) & 1) * TILE);  // the last term
+#pragma unroll
+  for (int kx = 0; kx < 2; kx++)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        u64x2 o;
+        o.x = to_u64(canon(acc[kx][c][2 * i], mod));
+        o.y = to_u64(canon(acc[kx][c][2 * i + 1], mod));
+        reinterpret_cast<u64x2 *>(part[kx] + c * comp)[lane + 64 * i] = o;
+      }
+}
+
 // out[set] = sum_chunk partial[chunk][set] (+ addend[set]) mod Q_j
 struct ReduceArgs {
   const uint64_t *addend[12];
@@ -1139,7 +1366,7 @@ static void launch_mac(rs_ctx *ctx, const MacArgs &a, const MsmScratch &sc, hipS
   RS_HIP(hipGetLastError());
 }
 
-extern int g_mac_variant, g_mac_ablate, g_plain_variant, g_mac_chunk_units;
+extern int g_mac_variant, g_mac_ablate, g_plain_variant, g_mac_chunk_units, g_mac_share_keys;
 static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, hipStream_t st) {
   const size_t lds = (padded_len((size_t)ctx->N_enc) + (size_t)ctx->N_enc) * sizeof(double);
   const int rows = a.n_chunks * ctx->L;
@@ -1213,7 +1440,18 @@ static void launch_mac_v3(rs_ctx *ctx, const MacArgs3 &a, const MsmScratch &sc, 
   RS_HIP(hipGetLastError());
 }
 
+static void launch_mac_v4(rs_ctx *ctx, const MacArgs4 &a, const MsmScratch &sc, hipStream_t st) {
+  const size_t lds = (size_t)2 * (4096 + 512) * sizeof(double);  // two tiles
+  const unsigned rows = (unsigned)ctx->L * (unsigned)a.n_chunks;
+  const NttTable *tabs = ctx->use_int ? static_cast<const NttTable *>(sc.d_coeff_tabs_f64) : sc.coeff<Mod>();
+  const unsigned blocks = ((rows + 7) / 8) * 8 * 4u * (unsigned)ctx->K * (unsigned)a.n_groups;
+  RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(mac_kernel_v4, dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K, tabs);
+  RS_HIP(hipGetLastError());
+}
+
 int g_mac_ablate = 0;
+int g_mac_share_keys = 1;  // tuning knob "mac_share_keys": two key vectors at 16384 points share the plaintext spectrum (mac_kernel_v4)
 int g_msm_host_tile = 1024;  // tuning knob "msm_host_tile": terms per staging buffer of a host-resident key
 int g_mac_chunk_units = 768;  // tuning knob "mac_chunk_units": (limb, prime, chunk) units per MAC launch (term chunks = units / (L K))
 int g_plain_variant = 1;  // 1: plain_center_wide_kernel at N_enc = 8192; 0: plain_center_kernel
@@ -1490,6 +1728,39 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
         uint64_t maxq = 0;
         for (int i = 0; i < L; i++) maxq = std::max(maxq, ctx->q[i]);
         const double b0 = 0.5 * (double)maxq * MAX_GROUP_VECS + (double)MAX_GROUP_VECS;
+        if (n == 16384 && n_crs == 2 && g_mac_share_keys) {
+          // Rinocchio's ten inner products (rinocchio.tcc:106-160): every vector against both key vectors, one transform
+          for (int g0 = 0; g0 < n_groups; g0 += RS_MAC4_GROUPS) {
+            const int ng = std::min(RS_MAC4_GROUPS, n_groups - g0);
+            MacArgs4 a4;
+            memset(&a4, 0, sizeof(a4));
+            unsigned long long tmax = 0;
+            double terms = 0;
+            for (int gi = 0; gi < ng; gi++) {
+              a4.C[gi] = reinterpret_cast<const double *>(Cptr(g0 + gi));
+              a4.terms[gi] = group_terms(g0 + gi);
+              for (int c = 0; c < 2; c++) a4.partial[c][gi] = d_partial + (size_t)(c * n_groups + g0 + gi) * enc_words;
+              tmax = std::max(tmax, a4.terms[gi]);
+              terms += (double)a4.terms[gi];
+            }
+            a4.crs[0] = crs_at(0, t0);
+            a4.crs[1] = crs_at(1, t0);
+            a4.part_stride = (size_t)n_sets * enc_words;
+            a4.n_groups = ng;
+            a4.n_chunks = base.n_chunks;
+            a4.terms_per_chunk = base.terms_per_chunk;
+            a4.accumulate = base.accumulate;
+            a4.acc_period = base.acc_period;
+            for (int jj = 0; jj < K; jj++) {
+              double end = 0;
+              a4.red_mask[jj] = fwd_reduce_mask_from(ctx->Q[jj], ctx->logN_enc, b0, &end);
+              if (end > 562949953421312.0) a4.reduce_u = 1;
+            }
+            ProfScope prof(ctx, st, "mac_kernel_v4", (double)tmax * 2.0 * (double)enc_words * 8.0 + terms * (double)L * nd * 8.0 + 2.0 * ng * (double)enc_words * 8.0,
+                           terms * L * K * (ntt_fp64(nd, logn_d) + 8.0 * nd / 2.0 + 2.0 * 15.0 * nd));
+            launch_mac_v4(ctx, a4, sc, st);
+          }
+        } else
         // chunks: two workgroups per CU in one wave of workgroups (512), shared by the groups of a launch
         for (int c = 0; c < n_crs; c++)
           for (int g0 = 0; g0 < n_groups; g0 += 2) {

@@ -933,6 +933,8 @@ int rs_set_tuning(const char *key, int value) {
     g_msm_host_tile = std::max(1, value);
   else if (std::string(key) == "mac_chunk_units")
     g_mac_chunk_units = std::max(1, value);
+  else if (std::string(key) == "mac_share_keys")
+    g_mac_share_keys = value != 0;
   else if (std::string(key) == "ntt_wide_grid")
     g_ntt_wide_grid = std::max(1, value);
   else if (std::string(key) == "witness_force_bc") {

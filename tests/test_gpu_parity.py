@@ -177,6 +177,30 @@ def test_quarter_spectrum_mac_at_16384_points(name):
         assert (got[0, 1] == ctx.enc_add(e[1], e[2])).all()
     out2, _ = dev.msm([dev.put(crs0), dev.put(crs1)], [(dv[0], None, 0)], 1, crs_len=T, window=8)
     assert (host(out2)[0, 0] == e[0]).all() and (host(out2)[1, 0] == ctx.inner_product(crs1, v[0], threads=0, window=8)[0]).all()
+    # Two key vectors (Rinocchio's s_pows / alpha_s_pows, rinocchio.tcc:106-160): mac_kernel_v4 computes a term's plaintext
+    # spectrum once for both.  Three groups in one launch, one of them shorter; against the oracle and the per-key kernels.
+    short = T - 7
+    g2 = [(dv[0], None, 0), (dv[1], None, 1), (dev.put(v[2][:short]), None, 2)]
+    dev.set_profiling(True)
+    out4, used4 = dev.msm([dev.put(crs0), dev.put(crs1)], g2, 3, want_used=True, crs_len=T, window=8)
+    names = {k["name"] for k in dev.profile_read()}
+    dev.set_profiling(False)
+    assert "mac_kernel_v4" in names, names
+    got4 = host(out4)
+    assert used4 == [T, T - 1, short]
+    for c, crs in enumerate((crs0, crs1)):
+        for k in range(3):
+            vk = v[k] if k < 2 else v[2][:short]
+            assert (got4[c, k] == ctx.inner_product(crs, vk, threads=0, window=8)[0]).all(), (c, k)
+    _set_tuning(b"mac_share_keys", 0)
+    try:
+        dev.set_profiling(True)
+        ref4, _ = dev.msm([dev.put(crs0), dev.put(crs1)], g2, 3, crs_len=T, window=8)
+        names = {k["name"] for k in dev.profile_read()}
+        dev.set_profiling(False)
+    finally:
+        _set_tuning(b"mac_share_keys", 1)
+    assert "mac_kernel_v4" not in names and (host(ref4) == got4).all()
     _set_tuning(b"mac_variant", 1)
     try:
         ref, _ = dev.msm([dev.put(crs0)], groups, ng, crs_len=T, window=8)

@@ -1019,7 +1019,7 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
     }
 }
 
-// mac_kernel_v4 (N_enc = 16384, FP64, TWO key vectors): Rinocchio multiplies every coefficient vector into BOTH s_pows and
+// mac_kernel_v4 (N_enc = 16384 -- described here -- and 8192; FP64, TWO key vectors): Rinocchio multiplies every coefficient vector into BOTH s_pows and
 // alpha_s_pows (rinocchio.tcc:106-160: a, b, c, h, z against each), so the plaintext spectrum -- 82 % of mac_kernel_v3's
 // arithmetic -- is wanted twice.  Four accumulator sets (2 keys x 2 components) of a spectrum quarter do not fit the
 // registers of 256 threads next to a 16-coefficient-per-thread transform; here 512 threads (one workgroup per CU, the same
@@ -1044,9 +1044,13 @@ struct MacArgs4 {
   int n_groups, terms_per_chunk, n_chunks, accumulate, acc_period, reduce_u;
   uint32_t red_mask[RS_MAX_K];
 };
+// LOGN = 13 (N_enc = 8192): the workgroup owns HALF of the spectrum and folds one stage while the row is loaded (PAIRED:
+// rows in plain_center_wide_kernel's paired layout, one 16-byte load per operand pair).
+template <int LOGN, bool PAIRED>
 __global__ void __launch_bounds__(512, 2)
 mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs) {
-  constexpr int n = 16384, H = 4096, LOGP = 2, PARTS = 4, TILE = H + H / 8;
+  constexpr int n = 1 << LOGN, H = 4096, LOGP = LOGN - 12, PARTS = 1 << LOGP, TILE = H + H / 8;
+  static_assert(LOGN == 14 ? !PAIRED : LOGN == 13, "quarter spectrum at 16384 points, half spectrum at 8192");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -1064,7 +1068,7 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
   const uint32_t red_mask = a.red_mask[j];
   const int root = PARTS + h;
   const double w0 = uniform_f64(tw[1]);
-  const double w1 = uniform_f64(tw[2 + (h >> 1)]);
+  const double w1 = uniform_f64(tw[2 + (h >> 1)]);  // LOGN = 14: stage 1 of this quarter's half
   double tw1[7], tw2[7], tw3[7], tw4[7];
 #pragma unroll
   for (int k = 0; k < 3; k++)
@@ -1103,7 +1107,7 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
   }
   const unsigned long long tbeg = (unsigned long long)chunk * a.terms_per_chunk;
   const unsigned long long tend = min(tbeg + (unsigned long long)a.terms_per_chunk, a.terms[g]);
-  const double *crow = a.C[g] + ((size_t)tbeg * L + limb) * (size_t)n + t;
+  const double *crow = a.C[g] + ((size_t)tbeg * L + limb) * (size_t)n + (PAIRED ? 2 * t : t);
   const uint64_t *ctp0 = a.crs[0] + (size_t)tbeg * enc_words + slab + r0;
   const uint64_t *ctp1 = a.crs[1] + (size_t)tbeg * enc_words + slab + r0;
   u64x2 ct[2][2][4];
@@ -1145,6 +1149,35 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
   for (unsigned long long tt = tbeg; tt < tend; tt++) {
     double *tile = s + (int)((tt - tbeg) & 1) * TILE;
     double v[8], c2[8], c3[8];
+    if (LOGN == 13) {
+      // stage 0 (gap 4096) on x[n'], x[n' + 4096], n' = t + 512 e: this half's operand of the 4096-point sub-transform
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        if (PAIRED) {
+          const double2 x2 = reinterpret_cast<const double2 *>(crow)[512 * e];
+          v[e] = x2.x;
+          c2[e] = x2.y;
+        } else {
+          v[e] = crow[512 * e];
+          c2[e] = crow[512 * e + H];
+        }
+      }
+      crow += (size_t)L * n;
+      mem_fence();
+      if (tt > tbeg) mac(s + (int)((tt - tbeg + 1) & 1) * TILE);  // term tt - 1, under the row loads
+      mem_fence();
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        double x0 = v[e], x1 = c2[e];
+        if (red_mask & 1u) {
+          x0 = reduce(x0, mod);
+          x1 = reduce(x1, mod);
+        }
+        x1 = mulmod(x1, w0, mod);
+        v[e] = h ? x0 - x1 : x0 + x1;
+        pin(v[e]);
+      }
+    } else {
     // stages 0 (gap 8192) and 1 (gap 4096) on x[n'], x[n' + 4096], x[n' + 8192], x[n' + 12288], n' = t + 512 e
 #pragma unroll
     for (int e = 0; e < 8; e++) {
@@ -1193,6 +1226,7 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
       u1 = mulmod(u1, w1, mod);
       v[e] = (h & 1) ? c2[e] - u1 : c2[e] + u1;
       pin(v[e]);
+    }
     }
     mem_fence();
     issue_ct();  // both keys' words of this term: a whole transform to land
@@ -1440,18 +1474,26 @@ static void launch_mac_v3(rs_ctx *ctx, const MacArgs3 &a, const MsmScratch &sc, 
   RS_HIP(hipGetLastError());
 }
 
-static void launch_mac_v4(rs_ctx *ctx, const MacArgs4 &a, const MsmScratch &sc, hipStream_t st) {
+static void launch_mac_v4(rs_ctx *ctx, const MacArgs4 &a, bool paired, const MsmScratch &sc, hipStream_t st) {
   const size_t lds = (size_t)2 * (4096 + 512) * sizeof(double);  // two tiles
   const unsigned rows = (unsigned)ctx->L * (unsigned)a.n_chunks;
   const NttTable *tabs = ctx->use_int ? static_cast<const NttTable *>(sc.d_coeff_tabs_f64) : sc.coeff<Mod>();
-  const unsigned blocks = ((rows + 7) / 8) * 8 * 4u * (unsigned)ctx->K * (unsigned)a.n_groups;
-  RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(mac_kernel_v4, dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K, tabs);
+  const unsigned parts = (unsigned)ctx->N_enc / 4096u;
+  const unsigned blocks = ((rows + 7) / 8) * 8 * parts * (unsigned)ctx->K * (unsigned)a.n_groups;
+#define RS_MAC4_LAUNCH(LOGN_, PAIRED_)                                                                                          \
+  do {                                                                                                                         \
+    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v4<LOGN_, PAIRED_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((mac_kernel_v4<LOGN_, PAIRED_>), dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K, tabs);             \
+  } while (0)
+  if (ctx->N_enc == 16384) RS_MAC4_LAUNCH(14, false);
+  else if (paired) RS_MAC4_LAUNCH(13, true);
+  else RS_MAC4_LAUNCH(13, false);
+#undef RS_MAC4_LAUNCH
   RS_HIP(hipGetLastError());
 }
 
 int g_mac_ablate = 0;
-int g_mac_share_keys = 1;  // tuning knob "mac_share_keys": two key vectors at 16384 points share the plaintext spectrum (mac_kernel_v4)
+int g_mac_share_keys = 1;  // tuning knob "mac_share_keys": two key vectors share the plaintext spectrum (mac_kernel_v4; 8192 and 16384 points)
 int g_msm_host_tile = 1024;  // tuning knob "msm_host_tile": terms per staging buffer of a host-resident key
 int g_mac_chunk_units = 768;  // tuning knob "mac_chunk_units": (limb, prime, chunk) units per MAC launch (term chunks = units / (L K))
 int g_plain_variant = 1;  // 1: plain_center_wide_kernel at N_enc = 8192; 0: plain_center_kernel
@@ -1728,7 +1770,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
         uint64_t maxq = 0;
         for (int i = 0; i < L; i++) maxq = std::max(maxq, ctx->q[i]);
         const double b0 = 0.5 * (double)maxq * MAX_GROUP_VECS + (double)MAX_GROUP_VECS;
-        if (n == 16384 && n_crs == 2 && g_mac_share_keys) {
+        if (n_crs == 2 && g_mac_share_keys) {
           // Rinocchio's ten inner products (rinocchio.tcc:106-160): every vector against both key vectors, one transform
           for (int g0 = 0; g0 < n_groups; g0 += RS_MAC4_GROUPS) {
             const int ng = std::min(RS_MAC4_GROUPS, n_groups - g0);
@@ -1756,9 +1798,9 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
               a4.red_mask[jj] = fwd_reduce_mask_from(ctx->Q[jj], ctx->logN_enc, b0, &end);
               if (end > 562949953421312.0) a4.reduce_u = 1;
             }
-            ProfScope prof(ctx, st, "mac_kernel_v4", (double)tmax * 2.0 * (double)enc_words * 8.0 + terms * (double)L * nd * 8.0 + 2.0 * ng * (double)enc_words * 8.0,
+            ProfScope prof(ctx, st, n == 16384 ? "mac_kernel_v4<14, false>" : (paired ? "mac_kernel_v4<13, true>" : "mac_kernel_v4<13, false>"), (double)tmax * 2.0 * (double)enc_words * 8.0 + terms * (double)L * nd * 8.0 + 2.0 * ng * (double)enc_words * 8.0,
                            terms * L * K * (ntt_fp64(nd, logn_d) + 8.0 * nd / 2.0 + 2.0 * 15.0 * nd));
-            launch_mac_v4(ctx, a4, sc, st);
+            launch_mac_v4(ctx, a4, paired, sc, st);
           }
         } else
         // chunks: two workgroups per CU in one wave of workgroups (512), shared by the groups of a launch

@@ -185,7 +185,7 @@ def test_quarter_spectrum_mac_at_16384_points(name):
     out4, used4 = dev.msm([dev.put(crs0), dev.put(crs1)], g2, 3, want_used=True, crs_len=T, window=8)
     names = {k["name"] for k in dev.profile_read()}
     dev.set_profiling(False)
-    assert "mac_kernel_v4" in names, names
+    assert "mac_kernel_v4<14, false>" in names, names
     got4 = host(out4)
     assert used4 == [T, T - 1, short]
     for c, crs in enumerate((crs0, crs1)):
@@ -200,7 +200,7 @@ def test_quarter_spectrum_mac_at_16384_points(name):
         dev.set_profiling(False)
     finally:
         _set_tuning(b"mac_share_keys", 1)
-    assert "mac_kernel_v4" not in names and (host(ref4) == got4).all()
+    assert not any(k.startswith("mac_kernel_v4") for k in names) and (host(ref4) == got4).all()
     _set_tuning(b"mac_variant", 1)
     try:
         ref, _ = dev.msm([dev.put(crs0)], groups, ng, crs_len=T, window=8)
@@ -237,6 +237,26 @@ def test_grouped_msm_with_vectors_of_different_lengths(name):
     for g, (v, k) in enumerate(zip(vs, kinds)):
         exp, _ = ctx.inner_product(crs, v, k, threads=0, window=16)
         assert (got[0, g] == exp).all(), g
+    if dev.prm.N_enc == 8192:
+        # the same groups against TWO key vectors (Rinocchio, rinocchio.tcc:106-160): one plaintext spectrum per term for both
+        # (mac_kernel_v4<13, *>: half spectrum per workgroup); against the oracle and the per-key kernels
+        crs1 = ctx.random_enc(142, 16)
+        groups = [(dev.put(v), k, g) for g, (v, k) in enumerate(zip(vs, kinds))]
+        dev.set_profiling(True)
+        out2, used2 = dev.msm([dev.put(crs), dev.put(crs1)], groups, 3, want_used=True, crs_len=T, window=16)
+        names = {k["name"] for k in dev.profile_read()}
+        dev.set_profiling(False)
+        assert any(k.startswith("mac_kernel_v4<13") for k in names), names
+        got2 = host(out2)
+        assert used2 == lens and (got2[0] == got[0]).all()
+        for g, (v, k) in enumerate(zip(vs, kinds)):
+            assert (got2[1, g] == ctx.inner_product(crs1, v, k, threads=0, window=16)[0]).all(), g
+        _set_tuning(b"mac_share_keys", 0)
+        try:
+            ref2, _ = dev.msm([dev.put(crs), dev.put(crs1)], groups, 3, crs_len=T, window=16)
+        finally:
+            _set_tuning(b"mac_share_keys", 1)
+        assert (host(ref2) == got2).all()
 
 
 @pytest.mark.parametrize("name", ["C2", "C3"])

@@ -1,5 +1,5 @@
 """Where the time of mac_kernel_v3<false, 14> goes at the configs[3] shape (preset C4, Rinocchio, m = 2^12, key window 2^9).
-Sweeps the term-chunk knob; run under RINGSNARK_AMD_LIB=<ablated build> (csrc/Makefile `experiments`, -DRS_MAC3_ABLATE=1|2|4:
+Sweeps the term-chunk knob (other knobs: RS_TUNING=key=value,...); run under RINGSNARK_AMD_LIB=<ablated build> (csrc/Makefile `experiments`, -DRS_MAC3_ABLATE=1|2|4:
 wrong results, timing only) to split row traffic / ciphertext traffic / transform.
 usage: mac16_probe.py [logm] [preset] [logw] [units,units,...]"""
 import os
@@ -27,6 +27,9 @@ dev.chain_assignment(asg, m)
 pk = dict(s_pows=dev.fill_uniform(dev.enc_empty(nk(m + 1)), 1, 3), alpha_s_pows=dev.fill_uniform(dev.enc_empty(nk(m + 1)), 1, 4),
           beta_prods=dev.fill_uniform(dev.enc_empty(nk(m)), 1, 5), beta_rv_ts=dev.fill_uniform(dev.enc_empty(), 1, 6),
           beta_rw_ts=dev.fill_uniform(dev.enc_empty(), 1, 7), beta_ry_ts=dev.fill_uniform(dev.enc_empty(), 1, 8))
+for kv in os.environ.get("RS_TUNING", "").split(","):  # e.g. RS_TUNING=mac_share_keys=0
+    if "=" in kv:
+        _lib.check(lib.rs_set_tuning(kv.split("=")[0].encode(), int(kv.split("=")[1])))
 dev.set_profiling(True)
 for u in units:
     _lib.check(lib.rs_set_tuning(b"mac_chunk_units", u))

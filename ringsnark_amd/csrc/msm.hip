@@ -1178,55 +1178,55 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
         pin(v[e]);
       }
     } else {
-    // stages 0 (gap 8192) and 1 (gap 4096) on x[n'], x[n' + 4096], x[n' + 8192], x[n' + 12288], n' = t + 512 e
+      // stages 0 (gap 8192) and 1 (gap 4096) on x[n'], x[n' + 4096], x[n' + 8192], x[n' + 12288], n' = t + 512 e
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-      c2[e] = crow[512 * e + 2 * H];
-      c3[e] = crow[512 * e + 3 * H];
-    }
-    mem_fence();
-    if (tt > tbeg) mac(s + (int)((tt - tbeg + 1) & 1) * TILE);  // term tt - 1, under the row loads
-    mem_fence();
-#pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = crow[512 * e];
-    mem_fence();
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      double x2 = c2[e], x3 = c3[e];
-      if (red_mask & 1u) {
-        x2 = reduce(x2, mod);
-        x3 = reduce(x3, mod);
+      for (int e = 0; e < 8; e++) {
+        c2[e] = crow[512 * e + 2 * H];
+        c3[e] = crow[512 * e + 3 * H];
       }
-      c2[e] = mulmod(x2, w0, mod);
-      c3[e] = mulmod(x3, w0, mod);
-      pin(c2[e]);
-      pin(c3[e]);
-    }
+      mem_fence();
+      if (tt > tbeg) mac(s + (int)((tt - tbeg + 1) & 1) * TILE);  // term tt - 1, under the row loads
+      mem_fence();
 #pragma unroll
-    for (int e = 0; e < 8; e++) {  // u0 = x0 +- w0 x2 (this quarter's half of stage 0)
-      double x0 = v[e];
-      if (red_mask & 1u) x0 = reduce(x0, mod);
-      c2[e] = (h & 2) ? x0 - c2[e] : x0 + c2[e];
-      pin(c2[e]);
-    }
-    mem_fence();
+      for (int e = 0; e < 8; e++) v[e] = crow[512 * e];
+      mem_fence();
 #pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = crow[512 * e + H];
-    crow += (size_t)L * n;
-    mem_fence();
-#pragma unroll
-    for (int e = 0; e < 8; e++) {  // u1 = x1 +- w0 x3, then stage 1: v = u0 +- w1 u1
-      double x1 = v[e];
-      if (red_mask & 1u) x1 = reduce(x1, mod);
-      double u1 = (h & 2) ? x1 - c3[e] : x1 + c3[e];
-      if (red_mask & 2u) {
-        u1 = reduce(u1, mod);
-        c2[e] = reduce(c2[e], mod);
+      for (int e = 0; e < 8; e++) {
+        double x2 = c2[e], x3 = c3[e];
+        if (red_mask & 1u) {
+          x2 = reduce(x2, mod);
+          x3 = reduce(x3, mod);
+        }
+        c2[e] = mulmod(x2, w0, mod);
+        c3[e] = mulmod(x3, w0, mod);
+        pin(c2[e]);
+        pin(c3[e]);
       }
-      u1 = mulmod(u1, w1, mod);
-      v[e] = (h & 1) ? c2[e] - u1 : c2[e] + u1;
-      pin(v[e]);
-    }
+#pragma unroll
+      for (int e = 0; e < 8; e++) {  // u0 = x0 +- w0 x2 (this quarter's half of stage 0)
+        double x0 = v[e];
+        if (red_mask & 1u) x0 = reduce(x0, mod);
+        c2[e] = (h & 2) ? x0 - c2[e] : x0 + c2[e];
+        pin(c2[e]);
+      }
+      mem_fence();
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = crow[512 * e + H];
+      crow += (size_t)L * n;
+      mem_fence();
+#pragma unroll
+      for (int e = 0; e < 8; e++) {  // u1 = x1 +- w0 x3, then stage 1: v = u0 +- w1 u1
+        double x1 = v[e];
+        if (red_mask & 1u) x1 = reduce(x1, mod);
+        double u1 = (h & 2) ? x1 - c3[e] : x1 + c3[e];
+        if (red_mask & 2u) {
+          u1 = reduce(u1, mod);
+          c2[e] = reduce(c2[e], mod);
+        }
+        u1 = mulmod(u1, w1, mod);
+        v[e] = (h & 1) ? c2[e] - u1 : c2[e] + u1;
+        pin(v[e]);
+      }
     }
     mem_fence();
     issue_ct();  // both keys' words of this term: a whole transform to land

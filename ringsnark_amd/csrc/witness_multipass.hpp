@@ -1,0 +1,660 @@
+// witness_multipass.hpp -- multi-pass column transforms: cross passes over global memory and rooted LDS sub-transforms (witness.hip)
+#pragma once
+#include "witness_cols.hpp"
+
+namespace rs {
+
+// =============================================================================================
+// Multi-pass column transforms for M > 2^g_witness_lds_logM (a column no longer fits one LDS tile).
+// A cyclic transform of length n = n1 * Bn over a column held in global memory is
+//     forward:  log2(n1) "cross" stages (gap >= Bn; twiddles depend on the block index only),
+//               then n1 independent length-Bn sub-transforms rooted at tree nodes n1 + b, in LDS;
+//     inverse:  the sub-transforms first, then the cross stages.
+// Both reuse the round functions of ntt_core.hpp (global-memory functors / `root`).
+// =============================================================================================
+struct TabPtrs {
+  const void *t[RS_MAX_L];  // tables of the context's arithmetic (8-byte words)
+};
+#ifndef RS_WORKSPACE_NT
+#define RS_WORKSPACE_NT 1
+#endif
+template <class T>
+struct GlobalIOT {
+  T *p;
+  __device__ __forceinline__ int pbase(int) const { return 0; }
+#if RS_WORKSPACE_NT  // the multi-pass workspaces are streamed once per pass and are far larger than L2 and the Infinity Cache
+  __device__ __forceinline__ T load(int base, int, int eoff, int) const { return __builtin_nontemporal_load(p + base + eoff); }
+  __device__ __forceinline__ void store(int base, int, int eoff, int, T v) const { __builtin_nontemporal_store(v, p + base + eoff); }
+#else
+  __device__ __forceinline__ T load(int base, int, int eoff, int) const { return p[base + eoff]; }
+  __device__ __forceinline__ void store(int base, int, int eoff, int, T v) const { p[base + eoff] = v; }
+#endif
+};
+using GlobalF64IO = GlobalIOT<double>;
+
+// ---- cross passes with fused sources and sinks ----------------------------------------------------
+// The first forward pass of a transform reads its input through a source functor (padding,
+// scaling, centring, node splitting, reversal happen on the fly, from the caller's buffer); the
+// last inverse pass hands its output to a sink functor (truncation, node recombination, H
+// extraction).  Every other pass works in place on the workspace.  This removes the separate
+// element-wise launches (and their HBM round trips) around every multi-pass transform.
+enum CrossSrc { CS_PLAIN = 0, CS_SCALE_PAD, CS_FILL_RIGHT, CS_PAD_CENTER, CS_REV_TRUNC };
+enum CrossDst { CD_PLAIN = 0, CD_TAKE_LOW, CD_COMBINE, CD_COMBINE_CANON, CD_H_FINISH, CD_H_FINISH_CANON };
+struct CrossArgs {
+  void *W;          // workspace columns [ncols][2^logtot]   (8-byte words of the context's arithmetic)
+  const void *src;  // source columns (CS_*): [ncols][M] (CS_REV_TRUNC: [ncols][2M])
+  void *dst;        // sink columns (CD_*): [ncols][M]
+  int logtot, logsub, s0, logM, l, m;
+  size_t col0;
+  unsigned S, slots_per_limb;
+};
+template <int SRC, class Mt>
+struct CrossIn {
+  using T = typename ArithOf<Mt>::T;
+  const T *p;  // this column of the source
+  const T *invfact;
+  Mt mod;
+  int M, m, n, h;
+  __device__ __forceinline__ int pbase(int) const { return 0; }
+  __device__ __forceinline__ T load(int base, int, int eoff, int) const {
+    const int k = base + eoff;
+    if (SRC == CS_SCALE_PAD) return k < M ? mulmod(p[k], invfact[k], mod) : T(0);  // values * 1/k!, zero padded
+    if (SRC == CS_FILL_RIGHT) return (k & (n - 1)) < h ? p[k + h] : T(0);         // per node: (F_right, 0)
+    if (SRC == CS_PAD_CENTER) return k < M ? center(p[k], mod) : T(0);
+    if (SRC == CS_REV_TRUNC) return k < m - 1 ? reduce(p[2 * m - 2 - k], mod) : T(0);  // T_k = P_{2m-2-k}, k < m-1
+    return p[k];
+  }
+};
+template <int DST, class Mt>
+struct CrossOut {
+  using T = typename ArithOf<Mt>::T;
+  T *p;  // this column of the sink
+  const T *invfact;
+  Mt mod;
+  int M, m, n, h;
+  __device__ __forceinline__ int pbase(int) const { return 0; }
+  __device__ __forceinline__ void store(int base, int, int eoff, int, T v) const {
+    const int k = base + eoff;
+    if (DST == CD_TAKE_LOW) {  // Newton coefficients k < m of the length-2M convolution
+      if (k < M) p[k] = (invfact[k] != T(0)) ? reduce(v, mod) : T(0);
+    } else if (DST == CD_COMBINE || DST == CD_COMBINE_CANON) {  // F_node = (F_left, 0) + D_left * F_right
+      const T f = reduce(addm(v, ((k & (n - 1)) < h ? p[k] : T(0)), mod), mod);
+      p[k] = DST == CD_COMBINE_CANON ? canon(f, mod) : f;
+    } else if (DST == CD_H_FINISH) {  // H_j = U_{m-2-j}; positions j > m-2 are cleared by h_patch_kernel
+      if (k <= m - 2) p[m - 2 - k] = reduce(v, mod);
+    } else if (DST == CD_H_FINISH_CANON) {  // no ZK patch to add: the finished column, canonical, zero above m-2
+      if (k <= m - 2)
+        p[m - 2 - k] = canon(v, mod);
+      else if (k < M)
+        p[k] = T(0);
+    } else {
+      p[k] = v;
+    }
+  }
+};
+
+// cross stages [s0, s0+R) of batched length-2^logsub transforms inside columns of length 2^logtot.
+// grid (x, columns).  MODE: CrossSrc for forward passes, CrossDst for inverse passes.
+template <bool INV, int R, int MODE, class CPS>
+__global__ void __launch_bounds__(256) cross_kernel(CrossArgs a, CPS plans) {
+  using T = typename CPS::T;
+  using Mt = typename CPS::M;
+  const size_t col = blockIdx.y;
+  const ColPlanT<Mt> &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const GlobalIOT<T> io{static_cast<T *>(a.W) + (col << a.logtot)};
+  const Lanes ln{(int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x)};
+  const int M = 1 << a.logM, n = 1 << a.l;
+  if (INV) {
+    if (MODE == CD_PLAIN) {
+      inv_round<R>(io, io, a.logtot, a.logsub, a.s0, P.itw, 1, P.mod, P.imask[a.logsub], ln);
+    } else {
+      const CrossOut<MODE, Mt> out{static_cast<T *>(a.dst) + (col << a.logM), P.invfact, P.mod, M, a.m, n, n >> 1};
+      inv_round<R>(io, out, a.logtot, a.logsub, a.s0, P.itw, 1, P.mod, P.imask[a.logsub], ln);
+    }
+  } else {
+    if (MODE == CS_PLAIN) {
+      fwd_round<R>(io, io, a.logtot, a.logsub, a.s0, P.tw, 1, P.mod, P.fmask[a.logsub], ln);
+    } else {
+      const size_t stride = MODE == CS_REV_TRUNC ? (size_t)2 << a.logM : (size_t)1 << a.logM;
+      const CrossIn<MODE, Mt> in{static_cast<const T *>(a.src) + col * stride, P.invfact, P.mod, M, a.m, n, n >> 1};
+      fwd_round<R>(in, io, a.logtot, a.logsub, a.s0, P.tw, 1, P.mod, P.fmask[a.logsub], ln);
+    }
+  }
+}
+
+// Sub-transforms on blocks of Bn = 2^logB doubles.  MODE 0: forward, 1: inverse, 2: forward,
+// multiply by tab[(blk % tab_period) * Bn + j], inverse (fused); 3: like 2 with a per-column table
+// (another workspace of the same shape, lazily reduced): tab[blk * Bn + j].  Block blk belongs to column
+// blk / blocks_per_col; inside its transform (n1 = 2^log_n1 blocks) it is block blk % n1.
+template <int MODE, class CPS>
+__global__ void __launch_bounds__(1024)
+sub_ntt_kernel(typename CPS::T *__restrict__ X, int logB, int log_n1, TabPtrs tabs, unsigned tab_period,
+               unsigned blocks_per_col, size_t col0, unsigned S, unsigned slots_per_limb, CPS plans) {
+  using T = typename CPS::T;
+  using Mt = typename CPS::M;
+  constexpr bool FP = std::is_same<Mt, Mod>::value;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T *s = reinterpret_cast<T *>(smem);
+  const int Bn = 1 << logB;
+  const size_t blk = blockIdx.x;
+  const size_t col = blk / blocks_per_col;
+  const int limb = (int)(((col0 + col) % S) / slots_per_limb);
+  const ColPlanT<Mt> &P = plans.l[limb];
+  const Mt mod = P.mod;
+  const int root = (1 << log_n1) + (int)(blk & ((1u << log_n1) - 1));
+  const int logn = logB + log_n1;
+  T *x = X + blk * (size_t)Bn;
+  for (int i = threadIdx.x; i < Bn; i += blockDim.x) s[pidx(i)] = x[i];
+  __syncthreads();
+  int logw = 0;
+  while ((64 << logw) < (int)blockDim.x) logw++;
+  const bool wp = FP && logw >= 1 && logw <= 4 && logB - logw >= 8;
+  if (MODE == 0 || MODE >= 2) {
+    bool done = false;
+    if constexpr (FP) {
+      if (wp) {
+        lds_ntt_fwd_wp<4, LdsIO, ColBlockFactory, 3>(s, LdsIO{s}, ColBlockFactory{s}, logB, logw, P.tw, mod, P.fmask[logn] >> log_n1, root);
+        __syncthreads();
+        done = true;
+      }
+    }
+    if (!done) lds_ntt_fwd<3>(s, logB, P.tw, root, mod, P.fmask[logn] >> log_n1);
+  }
+  if (MODE == 2) {  // table of slot-constant spectra: a table constant
+    const T *tab = static_cast<const T *>(tabs.t[limb]) + (size_t)(blk % tab_period) * Bn;
+    for (int i = threadIdx.x; i < Bn; i += blockDim.x) s[pidx(i)] = mulmod(reduce(s[pidx(i)], mod), tab[i], mod);
+    __syncthreads();
+  }
+  if (MODE == 3) {  // the other workspace: a spectrum computed on the device (data x data)
+    const T *tab = static_cast<const T *>(tabs.t[0]) + blk * (size_t)Bn;
+    for (int i = threadIdx.x; i < Bn; i += blockDim.x)
+      s[pidx(i)] = mulmod_dd(reduce(s[pidx(i)], mod), reduce(tab[i], mod), mod);
+    __syncthreads();
+  }
+  if (MODE >= 1) {
+    bool done = false;
+    if constexpr (FP) {
+      if (wp) {
+        lds_ntt_inv_wp<4, ColBlockFactory, LdsIO, 3>(s, ColBlockFactory{s}, LdsIO{s}, logB, logw, P.itw, mod, P.imask[logn], root);
+        done = true;
+      }
+    }
+    if (!done) lds_ntt_inv<3>(s, logB, P.itw, root, mod, P.imask[logn]);
+  }
+  for (int i = threadIdx.x; i < Bn; i += blockDim.x) x[i] = s[pidx(i)];
+}
+
+// Last forward round of a fused sub-transform: spectrum times a table that is itself a lazily reduced
+// spectrum (MODE 3: the other workspace).
+struct SubMulLazyOut {
+  double *sb;
+  const double *dh;
+  Mod mod;
+  __device__ __forceinline__ int pbase(int base) const { return pidx(base); }
+  __device__ __forceinline__ void store(int base, int pb, int eoff, int poff, double v) const {
+    sb[pcomb(pb, poff)] = mulmod(reduce(v, mod), reduce(dh[base + eoff], mod), mod);
+  }
+};
+struct SubMulLazyFactory {
+  double *s;
+  const double *dh_tile;
+  Mod mod;
+  __device__ __forceinline__ SubMulLazyOut operator()(int off) const { return SubMulLazyOut{s + pidx(off), dh_tile + off, mod}; }
+};
+
+#ifndef RS_SUB_MAXR
+#define RS_SUB_MAXR 4  // radix of the wave-private rounds of sub_ntt_ct_kernel
+#endif
+#ifdef RS_EXPERIMENTS  // superseded A/B variant (witness_sub_ct = 1): experiments build only
+// sub_ntt_kernel for the production tile (Bn = 2^LOGB, compile time; 512 threads, two workgroups per CU):
+//   * the cross-wave round of the forward transform reads the block straight from global memory and the
+//     cross-wave round of the inverse writes it straight back (no staging pass, no extra barriers);
+//   * the table product rides the last forward round's store (no separate pointwise pass);
+//   * forward-only blocks (MODE 0) are stored by the wave that finished them.
+// Same arithmetic and operation order per coefficient as sub_ntt_kernel: results are identical.
+template <int MODE, int LOGB>
+__global__ void __launch_bounds__(512, 4)
+sub_ntt_ct_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab_period, unsigned blocks_per_col, size_t col0,
+                  unsigned S, unsigned slots_per_limb, ColPlans plans) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  constexpr int LOGW = 3, Bn = 1 << LOGB;
+  const size_t blk = blockIdx.x;
+  const size_t col = blk / blocks_per_col;
+  const int limb = (int)(((col0 + col) % S) / slots_per_limb);
+  const ColPlan &P = plans.l[limb];
+  const Mod mod = P.mod;
+  const int root = (1 << log_n1) + (int)(blk & ((1u << log_n1) - 1));
+  const int logn = LOGB + log_n1;
+  double *x = X + blk * (size_t)Bn;
+  const GlobalF64IO gio{x};
+  const ColBlockFactory bf{s};
+  const uint32_t fmask = P.fmask[logn] >> log_n1, imask = P.imask[logn];
+  if (MODE == 0) {
+    lds_ntt_fwd_wp<RS_SUB_MAXR, GlobalF64IO, ColBlockFactory, 3>(s, gio, bf, LOGB, LOGW, P.tw, mod, fmask, root);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int BS = Bn >> LOGW;
+    const int off = wave * BS;
+    const double *sb = s + pidx(off);
+    const int p0 = pidx(lane);
+#pragma unroll
+    for (int j = 0; j < BS / 64; j++) x[off + lane + 64 * j] = sb[own_pidx(p0, lane, j)];
+    return;
+  }
+  if (MODE == 2) {
+    const double *tab = static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * Bn;
+    lds_ntt_fwd_wp<RS_SUB_MAXR, GlobalF64IO, TreeMulFactory, 3>(s, gio, TreeMulFactory{s, tab, mod}, LOGB, LOGW, P.tw, mod, fmask, root);
+  } else {
+    const double *tab = static_cast<const double *>(tabs.t[0]) + blk * (size_t)Bn;
+    lds_ntt_fwd_wp<RS_SUB_MAXR, GlobalF64IO, SubMulLazyFactory, 3>(s, gio, SubMulLazyFactory{s, tab, mod}, LOGB, LOGW, P.tw, mod, fmask, root);
+  }
+  lds_ntt_inv_wp<RS_SUB_MAXR, ColBlockFactory, GlobalF64IO, 3>(s, bf, gio, LOGB, LOGW, P.itw, mod, imask, root);
+}
+
+#endif  // RS_EXPERIMENTS
+
+// sub_ntt_ct_kernel in the wide form of ntt_wide.hpp (g_witness_sub_ct == 2): 256 threads x 32 coefficients per block of
+// 2^13, persistent, two workgroups per CU.  Forward rounds (4, 5, 4 stages); round 3 leaves every thread with 16
+// CONSECUTIVE spectrum points per group, which is exactly the operand set of the inverse's first round, so the table
+// product and inverse stages 0..3 follow in registers: the fused forward-multiply-inverse exchanges the tile four
+// times (eight LDS passes) instead of seven.  The twiddles of a block depend on its position in the long transform
+// (root), so they are fetched per block from the L2-resident table.  Same stage arithmetic and reduction points as
+// sub_ntt_ct_kernel: the stored (lazily reduced) values are identical.
+struct SubTw {  // twiddle fetch: 2^k consecutive table entries, 16-byte loads where the run allows
+  template <int CNT>
+  __device__ static __forceinline__ void run(const double *__restrict__ p, double *dst) {
+#ifdef RS_SUBW_ABLATE_TW  // experiment: no twiddle / table traffic (wrong results)
+#pragma unroll
+    for (int i = 0; i < CNT; i++) dst[i] = 3.0 + i + (double)threadIdx.x;
+    return;
+#endif
+    if (CNT == 1) {
+      dst[0] = p[0];
+    } else {
+#pragma unroll
+      for (int i = 0; i < CNT / 2; i++) {
+        const double2 v = reinterpret_cast<const double2 *>(p)[i];
+        dst[2 * i] = v.x;
+        dst[2 * i + 1] = v.y;
+      }
+    }
+  }
+};
+template <int MODE>
+__global__ void __launch_bounds__(256, 2)
+sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab_period, unsigned blocks_per_col, size_t col0,
+                    unsigned S_, unsigned slots_per_limb, ColPlans plans, unsigned long long nblocks,
+                    const double *__restrict__ Xsrc /* null: in place.  Else block b reads block b >> 1 of Xsrc: the two
+                    sub-transforms (roots 2 and 3) of ONE zero-padded block of 2^13 coefficients (two-dimensional block convolutions) */) {
+  using S = WideShape<13>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int t = threadIdx.x;
+  u64x2 pre[16];
+  auto issue_loads = [&](unsigned long long b) {
+    const u64x2 *src = reinterpret_cast<const u64x2 *>(Xsrc ? Xsrc + (b >> 1) * (size_t)S::N : X + b * (size_t)S::N) + t;
+#pragma unroll
+    for (int e = 0; e < 16; e++) pre[e] = src[(S::S / 2) * e];
+  };
+  unsigned long long blk = blockIdx.x;
+  if (blk < nblocks) issue_loads(blk);
+  for (; blk < nblocks; blk += gridDim.x) {
+    const size_t col = blk / blocks_per_col;
+    const int limb = (int)(((col0 + col) % S_) / slots_per_limb);
+    const ColPlan &P = plans.l[limb];
+    const Mod mod = P.mod;
+    const int root = (1 << log_n1) + (int)(blk & ((1u << log_n1) - 1));
+    const int logn = 13 + log_n1;
+    const uint32_t fmask = P.fmask[logn] >> log_n1, imask = P.imask[logn];
+    const double *__restrict__ tw = P.tw;
+    const double *__restrict__ itw = P.itw;
+    double v[2][16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      v[0][e] = u64_bits_as_double(pre[e].x);
+      v[1][e] = u64_bits_as_double(pre[e].y);
+      pin(v[0][e]);
+      pin(v[1][e]);
+    }
+    mem_fence();
+    const unsigned long long bn = blk + gridDim.x;
+    if (bn < nblocks) issue_loads(bn);
+    mem_fence();
+    // ---- forward round 1: stages 0..3 on elements 2t+c + 512e, twiddles tw[2^k root + blk] (uniform)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+      reg_fwd_stages<4, true>(v[c], mod, fmask, [&](int k, int b) { return tw[(root << k) + b]; });
+    __syncthreads();  // the previous block's last-round reads of the tile are done
+    {
+      const int pb = S::px(2 * t);
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        s[pb + S::SP * e] = v[0][e];
+        s[pb + S::SP * e + 1] = v[1][e];
+      }
+    }
+    __syncthreads();
+    // ---- forward round 2: stages 4..8 on hi*512 + lo + 16e
+    {
+      const int lo = t & 15, hi = t >> 4;
+      const int pb = hi * S::SP + lo;
+      double w[31];
+      SubTw::run<1>(tw + (root << 4) + hi, w);
+      SubTw::run<2>(tw + (root << 5) + (hi << 1), w + 1);
+      SubTw::run<4>(tw + (root << 6) + (hi << 2), w + 3);
+      SubTw::run<8>(tw + (root << 7) + (hi << 3), w + 7);
+      SubTw::run<16>(tw + (root << 8) + (hi << 4), w + 15);
+      double x[32];
+#pragma unroll
+      for (int e = 0; e < 32; e++) x[e] = s[pb + 17 * e];
+      reg_fwd_stages<5, true>(x, mod, fmask >> 4, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
+#pragma unroll
+      for (int e = 0; e < 32; e++) s[pb + 17 * e] = x[e];
+    }
+    __syncthreads();
+    // ---- forward round 3 (stages 9..12) on 16 consecutive points, table product, inverse round 1 (stages 0..3)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int g = t + 256 * j;
+      const int pb = S::px(16 * g);
+      double w[15];
+      SubTw::run<1>(tw + (root << 9) + g, w);
+      SubTw::run<2>(tw + (root << 10) + (g << 1), w + 1);
+      SubTw::run<4>(tw + (root << 11) + (g << 2), w + 3);
+      SubTw::run<8>(tw + (root << 12) + (g << 3), w + 7);
+      double x[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) x[e] = s[pb + e];
+      reg_fwd_stages<4, true>(x, mod, fmask >> 9, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) s[pb + e] = x[e];
+        continue;
+      }
+      {
+        // The table entries of the wave's 64 groups are 1024 consecutive words: fetched with coalesced 16-byte loads
+        // and handed to their owners through the wave's range of the tile, which is free once x has been read (a
+        // thread fetching its own 128-byte run touches 64 different lines per instruction).
+        const double *tab = (MODE == 2) ? static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * S::N
+                                        : static_cast<const double *>(tabs.t[0]) + blk * (size_t)S::N;
+        const int wave = t >> 6, lane = t & 63;
+        const int r0 = (j * 256 + wave * 64) * 16;
+        const int p0 = S::px(r0 + 2 * lane);
+        const double2 *t2 = reinterpret_cast<const double2 *>(tab + r0) + lane;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+#ifdef RS_SUBW_ABLATE_TW
+          const double2 v2 = make_double2(3.0 + i, 5.0 + lane);
+#else
+          const double2 v2 = t2[64 * i];
+#endif
+          s[p0 + S::px128(i)] = v2.x;
+          s[p0 + S::px128(i) + 1] = v2.y;
+        }
+        wave_sync();
+        if (MODE == 2) {
+#pragma unroll
+          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), s[pb + e], mod);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), reduce(s[pb + e], mod), mod);
+        }
+      }
+      // inverse stage k of the block: twiddle itw[(n >> (k+1)) root + (position >> (k+1))]
+      SubTw::run<8>(itw + ((size_t)root << 12) + (g << 3), w);
+      SubTw::run<4>(itw + ((size_t)root << 11) + (g << 2), w + 8);
+      SubTw::run<2>(itw + ((size_t)root << 10) + (g << 1), w + 12);
+      SubTw::run<1>(itw + ((size_t)root << 9) + g, w + 14);
+      reg_inv_stages<4, true>(x, mod, imask, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[pb + e] = x[e];
+    }
+    if (MODE == 0) {  // forward only: every wave streams out the ranges its own groups cover
+      wave_sync();
+      const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int r0 = (j * 256 + wave * 64) * 16;
+        const int p0 = S::px(r0 + 2 * lane);
+        double2 *d2 = reinterpret_cast<double2 *>(X + blk * (size_t)S::N + r0) + lane;
+#pragma unroll
+        for (int i = 0; i < 8; i++) d2[64 * i] = make_double2(s[p0 + S::px128(i)], s[p0 + S::px128(i) + 1]);
+      }
+      continue;
+    }
+    __syncthreads();
+    // ---- inverse round 2: stages 4..8; block of stage 4+k: (hi << (4-k)) + (e >> (k+1))
+    {
+      const int lo = t & 15, hi = t >> 4;
+      const int pb = hi * S::SP + lo;
+      double w[31];
+      SubTw::run<16>(itw + ((size_t)root << 8) + (hi << 4), w);
+      SubTw::run<8>(itw + ((size_t)root << 7) + (hi << 3), w + 16);
+      SubTw::run<4>(itw + ((size_t)root << 6) + (hi << 2), w + 24);
+      SubTw::run<2>(itw + ((size_t)root << 5) + (hi << 1), w + 28);
+      SubTw::run<1>(itw + ((size_t)root << 4) + hi, w + 30);
+      double x[32];
+#pragma unroll
+      for (int e = 0; e < 32; e++) x[e] = s[pb + 17 * e];
+      reg_inv_stages<5, true>(x, mod, imask >> 4, [&](int k, int i) { return w[32 - (32 >> k) + i]; });
+#pragma unroll
+      for (int e = 0; e < 32; e++) s[pb + 17 * e] = x[e];
+    }
+    __syncthreads();
+    // ---- inverse round 3: stages 9..12 on elements 2t+c + 512e; block of stage 9+k: e >> (k+1) of 8 >> k
+    {
+      const int pb = S::px(2 * t);
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        v[0][e] = s[pb + S::SP * e];
+        v[1][e] = s[pb + S::SP * e + 1];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+      reg_inv_stages<4, true>(v[c], mod, imask >> 9, [&](int k, int i) { return itw[((8 >> k) * root) + i]; });
+    {
+      double2 *dst = reinterpret_cast<double2 *>(X + blk * (size_t)S::N) + t;
+#pragma unroll
+      for (int e = 0; e < 16; e++) dst[(S::S / 2) * e] = make_double2(v[0][e], v[1][e]);
+    }
+  }
+}
+
+#ifdef RS_EXPERIMENTS  // superseded A/B variant (witness_sub_ct = 3, measured 11 % slower): experiments build only
+// sub_ntt_wide_kernel at FOUR waves per SIMD (g_witness_sub_ct == 3): 512 threads x 16 coefficients per block of 2^13,
+// <= 128 registers, two workgroups (16 waves) per CU.  Forward rounds of 4, 3 and 2 stages, then the same fused middle
+// as the 32-coefficient form on 16 consecutive points (forward stages 9..12, table product, inverse stages 0..3), then
+// the mirror image: six tile exchanges instead of four, twice the waves to hide them behind.  Same stages, reduction
+// points and products: identical stored values.
+template <int MODE>
+__global__ void __launch_bounds__(512, 4)
+sub_ntt_wide16_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab_period, unsigned blocks_per_col, size_t col0,
+                      unsigned S_, unsigned slots_per_limb, ColPlans plans, unsigned long long nblocks) {
+  using S = WideShape<13>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int pt = t + (t >> 4);  // px(t), t < 512
+  double pre[16];
+  auto issue_loads = [&](unsigned long long b) {
+    const double *src = X + b * (size_t)S::N + t;
+#pragma unroll
+    for (int e = 0; e < 16; e++) pre[e] = src[512 * e];
+  };
+  unsigned long long blk = blockIdx.x;
+  if (blk < nblocks) issue_loads(blk);
+  for (; blk < nblocks; blk += gridDim.x) {
+    const size_t col = blk / blocks_per_col;
+    const int limb = (int)(((col0 + col) % S_) / slots_per_limb);
+    const ColPlan &P = plans.l[limb];
+    const Mod mod = P.mod;
+    const int root = (1 << log_n1) + (int)(blk & ((1u << log_n1) - 1));
+    const int logn = 13 + log_n1;
+    const uint32_t fmask = P.fmask[logn] >> log_n1, imask = P.imask[logn];
+    const double *__restrict__ tw = P.tw;
+    const double *__restrict__ itw = P.itw;
+    double v[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      v[e] = pre[e];
+      pin(v[e]);
+    }
+    mem_fence();
+    const unsigned long long bn = blk + gridDim.x;
+    if (bn < nblocks) issue_loads(bn);
+    mem_fence();
+    // ---- forward round 1: stages 0..3 on elements t + 512 e (uniform twiddles)
+    reg_fwd_stages<4, true>(v, mod, fmask, [&](int k, int b) { return tw[(root << k) + b]; });
+    __syncthreads();  // the previous block's last-round reads of the tile are done
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[pt + S::SP * e] = v[e];
+    __syncthreads();
+    // ---- forward round 2: stages 4..6 on hi*512 + lo + 64 e; hi = wave + 8 j is wave-uniform
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int hi = __builtin_amdgcn_readfirstlane(wave + 8 * j);
+      const int pb = hi * S::SP + lane + (lane >> 4);
+      double x[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) x[e] = s[pb + 68 * e];
+      reg_fwd_stages<3, true>(x, mod, fmask >> 4, [&](int k, int b) { return tw[(root << (4 + k)) + (hi << k) + b]; });
+#pragma unroll
+      for (int e = 0; e < 8; e++) s[pb + 68 * e] = x[e];
+    }
+    __syncthreads();
+    // ---- forward round 3: stages 7..8 on hi*64 + lo + 16 e
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int g = t + 512 * j, lo = g & 15, hi = g >> 4;
+      const int pb = hi * 68 + (hi >> 3) * 16 + lo;
+      double x[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) x[e] = s[pb + 17 * e];
+      const double w0 = tw[(root << 7) + hi];
+      const double2 w12 = reinterpret_cast<const double2 *>(tw + (root << 8) + (hi << 1))[0];
+      reg_fwd_stages<2, true>(x, mod, fmask >> 7, [&](int k, int b) { return k == 0 ? w0 : (b == 0 ? w12.x : w12.y); });
+#pragma unroll
+      for (int e = 0; e < 4; e++) s[pb + 17 * e] = x[e];
+    }
+    __syncthreads();
+    // ---- the middle on the 16 consecutive points of group t: forward stages 9..12, table product, inverse stages 0..3
+    {
+      const int pb = 17 * t + (t >> 5) * 16;  // px(16 t)
+      double w[15];
+      SubTw::run<1>(tw + (root << 9) + t, w);
+      SubTw::run<2>(tw + (root << 10) + (t << 1), w + 1);
+      SubTw::run<4>(tw + (root << 11) + (t << 2), w + 3);
+      SubTw::run<8>(tw + (root << 12) + (t << 3), w + 7);
+      double x[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) x[e] = s[pb + e];
+      reg_fwd_stages<4, true>(x, mod, fmask >> 9, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
+      if (MODE != 0) {
+        // the wave's 64 groups are 1024 consecutive table words: coalesced loads, handed over through its (free) range
+        const double *tab = (MODE == 2) ? static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * S::N
+                                        : static_cast<const double *>(tabs.t[0]) + blk * (size_t)S::N;
+        const int r0 = wave * 1024;
+        const int p0 = S::px(r0 + 2 * lane);
+        const double2 *t2 = reinterpret_cast<const double2 *>(tab + r0) + lane;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const double2 v2 = t2[64 * i];
+          s[p0 + S::px128(i)] = v2.x;
+          s[p0 + S::px128(i) + 1] = v2.y;
+        }
+        wave_sync();
+        if (MODE == 2) {
+#pragma unroll
+          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), s[pb + e], mod);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), reduce(s[pb + e], mod), mod);
+        }
+        SubTw::run<8>(itw + ((size_t)root << 12) + (t << 3), w);
+        SubTw::run<4>(itw + ((size_t)root << 11) + (t << 2), w + 8);
+        SubTw::run<2>(itw + ((size_t)root << 10) + (t << 1), w + 12);
+        SubTw::run<1>(itw + ((size_t)root << 9) + t, w + 14);
+        reg_inv_stages<4, true>(x, mod, imask, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[pb + e] = x[e];
+    }
+    if (MODE == 0) {  // forward only: every wave streams out the 1024 points its own groups cover
+      wave_sync();
+      const int r0 = wave * 1024;
+      const int p0 = S::px(r0 + 2 * lane);
+      double2 *d2 = reinterpret_cast<double2 *>(X + blk * (size_t)S::N + r0) + lane;
+#pragma unroll
+      for (int i = 0; i < 8; i++) d2[64 * i] = make_double2(s[p0 + S::px128(i)], s[p0 + S::px128(i) + 1]);
+      continue;
+    }
+    __syncthreads();
+    // ---- inverse round 3: stages 4..5 on hi*64 + lo + 16 e; block of stage 4+k: (hi << (1-k)) + (e >> (k+1)) of 256 >> k
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int g = t + 512 * j, lo = g & 15, hi = g >> 4;
+      const int pb = hi * 68 + (hi >> 3) * 16 + lo;
+      double x[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) x[e] = s[pb + 17 * e];
+      const double2 w01 = reinterpret_cast<const double2 *>(itw + ((size_t)root << 8) + (hi << 1))[0];
+      const double w2 = itw[((size_t)root << 7) + hi];
+      reg_inv_stages<2, true>(x, mod, imask >> 4, [&](int k, int i) { return k == 0 ? (i == 0 ? w01.x : w01.y) : w2; });
+#pragma unroll
+      for (int e = 0; e < 4; e++) s[pb + 17 * e] = x[e];
+    }
+    __syncthreads();
+    // ---- inverse round 2: stages 6..8 on hi*512 + lo + 64 e; block of stage 6+k: (hi << (2-k)) + (e >> (k+1)) of 64 >> k
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int hi = __builtin_amdgcn_readfirstlane(wave + 8 * j);
+      const int pb = hi * S::SP + lane + (lane >> 4);
+      double x[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) x[e] = s[pb + 68 * e];
+      reg_inv_stages<3, true>(x, mod, imask >> 6, [&](int k, int i) { return itw[((size_t)root << (6 - k)) + (hi << (2 - k)) + i]; });
+#pragma unroll
+      for (int e = 0; e < 8; e++) s[pb + 68 * e] = x[e];
+    }
+    __syncthreads();
+    // ---- inverse round 1: stages 9..12 on elements t + 512 e; block of stage 9+k: e >> (k+1) of 8 >> k
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = s[pt + S::SP * e];
+    reg_inv_stages<4, true>(v, mod, imask >> 9, [&](int k, int i) { return itw[((8 >> k) * root) + i]; });
+    {
+      double *dst = X + blk * (size_t)S::N + t;
+#pragma unroll
+      for (int e = 0; e < 16; e++) dst[512 * e] = v[e];
+    }
+  }
+}
+#endif  // RS_EXPERIMENTS
+
+// ZK patch of the multi-pass H: H += d2*A + d1*B + d1*d2*Z, H[0] -= d3; then canonical form.
+template <class CPS>
+__global__ void __launch_bounds__(256)
+h_patch_kernel(typename CPS::T *__restrict__ H, const typename CPS::T *__restrict__ A, const typename CPS::T *__restrict__ B, int logM,
+               int m, size_t cols, size_t col0, unsigned S, unsigned slots_per_limb, CPS plans, const uint64_t *__restrict__ d1,
+               const uint64_t *__restrict__ d2, const uint64_t *__restrict__ d3, ColMap cm) {
+  using T = typename CPS::T;
+  const size_t M = (size_t)1 << logM, total = cols * M, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t col = i / M, k = i % M, gcol = (col0 + col) % S;
+    const ColPlanT<typename CPS::M> &P = plans.l[gcol / slots_per_limb];
+    const typename CPS::M mod = P.mod;
+    T h = ((long long)k <= (long long)m - 2) ? H[i] : T(0);
+    if (d1) {
+      int dlimb, dslot;
+      cm.locate(gcol, dlimb, dslot);
+      const size_t di = cm.in_index(dlimb, dslot);
+      const T e1 = center(from_res<T>(d1[di]), mod), e2 = center(from_res<T>(d2[di]), mod);
+      h = addm(h, addm(addm(mulmod_dd(e2, center(A[i], mod), mod), mulmod_dd(e1, center(B[i], mod), mod), mod),
+                       mulmod(mulmod_dd(e1, e2, mod), P.ztab[k], mod), mod), mod);
+      if (k == 0) h = subm(h, center(from_res<T>(d3[di]), mod), mod);
+    }
+    H[i] = canon(h, mod);
+  }
+}
+
+}  // namespace rs

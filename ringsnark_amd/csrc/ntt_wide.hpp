@@ -213,7 +213,9 @@ __device__ __forceinline__ void wide_fwd_body(double *s, const double *twl, cons
 #pragma unroll
     for (int e = 0; e < S::E2; e++) s[pb + S::px2(e)] = x[e];
   }
-  __syncthreads();
+  // 16384 points: a thread's round-2 group and its round-3 group lie in the same S-element block, which 32 consecutive
+  // threads own in both rounds -- no workgroup barrier (8192 / 4096 points: round 3's second group is another wave's block)
+  if (S::G2 == 1 && S::G3 == 1) wave_sync(); else __syncthreads();
   // round 3: stages LOGN-R3..LOGN-1 on E3 consecutive elements; results parked canonical for the flush
 #pragma unroll
   for (int j = 0; j < S::G3; j++) {
@@ -371,7 +373,7 @@ ntt_inv_wide_kernel(uint64_t *__restrict__ data, unsigned long long batch, const
 #pragma unroll
       for (int e = 0; e < S::E3; e++) s[pb + e + (e >> 4)] = x[e];
     }
-    __syncthreads();
+    if (S::G2 == 1 && S::G3 == 1) wave_sync(); else __syncthreads();  // 16384 points: rounds 1 and 2 share their 32-thread blocks
     // round 2: inverse stages R3..R3+R2-1 on groups hi*S + lo + ST2*e; block of stage R3+k: (hi << (R2-1-k)) + (e >> (k+1))
 #pragma unroll
     for (int j = 0; j < S::G2; j++) {

@@ -59,6 +59,15 @@ struct WideShape {
   static constexpr size_t LDS_BYTES = (size_t)(TILE + TWL) * sizeof(double);
 };
 
+// Group j of thread t in the round on consecutive elements.  One middle-round group per thread (8192, 16384 points): the
+// thread's groups are NEIGHBOURS (32 consecutive elements), inside the S-element block its middle-round group lies in, so
+// the exchange between the two rounds stays within the block's 16 / 32 consecutive threads.  4096 points: groups t, t + T.
+template <int LOGN>
+__device__ __forceinline__ int wide_group(int t, int j) {
+  using S = WideShape<LOGN>;
+  return S::G2 == 1 ? S::G3 * t + j : t + S::T * j;
+}
+
 // R forward stages on a register tile of 2^R values; tw(k, blk) = twiddle of block blk of local stage k.
 template <int R, bool RED, class TwFn>
 __device__ __forceinline__ void reg_fwd_stages(double (&v)[1 << R], const Mod mod, uint32_t red_mask, TwFn tw) {
@@ -153,11 +162,12 @@ __device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void mem_fence() { asm volatile("" ::: "memory"); }
 
 // First element of the j-th (j = 0, 1) 1024-element range covered by the consecutive-element groups of wave `wave`:
-// two groups of 16 per thread (groups t and t + T), or one group of 32 (16384 points).
+// 32 consecutive elements per thread (8192 points: two neighbouring groups of 16; 16384 points: one group of 32), or --
+// 4096 points -- the groups t and t + T.
 template <int LOGN>
 __device__ __forceinline__ int wide_wave_range(int wave, int j) {
   using S = WideShape<LOGN>;
-  return S::G3 == 2 ? (j * S::T + wave * 64) * 16 : (2 * wave + j) * 1024;
+  return (S::G3 == 2 && S::G2 != 1) ? (j * S::T + wave * 64) * 16 : (2 * wave + j) * 1024;
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------
@@ -213,13 +223,13 @@ __device__ __forceinline__ void wide_fwd_body(double *s, const double *twl, cons
 #pragma unroll
     for (int e = 0; e < S::E2; e++) s[pb + S::px2(e)] = x[e];
   }
-  // 16384 points: a thread's round-2 group and its round-3 group lie in the same S-element block, which 32 consecutive
-  // threads own in both rounds -- no workgroup barrier (8192 / 4096 points: round 3's second group is another wave's block)
-  if (S::G2 == 1 && S::G3 == 1) wave_sync(); else __syncthreads();
+  // 8192 / 16384 points: a thread's round-2 group and its round-3 groups lie in the same S-element block, which 16 / 32
+  // consecutive threads own in both rounds -- no workgroup barrier (4096 points: two round-2 groups per thread, two blocks)
+  if (S::G2 == 1) wave_sync(); else __syncthreads();
   // round 3: stages LOGN-R3..LOGN-1 on E3 consecutive elements; results parked canonical for the flush
 #pragma unroll
   for (int j = 0; j < S::G3; j++) {
-    const int g = t + S::T * j;
+    const int g = wide_group<LOGN>(t, j);
     const int pb = S::px(S::E3 * g);
     double x[S::E3];
 #pragma unroll
@@ -245,7 +255,7 @@ ntt_fwd_wide_kernel(uint64_t *__restrict__ data, unsigned long long batch, const
   double tw3[S::G3][S::E3 - 1];
 #pragma unroll
   for (int j = 0; j < S::G3; j++) {
-    const int g = t + S::T * j;
+    const int g = wide_group<LOGN>(t, j);
 #pragma unroll
     for (int k = 0; k < S::R3; k++)
 #pragma unroll
@@ -305,7 +315,7 @@ ntt_inv_wide_kernel(uint64_t *__restrict__ data, unsigned long long batch, const
   double tw1[S::G3][S::E3 - 1];
 #pragma unroll
   for (int j = 0; j < S::G3; j++) {
-    const int g = t + S::T * j;
+    const int g = wide_group<LOGN>(t, j);
 #pragma unroll
     for (int k = 0; k < S::R3; k++)
 #pragma unroll
@@ -364,7 +374,7 @@ ntt_inv_wide_kernel(uint64_t *__restrict__ data, unsigned long long batch, const
     // round 1: inverse stages 0..R3-1 on E3 consecutive elements
 #pragma unroll
     for (int j = 0; j < S::G3; j++) {
-      const int g = t + S::T * j;
+      const int g = wide_group<LOGN>(t, j);
       const int pb = S::px(S::E3 * g);
       double x[S::E3];
 #pragma unroll
@@ -373,7 +383,7 @@ ntt_inv_wide_kernel(uint64_t *__restrict__ data, unsigned long long batch, const
 #pragma unroll
       for (int e = 0; e < S::E3; e++) s[pb + e + (e >> 4)] = x[e];
     }
-    if (S::G2 == 1 && S::G3 == 1) wave_sync(); else __syncthreads();  // 16384 points: rounds 1 and 2 share their 32-thread blocks
+    if (S::G2 == 1) wave_sync(); else __syncthreads();  // 8192 / 16384 points: rounds 1 and 2 share their 16- / 32-thread blocks
     // round 2: inverse stages R3..R3+R2-1 on groups hi*S + lo + ST2*e; block of stage R3+k: (hi << (R2-1-k)) + (e >> (k+1))
 #pragma unroll
     for (int j = 0; j < S::G2; j++) {

@@ -331,7 +331,16 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     if (crs_on_host) return stage_at(cur_tile & 1, c);
     return d_crs[c] + (crs_window ? t0 % crs_window : t0) * enc_words;
   };
-  int n_chunks = (int)std::min<size_t>(tile_terms, (size_t)std::max(1, (g_mac_chunk_units + L * K - 1) / (L * K)));
+  // mac_kernel_v4 (two key vectors) runs ONE workgroup per CU: half the workgroup slots, half the chunks (measured at the
+  // configs[3] shape: 111 -> 106 ms)
+  const int chunk_units = (n_crs == 2 && g_mac_share_keys && g_mac_variant == 5 && (n == 8192 || n == 16384)) ? (g_mac_chunk_units + 1) / 2
+                                                                                                              : g_mac_chunk_units;
+  int n_chunks = (int)std::min<size_t>(tile_terms, (size_t)std::max(1, (chunk_units + L * K - 1) / (L * K)));
+  {  // the (chunk, limb) rows of a launch are dealt to the 8 XCDs: a row count that is not a multiple of 8 leaves slots idle
+    int step = 8;
+    while (step > 1 && (L * (step / 2)) % 8 == 0) step /= 2;  // smallest chunk-count granule with L * granule = 0 mod 8
+    if (n_chunks >= step && (size_t)((n_chunks + step - 1) / step * step) <= tile_terms) n_chunks = (n_chunks + step - 1) / step * step;
+  }
   if (Tmax == 0) n_chunks = 1;
   Lift *d_C = (Lift *)ws_get(ctx, 0, std::max<size_t>(256, tile_terms * c_bytes_per_term));
   uint64_t *d_partial = (uint64_t *)ws_get(ctx, 1, (size_t)n_chunks * n_sets * enc_words * sizeof(uint64_t));

@@ -370,8 +370,10 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
   for (int i = 0; i < 15; i++) pin(tw3[i]);
   // wave-uniform twiddles of stage 0 and round 1, as scalar registers: fetched through the table pointer inside the
   // term loop they would be vector loads, and waiting for the youngest vector load drains the ciphertext stream
+  // twiddles of the folded stages, with the sign of this workgroup's half: x + w y for the low half, x - w y for the high
   const double w0 = uniform_f64(tw[1]);
   const double w1 = uniform_f64(tw[2 + (h >> 1)]);  // LOGN = 14: stage 1 of this quarter's half
+  const double w0s = (LOGN == 13 ? (h & 1) : (h & 2)) ? -w0 : w0, w1s = (h & 1) ? -w1 : w1;
   double tw1[15];
 #pragma unroll
   for (int k = 0; k < 4; k++)
@@ -490,19 +492,25 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
       load_row_b();
       crow += (size_t)L * n;
       mem_fence();
-      // stage 0 (gap 4096): this half's operand of the 4096-point sub-transform
+      // stage 0 (gap 4096): this half's operand of the 4096-point sub-transform, x[n'] + (+-w0) x[n' + 4096] (the sign of
+      // the half rides on the twiddle: mulmod(a, -w) = -mulmod(a, w) exactly).  The reductions the mask asks for are whole
+      // guarded passes over the registers: inside the element loops the compiler turns them into compute-and-select.
+      if (red_mask & 1u) {
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        double bq = ch[e];
-        if (red_mask & 1u) bq = reduce(bq, mod);
-        ch[e] = mulmod(bq, w0, mod);
-        pin(ch[e]);
+        for (int e = 0; e < 16; e++) ch[e] = reduce(ch[e], mod);
       }
 #pragma unroll
       for (int e = 0; e < 16; e++) {
-        double aq = cl[e];
-        if (red_mask & 1u) aq = reduce(aq, mod);
-        v[e] = h ? aq - ch[e] : aq + ch[e];
+        ch[e] = mulmod(ch[e], w0s, mod);
+        pin(ch[e]);
+      }
+      if (red_mask & 1u) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) cl[e] = reduce(cl[e], mod);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        v[e] = cl[e] + ch[e];
         pin(v[e]);
       }
     } else {
@@ -520,23 +528,27 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
 #pragma unroll
       for (int e = 0; e < 16; e++) v[e] = crow[256 * e];
       mem_fence();
+      if (red_mask & 1u) {
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        double x2 = cl[e], x3 = ch[e];
-        if (red_mask & 1u) {
-          x2 = reduce(x2, mod);
-          x3 = reduce(x3, mod);
+        for (int e = 0; e < 16; e++) {
+          cl[e] = reduce(cl[e], mod);
+          ch[e] = reduce(ch[e], mod);
         }
-        cl[e] = mulmod(x2, w0, mod);
-        ch[e] = mulmod(x3, w0, mod);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) {  // (+-w0) x2, (+-w0) x3: the sign of this quarter's half of stage 0 rides on the twiddle
+        cl[e] = mulmod(cl[e], w0s, mod);
+        ch[e] = mulmod(ch[e], w0s, mod);
         pin(cl[e]);
         pin(ch[e]);
       }
+      if (red_mask & 1u) {
 #pragma unroll
-      for (int e = 0; e < 16; e++) {  // u0 = x0 +- w0 x2 (this quarter's half of stage 0)
-        double x0 = v[e];
-        if (red_mask & 1u) x0 = reduce(x0, mod);
-        cl[e] = (h & 2) ? x0 - cl[e] : x0 + cl[e];
+        for (int e = 0; e < 16; e++) v[e] = reduce(v[e], mod);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) {  // u0 = x0 +- w0 x2
+        cl[e] = v[e] + cl[e];
         pin(cl[e]);
       }
       mem_fence();
@@ -544,17 +556,25 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
       for (int e = 0; e < 16; e++) v[e] = crow[256 * e + H];
       crow += (size_t)L * n;
       mem_fence();
+      if (red_mask & 1u) {
 #pragma unroll
-      for (int e = 0; e < 16; e++) {  // u1 = x1 +- w0 x3, then stage 1: v = u0 +- w1 u1
-        double x1 = v[e];
-        if (red_mask & 1u) x1 = reduce(x1, mod);
-        double u1 = (h & 2) ? x1 - ch[e] : x1 + ch[e];
-        if (red_mask & 2u) {
-          u1 = reduce(u1, mod);
+        for (int e = 0; e < 16; e++) v[e] = reduce(v[e], mod);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) {  // u1 = x1 +- w0 x3
+        ch[e] = v[e] + ch[e];
+        pin(ch[e]);
+      }
+      if (red_mask & 2u) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          ch[e] = reduce(ch[e], mod);
           cl[e] = reduce(cl[e], mod);
         }
-        u1 = mulmod(u1, w1, mod);
-        v[e] = (h & 1) ? cl[e] - u1 : cl[e] + u1;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) {  // stage 1: v = u0 + (+-w1) u1
+        v[e] = cl[e] + mulmod(ch[e], w1s, mod);
         pin(v[e]);
       }
     }
@@ -655,6 +675,7 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
   const int root = PARTS + h;
   const double w0 = uniform_f64(tw[1]);
   const double w1 = uniform_f64(tw[2 + (h >> 1)]);  // LOGN = 14: stage 1 of this quarter's half
+  const double w0s = (LOGN == 13 ? (h & 1) : (h & 2)) ? -w0 : w0, w1s = (h & 1) ? -w1 : w1;  // with the sign of this workgroup's half
   double tw1[7], tw2[7], tw3[7], tw4[7];
 #pragma unroll
   for (int k = 0; k < 3; k++)
@@ -752,15 +773,16 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
       mem_fence();
       if (tt > tbeg) mac(s + (int)((tt - tbeg + 1) & 1) * TILE);  // term tt - 1, under the row loads
       mem_fence();
+      if (red_mask & 1u) {  // a guarded pass: inside the element loop the reduction becomes compute-and-select
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        double x0 = v[e], x1 = c2[e];
-        if (red_mask & 1u) {
-          x0 = reduce(x0, mod);
-          x1 = reduce(x1, mod);
+        for (int e = 0; e < 8; e++) {
+          v[e] = reduce(v[e], mod);
+          c2[e] = reduce(c2[e], mod);
         }
-        x1 = mulmod(x1, w0, mod);
-        v[e] = h ? x0 - x1 : x0 + x1;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) {  // the sign of the half rides on the twiddle: mulmod(a, -w) = -mulmod(a, w) exactly
+        v[e] = v[e] + mulmod(c2[e], w0s, mod);
         pin(v[e]);
       }
     } else {
@@ -776,23 +798,27 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
 #pragma unroll
       for (int e = 0; e < 8; e++) v[e] = crow[512 * e];
       mem_fence();
+      if (red_mask & 1u) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        double x2 = c2[e], x3 = c3[e];
-        if (red_mask & 1u) {
-          x2 = reduce(x2, mod);
-          x3 = reduce(x3, mod);
+        for (int e = 0; e < 8; e++) {
+          c2[e] = reduce(c2[e], mod);
+          c3[e] = reduce(c3[e], mod);
         }
-        c2[e] = mulmod(x2, w0, mod);
-        c3[e] = mulmod(x3, w0, mod);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) {  // (+-w0) x2, (+-w0) x3: the sign of this quarter's half of stage 0 rides on the twiddle
+        c2[e] = mulmod(c2[e], w0s, mod);
+        c3[e] = mulmod(c3[e], w0s, mod);
         pin(c2[e]);
         pin(c3[e]);
       }
+      if (red_mask & 1u) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) {  // u0 = x0 +- w0 x2 (this quarter's half of stage 0)
-        double x0 = v[e];
-        if (red_mask & 1u) x0 = reduce(x0, mod);
-        c2[e] = (h & 2) ? x0 - c2[e] : x0 + c2[e];
+        for (int e = 0; e < 8; e++) v[e] = reduce(v[e], mod);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) {  // u0 = x0 +- w0 x2
+        c2[e] = v[e] + c2[e];
         pin(c2[e]);
       }
       mem_fence();
@@ -800,17 +826,25 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
       for (int e = 0; e < 8; e++) v[e] = crow[512 * e + H];
       crow += (size_t)L * n;
       mem_fence();
+      if (red_mask & 1u) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) {  // u1 = x1 +- w0 x3, then stage 1: v = u0 +- w1 u1
-        double x1 = v[e];
-        if (red_mask & 1u) x1 = reduce(x1, mod);
-        double u1 = (h & 2) ? x1 - c3[e] : x1 + c3[e];
-        if (red_mask & 2u) {
-          u1 = reduce(u1, mod);
+        for (int e = 0; e < 8; e++) v[e] = reduce(v[e], mod);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) {  // u1 = x1 +- w0 x3
+        c3[e] = v[e] + c3[e];
+        pin(c3[e]);
+      }
+      if (red_mask & 2u) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          c3[e] = reduce(c3[e], mod);
           c2[e] = reduce(c2[e], mod);
         }
-        u1 = mulmod(u1, w1, mod);
-        v[e] = (h & 1) ? c2[e] - u1 : c2[e] + u1;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) {  // stage 1: v = u0 + (+-w1) u1
+        v[e] = c2[e] + mulmod(c3[e], w1s, mod);
         pin(v[e]);
       }
     }

@@ -79,5 +79,10 @@ RS_HD uint64_t to_u64(double v) {
 // balanced representative of a canonical residue (|result| <= (p-1)/2): the SEAL centred lift
 // rule c >= (t+1)/2  =>  c - t   (Evaluator::transform_to_ntt_inplace on a Plaintext).
 RS_HD double center(double c, const Mod &m) { return (c + c > m.p) ? c - m.p : c; }
+// The same centred representative straight from a balanced value with |a| <= p (a mulmod result, a partially reduced
+// sum): one reduction step decides exactly, because the integer a is at least 1/(2p) >= 2^-51 away from the rounding
+// boundaries +-p/2 in units of p while the computed quotient a*pinv errs by less than 2^-52.  Equals center(canon(a)):
+// three instructions instead of twelve (two compares and four 64-bit selects among them).
+RS_HD double center_balanced(double a, const Mod &m) { return reduce(a, m); }
 
 }  // namespace rs

@@ -322,8 +322,8 @@ plain_center_wide_kernel(PlainArgs args, double *__restrict__ C, unsigned long l
 #pragma unroll
         for (int e = 0; e < 8; e++) {
           const double a = w[c][e], b = w[c][e + 8];
-          acc[c][e] += lift_centered(canon(mulmod(a + b, ninv, mod), mod), mod);
-          acc[c][e + 8] += lift_centered(canon(mulmod(a - b, w_last, mod), mod), mod);
+          acc[c][e] += center_balanced(mulmod(a + b, ninv, mod), mod);
+          acc[c][e + 8] += center_balanced(mulmod(a - b, w_last, mod), mod);
         }
       }
     }
@@ -355,7 +355,7 @@ plain_center_wide_kernel(PlainArgs args, double *__restrict__ C, unsigned long l
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
-          for (int e = 0; e < 8; e++) acc[c][8 * half + e] += lift_centered(canon(a[c][e], mod), mod);
+          for (int e = 0; e < 8; e++) acc[c][8 * half + e] += center_balanced(reduce(a[c][e], mod), mod);
       }
     }
     double *dst = C + (((size_t)g * tile_terms + tt) * L + limb) * (size_t)S::N;

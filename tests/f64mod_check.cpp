@@ -56,7 +56,18 @@ int main(int argc, char **argv) {
       expect(rs::to_u64(rs::from_u64(u)) == u && rs::from_u64(u) == (double)u, "u64 roundtrip");
       double ce = rs::center((double)u, m);
       expect((u >= (p + 1) / 2) ? (ce == (double)u - (double)p) : (ce == (double)u), "center");
+      // center_balanced: the same representative straight from a mulmod result (|r| <= 0.75 p) and from reduce(big)
+      expect(rs::center_balanced(r, m) == rs::center(c, m), "center_balanced of a product");
+      expect(rs::center_balanced(rr, m) == rs::center(cc, m), "center_balanced of a reduced value");
     }
+    // the decision boundaries themselves: a = +-(p-1)/2 stays, +-(p+1)/2 wraps, and everything within 3 of +-p/2, +-p, 0
+    for (int64_t base : {(int64_t)(p / 2), -(int64_t)(p / 2), (int64_t)p, -(int64_t)p, (int64_t)0, (int64_t)(p - p / 4), -(int64_t)(p - p / 4)})
+      for (int64_t d = -3; d <= 3; d++) {
+        const int64_t a = base + d;
+        if (a > (int64_t)p || a < -(int64_t)p) continue;
+        const double want = rs::center((double)imod((i128)a, p), m);
+        expect(rs::center_balanced((double)a, m) == want, "center_balanced at a boundary");
+      }
   }
   if (fails) { fprintf(stderr, "%lld failures\n", fails); return 1; }
   printf("ok\n");

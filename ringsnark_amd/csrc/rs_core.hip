@@ -89,6 +89,17 @@ uint32_t fwd_reduce_mask(uint64_t p, int logn) {
   }
   return mask;
 }
+// Whether the outputs of a forward transform of length 2^logn (masks as above, inputs |v| <= p) may exceed 2^50: then
+// they are reduced before the pointwise product with a (balanced) table entry; below that the product is exact as is.
+bool fwd_end_needs_reduce(uint64_t p, int logn) {
+  const double lim = 1125899906842624.0 / (double)p;
+  double B = 1.0;
+  for (int s = 0; s < logn; s++) {
+    if (B > lim) B = 0.51;
+    B += 0.75;
+  }
+  return B > lim;
+}
 uint32_t inv_reduce_mask(uint64_t p, int logn) {
   const double lim = 1125899906842624.0 / (double)p;
   double B = 1.0;

@@ -267,6 +267,7 @@ void free_table(NttTableT<T, M> &t) {
 }
 uint32_t fwd_reduce_mask(uint64_t p, int logn);
 uint32_t inv_reduce_mask(uint64_t p, int logn);
+bool fwd_end_needs_reduce(uint64_t p, int logn);
 inline hipStream_t S(rs_stream s) { return (hipStream_t)s; }
 
 // launch helpers implemented in the .hip files

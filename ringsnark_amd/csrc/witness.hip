@@ -469,9 +469,11 @@ static ColPlansT<M> make_colplans(rs_ctx *ctx, const WitnessPlan *P, int limb0 =
     c.b2_inv = P->bc2 ? HostArith<M>::konst(host::invmod((uint64_t)(4 * P->M) % lp.p, lp.p), lp.p) : T(0);
     c.fwd_mask2 = lp.fwd_mask2;
     c.inv_mask2 = lp.inv_mask2;
+    c.pwmask = 0;
     for (int l = 0; l < 24; l++) {
       c.fmask[l] = fwd_reduce_mask(lp.p, l);
       c.imask[l] = inv_reduce_mask(lp.p, l);
+      if (fwd_end_needs_reduce(lp.p, l)) c.pwmask |= 1u << l;
     }
   }
   return cp;

@@ -22,6 +22,7 @@ struct ColPlanT {
   T b2_inv;                     // 1 / (2B * 2M/B) = 1 / (4M): both unscaled inverse transforms of a two-dimensional data x data product
   uint32_t fwd_mask2, inv_mask2;
   uint32_t fmask[24], imask[24];  // reduce masks for transforms of length 2^l (FP64 arithmetic)
+  uint32_t pwmask;                // bit l: the spectrum of a length-2^l forward transform must be reduced before it meets a table entry
 };
 template <class M_>
 struct ColPlansT {

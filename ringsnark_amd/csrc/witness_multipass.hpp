@@ -393,8 +393,12 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
         }
         wave_sync();
         if (MODE == 2) {
+          if ((P.pwmask >> logn) & 1u) {  // primes above ~2^46 only (a guarded pass, not a select)
 #pragma unroll
-          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), s[pb + e], mod);
+            for (int e = 0; e < 16; e++) x[e] = reduce(x[e], mod);
+          }
+#pragma unroll
+          for (int e = 0; e < 16; e++) x[e] = mulmod(x[e], s[pb + e], mod);
         } else {
 #pragma unroll
           for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), reduce(s[pb + e], mod), mod);

@@ -133,8 +133,12 @@ __device__ __forceinline__ void tree_wide_middle(double (&b)[32], double *s, con
   else
     reg_fwd_stages<5, true>(b, mod, fmask, [&](int k, int blk) { return w[(1 << k) - 1 + blk]; });
   wave_sync();
+  if ((P.pwmask >> LV) & 1u) {  // primes above ~2^46: the spectrum may exceed the multiplier range (a guarded pass, not a select)
 #pragma unroll
-  for (int e = 0; e < 32; e++) b[e] = mulmod(reduce(b[e], mod), s[33 * t + e], mod);
+    for (int e = 0; e < 32; e++) b[e] = reduce(b[e], mod);
+  }
+#pragma unroll
+  for (int e = 0; e < 32; e++) b[e] = mulmod(b[e], s[33 * t + e], mod);
   tree_wide_mid_tw_inv<LV>(P, u, w);
   reg_inv_stages<5, true>(b, mod, imask, [&](int k, int i) { return w[32 - (32 >> k) + i]; });
 }

@@ -608,8 +608,12 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
 #pragma unroll
       for (int e = 0; e < 16; e++) v[e] = tile[pb + e];
       reg_fwd_stages<4, true>(v, mod, red_mask >> (LOGP + 8), [&](int k, int bk) { return tw3[(1 << k) - 1 + bk]; });
+      if (a.reduce_u) {  // a guarded pass: as a per-element choice it becomes compute-and-select
 #pragma unroll
-      for (int e = 0; e < 16; e++) tile[pb + e] = a.reduce_u ? reduce(v[e], mod) : v[e];
+        for (int e = 0; e < 16; e++) v[e] = reduce(v[e], mod);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) tile[pb + e] = v[e];
     }
     wave_sync();
   }
@@ -881,8 +885,12 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
 #pragma unroll
       for (int e = 0; e < 8; e++) v[e] = tile[pb + e];
       reg_fwd_stages<3, true>(v, mod, red_mask >> (LOGP + 9), [&](int k, int bk) { return tw4[(1 << k) - 1 + bk]; });
+      if (a.reduce_u) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) tile[pb + e] = a.reduce_u ? reduce(v[e], mod) : v[e];
+        for (int e = 0; e < 8; e++) v[e] = reduce(v[e], mod);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) tile[pb + e] = v[e];
     }
     wave_sync();
   }

@@ -491,9 +491,11 @@ int g_witness_sub_ct = 2;     // 1: compile-time-length sub-transform kernel for
 // FP64 instructions (per lane) of the product tree on one tile of T = 2^logT coefficients: levels
 // 1..4 by schoolbook (120 modular multiplies + as many additions per 16 coefficients), every level
 // above by a forward and an inverse batched transform plus the spectrum product and the recombination
-static double tree_fp64(double T, int logT) {
+// pw_reduce: the spectrum is reduced before it meets the table entry (3 more instructions per coefficient and level;
+// the wide kernel does it only where ColPlan::pwmask asks for it)
+static double tree_fp64(double T, int logT, bool pw_reduce = true) {
   double f = T / 16.0 * (120.0 * 7.0 + 4.0 * 16.0 * 3.0);
-  for (int l = SCHOOL_LEVELS + 1; l <= logT; l++) f += 2.0 * ntt_fp64(T, l) + 10.0 * T;
+  for (int l = SCHOOL_LEVELS + 1; l <= logT; l++) f += 2.0 * ntt_fp64(T, l) + (pw_reduce ? 10.0 : 7.0) * T;
   return f;
 }
 static void launch_tree_tiles(rs_ctx *ctx, double *cols, size_t ncols, size_t col0, int logM, int logT, size_t S,
@@ -508,7 +510,10 @@ static void launch_tree_tiles(rs_ctx *ctx, double *cols, size_t ncols, size_t co
   const char *pname = wide ? (logT == 14 ? "tree_wide_kernel<14>" : "tree_wide_kernel<13>")
                       : ct13 ? (newton ? "tree_columns_kernel<512, 13, true>" : "tree_columns_kernel<512, 13, false>")
                            : (newton ? "tree_columns_kernel<NEWTON>" : "tree_columns_kernel");
-  ProfScope prof(ctx, st, pname, tiles * (double)T * 16.0, tiles * (tree_fp64((double)T, logT) + newton_fp64));
+  bool pw = !wide;  // the model count follows what the wide kernel executes: the pre-product reduction per level only where asked for
+  if (wide)
+    for (int i = 0; i < RS_MAX_L; i++) pw = pw || ((cp.l[i].pwmask >> logT) & 1u);
+  ProfScope prof(ctx, st, pname, tiles * (double)T * 16.0, tiles * (tree_fp64((double)T, logT, pw) + newton_fp64));
   const size_t lds1 = padded_len(T) * sizeof(double);
   const unsigned grid = (unsigned)(ncols << (logM - logT));
   const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, T / 16));  // 1024 only for a 2^14 tile (one workgroup per CU)

@@ -50,8 +50,9 @@ int rs_version(void);
 
 /* RingElem::set_context + EncodingElem::set_context(s) (seal/seal_ring.hpp:52-58, 266-320):
  * ring Z_q[X]/(X^N+1), q = prod q[i]; L encoding contexts of degree N_enc with data primes Q[j]
- * and plain modulus q[i].  Requires q[i], Q[j] prime, = 1 mod 2*N_enc, < 2^50, pairwise
- * distinct. */
+ * and plain modulus q[i].  Requires q[i], Q[j] prime, = 1 mod 2*N_enc, < 2^62, pairwise
+ * distinct.  Moduli below 2^50 run on the exact-FP64 arithmetic (the tuned kernels); a context with a modulus in
+ * [2^50, 2^62) runs on Montgomery integers (the generic kernels; a ring-side-only big prime keeps the data side on FP64). */
 int rs_ctx_create(int device, int N, int L, const uint64_t *q, int N_enc, int K, const uint64_t *Q,
                   rs_ctx **out);
 void rs_ctx_destroy(rs_ctx *ctx);
@@ -258,6 +259,14 @@ typedef struct rs_groth16_pk {
 } rs_groth16_pk;
 int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, const uint64_t *d_assignment,
                      uint64_t *d_proof, int *h_empty /* [3] or NULL */, rs_stream stream);
+/* The same with the REPRESENTATION of every assignment wire: h_assignment_kinds [n_vars] (RS_KIND_*), NULL = all
+ * polynomials.  The reference hands auxiliary_input to inner_product as it is (groth16.tcc:108-111), and
+ * EncodingElem::operator*= passes the ciphertext through unchanged for a RingElem holding Scalar 1
+ * (seal/seal_ring.tcc:525-527) -- which is NOT the product with the batch encoding of all-ones when N_enc > N, so the
+ * proof bytes depend on it (decryptions do not).  Every other Scalar is flattened by to_poly() there (:529): its row of
+ * d_assignment (all slots = the scalar) is exact under RS_KIND_POLY, a Scalar 0 is skipped like a zero polynomial. */
+int rs_groth16_prove_kinds(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, const uint64_t *d_assignment,
+                           const uint8_t *h_assignment_kinds, uint64_t *d_proof, int *h_empty, rs_stream stream);
 
 /* rinocchio::prover (zk_proof_systems/rinocchio/rinocchio.tcc:75-190); d1,d2,d3 are the ZK
  * blinding elements the reference samples at :88-90 (all NULL = non-ZK branch).  proof =
@@ -272,6 +281,11 @@ typedef struct rs_rinocchio_pk {
 int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk, const uint64_t *d_assignment,
                        const uint64_t *d_d1, const uint64_t *d_d2, const uint64_t *d_d3, uint64_t *d_proof,
                        int *h_empty /* [9] or NULL */, rs_stream stream);
+/* with wire representations (see rs_groth16_prove_kinds): auxiliary_input is the operand of <beta_prods, aux>
+ * (rinocchio.tcc:176-180). */
+int rs_rinocchio_prove_kinds(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk, const uint64_t *d_assignment,
+                             const uint8_t *h_assignment_kinds, const uint64_t *d_d1, const uint64_t *d_d2, const uint64_t *d_d3,
+                             uint64_t *d_proof, int *h_empty, rs_stream stream);
 
 /* ---- measurement hooks (bench.py): per-phase device time of the last prover call, in ms ---- */
 typedef struct rs_timings {

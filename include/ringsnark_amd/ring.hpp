@@ -619,6 +619,16 @@ inline std::vector<uint64_t> flatten(const std::vector<RingElem> &v) {
   return out;
 }
 
+// The representation of each wire as the reference's provers hand it to inner_product (groth16.tcc:108-111,
+// rinocchio.tcc:176-180): a RingElem holding Scalar 1 passes its key element through unchanged
+// (seal_ring.tcc:525-527); every other Scalar is flattened by to_poly() there, as flatten() does here.
+inline std::vector<uint8_t> wire_kinds(const std::vector<RingElem> &v) {
+  std::vector<uint8_t> k(v.size(), RS_KIND_POLY);
+  for (size_t t = 0; t < v.size(); t++)
+    if (v[t].is_scalar() && v[t].get_scalar() == 1) k[t] = RS_KIND_ONE;
+  return k;
+}
+
 // CSR export of the reference's r1cs_constraint_system<RingElem>
 // (relations/constraint_satisfaction_problems/r1cs/r1cs.hpp:118-123; linear_combination::terms of
 // linear_term{index, coeff}, relations/variable.hpp).  Duck-typed, so this header needs none of the
@@ -765,7 +775,8 @@ inline proof prover(const proving_key_device &pk, const std::vector<RingElem> &p
   DeviceWords dasg(asg.data(), asg.size()), dproof(3 * Context::enc_words());
   rs_groth16_pk k{pk.s_pows_.get(), pk.delta_ts_.get(), pk.delta_mid_.get(), pk.alpha_.get(), pk.beta_.get(), 0, 0};
   int empty[3] = {0, 0, 0};
-  check(rs_groth16_prove(Context::get_context(), pk.cs.get(), &k, dasg.get(), dproof.get(), empty, nullptr));
+  const std::vector<uint8_t> kinds = wire_kinds(full);
+  check(rs_groth16_prove_kinds(Context::get_context(), pk.cs.get(), &k, dasg.get(), kinds.data(), dproof.get(), empty, nullptr));
   std::vector<uint64_t> w(3 * Context::enc_words());
   dproof.download(w.data());
   proof p;
@@ -833,7 +844,9 @@ inline proof prover(const proving_key_device &pk, const std::vector<RingElem> &p
   rs_rinocchio_pk k{pk.s_pows_.get(), pk.alpha_s_pows_.get(), pk.beta_prods_.get(), pk.beta_rv_ts_.get(),
                     pk.beta_rw_ts_.get(), pk.beta_ry_ts_.get(), 0, 0};
   int empty[9] = {0};
-  check(rs_rinocchio_prove(Context::get_context(), pk.cs.get(), &k, dasg.get(), dp[0], dp[1], dp[2], dproof.get(), empty, nullptr));
+  const std::vector<uint8_t> kinds = wire_kinds(full);
+  check(rs_rinocchio_prove_kinds(Context::get_context(), pk.cs.get(), &k, dasg.get(), kinds.data(), dp[0], dp[1], dp[2], dproof.get(), empty,
+                                 nullptr));
   std::vector<uint64_t> w(9 * Context::enc_words());
   dproof.download(w.data());
   proof p;

@@ -123,6 +123,10 @@ def lib():
                                              C.c_size_t, u64p, C.c_int]
         L.rso_groth16_prove.argtypes = [C.c_void_p, C.POINTER(R1CS), C.POINTER(Groth16PK), u64p, u64p, C.POINTER(C.c_int)]
         L.rso_rinocchio_prove.argtypes = [C.c_void_p, C.POINTER(R1CS), C.POINTER(RinocchioPK)] + [u64p] * 5 + [C.POINTER(C.c_int)]
+        L.rso_groth16_prove_kinds.argtypes = [C.c_void_p, C.POINTER(R1CS), C.POINTER(Groth16PK), u64p, u8p, u64p, C.POINTER(C.c_int)]
+        L.rso_groth16_prove_kinds.restype = None
+        L.rso_rinocchio_prove_kinds.argtypes = [C.c_void_p, C.POINTER(R1CS), C.POINTER(RinocchioPK), u64p, u8p] + [u64p] * 4 + [C.POINTER(C.c_int)]
+        L.rso_rinocchio_prove_kinds.restype = None
         L.rso_fill_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, u64p]
         _lib = L
     return _lib
@@ -473,23 +477,34 @@ def witness_map(q, cs, limb, assignment, d1=None, d2=None, d3=None, threads=1):
     return o
 
 
-def groth16_prove(ctx, cs, pk, assignment):
-    """pk: dict s_pows, delta_ts, delta_mid, alpha, beta (numpy, encoding layout)."""
+def _kinds_arg(kinds, n):
+    if kinds is None:
+        return None, None
+    k = np.ascontiguousarray(kinds, dtype=np.uint8)
+    assert k.shape == (n,)
+    return k, k.ctypes.data_as(u8p)
+
+
+def groth16_prove(ctx, cs, pk, assignment, kinds=None):
+    """pk: dict s_pows, delta_ts, delta_mid, alpha, beta (numpy, encoding layout).  kinds: per assignment wire,
+    KIND_ONE for a RingElem holding Scalar 1 (seal_ring.tcc:525-527), None = all polynomials."""
     keep = {k: np.ascontiguousarray(v, dtype=np.uint64) for k, v in pk.items()}
     s = Groth16PK(*[p64(keep[k]) for k in ("s_pows", "delta_ts", "delta_mid", "alpha", "beta")])
     proof = np.zeros(ctx.enc_shape(3), dtype=np.uint64)
     empty = (C.c_int * 3)()
     assignment = np.ascontiguousarray(assignment, dtype=np.uint64)
-    lib().rso_groth16_prove(ctx.h, cs.ref(), C.byref(s), p64(assignment), p64(proof), empty)
+    keep_k, kp = _kinds_arg(kinds, assignment.shape[0])
+    lib().rso_groth16_prove_kinds(ctx.h, cs.ref(), C.byref(s), p64(assignment), kp, p64(proof), empty)
     return proof, [int(e) for e in empty]
 
 
-def rinocchio_prove(ctx, cs, pk, assignment, d1=None, d2=None, d3=None):
+def rinocchio_prove(ctx, cs, pk, assignment, d1=None, d2=None, d3=None, kinds=None):
     keep = {k: np.ascontiguousarray(v, dtype=np.uint64) for k, v in pk.items()}
     s = RinocchioPK(*[p64(keep[k]) for k in ("s_pows", "alpha_s_pows", "beta_prods", "beta_rv_ts", "beta_rw_ts", "beta_ry_ts")])
     proof = np.zeros(ctx.enc_shape(9), dtype=np.uint64)
     empty = (C.c_int * 9)()
     assignment = np.ascontiguousarray(assignment, dtype=np.uint64)
     ds = [None if d is None else np.ascontiguousarray(d, dtype=np.uint64) for d in (d1, d2, d3)]
-    lib().rso_rinocchio_prove(ctx.h, cs.ref(), C.byref(s), p64(assignment), p64(ds[0]), p64(ds[1]), p64(ds[2]), p64(proof), empty)
+    keep_k, kp = _kinds_arg(kinds, assignment.shape[0])
+    lib().rso_rinocchio_prove_kinds(ctx.h, cs.ref(), C.byref(s), p64(assignment), kp, p64(ds[0]), p64(ds[1]), p64(ds[2]), p64(proof), empty)
     return proof, [int(e) for e in empty]

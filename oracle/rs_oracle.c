@@ -936,9 +936,13 @@ static void enc_acc(const rso_ctx *c, uint64_t *res, int *res_empty, const uint6
     rso_enc_add(c, res, o);
 }
 
-/* zk_proof_systems/groth16/groth16.tcc:70-115. */
-void rso_groth16_prove(const rso_ctx *c, const rso_r1cs *cs, const rso_groth16_pk *pk,
-                       const uint64_t *assignment, uint64_t *proof, int *empty) {
+/* zk_proof_systems/groth16/groth16.tcc:70-115.  asg_kinds (may be NULL: every wire a polynomial): the representation
+ * of each assignment wire, RSO_KIND_ONE for a RingElem holding Scalar 1 -- auxiliary_input goes to inner_product as it
+ * is (:108-111), where operator*= passes the ciphertext through unchanged for such a wire (seal_ring.tcc:525-527)
+ * instead of multiplying by the batch encoding of all-ones (a different plaintext whenever N_enc > N).  Every other
+ * Scalar is flattened by to_poly() there (:529), so its row of `assignment` (all slots = the scalar) is exact. */
+void rso_groth16_prove_kinds(const rso_ctx *c, const rso_r1cs *cs, const rso_groth16_pk *pk,
+                             const uint64_t *assignment, const uint8_t *asg_kinds, uint64_t *proof, int *empty) {
   size_t m = cs->m, ew = rso_enc_words(c), rw = rso_ring_words(c);
   size_t n_aux = cs->n_vars - cs->n_inputs;
   wit w;
@@ -958,17 +962,22 @@ void rso_groth16_prove(const rso_ctx *c, const rso_r1cs *cs, const rso_groth16_p
   /* :105-112 */
   empty[2] = rso_inner_product(c, pk->delta_ts, w.H, NULL, m + 1, cc) == 0;
   if (n_aux) {
-    e = rso_inner_product(c, pk->delta_mid, assignment + cs->n_inputs * rw, NULL, n_aux, tmp) == 0;
+    e = rso_inner_product(c, pk->delta_mid, assignment + cs->n_inputs * rw, asg_kinds ? asg_kinds + cs->n_inputs : NULL, n_aux, tmp) == 0;
     enc_acc(c, cc, &empty[2], tmp, e);
   }
   free(tmp);
   wit_free(&w);
 }
+void rso_groth16_prove(const rso_ctx *c, const rso_r1cs *cs, const rso_groth16_pk *pk,
+                       const uint64_t *assignment, uint64_t *proof, int *empty) {
+  rso_groth16_prove_kinds(c, cs, pk, assignment, NULL, proof, empty);
+}
 
-/* zk_proof_systems/rinocchio/rinocchio.tcc:75-190. */
-void rso_rinocchio_prove(const rso_ctx *c, const rso_r1cs *cs, const rso_rinocchio_pk *pk,
-                         const uint64_t *assignment, const uint64_t *d1, const uint64_t *d2,
-                         const uint64_t *d3, uint64_t *proof, int *empty) {
+/* zk_proof_systems/rinocchio/rinocchio.tcc:75-190.  asg_kinds: as for rso_groth16_prove_kinds; auxiliary_input is the
+ * operand of <beta_prods, aux> (:176-180). */
+void rso_rinocchio_prove_kinds(const rso_ctx *c, const rso_r1cs *cs, const rso_rinocchio_pk *pk,
+                               const uint64_t *assignment, const uint8_t *asg_kinds, const uint64_t *d1, const uint64_t *d2,
+                               const uint64_t *d3, uint64_t *proof, int *empty) {
   size_t m = cs->m, ew = rso_enc_words(c), rw = rso_ring_words(c), N = (size_t)c->N;
   size_t n_aux = cs->n_vars - cs->n_inputs;
   int use_zk = d1 && d2 && d3; /* :81-90 */
@@ -1014,7 +1023,7 @@ void rso_rinocchio_prove(const rso_ctx *c, const rso_r1cs *cs, const rso_rinocch
   memset(proof + 8 * ew, 0, sizeof(uint64_t) * ew);
   if (n_aux) {
     empty[8] =
-        rso_inner_product(c, pk->beta_prods, assignment + cs->n_inputs * rw, NULL, n_aux, proof + 8 * ew) == 0;
+        rso_inner_product(c, pk->beta_prods, assignment + cs->n_inputs * rw, asg_kinds ? asg_kinds + cs->n_inputs : NULL, n_aux, proof + 8 * ew) == 0;
     if (use_zk) {
       const uint64_t *ds[3] = {d1, d2, d3};
       const uint64_t *bs[3] = {pk->beta_rv_ts, pk->beta_rw_ts, pk->beta_ry_ts};
@@ -1031,4 +1040,9 @@ void rso_rinocchio_prove(const rso_ctx *c, const rso_r1cs *cs, const rso_rinocch
   free(z_enc);
   free(az_enc);
   wit_free(&w);
+}
+void rso_rinocchio_prove(const rso_ctx *c, const rso_r1cs *cs, const rso_rinocchio_pk *pk,
+                         const uint64_t *assignment, const uint64_t *d1, const uint64_t *d2,
+                         const uint64_t *d3, uint64_t *proof, int *empty) {
+  rso_rinocchio_prove_kinds(c, cs, pk, assignment, NULL, d1, d2, d3, proof, empty);
 }

@@ -195,6 +195,11 @@ void rso_groth16_prove(const rso_ctx *c, const rso_r1cs *cs, const rso_groth16_p
                        const uint64_t *assignment /* [n_vars][L][N] */, uint64_t *proof /* [3] */,
                        int *empty /* [3] */);
 
+/* the same with the representation of every assignment wire (asg_kinds [n_vars], NULL = all polynomials): a wire
+ * holding Scalar 1 (RSO_KIND_ONE) passes the ciphertext through in <delta_mid, aux> (seal_ring.tcc:525-527) */
+void rso_groth16_prove_kinds(const rso_ctx *c, const rso_r1cs *cs, const rso_groth16_pk *pk,
+                             const uint64_t *assignment, const uint8_t *asg_kinds, uint64_t *proof, int *empty);
+
 typedef struct rso_rinocchio_pk {
   const uint64_t *s_pows, *alpha_s_pows; /* m+1 each */
   const uint64_t *beta_prods;            /* n_aux */
@@ -204,6 +209,10 @@ typedef struct rso_rinocchio_pk {
 void rso_rinocchio_prove(const rso_ctx *c, const rso_r1cs *cs, const rso_rinocchio_pk *pk,
                          const uint64_t *assignment, const uint64_t *d1, const uint64_t *d2,
                          const uint64_t *d3, uint64_t *proof /* [9] */, int *empty /* [9] */);
+
+void rso_rinocchio_prove_kinds(const rso_ctx *c, const rso_r1cs *cs, const rso_rinocchio_pk *pk,
+                               const uint64_t *assignment, const uint8_t *asg_kinds, const uint64_t *d1, const uint64_t *d2,
+                               const uint64_t *d3, uint64_t *proof /* [9] */, int *empty /* [9] */);
 
 /* ---- rs_fastcpu.c (librs_oracle_fast.so only): the timed CPU-baseline leg -- EncodingElem::inner_product with SEAL's
  * published arithmetic (Harvey lazy NTT with Shoup quotients, Barrett dyadic products).  Same results as above. ---- */

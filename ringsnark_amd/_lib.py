@@ -103,6 +103,8 @@ SIGNATURES = {
     "rs_poly_divide": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.POINTER(C.c_size_t), vp]),
     "rs_groth16_prove": (C.c_int, [vp, vp, C.POINTER(Groth16PK), vp, vp, C.POINTER(C.c_int), vp]),
     "rs_rinocchio_prove": (C.c_int, [vp, vp, C.POINTER(RinocchioPK), vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]),
+    "rs_groth16_prove_kinds": (C.c_int, [vp, vp, C.POINTER(Groth16PK), vp, u8p, vp, C.POINTER(C.c_int), vp]),
+    "rs_rinocchio_prove_kinds": (C.c_int, [vp, vp, C.POINTER(RinocchioPK), vp, u8p, vp, vp, vp, vp, C.POINTER(C.c_int), vp]),
     "rs_last_timings": (C.c_int, [vp, C.POINTER(Timings)]),
     "rs_set_profiling": (C.c_int, [vp, C.c_int]),
     "rs_profile_read": (C.c_int, [vp, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int)]),

@@ -301,7 +301,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     if (crs_window) {
       size_t p2 = 1;
       while (p2 * 2 <= tile_terms) p2 *= 2;
-      tile_terms = std::min(p2, crs_window);
+      tile_terms = std::min(p2, crs_window);  // may no longer divide the window: issue_copy splits a tile at the wrap
     }
     stage_words = tile_terms * enc_words;
     stage = (uint64_t *)ws_get(ctx, 7, (size_t)2 * n_crs * stage_words * sizeof(uint64_t));
@@ -321,9 +321,20 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     const int buf = tile & 1;
     const size_t tt = std::min(tile_terms, Tmax - t0);
     RS_HIP(hipStreamWaitEvent(sc.copy_stream, sc.ev_freed[buf], 0));
-    for (int c = 0; c < n_crs; c++)
-      RS_HIP(hipMemcpyAsync(stage_at(buf, c), d_crs[c] + (crs_window ? t0 % crs_window : t0) * enc_words, tt * enc_words * sizeof(uint64_t),
-                            hipMemcpyHostToDevice, sc.copy_stream));
+    // the staging buffer linearises a tile that straddles the wrap of a windowed key (a window of 1536 elements with
+    // 1024-element staging tiles: the tile at 1024 is elements 1024..1535, then 0..511)
+    const size_t o0 = crs_window ? t0 % crs_window : t0;
+    const size_t first = crs_window ? std::min(tt, crs_window - o0) : tt;
+    for (int c = 0; c < n_crs; c++) {
+      RS_HIP(hipMemcpyAsync(stage_at(buf, c), d_crs[c] + o0 * enc_words, first * enc_words * sizeof(uint64_t), hipMemcpyHostToDevice,
+                            sc.copy_stream));
+      for (size_t done = first; done < tt;) {  // wrapped remainder (several rounds if the tile exceeds the window)
+        const size_t part = std::min(tt - done, crs_window);
+        RS_HIP(hipMemcpyAsync(stage_at(buf, c) + done * enc_words, d_crs[c], part * enc_words * sizeof(uint64_t), hipMemcpyHostToDevice,
+                              sc.copy_stream));
+        done += part;
+      }
+    }
     RS_HIP(hipEventRecord(sc.ev_copied[buf], sc.copy_stream));
   };
   int cur_tile = 0;

@@ -106,6 +106,11 @@ extern "C" {
 
 int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, const uint64_t *d_assignment,
                      uint64_t *d_proof, int *h_empty, rs_stream stream) {
+  return rs_groth16_prove_kinds(ctx, cs, pk, d_assignment, nullptr, d_proof, h_empty, stream);
+}
+
+int rs_groth16_prove_kinds(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, const uint64_t *d_assignment,
+                           const uint8_t *h_assignment_kinds, uint64_t *d_proof, int *h_empty, rs_stream stream) {
   RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && cs && pk && d_assignment && d_proof, "null argument");
   RS_REQUIRE(pk->d_s_pows && pk->d_delta_ts && pk->d_alpha && pk->d_beta, "incomplete proving key");
@@ -161,7 +166,8 @@ int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, co
   uint64_t *C = d_proof + 2 * ew;
   if (n_aux) {
     const uint64_t *crs[1] = {pk->d_delta_mid};
-    rs_msm_vec v{d_assignment + cs->n_inputs * rw, nullptr, n_aux, 0};
+    // the wires as the caller holds them: a Scalar-1 wire passes its key element through (seal_ring.tcc:525-527)
+    rs_msm_vec v{d_assignment + cs->n_inputs * rw, h_assignment_kinds ? h_assignment_kinds + cs->n_inputs : nullptr, n_aux, 0};
     msm_run(ctx, crs, 1, n_aux, &v, 1, 1, C, nullptr, h_empty ? &used_aux : nullptr, st, pk->window, nullptr, host_key);
   }
   {
@@ -172,7 +178,7 @@ int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, co
   }
   pt.mark(2);
   pt.finish();
-  if (host_key) RS_HIP(hipStreamSynchronize(st));  // the caller may release or rewrite the host key on return
+  if (host_key || h_assignment_kinds) RS_HIP(hipStreamSynchronize(st));  // the caller may release or rewrite the host key / the kinds on return
   if (h_empty) {
     h_empty[0] = h_empty[1] = 0;  // alpha / beta are always added
     h_empty[2] = (used_h == 0 && used_aux == 0) ? 1 : 0;
@@ -183,6 +189,12 @@ int rs_groth16_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_groth16_pk *pk, co
 int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk, const uint64_t *d_assignment,
                        const uint64_t *d_d1, const uint64_t *d_d2, const uint64_t *d_d3, uint64_t *d_proof, int *h_empty,
                        rs_stream stream) {
+  return rs_rinocchio_prove_kinds(ctx, cs, pk, d_assignment, nullptr, d_d1, d_d2, d_d3, d_proof, h_empty, stream);
+}
+
+int rs_rinocchio_prove_kinds(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk, const uint64_t *d_assignment,
+                             const uint8_t *h_assignment_kinds, const uint64_t *d_d1, const uint64_t *d_d2, const uint64_t *d_d3,
+                             uint64_t *d_proof, int *h_empty, rs_stream stream) {
   RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && cs && pk && d_assignment && d_proof, "null argument");
   RS_REQUIRE(pk->d_s_pows && pk->d_alpha_s_pows, "incomplete proving key");
@@ -255,7 +267,7 @@ int rs_rinocchio_prove(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_pk *pk
   if (n_aux) {
     size_t used_f = 0;
     const uint64_t *crs[1] = {pk->d_beta_prods};
-    rs_msm_vec v{d_assignment + cs->n_inputs * rw, nullptr, n_aux, 0};
+    rs_msm_vec v{d_assignment + cs->n_inputs * rw, h_assignment_kinds ? h_assignment_kinds + cs->n_inputs : nullptr, n_aux, 0};
     msm_run(ctx, crs, 1, n_aux, &v, 1, 1, F, nullptr, &used_f, st, pk->window, nullptr, pk->host_key != 0);
     empty[8] = used_f == 0;
     if (zk) {

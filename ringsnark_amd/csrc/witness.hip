@@ -711,14 +711,22 @@ static void bc2_conv(rs_ctx *ctx, Bc2Args a, int logY, size_t ncols, const TabPt
                      hipStream_t st) {
   const size_t Y = (size_t)1 << logY, cu = ncols * (size_t)a.units;
   const dim3 grid((unsigned)(BC2_B / 2 / 256), (unsigned)cu);
-  RS_REQUIRE(cu <= 65535 && logY >= 2 && logY <= 5, "two-dimensional block convolution out of range");
+  // Y <= 32: the transform across blocks in one thread's registers; Y = 64 .. 256 (M >= 2^18): in two levels
+  RS_REQUIRE(cu <= 65535 && logY >= 2 && logY <= 8, "two-dimensional block convolution out of range");
+  const dim3 grid_parts(grid.x << std::max(0, logY - 5), grid.y);  // one workgroup per (position range, part of 32 blocks)
   {
-    ProfScope prof(ctx, st, "bc2_yfwd_kernel", (double)cu * (double)Y * BC2_B * 12.0, (double)cu * BC2_B * ntt_fp64((double)Y, logY));
+    // words: the Y/2 source blocks (read once per part in the two-level form) + Y blocks written
+    const double reads = logY > 5 ? (double)(Y / 2) * (double)(1 << (logY - 5)) : (double)(Y / 2);
+    ProfScope prof(ctx, st, logY > 5 ? "bc2_yfwd_big_kernel" : "bc2_yfwd_kernel", (double)cu * ((double)Y + reads) * BC2_B * 8.0,
+                   (double)cu * BC2_B * ntt_fp64((double)Y, logY));
     switch (logY) {
       case 2: hipLaunchKernelGGL((bc2_yfwd_kernel<SRC, 2>), grid, dim3(256), 0, st, a, cp); break;
       case 3: hipLaunchKernelGGL((bc2_yfwd_kernel<SRC, 3>), grid, dim3(256), 0, st, a, cp); break;
       case 4: hipLaunchKernelGGL((bc2_yfwd_kernel<SRC, 4>), grid, dim3(256), 0, st, a, cp); break;
-      default: hipLaunchKernelGGL((bc2_yfwd_kernel<SRC, 5>), grid, dim3(256), 0, st, a, cp); break;
+      case 5: hipLaunchKernelGGL((bc2_yfwd_kernel<SRC, 5>), grid, dim3(256), 0, st, a, cp); break;
+      case 6: hipLaunchKernelGGL((bc2_yfwd_big_kernel<SRC, 1>), grid_parts, dim3(256), 0, st, a, cp); break;
+      case 7: hipLaunchKernelGGL((bc2_yfwd_big_kernel<SRC, 2>), grid_parts, dim3(256), 0, st, a, cp); break;
+      default: hipLaunchKernelGGL((bc2_yfwd_big_kernel<SRC, 3>), grid_parts, dim3(256), 0, st, a, cp); break;
     }
   }
   {
@@ -736,13 +744,29 @@ static void bc2_conv(rs_ctx *ctx, Bc2Args a, int logY, size_t ncols, const TabPt
                        (unsigned)((size_t)a.units * Y * 2), (unsigned)((size_t)a.units * Y * 2), a.col0, a.S, a.slots_per_limb, cp, nb,
                        (const double *)a.Wy);
   }
-  if (MODE != 0) {
+  if (MODE != 0 && logY <= 5) {
     ProfScope prof(ctx, st, "bc2_yinv_kernel", (double)cu * (double)Y * BC2_B * 24.0, (double)cu * 2.0 * BC2_B * ntt_fp64((double)Y, logY));
     switch (logY) {
       case 2: hipLaunchKernelGGL((bc2_yinv_kernel<DST, 2>), grid, dim3(256), 0, st, a, cp); break;
       case 3: hipLaunchKernelGGL((bc2_yinv_kernel<DST, 3>), grid, dim3(256), 0, st, a, cp); break;
       case 4: hipLaunchKernelGGL((bc2_yinv_kernel<DST, 4>), grid, dim3(256), 0, st, a, cp); break;
       default: hipLaunchKernelGGL((bc2_yinv_kernel<DST, 5>), grid, dim3(256), 0, st, a, cp); break;
+    }
+  } else if (MODE != 0) {
+    {  // in place on Ws: 2 x Y x 2B words
+      ProfScope prof(ctx, st, "bc2_yinv_a_kernel", (double)cu * (double)Y * BC2_B * 32.0, (double)cu * 2.0 * BC2_B * ntt_fp64((double)Y, 5));
+      switch (logY) {
+        case 6: hipLaunchKernelGGL((bc2_yinv_a_kernel<1>), grid_parts, dim3(256), 0, st, a, cp); break;
+        case 7: hipLaunchKernelGGL((bc2_yinv_a_kernel<2>), grid_parts, dim3(256), 0, st, a, cp); break;
+        default: hipLaunchKernelGGL((bc2_yinv_a_kernel<3>), grid_parts, dim3(256), 0, st, a, cp); break;
+      }
+    }
+    const dim3 grid32(grid.x * 32, grid.y);
+    ProfScope prof(ctx, st, "bc2_yinv_b_kernel", (double)cu * (double)Y * BC2_B * 24.0, (double)cu * 2.0 * BC2_B * ntt_fp64((double)Y, logY - 5));
+    switch (logY) {
+      case 6: hipLaunchKernelGGL((bc2_yinv_b_kernel<DST, 1>), grid32, dim3(256), 0, st, a, cp); break;
+      case 7: hipLaunchKernelGGL((bc2_yinv_b_kernel<DST, 2>), grid32, dim3(256), 0, st, a, cp); break;
+      default: hipLaunchKernelGGL((bc2_yinv_b_kernel<DST, 3>), grid32, dim3(256), 0, st, a, cp); break;
     }
   }
   RS_HIP(hipGetLastError());

@@ -262,4 +262,169 @@ __global__ void __launch_bounds__(256) bc2_yinv_kernel(Bc2Args a, ColPlans plans
   }
 }
 
+// ---- Y > 32 blocks (M >= 2^18 at B = 2^13): the transform across blocks in two levels -----------------------------
+// A thread cannot hold Y = 64 .. 256 values of two positions.  Y = R x 32, R = 2^S1:
+//   forward   the first S1 stages mix elements 32 apart, the last five are R independent 32-point sub-transforms rooted
+//             at nodes R + part.  A workgroup owns ONE part: element j of it depends on the inputs j + 32 e only (the
+//             upper half of them padding), which are read through the step's source functor once per part (R/2 loads
+//             per element; the parts of a position are neighbouring workgroups, so the re-reads hit the caches)
+//   inverse   bc2_yinv_a_kernel: per group of 32 consecutive blocks the last stage of the 2B-point transforms and the
+//             first five stages across blocks, in place on Ws; bc2_yinv_b_kernel: per element j the last S1 stages on
+//             j + 32 g, the overlap-add (which needs the HIGH halves of element j - 1: carried by the same thread) and
+//             the step's sink functor.
+// Same arithmetic as the one-level kernels up to the points of lazy reduction; outputs are canonical, hence identical.
+template <int SRC, int S1>
+__global__ void __launch_bounds__(256) bc2_yfwd_big_kernel(Bc2Args a, ColPlans plans) {
+  constexpr int R = 1 << S1, Y = 32 * R, B = BC2_B;
+  const int part = (int)(blockIdx.x % R);
+  const int r = 2 * (int)((blockIdx.x / R) * 256 + threadIdx.x);
+  const size_t cu = blockIdx.y, unit = cu % (size_t)a.units, col = cu / (size_t)a.units, M = (size_t)1 << a.logM;
+  const ColPlan &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const Mod mod = P.mod;
+  const double *__restrict__ tw = P.tw;
+  const uint32_t mask = P.fmask[S1 + 5];
+  double v0[32], v1[32];
+#pragma unroll
+  for (int j = 0; j < 32; j++) {
+    double x0[R], x1[R];
+#pragma unroll
+    for (int e = 0; e < R / 2; e++) {
+      const size_t k = (size_t)(j + 32 * e) * B + r;  // position inside the operand (pairs k, k + 1 never straddle a limit)
+      double y0 = 0.0, y1 = 0.0;
+      if (SRC == BS_SCALE) {
+        if (k < M) {
+          const double2 d = *reinterpret_cast<const double2 *>(a.src + col * M + k), f = *reinterpret_cast<const double2 *>(P.invfact + k);
+          y0 = mulmod(d.x, f.x, mod);
+          y1 = mulmod(d.y, f.y, mod);
+        }
+      } else if (SRC == BS_CENTER) {
+        if (k < M) {
+          const double2 d = *reinterpret_cast<const double2 *>(a.src + col * M + k);
+          y0 = center(d.x, mod);
+          y1 = center(d.y, mod);
+        }
+      } else if (SRC == BS_REVTRUNC) {
+        const long long lim = (long long)a.m - 1;
+        if ((long long)k < lim) y0 = reduce(a.src[col * 2 * M + (size_t)(2 * a.m - 2) - k], mod);
+        if ((long long)k + 1 < lim) y1 = reduce(a.src[col * 2 * M + (size_t)(2 * a.m - 2) - k - 1], mod);
+      } else {  // BS_RIGHT
+        const size_t n = (size_t)1 << a.l, h = n >> 1;
+        const double2 d = *reinterpret_cast<const double2 *>(a.src + col * M + unit * n + h + k);
+        y0 = d.x;
+        y1 = d.y;
+      }
+      x0[e] = y0;
+      x1[e] = y1;
+    }
+    // stages 0 .. S1-1 on the elements j + 32 e (stage 0 is a copy: the upper half is padding); keep element `part`
+    reg_fwd_stages_zu<S1>(x0, mod, mask, [&](int st, int blk) { return tw[(1 << st) + blk]; });
+    reg_fwd_stages_zu<S1>(x1, mod, mask, [&](int st, int blk) { return tw[(1 << st) + blk]; });
+    double s0 = x0[0], s1 = x1[0];
+#pragma unroll
+    for (int e = 1; e < R; e++) {
+      s0 = part == e ? x0[e] : s0;
+      s1 = part == e ? x1[e] : s1;
+    }
+    v0[j] = s0;
+    v1[j] = s1;
+    // bound the loads in flight (fully hoisted, the R/2 x 32 source loads of a part would not fit the register file)
+    if (R >= 4 && (j % (16 / R)) == 16 / R - 1) mem_fence();
+  }
+  // stages S1 .. S1+4: the 32-point sub-transform rooted at node R + part
+  reg_fwd_stages<5, true>(v0, mod, mask >> S1, [&](int k, int blk) { return tw[(R << k) + (part << k) + blk]; });
+  reg_fwd_stages<5, true>(v1, mod, mask >> S1, [&](int k, int blk) { return tw[(R << k) + (part << k) + blk]; });
+  double *out = a.Wy + cu * (size_t)Y * B + (size_t)(32 * part) * B + r;
+#pragma unroll
+  for (int y = 0; y < 32; y++) *reinterpret_cast<double2 *>(out + (size_t)y * B) = make_double2(reduce(v0[y], mod), reduce(v1[y], mod));
+}
+
+template <int S1>
+__global__ void __launch_bounds__(256) bc2_yinv_a_kernel(Bc2Args a, ColPlans plans) {
+  constexpr int R = 1 << S1, Y = 32 * R, B = BC2_B;
+  const int g = (int)(blockIdx.x % R);
+  const int r = 2 * (int)((blockIdx.x / R) * 256 + threadIdx.x);
+  const size_t cu = blockIdx.y, col = cu / (size_t)a.units;
+  const ColPlan &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const Mod mod = P.mod;
+  const double *__restrict__ itw = P.itw;
+  double lo[2][32], hi[2][32];
+  double *ws = a.Ws + cu * (size_t)Y * 2 * B + (size_t)(64 * g) * B + r;
+#pragma unroll
+  for (int y = 0; y < 32; y++) {
+    const double2 u = *reinterpret_cast<const double2 *>(ws + (size_t)(2 * y) * B), w = *reinterpret_cast<const double2 *>(ws + (size_t)(2 * y + 1) * B);
+    lo[0][y] = reduce(u.x + w.x, mod);  // last inverse stage of the 2B-point transform: its twiddle is 1
+    hi[0][y] = reduce(u.x - w.x, mod);
+    lo[1][y] = reduce(u.y + w.y, mod);
+    hi[1][y] = reduce(u.y - w.y, mod);
+  }
+  // inverse stages 0..4 across blocks; block of stage k: (32 g + e) >> (k + 1)
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    reg_inv_stages<5, true>(lo[c], mod, P.imask[S1 + 5], [&](int k, int i) { return itw[(Y >> (k + 1)) + (g << (4 - k)) + i]; });
+    reg_inv_stages<5, true>(hi[c], mod, P.imask[S1 + 5], [&](int k, int i) { return itw[(Y >> (k + 1)) + (g << (4 - k)) + i]; });
+  }
+#pragma unroll
+  for (int y = 0; y < 32; y++) {
+    *reinterpret_cast<double2 *>(ws + (size_t)(2 * y) * B) = make_double2(lo[0][y], lo[1][y]);
+    *reinterpret_cast<double2 *>(ws + (size_t)(2 * y + 1) * B) = make_double2(hi[0][y], hi[1][y]);
+  }
+}
+
+template <int DST, int S1>
+__global__ void __launch_bounds__(256) bc2_yinv_b_kernel(Bc2Args a, ColPlans plans) {
+  constexpr int R = 1 << S1, Y = 32 * R, B = BC2_B;
+  const int j = (int)(blockIdx.x % 32), jp = (j + 31) % 32;
+  const int r = 2 * (int)((blockIdx.x / 32) * 256 + threadIdx.x);
+  const size_t cu = blockIdx.y, unit = cu % (size_t)a.units, col = cu / (size_t)a.units, M = (size_t)1 << a.logM;
+  const ColPlan &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const Mod mod = P.mod;
+  const double *__restrict__ itw = P.itw;
+  // lo: low halves of blocks j + 32 g; hi: high halves of blocks jp + 32 g (block k - 1 of the overlap-add)
+  double lo[2][R], hi[2][R];
+  const double *in = a.Ws + cu * (size_t)Y * 2 * B + r;
+#pragma unroll
+  for (int g = 0; g < R; g++) {
+    const double2 u = *reinterpret_cast<const double2 *>(in + (size_t)(2 * (32 * g + j)) * B), w = *reinterpret_cast<const double2 *>(in + (size_t)(2 * (32 * g + jp) + 1) * B);
+    lo[0][g] = u.x;
+    lo[1][g] = u.y;
+    hi[0][g] = w.x;
+    hi[1][g] = w.y;
+  }
+  // inverse stages 5 .. 5+S1-1: element g <-> block j + 32 g, block of stage 5 + k: g >> (k + 1)
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    reg_inv_stages<S1, true>(lo[c], mod, P.imask[S1 + 5] >> 5, [&](int k, int i) { return itw[(R >> (k + 1)) + i]; });
+    reg_inv_stages<S1, true>(hi[c], mod, P.imask[S1 + 5] >> 5, [&](int k, int i) { return itw[(R >> (k + 1)) + i]; });
+  }
+#pragma unroll
+  for (int e = 0; e < R; e++) {
+    const size_t t = (size_t)(j + 32 * e) * B + r;  // output coefficient (and t + 1): block k = j + 32 e
+    double o0 = lo[0][e], o1 = lo[1][e];
+    if (j >= 1) {  // block k - 1 = jp + 32 e
+      o0 += hi[0][e];
+      o1 += hi[1][e];
+    } else if (e >= 1) {  // block k - 1 = 31 + 32 (e - 1)
+      o0 += hi[0][e - 1];
+      o1 += hi[1][e - 1];
+    }
+    if (DST == BD_NEWTON) {
+      if (t < M) {
+        const double2 f = *reinterpret_cast<const double2 *>(P.invfact + t);
+        *reinterpret_cast<double2 *>(a.dst + col * M + t) = make_double2(f.x != 0.0 ? reduce(o0, mod) : 0.0, f.y != 0.0 ? reduce(o1, mod) : 0.0);
+      }
+    } else if (DST == BD_PLAIN_SCALED) {
+      *reinterpret_cast<double2 *>(a.dst + col * 2 * M + t) = make_double2(mulmod(reduce(o0, mod), P.b2_inv, mod), mulmod(reduce(o1, mod), P.b2_inv, mod));
+    } else if (DST == BD_HFIN) {
+      const long long top = (long long)a.m - 2;
+      if ((long long)t <= top) a.dst[col * M + (size_t)(top - (long long)t)] = reduce(o0, mod);
+      if ((long long)t + 1 <= top) a.dst[col * M + (size_t)(top - (long long)t - 1)] = reduce(o1, mod);
+    } else {
+      double2 *p = reinterpret_cast<double2 *>(a.dst + col * M + unit * ((size_t)1 << a.l) + t);
+      const double2 d = *p;
+      const double f0 = reduce(o0 + d.x, mod), f1 = reduce(o1 + d.y, mod);
+      *p = DST == BD_COMBINE_CANON ? make_double2(canon(f0, mod), canon(f1, mod)) : make_double2(f0, f1);
+    }
+  }
+}
+
 }  // namespace rs

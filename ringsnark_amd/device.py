@@ -386,10 +386,19 @@ class Device:
         """Page-locked host memory of `words` uint64 (rs_host_alloc): where a proving key larger than HBM lives."""
         return HostWords(self, words)
 
-    def groth16_prove(self, dcs, pk, assignment, want_empty=True, window=0):
+    def _kinds(self, kinds, n):
+        """per-wire representation (RS_KIND_*) as a host uint8 array, or (None, None)"""
+        if kinds is None:
+            return None, None
+        k = np.ascontiguousarray(kinds, dtype=np.uint8)
+        assert k.shape == (n,), (k.shape, n)
+        return k, k.ctypes.data_as(_lib.u8p)
+
+    def groth16_prove(self, dcs, pk, assignment, want_empty=True, window=0, kinds=None):
         """pk: dict s_pows, delta_ts, delta_mid, alpha, beta (CUDA tensors).  window != 0: the key vectors hold
         `window` elements each, element t read from t % window (tiled synthetic key, ringsnark_amd.h).
-        Key VECTORS given as HostWords: a host-resident key, streamed tile by tile (rs_groth16_pk.host_key)."""
+        Key VECTORS given as HostWords: a host-resident key, streamed tile by tile (rs_groth16_pk.host_key).
+        kinds [n_vars]: RS_KIND_ONE for assignment wires held as RingElem Scalar 1 (rs_groth16_prove_kinds)."""
         host_key = isinstance(pk["s_pows"], HostWords)
         addr = lambda v: None if v is None else (v.ptr if isinstance(v, HostWords) else v.data_ptr())
         assert all(isinstance(pk[k], HostWords) == host_key for k in ("s_pows", "delta_ts") + (("delta_mid",) if pk.get("delta_mid") is not None else ()))
@@ -397,19 +406,21 @@ class Device:
                            pk["alpha"].data_ptr(), pk["beta"].data_ptr(), window, 1 if host_key else 0)
         proof = self.enc_empty(3)
         empty = (C.c_int * 3)()
-        _lib.check(self.lib.rs_groth16_prove(self.h, dcs.h, C.byref(s), _ptr(assignment), _ptr(proof),
-                                             empty if want_empty else None, self.stream()))
+        keep, kp = self._kinds(kinds, dcs.n_vars)
+        _lib.check(self.lib.rs_groth16_prove_kinds(self.h, dcs.h, C.byref(s), _ptr(assignment), kp, _ptr(proof),
+                                                   empty if want_empty else None, self.stream()))
         return proof, [int(e) for e in empty]
 
-    def rinocchio_prove(self, dcs, pk, assignment, d1=None, d2=None, d3=None, window=0):
+    def rinocchio_prove(self, dcs, pk, assignment, d1=None, d2=None, d3=None, window=0, kinds=None):
         host_key = isinstance(pk.get("s_pows"), HostWords)
         g = lambda k: None if pk.get(k) is None else (pk[k].ptr if isinstance(pk[k], HostWords) else pk[k].data_ptr())
         s = _lib.RinocchioPK(g("s_pows"), g("alpha_s_pows"), g("beta_prods"), g("beta_rv_ts"), g("beta_rw_ts"), g("beta_ry_ts"),
                              window, 1 if host_key else 0)
         proof = self.enc_empty(9)
         empty = (C.c_int * 9)()
-        _lib.check(self.lib.rs_rinocchio_prove(self.h, dcs.h, C.byref(s), _ptr(assignment), _ptr(d1), _ptr(d2), _ptr(d3),
-                                               _ptr(proof), empty, self.stream()))
+        keep, kp = self._kinds(kinds, dcs.n_vars)
+        _lib.check(self.lib.rs_rinocchio_prove_kinds(self.h, dcs.h, C.byref(s), _ptr(assignment), kp, _ptr(d1), _ptr(d2), _ptr(d3),
+                                                     _ptr(proof), empty, self.stream()))
         return proof, [int(e) for e in empty]
 
     # ---- measurement / synthetic workloads

@@ -241,15 +241,21 @@ def _gather_limbs(plan: ShardPlan, piece, n_elems):
     return full
 
 
-def groth16_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_local, assignment_local, m, n_inputs, n_aux):
+def groth16_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_local, assignment_local, m, n_inputs, n_aux,
+                          aux_kinds=None):
     """groth16::prover (zk_proof_systems/groth16/groth16.tcc:70-115) on this rank's shard.
 
-    *_local hold only this rank's limbs.  Returns the full proof [3][L][2][K][N_enc] (int64) on
-    every rank."""
+    *_local hold only this rank's limbs.  aux_kinds [n_aux] (uint8, RS_KIND_*; None = polynomials): auxiliary wires held
+    as RingElem Scalar 1 pass their key element through (seal_ring.tcc:525-527) -- a property of the wire, the same on
+    every limb.  Returns the full proof [3][L][2][K][N_enc] (int64) on every rank."""
+    if aux_kinds is not None:
+        aux_kinds = np.ascontiguousarray(aux_kinds, dtype=np.uint8)
+        assert aux_kinds.shape == (n_aux,)
     if plan.term_shards == 1 and hasattr(backend, "groth16_prove_local"):
         # limbs only: this rank's limbs of the proof are an ordinary proof over its own context (the fused device prover,
         # rs_groth16_prove), and nothing is exchanged before the proof is assembled
-        piece = backend.groth16_prove_local(cs_local, pk_local, assignment_local)
+        kinds_all = None if aux_kinds is None else np.concatenate([np.zeros(n_inputs, dtype=np.uint8), aux_kinds])
+        piece = backend.groth16_prove_local(cs_local, pk_local, assignment_local, kinds_all)
         if piece is not None:
             return _gather_limbs(plan, piece.contiguous(), 3)
     rng_ab = lambda s: plan.term_range(m, s)
@@ -262,7 +268,7 @@ def groth16_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_loc
     if n_aux:  # <delta_mid, aux> reads the assignment only: it runs while the coefficient rows are exchanged
         lo, hi = ranges["delta_mid"]
         aux = assignment_local[n_inputs:]
-        c2, _ = backend.msm([key_slice(pk_local["delta_mid"], lo, hi)], [(aux[lo:hi], None, 0)], 1)
+        c2, _ = backend.msm([key_slice(pk_local["delta_mid"], lo, hi)], [(aux[lo:hi], None if aux_kinds is None else aux_kinds[lo:hi], 0)], 1)
     finish()
     lo, hi = ranges["s_pows"]
     ab, _ = backend.msm([key_slice(pk_local["s_pows"], lo, hi)], [(w["A_io"], None, 0), (w["A_mid"], None, 0), (w["B_io"], None, 1), (w["B_mid"], None, 1)], 2,
@@ -282,7 +288,7 @@ def groth16_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_loc
 
 
 def rinocchio_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_local, assignment_local, m, n_inputs, n_aux,
-                            d1=None, d2=None, d3=None):
+                            d1=None, d2=None, d3=None, aux_kinds=None):
     """rinocchio::prover (zk_proof_systems/rinocchio/rinocchio.tcc:75-190) on this rank's shard: the ten inner
     products of :106-163 over this rank's term range in one grouped pass over both key vectors, F over its range
     of beta_prods (:176-185), one all-reduce of the eleven partial sums, then the ZK shifts (:167-174, 181-183) on
@@ -311,7 +317,8 @@ def rinocchio_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_l
     used_f = 0
     if n_aux:
         flo, fhi = ranges["beta_prods"]
-        f, uf = backend.msm([key_slice(pk_local["beta_prods"], flo, fhi)], [(assignment_local[n_inputs:][flo:fhi], None, 0)], 1, want_used=True)
+        fk = None if aux_kinds is None else np.ascontiguousarray(aux_kinds, dtype=np.uint8)[flo:fhi]  # Scalar-1 wires (seal_ring.tcc:525-527)
+        f, uf = backend.msm([key_slice(pk_local["beta_prods"], flo, fhi)], [(assignment_local[n_inputs:][flo:fhi], fk, 0)], 1, want_used=True)
         f, used_f = f.reshape((1,) + enc_shape), uf[0]
     else:
         f = torch.zeros((1,) + enc_shape, dtype=mo.dtype, device=mo.device)
@@ -398,7 +405,7 @@ class DeviceBackend:
             out = torch.stack([torch.stack([self.dev.enc_add(out[c][g], addends[g]) for g in range(n_groups)]) for c in range(len(crs_list))])
         return out, used
 
-    def groth16_prove_local(self, dcs, pk_local, assignment):
+    def groth16_prove_local(self, dcs, pk_local, assignment, kinds=None):
         """The whole prover on this rank's context (rs_groth16_prove); None when a key vector does not start at term 0
         or stops short of what the fused prover reads, or the vectors are not equally windowed (then the caller runs
         the piecewise plan)."""
@@ -406,7 +413,7 @@ class DeviceBackend:
         if pk1 is None:
             return None
         window = pk1.pop("window")
-        return self.dev.groth16_prove(dcs, pk1, assignment, want_empty=False, window=window)[0]
+        return self.dev.groth16_prove(dcs, pk1, assignment, want_empty=False, window=window, kinds=kinds)[0]
 
     def enc_add(self, a, b):
         return self.dev.enc_add(a.contiguous(), b.contiguous())

@@ -268,7 +268,7 @@ def test_limb_only_plans_take_the_fused_device_prover():
     class FakeDev:
         calls = []
 
-        def groth16_prove(self, dcs, pk, asg, want_empty, window):
+        def groth16_prove(self, dcs, pk, asg, want_empty, window, kinds=None):
             self.calls.append((sorted(pk), {k: len(v) for k, v in pk.items() if k in ("s_pows", "delta_ts", "delta_mid")}, window))
             return ["proof"]
 

@@ -860,6 +860,10 @@ def test_host_resident_key_equals_the_device_resident_one(name, tile):
         # a tiled host key: window of 8 stored elements, logical length m + 1
         w8 = on_host(pk["s_pows"][:8])
         ip_w, _ = dev.msm([w8], [(dev.put(rings), None, 0)], 1, crs_len=m + 1, window=8)
+        # a window that is NOT a multiple of the staging tile (12 elements, tiles of 2 / 8 / 4): a tile straddles the wrap
+        # and is staged by two copies (round-3 advice: the single copy read past the end of the host buffer)
+        w12 = on_host(pk["s_pows"][:12])
+        ip_w12, _ = dev.msm([w12], [(dev.put(rings), kinds, 0)], 1, crs_len=m + 1, window=12)
     finally:
         _set_tuning(b"msm_host_tile", 1024)
     got_d, empty_d = dev.groth16_prove(dcs, dk, dasg)
@@ -872,6 +876,8 @@ def test_host_resident_key_equals_the_device_resident_one(name, tile):
         assert used_h[0] == used and (host(ip_h)[c, 0] == exp).all()
     exp, _ = ctx.inner_product(pk["s_pows"][:8], rings, None, threads=0, window=8)
     assert (host(ip_w)[0, 0] == exp).all()
+    exp, _ = ctx.inner_product(pk["s_pows"][:12], rings, kinds, threads=0, window=12)
+    assert (host(ip_w12)[0, 0] == exp).all()
 
 
 @pytest.mark.parametrize("m,zk", [(20000, True), (40000, False)])

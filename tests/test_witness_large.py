@@ -1,0 +1,119 @@
+"""The witness map beyond 2^16 constraints -- the sizes BASELINE.json configs[3] (2^18 constraints) needs and the
+reference's O(m^2) map (reductions/r1cs_to_qrp/r1cs_to_qrp.tcc:149-259) serves for any m, on the ring primes its recipe
+produces (seal/seal_util.hpp:20-32: q_i = 1 mod 2 N_enc only) as well as on well-endowed ones.
+
+M = 2^17 and 2^18 on a SMALL ring (toy44: 64 columns, headline-size primes), every path:
+  full-length transforms (three cross passes per transform: logM + 1 - 13 = 5, 6 stages over global memory),
+  two-dimensional block convolutions forced on the same primes (witness_force_bc = 14): Y = 32 blocks at 2^17 (the
+  transform across blocks in one thread's registers), Y = 64 at 2^18 (the two-level kernels bc2_yfwd_big / bc2_yinv_a / _b).
+Checked the way bench.py checks the headline: every output vector on sampled columns against the Lagrange form of the
+interpolants at random points -- sum_j y_j L_j(r), O(m) exact integer operations, no oracle run of the O(m^2) map needed --
+and H Z = A B - C (+ the ZK patch), plus bit-equality of the two paths with each other."""
+import numpy as np
+import pytest
+
+from ringsnark_amd import params as P
+from ringsnark_amd import r1cs as R
+from tests import helpers as H
+from tests import proof_check
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
+
+
+def _set_tuning(key, value):
+    from ringsnark_amd import _lib
+    _lib.check(_lib.load().rs_set_tuning(key, value))
+
+
+def _run(prm, m, zk, force, int_arith=False, want=KEYS):
+    """Fresh context (plans are cached per context and read the knobs when they are built)."""
+    import torch
+
+    from ringsnark_amd.device import Device
+    octx = H.oracle_ctx(prm)
+    cs = R.chain_r1cs(m, prm.q)
+    _set_tuning(b"witness_force_bc", force)
+    if int_arith:
+        _set_tuning(b"force_int_arith", 1)
+    try:
+        dev = Device(prm)
+    finally:
+        if int_arith:
+            _set_tuning(b"force_int_arith", 0)
+    try:
+        asg = dev.ring_empty(m + 2)
+        dev.fill_uniform(asg[:2], 0, 9)
+        dev.chain_assignment(asg, m)
+        ds = [dev.put(octx.random_ring(60 + k)) for k in range(3)] if zk else [None] * 3
+        dev.set_profiling(True)
+        w = dev.witness_map(dev.r1cs(cs), asg, *ds, want=want)
+        torch.cuda.synchronize()
+        names = {k["name"] for k in dev.profile_read()}
+        dev.set_profiling(False)
+    finally:
+        _set_tuning(b"witness_force_bc", 0)
+    return dev, cs, asg, ds, w, names
+
+
+@pytest.mark.parametrize("m,zk,force", [(100000, True, 0), (131072, False, 0), (262144, True, 0), (200000, False, 0),
+                                        (131072, True, 14), (100000, False, 14), (262144, True, 14), (180000, False, 14)])
+def test_witness_map_at_2_17_and_2_18(m, zk, force):
+    prm = P.preset("toy44")
+    dev, cs, asg, ds, w, names = _run(prm, m, zk, force)
+    logM = (m - 1).bit_length()
+    if force:
+        assert ("bc2_yfwd_big_kernel" in names) == (logM == 18), names
+        assert ("bc2_yinv_b_kernel" in names) == (logM == 18), names
+        assert "bc2_yfwd_kernel" in names, names  # the tree levels above the 2^14 tiles (Y <= 32) at either size
+    else:
+        assert not any(n.startswith("bc") for n in names), names
+        assert any(n.startswith("cross_kernel") for n in names), names
+    rng = np.random.RandomState(m % 1000 + force)
+    cols = [(0, 0), (prm.L - 1, prm.N - 1), (int(rng.randint(prm.L)), int(rng.randint(prm.N)))]
+    err = proof_check.check_columns(prm, cs, asg, {k: w[k] for k in KEYS}, cols, rng, tuple(ds))
+    assert err is None, err
+    # rows beyond the degree bound: H has m + 1 rows, row m is d1 d2 (the top of the ZK patch) or zero
+    from ringsnark_amd.device import to_host
+    if not zk:
+        assert not to_host(w["H"][m - 1:]).any()
+
+
+@pytest.mark.parametrize("m,force", [(400000, 14), (1048576, 0)])
+def test_two_level_transform_across_blocks_at_2_19_and_2_20(m, force):
+    """Y = 128 and 256 blocks (bc2_yfwd_big_kernel<., 2 | 3>).  2^20 constraints is the limit the plan accepts
+    (witness.hip build_plan); toy44's primes (= 1 mod 2^20) have no 2^21-th root, so that size takes the block path unforced."""
+    prm = P.preset("toy44")
+    dev, cs, asg, ds, w, names = _run(prm, m, False, force, want=("A_mid", "B_mid", "H"))
+    assert "bc2_yfwd_big_kernel" in names and "bc2_yinv_a_kernel" in names and "bc2_yinv_b_kernel" in names, names
+    rng = np.random.RandomState(3)
+    err = proof_check.check_columns(prm, cs, asg, {k: w[k] for k in ("A_mid", "B_mid", "H")}, [(1, 17)], rng, tuple(ds))
+    assert err is None, err
+
+
+@pytest.mark.parametrize("m", [131072, 262144])
+def test_block_convolutions_equal_full_length_transforms_beyond_2_16(m):
+    """Bit equality of the two exact paths on every slot (64 columns x 7 vectors)."""
+    from ringsnark_amd.device import to_host
+    prm = P.preset("toy44")
+    runs = {}
+    for force in (0, 14):
+        dev, cs, asg, ds, w, names = _run(prm, m, True, force)
+        runs[force] = {k: to_host(w[k]) for k in KEYS}
+        del dev, asg, w
+    for k in KEYS:
+        assert (runs[0][k] == runs[14][k]).all(), k
+
+
+def test_integer_arithmetic_at_2_17():
+    """The Montgomery-integer contexts (moduli >= 2^50: microbench.cpp:33-36, BFVDefault(2048)) run the generic kernels of
+    the multi-pass path; M = 2^17 forced on toy44's primes, equal to the FP64 context bit for bit."""
+    from ringsnark_amd.device import to_host
+    prm = P.preset("toy44")
+    m = 70000
+    want = ("A_mid", "B_mid", "H")
+    a = _run(prm, m, True, 0, want=want)
+    b = _run(prm, m, True, 0, int_arith=True, want=want)
+    for k in want:
+        assert (to_host(a[4][k]) == to_host(b[4][k])).all(), k

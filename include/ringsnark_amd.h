@@ -224,6 +224,15 @@ int rs_witness_map_slots(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_assig
                          const uint64_t *d_d2, const uint64_t *d_d3, int slot0, int nslots, uint64_t *d_A_io,
                          uint64_t *d_B_io, uint64_t *d_C_io, uint64_t *d_A_mid, uint64_t *d_B_mid, uint64_t *d_C_mid,
                          uint64_t *d_H, uint64_t *h_Z, rs_stream stream);
+/* The same map keeping only a ROW range of every output: h_rows[7][2] = {lo, hi} per vector in the order A_io, B_io,
+ * C_io, A_mid, B_mid, C_mid, H; output k holds rows [lo, hi) -- row r at index r - lo, [hi - lo][L][N].  The ranks that
+ * share a ring limb each run the whole map of that limb and keep the rows of their TERM range of the inner products
+ * (ringsnark_amd/dist.py); full-length outputs (five vectors of 96 GiB for three limbs of the
+ * configs[3] shape at 2^18 constraints) would not fit.  The io and mid vectors of one matrix take the same range. */
+int rs_witness_map_rows(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_assignment, const uint64_t *d_d1,
+                        const uint64_t *d_d2, const uint64_t *d_d3, const size_t *h_rows, uint64_t *d_A_io, uint64_t *d_B_io,
+                        uint64_t *d_C_io, uint64_t *d_A_mid, uint64_t *d_B_mid, uint64_t *d_C_mid, uint64_t *d_H, uint64_t *h_Z,
+                        rs_stream stream);
 /* util/polynomials.tcc:10-43 on the domain {0..n-1}: d_y, d_out [n][L][N] (may alias). */
 int rs_interpolate(rs_ctx *ctx, const uint64_t *d_y, uint64_t *d_out, size_t n, rs_stream stream);
 

@@ -97,6 +97,7 @@ SIGNATURES = {
     "rs_r1cs_evaluate": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "rs_witness_map": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64p, vp]),
     "rs_witness_map_slots": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, u64p, vp]),
+    "rs_witness_map_rows": (C.c_int, [vp, vp, vp, vp, vp, vp, C.POINTER(C.c_size_t), vp, vp, vp, vp, vp, vp, vp, u64p, vp]),
     "rs_interpolate": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "rs_poly_multiply": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.POINTER(C.c_size_t), vp]),
     "rs_poly_add": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.POINTER(C.c_size_t), vp]),

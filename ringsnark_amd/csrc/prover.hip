@@ -15,7 +15,7 @@ bool witness_io_shortcut(const rs_r1cs *cs);
 void enc_add_run(rs_ctx *ctx, uint64_t *dst, const uint64_t *x, const uint64_t *y, size_t count, hipStream_t st);
 void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const uint64_t *d1, const uint64_t *d2,
                  const uint64_t *d3, uint64_t *const outs[7], uint64_t *h_Z, hipStream_t st, int slot0 = 0, int nslots = -1,
-                 bool compact = false);
+                 bool compact = false, const size_t (*rows)[2] = nullptr);
 void msm_scratch_release(rs_ctx *ctx);
 
 int g_prover_lin_io = 1;  // tuning knob "prover_lin_io": io vectors of groth16::prover as linear forms (MsmLin)

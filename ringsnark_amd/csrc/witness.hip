@@ -1282,7 +1282,7 @@ int g_witness_col_budget_mib = 16 * 1024;  // column workspace of one chunk (tun
 template <class M_>
 static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const uint64_t *d_asg, const uint64_t *d1,
                           const uint64_t *d2, const uint64_t *d3, uint64_t *const outs[7], const ColMap &cm, int nl,
-                          const void *d_const_, hipStream_t st) {
+                          const void *d_const_, hipStream_t st, const size_t (*rows)[2]) {
   using T = typename ArithOf<M_>::T;
   using CPS = ColPlansT<M_>;
   const T *d_const = static_cast<const T *>(d_const_);
@@ -1318,6 +1318,15 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
   const dim3 tgrid((unsigned)((C + 31) / 32), (unsigned)((M + 31) / 32));
   const dim3 tgrid64((unsigned)((C + 63) / 64), (unsigned)((M + 31) / 32));
   const T *ptab = reinterpret_cast<const T *>(cs->d_ptab);
+  // the map of output vector k: its row range (rows == null: every row)
+  auto cm_for = [&](int k) {
+    ColMap c = cm;
+    if (rows) {
+      c.row0 = rows[k][0];
+      c.row1 = rows[k][1];
+    }
+    return c;
+  };
   for (int w = 0; w < 3; w++)
     for (int kind = 0; kind < 3; kind++) {  // io, full, constant part
       const int k = kind == 2 ? 7 + w : 3 * kind + w;
@@ -1352,7 +1361,7 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
     for (int k = 0; k < 6; k++)
       if (outs[k]) {
         ProfScope prof(ctx, st, "transpose_out_kernel", (double)C * (double)m * 16.0, 0.0);
-        hipLaunchKernelGGL(transpose_out_kernel<T>, tgrid, dim3(256), 0, st, colv(k), outs[k], m, C, M, cm);
+        hipLaunchKernelGGL(transpose_out_kernel<T>, tgrid, dim3(256), 0, st, colv(k), outs[k], m, C, M, cm_for(k));
       }
   } else {
     for (int w = 0; w < 3; w++) {
@@ -1364,11 +1373,14 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
         ProfScope prof(ctx, st, "io_mid_out_kernel", (double)C * (double)m * (outs[w] ? 24.0 : 16.0),
                        (double)C * (double)m * (7.0 * io.count + 4.0));
         hipLaunchKernelGGL(io_mid_out_kernel<M_>, tgrid64, dim3(256), 0, st, colv(3 + w), io, io_cols, d_asg, cst, outs[w],
-                           outs[3 + w], m, C, M, qmod, cm);
+                           outs[3 + w], m, C, M, qmod, cm_for(3 + w));  // io and mid of one matrix share their row range (checked by the caller)
       } else {  // io alone: no column work at all
         const unsigned by = (unsigned)((C / 2 + 255) / 256);
-        ProfScope prof(ctx, st, "io_coeff_kernel", (double)C * (double)m * 8.0, (double)C * (double)m * 7.0 * io.count);
-        hipLaunchKernelGGL(io_coeff_kernel<M_>, dim3((unsigned)m, by), dim3(256), 0, st, io, io_cols, d_asg, outs[w], C, M, qmod, cm);
+        const ColMap cw = cm_for(w);
+        const size_t r1 = std::min(m, cw.row1);
+        if (r1 <= cw.row0) continue;
+        ProfScope prof(ctx, st, "io_coeff_kernel", (double)C * (double)(r1 - cw.row0) * 8.0, (double)C * (double)(r1 - cw.row0) * 7.0 * io.count);
+        hipLaunchKernelGGL(io_coeff_kernel<M_>, dim3((unsigned)(r1 - cw.row0), by), dim3(256), 0, st, io, io_cols, d_asg, outs[w], C, M, qmod, cw);
       }
     }
   }
@@ -1376,10 +1388,11 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
   if (needH) {
     {
       ProfScope prof(ctx, st, "transpose_out_kernel", (double)C * (double)m * 16.0, 0.0);
-      hipLaunchKernelGGL(transpose_out_kernel<T>, tgrid, dim3(256), 0, st, colv(6), outs[6], std::min(m + 1, M), C, M, cm);
+      hipLaunchKernelGGL(transpose_out_kernel<T>, tgrid, dim3(256), 0, st, colv(6), outs[6], std::min(m + 1, M), C, M, cm_for(6));
     }
-    if (m == M)  // row m does not exist in the M-row column tile
-      hipLaunchKernelGGL(h_top_kernel<M_>, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, outs[6] + m * cm.out_stride(), d1, d2, C,
+    const ColMap ch = cm_for(6);
+    if (m == M && m >= ch.row0 && m < ch.row1)  // row m does not exist in the M-row column tile
+      hipLaunchKernelGGL(h_top_kernel<M_>, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, outs[6] + (m - ch.row0) * cm.out_stride(), d1, d2, C,
                          qmod, cm);
     RS_HIP(hipGetLastError());
   }
@@ -1393,13 +1406,20 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
 template <class M_>
 static void witness_run_arith(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const uint64_t *d1, const uint64_t *d2,
                               const uint64_t *d3, uint64_t *const outs[7], uint64_t *h_Z, hipStream_t st, int slot0, int nslots,
-                              bool compact) {
+                              bool compact, const size_t (*rows)[2]) {
   using T = typename ArithOf<M_>::T;
   RS_REQUIRE((d1 && d2 && d3) || (!d1 && !d2 && !d3), "d1,d2,d3 must be all set or all null");
   if (nslots < 0) nslots = ctx->N - slot0;
   RS_REQUIRE(slot0 >= 0 && nslots >= 2 && slot0 + nslots <= ctx->N && !(slot0 & 1) && !(nslots & 1),
              "slot range must be even-aligned and inside the ring");
   const size_t m = cs->m;
+  if (rows) {
+    for (int k = 0; k < 7; k++)
+      RS_REQUIRE(!outs[k] || (rows[k][0] <= rows[k][1] && rows[k][1] <= m + (k == 6 ? 1 : 0)), "row range outside the vector");
+    for (int w = 0; w < 3; w++)
+      RS_REQUIRE(!outs[w] || !outs[3 + w] || (rows[w][0] == rows[3 + w][0] && rows[w][1] == rows[3 + w][1]),
+                 "the io and mid vectors of one matrix take the same row range");
+  }
   WitnessPlan *P = get_plan(ctx, m);
   const size_t M = P->M;
   const int L = ctx->L;
@@ -1436,7 +1456,7 @@ static void witness_run_arith(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_
     const int per = (int)std::max<size_t>(1, std::min<size_t>((size_t)L, budget_cols / (size_t)nslots));
     for (int l0 = 0; l0 < L; l0 += per) {
       cm.limb0 = l0;
-      witness_chunk<M_>(ctx, cs, P, d_asg, d1, d2, d3, outs, cm, std::min(per, L - l0), d_const, st);
+      witness_chunk<M_>(ctx, cs, P, d_asg, d1, d2, d3, outs, cm, std::min(per, L - l0), d_const, st, rows);
     }
   } else {
     const int piece = (int)std::max<size_t>(64, (budget_cols / 64) * 64);
@@ -1445,15 +1465,15 @@ static void witness_run_arith(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_
         cm.limb0 = l0;
         cm.slot0 = slot0 + s0;
         cm.ns = std::min(piece, nslots - s0);
-        witness_chunk<M_>(ctx, cs, P, d_asg, d1, d2, d3, outs, cm, 1, d_const, st);
+        witness_chunk<M_>(ctx, cs, P, d_asg, d1, d2, d3, outs, cm, 1, d_const, st, rows);
       }
   }
 }
 void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const uint64_t *d1, const uint64_t *d2,
                  const uint64_t *d3, uint64_t *const outs[7], uint64_t *h_Z, hipStream_t st, int slot0 = 0, int nslots = -1,
-                 bool compact = false) {
-  RS_DISPATCH_ARITH(ctx, (witness_run_arith<Mod>(ctx, cs, d_asg, d1, d2, d3, outs, h_Z, st, slot0, nslots, compact)),
-                    (witness_run_arith<ModI>(ctx, cs, d_asg, d1, d2, d3, outs, h_Z, st, slot0, nslots, compact)));
+                 bool compact = false, const size_t (*rows)[2] = nullptr) {
+  RS_DISPATCH_ARITH(ctx, (witness_run_arith<Mod>(ctx, cs, d_asg, d1, d2, d3, outs, h_Z, st, slot0, nslots, compact, rows)),
+                    (witness_run_arith<ModI>(ctx, cs, d_asg, d1, d2, d3, outs, h_Z, st, slot0, nslots, compact, rows)));
 }
 
 template <class M_>
@@ -1615,6 +1635,20 @@ int rs_witness_map_slots(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_assig
   WsScope ws_scope(ctx, S(stream));
   uint64_t *outs[7] = {d_A_io, d_B_io, d_C_io, d_A_mid, d_B_mid, d_C_mid, d_H};
   witness_run(ctx, cs, d_assignment, d_d1, d_d2, d_d3, outs, h_Z, S(stream), slot0, nslots, true);
+  RS_API_END
+}
+
+int rs_witness_map_rows(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_assignment, const uint64_t *d_d1,
+                        const uint64_t *d_d2, const uint64_t *d_d3, const size_t *h_rows, uint64_t *d_A_io, uint64_t *d_B_io,
+                        uint64_t *d_C_io, uint64_t *d_A_mid, uint64_t *d_B_mid, uint64_t *d_C_mid, uint64_t *d_H, uint64_t *h_Z,
+                        rs_stream stream) {
+  RS_API_BEGIN_CTX(ctx)
+  RS_REQUIRE(ctx && cs && d_assignment && h_rows, "null argument");
+  WsScope ws_scope(ctx, S(stream));
+  uint64_t *outs[7] = {d_A_io, d_B_io, d_C_io, d_A_mid, d_B_mid, d_C_mid, d_H};
+  size_t rows[7][2];
+  for (int k = 0; k < 7; k++) rows[k][0] = h_rows[2 * k], rows[k][1] = h_rows[2 * k + 1];
+  witness_run(ctx, cs, d_assignment, d_d1, d_d2, d_d3, outs, h_Z, S(stream), 0, -1, false, rows);
   RS_API_END
 }
 

@@ -44,8 +44,11 @@ struct ColBlockFactory {
 // [t][L][out_N] with slot s stored at s - out_slot0 (out_N = N, out_slot0 = 0: the full layout;
 // out_N = ns, out_slot0 = slot0: the compact layout of a slot-sharded rank).
 // slot0, ns, out_slot0 are even (lanes move slot PAIRS with 16-byte accesses).
+// row0, row1: only output rows [row0, row1) are written, row r at index r - row0 of the output (a rank of a limb group
+// keeps the rows of its TERM range only, ringsnark_amd/dist.py; witness.hip sets them per output vector).
 struct ColMap {
   int limb0, ns, slot0, N, L, out_N, out_slot0;
+  size_t row0 = 0, row1 = ~(size_t)0;
   __device__ __forceinline__ void locate(size_t c, int &limb, int &slot) const {
     limb = limb0 + (int)(c / (size_t)ns);
     slot = slot0 + (int)(c % (size_t)ns);
@@ -79,6 +82,7 @@ __global__ void __launch_bounds__(256) transpose_out_kernel(const T *__restrict_
                                                             size_t m_out, size_t C, size_t M, ColMap cm) {
   __shared__ T tile[32][33];
   const size_t s0 = (size_t)blockIdx.x * 32, r0 = (size_t)blockIdx.y * 32;
+  if (r0 + 32 <= cm.row0 || r0 >= cm.row1) return;  // no row of this tile is wanted
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int k = ty; k < 32; k += 8) {
     const size_t c = s0 + k, r = r0 + tx;
@@ -92,7 +96,7 @@ __global__ void __launch_bounds__(256) transpose_out_kernel(const T *__restrict_
   const size_t o = cm.out_index(limb, slot), So = cm.out_stride();
   for (int k = ty; k < 32; k += 8) {
     const size_t r = r0 + k;
-    if (r < m_out) dst[r * So + o] = to_res(tile[tx][k]);
+    if (r < m_out && r >= cm.row0 && r < cm.row1) dst[(r - cm.row0) * So + o] = to_res(tile[tx][k]);
   }
 }
 

@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(256)
 io_coeff_kernel(IoDesc io, const typename ArithOf<M>::T *__restrict__ Lcols /* [ncols][Ltot][M] */, const uint64_t *__restrict__ asg,
                 uint64_t *__restrict__ out, size_t C, size_t Mlen, const M *__restrict__ qmod, ColMap cm) {
   using T = typename ArithOf<M>::T;
-  const size_t t = blockIdx.x;
+  const size_t t = cm.row0 + blockIdx.x;  // grid.x = the rows wanted
   const size_t c = 2 * ((size_t)blockIdx.y * blockDim.x + threadIdx.x);
   if (c >= C) return;
   int limb, slot;
@@ -45,7 +45,7 @@ io_coeff_kernel(IoDesc io, const typename ArithOf<M>::T *__restrict__ Lcols /* [
   ulonglong2 o;
   o.x = to_res(canon(a0, mod));
   o.y = to_res(canon(a1, mod));
-  reinterpret_cast<ulonglong2 *>(out + t * cm.out_stride())[cm.out_index(limb, slot) >> 1] = o;
+  reinterpret_cast<ulonglong2 *>(out + (t - cm.row0) * cm.out_stride())[cm.out_index(limb, slot) >> 1] = o;
 }
 
 // Column-major interpolated `full` vector -> term-major io AND mid vectors in one pass:
@@ -63,6 +63,7 @@ io_mid_out_kernel(const typename ArithOf<M>::T *__restrict__ cols, IoDesc io,
   using T = typename ArithOf<M>::T;
   __shared__ T tile[64][33];  // [column][row]
   const size_t s0 = (size_t)blockIdx.x * 64, r0 = (size_t)blockIdx.y * 32;
+  if (r0 + 32 <= cm.row0 || r0 >= cm.row1) return;  // no row of this tile is wanted (uniform: before the barrier)
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int k = ty; k < 64; k += 8) {
     const size_t c = s0 + k, r = r0 + tx;
@@ -78,7 +79,8 @@ io_mid_out_kernel(const typename ArithOf<M>::T *__restrict__ cols, IoDesc io,
   const M mod = qmod[limb];
   for (int k = ty; k < 32; k += 8) {
     const size_t r = r0 + k;
-    if (r >= m) continue;
+    if (r >= m || r < cm.row0 || r >= cm.row1) continue;
+    const size_t ro = r - cm.row0;  // output row
     T a0 = T(0), a1 = T(0);
     for (int e = 0; e < io.count; e++) {
       const T lv = center(Lcols[((size_t)io.column[e] * cm.L + limb) * Mlen + r], mod);
@@ -102,13 +104,13 @@ io_mid_out_kernel(const typename ArithOf<M>::T *__restrict__ cols, IoDesc io,
       ulonglong2 o;
       o.x = to_res(a0);
       o.y = to_res(a1);
-      reinterpret_cast<ulonglong2 *>(io_out + r * So)[opair] = o;
+      reinterpret_cast<ulonglong2 *>(io_out + ro * So)[opair] = o;
     }
     const T cc = cst ? cst[(size_t)limb * Mlen + r] : T(0);
     ulonglong2 o;
     o.x = to_res(canon(addm(subm(tile[2 * tx][k], a0, mod), cc, mod), mod));
     o.y = to_res(canon(addm(subm(tile[2 * tx + 1][k], a1, mod), cc, mod), mod));
-    reinterpret_cast<ulonglong2 *>(mid_out + r * So)[opair] = o;
+    reinterpret_cast<ulonglong2 *>(mid_out + ro * So)[opair] = o;
   }
 }
 

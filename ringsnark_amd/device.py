@@ -328,8 +328,30 @@ class Device:
         _lib.check(self.lib.rs_interpolate(self.h, _ptr(y), _ptr(out), n, self.stream()))
         return out
 
-    def witness_map(self, dcs, assignment, d1=None, d2=None, d3=None, want=("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")):
+    def witness_map(self, dcs, assignment, d1=None, d2=None, d3=None, want=("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H"),
+                    rows=None):
+        """rows: {name: (lo, hi)} -- keep only rows [lo, hi) of those outputs (rs_witness_map_rows: a rank of a limb
+        group keeps the rows of its term range); outputs not named keep every row."""
         m = dcs.m
+        names = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
+        if rows is not None:
+            full = {k: (0, m + 1 if k == "H" else m) for k in names}
+            rr = {k: tuple(int(x) for x in rows.get(k, full[k])) for k in names}
+            for a, b in (("A_io", "A_mid"), ("B_io", "B_mid"), ("C_io", "C_mid")):  # one pass writes both: same range
+                if a in want and b in want:
+                    assert rr[a] == rr[b], (a, b, rr[a], rr[b])
+                elif a in want:
+                    rr[b] = rr[a]
+                else:
+                    rr[a] = rr[b]
+            o = {k: (torch.empty((rr[k][1] - rr[k][0], self.L, self.N), dtype=torch.int64, device=self.device) if k in want else None) for k in names}
+            flat = (C.c_size_t * 14)(*[x for k in names for x in rr[k]])
+            Z = np.zeros((self.L, m + 1), dtype=np.uint64)
+            _lib.check(self.lib.rs_witness_map_rows(
+                self.h, dcs.h, _ptr(assignment), _ptr(d1), _ptr(d2), _ptr(d3), flat, _ptr(o["A_io"]), _ptr(o["B_io"]), _ptr(o["C_io"]),
+                _ptr(o["A_mid"]), _ptr(o["B_mid"]), _ptr(o["C_mid"]), _ptr(o["H"]), Z.ctypes.data_as(_lib.u64p), self.stream()))
+            o["Z"] = Z
+            return o
         o = {}
         for k in ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid"):
             o[k] = self.ring_empty(m) if k in want else None

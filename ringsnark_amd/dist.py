@@ -186,10 +186,9 @@ def sharded_witness(backend, plan: ShardPlan, group, cs_local, assignment_local,
     (the inner product over the auxiliary inputs) goes in between and overlaps the exchange."""
     if plan.term_shards == 1 or WITNESS_SPLIT == "replicate":
         # every rank of the limb group runs the whole witness map of its limbs and keeps the rows of its term range
-        w = backend.witness(cs_local, assignment_local, want, ds)
+        # (only those rows are written: five full-length vectors of a three-limb configs[3] rank would be 480 GiB)
         me = plan.term_shard
-        out = {k: w[k][ranges[k](me)[0]:ranges[k](me)[1]] for k in want}
-        out["Z"] = w["Z"]
+        out = backend.witness(cs_local, assignment_local, want, ds, rows={k: ranges[k](me) for k in want} if plan.term_shards > 1 else None)
         return (out, lambda: None) if defer else out
     N = backend.N
     s0, ns = plan.slot_range(N)
@@ -389,8 +388,9 @@ class DeviceBackend:
         self.dev = dev
         self.N = dev.N
 
-    def witness(self, dcs, assignment, want, ds=(None, None, None)):
-        return self.dev.witness_map(dcs, assignment, *ds, want=want)
+    def witness(self, dcs, assignment, want, ds=(None, None, None), rows=None):
+        """rows: {name: (lo, hi)} -> those outputs hold rows [lo, hi) only (rs_witness_map_rows)"""
+        return self.dev.witness_map(dcs, assignment, *ds, want=want, rows=rows)
 
     def witness_slots(self, dcs, assignment, slot0, nslots, want, ds=(None, None, None)):
         return self.dev.witness_map_slots(dcs, assignment, slot0, nslots, *ds, want=want)

@@ -49,8 +49,12 @@ class OracleBackend:
         res["Z"] = Z
         return res
 
-    def witness(self, cs, assignment, want, ds=(None, None, None)):
-        return self.witness_slots(cs, assignment, 0, self.ctx.N, want, ds)
+    def witness(self, cs, assignment, want, ds=(None, None, None), rows=None):
+        w = self.witness_slots(cs, assignment, 0, self.ctx.N, want, ds)
+        if rows is not None:
+            for k, (lo, hi) in rows.items():
+                w[k] = w[k][lo:hi]
+        return w
 
     def msm(self, crs_list, vecs, n_groups, addends=None, want_used=False):
         outs, used = [], [0] * len(vecs)

@@ -338,12 +338,13 @@ class Device:
             full = {k: (0, m + 1 if k == "H" else m) for k in names}
             rr = {k: tuple(int(x) for x in rows.get(k, full[k])) for k in names}
             for a, b in (("A_io", "A_mid"), ("B_io", "B_mid"), ("C_io", "C_mid")):  # one pass writes both: same range
-                if a in want and b in want:
-                    assert rr[a] == rr[b], (a, b, rr[a], rr[b])
-                elif a in want:
-                    rr[b] = rr[a]
-                else:
+                if (a in rows) != (b in rows):  # a range given for one of the pair holds for both
+                    rr[a] = rr[b] = rr[a if a in rows else b]
+                assert rr[a] == rr[b] or a not in want or b not in want, (a, b, rr[a], rr[b])
+                if a not in want:
                     rr[a] = rr[b]
+                if b not in want:
+                    rr[b] = rr[a]
             o = {k: (torch.empty((rr[k][1] - rr[k][0], self.L, self.N), dtype=torch.int64, device=self.device) if k in want else None) for k in names}
             flat = (C.c_size_t * 14)(*[x for k in names for x in rr[k]])
             Z = np.zeros((self.L, m + 1), dtype=np.uint64)

@@ -171,6 +171,9 @@ def preset(name: str) -> RingParams:
     if name == "C3R":  # the headline shape with recipe primes (q_i = 1 mod 2*N_enc = 2^14 only): the witness map runs on block convolutions
         return make_params(8192, BFV_DEFAULT_BITS[8192][:-1], 8192, BFV_DEFAULT_BITS[8192][:-1], name="C3R",
                            notes="default_double_batching_modulus(8192, 8192): what a SEAL-produced headline key has")
+    if name == "C4R":  # configs[3]'s shape on recipe primes: q_i = 1 mod 2*N_enc = 2^15 only (2-adicity 15..), block-convolution witness map beyond 2^14 constraints
+        return make_params(16384, [48, 48, 48, 49, 49, 49], 16384, BFV_DEFAULT_BITS[16384][:-1], name="C4R",
+                           notes="C4 with the ring primes default_double_batching_modulus-style recipe yields (seal_util.hpp:20-32)")
     if name == "toy":  # CPU-test scale
         return make_params(32, [30, 30], 64, [40, 40, 41], ring_factor=1 << 12, name="toy")
     if name == "toy44":  # small ring, headline-size primes (= 1 mod 2^20): large-m witness-map tests

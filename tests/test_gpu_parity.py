@@ -800,6 +800,50 @@ def test_witness_map_slot_ranges_and_chunks_equal_the_whole(name, m, kind, zk):
         _set_tuning(b"witness_col_budget_mib", 16 * 1024)
 
 
+@pytest.mark.parametrize("name,m,kind,zk", [("toy", 40, "wide", True), ("toy", 64, "chain", False), ("toy", 100, "many_inputs", True),
+                                            ("toy60", 33, "wide", True), ("toy44", 1500, "chain", True), ("toy44", 20000, "chain", False)])
+def test_witness_map_row_ranges_equal_slices_of_the_whole(name, m, kind, zk):
+    """rs_witness_map_rows: a rank that shares its limbs with others runs the whole map and keeps the rows of its TERM
+    range (ringsnark_amd/dist.py "replicate"; full-length vectors of a configs[3] rank would not fit HBM).  Every output
+    equals the corresponding row slice of the full map: the ranges of the sharded provers (m rows for the A / B vectors,
+    m + 1 for H, 2..4 shards), ranges that start and stop inside a 32-row tile, empty ranges, the lone top row of H
+    (row m when m is a power of two comes from its own kernel), and a subset of outputs."""
+    from ringsnark_amd import dist as RD
+    dev = dev_for(name)
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    cs = {"wide": lambda: R.wide_r1cs(m, prm.q), "chain": lambda: R.chain_r1cs(m, prm.q),
+          "many_inputs": lambda: R.wide_r1cs(m, prm.q, n_inputs=70)}[kind]()
+    if m <= 100:
+        asg = dev.put(H.make_assignment(ctx, cs))
+    else:
+        asg = dev.ring_empty(m + 2)
+        dev.fill_uniform(asg[:2], 0, 5)
+        dev.chain_assignment(asg, m)
+    ds = [dev.put(ctx.random_ring(60 + k)) for k in range(3)] if zk else [None] * 3
+    dcs = dev.r1cs(cs)
+    keys = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
+    full = {k: host(v) for k, v in dev.witness_map(dcs, asg, *ds).items() if k in keys}
+    cases = []
+    for shards in (2, 3, 4):
+        for s in range(shards):
+            plan = RD.ShardPlan(shards, s, 1, 1, shards, [0], s, 0)
+            ab, h = plan.term_range(m), plan.term_range(m + 1)
+            cases.append({"A_io": ab, "A_mid": ab, "B_io": ab, "B_mid": ab, "C_io": ab, "C_mid": ab, "H": h})
+    cases.append({k: (5, min(37, m)) for k in keys})
+    cases.append({"A_io": (0, 0), "A_mid": (0, 0), "B_io": (m - 1, m), "B_mid": (m - 1, m), "H": (m, m + 1)})  # C vectors: every row
+    cases.append({"H": (m - 3, m + 1), "A_mid": (31, 33)})
+    for rows in cases:
+        part = dev.witness_map(dcs, asg, *ds, rows=rows)
+        for k in keys:
+            lo, hi = rows.get(k, (0, full[k].shape[0]))
+            if k.endswith("_io") and k not in rows and k.replace("_io", "_mid") in rows:
+                lo, hi = rows[k.replace("_io", "_mid")]  # io and mid of one matrix share a range
+            assert part[k].shape[0] == hi - lo and (host(part[k]) == full[k][lo:hi]).all(), (k, rows)
+    sub = dev.witness_map(dcs, asg, *ds, want=("A_mid", "H"), rows={"A_mid": (3, 9), "H": (1, m + 1)})
+    assert (host(sub["A_mid"]) == full["A_mid"][3:9]).all() and (host(sub["H"]) == full["H"][1:]).all() and sub["B_mid"] is None
+
+
 def test_msm_with_a_tiled_key_equals_the_explicit_key():
     """crs_window (ringsnark_amd.h): logical element t is read from index t % window."""
     import torch

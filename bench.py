@@ -49,7 +49,29 @@ def rocprof_name(name):
     return "rs::" + name
 
 
-def kernel_roofline(k, pmc, fp64_pmc=None):
+def load_pmc(kind, preset, m):
+    """The newest committed counter file of this kind ("traffic" / "fp64") for (preset, m) -- and whether it was collected on
+    the device-library sources of THIS tree (tools/pmc_*.py record ringsnark_amd._lib.source_hash()).  A file without the
+    hash, or with another one, is NOT joined: the line then carries null and the reason (round-3 verdict, "What's weak" 8)."""
+    from ringsnark_amd._lib import source_hash
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_%s_m%d.json" % (kind, preset, m))))
+    if not cands:
+        return None, "no profiles/r*_pmc_%s_%s_m%d.json" % (kind, preset, m)
+    path = cands[-1]
+    d = json.load(open(path))
+    here = source_hash()
+    if d.get("source_hash") != here:
+        return None, "%s was collected on library sources %s (commit %s), this tree is %s: re-run tools/collect_profiles.sh" % (
+            os.path.basename(path), d.get("source_hash"), d.get("commit"), here)
+    d["_file"] = os.path.basename(path)
+    return d, None
+
+
+MEASURED = {}  # rs_measure_peaks of this run: the second denominators of SURVEY.md 8(d)
+
+
+def kernel_roofline(k, pmc, fp64_pmc=None, stale=None):
     """Roofline object of one per-kernel record from rs_profile_read (live HIP events on the launch stream).
     pmc: profiles/*_pmc_traffic_*.json (HBM bytes per kernel); fp64_pmc: profiles/*_pmc_fp64_*.json (SQ opcode counters per
     launch, tools/pmc_fp64.py) -- both from rocprofv3 passes of this very command, joined by the kernel name rocprofv3 prints."""
@@ -63,13 +85,17 @@ def kernel_roofline(k, pmc, fp64_pmc=None):
                     "numerator": "model count of the library (8 FP64 instructions per lazy butterfly, 7 per pointwise modular multiply, "
                                  "v_rndne_f64 included; DESIGN.md section 3)",
                     "hbm_frac": round(k["alg_bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4)})
+        if MEASURED.get("fp64_fma_T"):  # against the v_fma_f64 rate this box sustains (clocks under FP64 load), not the spec sheet's
+            out["frac_of_measured"] = round(ach / MEASURED["fp64_fma_T"], 4)
+            out["peak_measured"] = round(MEASURED["fp64_fma_T"], 2)
         if fp64_pmc:
             fam = [v for n, v in fp64_pmc.get("kernels", {}).items() if n.startswith(rocprof_name(k["name"]))]
             if fam:  # per-proof totals of the counters over the live per-proof time of the same kernel (this step = one proof)
                 cnt = sum(v["fp64_lane_ops"] for v in fam)
                 valu = sum(v["valu_lane_ops"] for v in fam)
                 out["counted"] = {
-                    "source": "SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 per proof (rocprofv3 --pmc, profiles/r03_pmc_fp64_*.json) over this run's time; "
+                    "source": "SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 per proof (rocprofv3 --pmc, profiles/" + fp64_pmc.get("_file", "?") + ", collected on the "
+                              "library sources of this tree: hash " + str(fp64_pmc.get("source_hash")) + ") over this run's time; "
                               "v_rndne_f64 has no opcode counter and is NOT in this figure (one per modular multiply: the model count minus ~1/8)",
                     "fp64_lane_ops_per_proof": int(cnt), "valu_lane_ops_per_proof": int(valu),
                     "launches_per_proof": round(sum(v["launches_per_proof"] for v in fam), 1),
@@ -78,6 +104,12 @@ def kernel_roofline(k, pmc, fp64_pmc=None):
     else:
         ach = k["alg_bytes"] / sec / 1e9
         out.update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)})
+        if MEASURED.get("hbm_copy_gbs"):  # against the device-to-device copy bandwidth measured in this run
+            out["frac_of_measured"] = round(ach / MEASURED["hbm_copy_gbs"], 4)
+            out["peak_measured"] = round(MEASURED["hbm_copy_gbs"], 1)
+    if fp64 and "counted" not in out:
+        out["counted"] = None
+        out["counted_reason"] = (stale or {}).get("fp64") or "kernel not in the counter file"
     out["algorithmic_bytes_per_launch"] = int(k["alg_bytes"] / max(1, k["launches"]))
     # HBM traffic from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE; tools/pmc_summary.py), same configuration,
     # keyed by the exact kernel family; null when the committed file does not hold this kernel
@@ -87,6 +119,8 @@ def kernel_roofline(k, pmc, fp64_pmc=None):
         if fam:
             traffic = int(sum(v["hbm_bytes"] for v in fam) / max(1, sum(v["launches_per_proof"] for v in fam)))
     out["traffic"] = traffic
+    if traffic is None:
+        out["traffic_reason"] = (stale or {}).get("traffic") or "kernel not in the counter file"
     return out
 
 
@@ -304,9 +338,16 @@ def main():
     m = 1 << args.logm
     plan = RD.make_plan(world, rank, prm.L)
     prm_local = P.RingParams(prm.N, [prm.q[i] for i in plan.limbs], prm.N_enc, prm.Q, name=prm.name)
+    setup = {}
+    t_s = time.perf_counter()
     dev = Device(prm_local, local_rank)
+    setup["context_ms"] = round((time.perf_counter() - t_s) * 1e3, 1)  # rs_ctx_create: transform tables of every prime, index map
+    if world == 1:
+        MEASURED.update(dev.measure_peaks())
     cs = R.chain_r1cs(m, prm_local.q)
+    t_s = time.perf_counter()
     dcs = dev.r1cs(cs)
+    setup["r1cs_upload_ms"] = round((time.perf_counter() - t_s) * 1e3, 1)
     n_aux = cs.n_aux
     # synthetic inputs, generated on device (seeded per (limb group, role))
     seed0 = 1000 * (plan.limb_group + 1)
@@ -359,7 +400,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # the FIRST proof pays for what a prover process does once per (context, m): the witness-map plan (product-tree spectra,
+    # rev(Z)^-1 by Newton iteration on the host), the io-vector cache of the circuit, first-call workspace allocations.
+    # Excluded from the timed region, reported here (excluded work is "reported separately").
+    fence()
+    t_s = time.perf_counter()
+    step()
+    fence()
+    first_ms = (time.perf_counter() - t_s) * 1e3
+    for _ in range(max(0, args.warmup - 1)):
         step()
     fence()
     t0 = time.perf_counter()
@@ -373,17 +422,17 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = m * args.steps / elapsed
+    setup["first_proof_ms"] = round(first_ms, 1)
+    setup["first_proof_extra_ms"] = round(first_ms - ms_per_step, 1)
+    setup["note"] = ("not in the timed region: context creation, R1CS upload, and what the first proof of a (context, m) pays once -- witness-map "
+                     "plan and tables built on the host, the circuit's io-vector cache, workspace allocations" + (" (a warm-up step here)" if args.warmup else ""))
 
     # ---- per-kernel device time of one more (untimed) step: HIP events on the launch stream inside the library
     roofline = mac_roofline = timings = kernels = None
     if world == 1:
-        pmc = fp64_pmc = None
-        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_%s_m%d.json" % (prm.name, m))
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-        fp64_path = os.path.join(ROOT, "profiles", "r03_pmc_fp64_%s_m%d.json" % (prm.name, m))
-        if os.path.exists(fp64_path):
-            fp64_pmc = json.load(open(fp64_path))
+        stale = {}
+        pmc, stale["traffic"] = load_pmc("traffic", prm.name, m)
+        fp64_pmc, stale["fp64"] = load_pmc("fp64", prm.name, m)
         dev.set_profiling(True)
         dev.profile_read()
         step()
@@ -395,10 +444,10 @@ def main():
         kernels = [{"name": k["name"], "ms": round(k["total_ms"], 2), "share": round(k["total_ms"] / tot, 4),
                     "launches": k["launches"]} for k in stats[:10]]
         if stats:
-            roofline = kernel_roofline(stats[0], pmc, fp64_pmc)  # the dominant kernel by time
+            roofline = kernel_roofline(stats[0], pmc, fp64_pmc, stale)  # the dominant kernel by time
         mac = [k for k in stats if k["name"].startswith("mac_kernel")]
         if mac:
-            mac_roofline = kernel_roofline(mac[0], pmc, fp64_pmc)
+            mac_roofline = kernel_roofline(mac[0], pmc, fp64_pmc, stale)
 
     # ---- the standalone transform (row a4), HBM bound by design: 16 bytes per coefficient per transform, on 4 GiB
     ntt_roofline = None
@@ -425,10 +474,14 @@ def main():
                     rates.append(batch * p.N_enc * 16 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9)
                 res.append(sorted(rates)[len(rates) // 2])  # median of the blocks
             del polys
-            return {"bound": "hbm", "kernel": "forward NTT, %d transforms of %d points per launch (4 GiB in place, preset %s), median of %d blocks of %d launches"
-                                              % (batch, p.N_enc, p.name, blocks, reps),
-                    "achieved": round(res[0], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(res[0] / HBM_PEAK_GBS, 4),
-                    "inverse": {"achieved": round(res[1], 1), "frac": round(res[1] / HBM_PEAK_GBS, 4)}}
+            o = {"bound": "hbm", "kernel": "forward NTT, %d transforms of %d points per launch (4 GiB in place, preset %s), median of %d blocks of %d launches"
+                                           % (batch, p.N_enc, p.name, blocks, reps),
+                 "achieved": round(res[0], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(res[0] / HBM_PEAK_GBS, 4),
+                 "inverse": {"achieved": round(res[1], 1), "frac": round(res[1] / HBM_PEAK_GBS, 4)}}
+            if MEASURED.get("hbm_copy_gbs"):
+                o["frac_of_measured"] = round(res[0] / MEASURED["hbm_copy_gbs"], 4)
+                o["inverse"]["frac_of_measured"] = round(res[1] / MEASURED["hbm_copy_gbs"], 4)
+            return o
 
         ntt_roofline = ntt_leg(dev, prm)
         # the same at 16384 points (the reference's micro-benchmark length, microbench.cpp:13-14; the encoding degree of
@@ -479,6 +532,13 @@ def main():
                        "key_window": (min(W, m + 1) if tiled else None),
                        "parallelism": "limbs%d x shards%d" % (plan.limb_groups, plan.term_shards)},
         }
+        out["setup"] = setup
+        if MEASURED:
+            out["measured_peaks"] = {"hbm_copy_gbs": round(MEASURED["hbm_copy_gbs"], 1), "fp64_fma_T": round(MEASURED["fp64_fma_T"], 2),
+                                     "fp64_mulmod_G": round(MEASURED["fp64_mulmod_G"], 1), "int_montmul_G": round(MEASURED["int_montmul_G"], 1),
+                                     "how": "rs_measure_peaks at the start of this run: 1 GiB device-to-device copy (read + written bytes), v_fma_f64 "
+                                            "lane-operations/s, exact-FP64 modular multiplies/s (6 instructions each), Montgomery products/s on a 60-bit prime; "
+                                            "`frac_of_measured` in the rooflines divides by these, `frac` by the spec sheet"}
         if timings:
             out["phase_ms"] = {"witness_map": round(timings["witness_ms"], 3), "msm": round(timings["msm_ms"], 3)}
         if kernels:

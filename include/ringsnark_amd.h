@@ -302,6 +302,14 @@ typedef struct rs_timings {
 } rs_timings;
 int rs_last_timings(rs_ctx *ctx, rs_timings *out);
 int rs_set_profiling(rs_ctx *ctx, int enabled);
+/* Measured denominators for the rooflines, on THIS device, now (the reference's micro-benchmark of the same
+ * primitives: microbench.cpp:147-205): device-to-device copy bandwidth (GB/s, read + written bytes of a 1 GiB copy with
+ * 16-byte accesses), the v_fma_f64 issue rate (T lane-operations/s), the exact-FP64 modular multiply of f64mod.hpp and the
+ * Montgomery product of intmod.hpp on a 60-bit prime (G modular multiplies/s).  About 50 ms.  Synchronises. */
+typedef struct rs_peaks {
+  double hbm_copy_gbs, fp64_fma_T, fp64_mulmod_G, int_montmul_G;
+} rs_peaks;
+int rs_measure_peaks(rs_ctx *ctx, rs_peaks *out, rs_stream stream);
 /* Per-kernel device time of everything launched on the context since profiling was enabled (or
  * since the last read): HIP events on the launch stream around every launch, summed per kernel,
  * sorted by time.  alg_bytes / fp64_ops: the ALGORITHMIC HBM bytes and FP64 instructions (per lane)

@@ -45,6 +45,10 @@ class Timings(C.Structure):
     _fields_ = [("evaluate_ms", C.c_float), ("witness_ms", C.c_float), ("msm_ms", C.c_float), ("total_ms", C.c_float)]
 
 
+class Peaks(C.Structure):
+    _fields_ = [("hbm_copy_gbs", C.c_double), ("fp64_fma_T", C.c_double), ("fp64_mulmod_G", C.c_double), ("int_montmul_G", C.c_double)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int), ("total_ms", C.c_float), ("alg_bytes", C.c_double),
                 ("fp64_ops", C.c_double)]
@@ -107,6 +111,7 @@ SIGNATURES = {
     "rs_groth16_prove_kinds": (C.c_int, [vp, vp, C.POINTER(Groth16PK), vp, u8p, vp, C.POINTER(C.c_int), vp]),
     "rs_rinocchio_prove_kinds": (C.c_int, [vp, vp, C.POINTER(RinocchioPK), vp, u8p, vp, vp, vp, vp, C.POINTER(C.c_int), vp]),
     "rs_last_timings": (C.c_int, [vp, C.POINTER(Timings)]),
+    "rs_measure_peaks": (C.c_int, [vp, C.POINTER(Peaks), vp]),
     "rs_set_profiling": (C.c_int, [vp, C.c_int]),
     "rs_profile_read": (C.c_int, [vp, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int)]),
     "rs_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
@@ -138,3 +143,19 @@ def load():
 def check(status):
     if status != RS_OK:
         raise RsError(status, load().rs_last_error().decode("utf-8", "replace"))
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the sources the device library is built from: ringsnark_amd/csrc/*.{hip,hpp},
+    csrc/Makefile and include/ringsnark_amd.h.  profiles/*_pmc_*.json carry it, so that bench.py can tell whether a
+    committed counter file was collected on the kernels it is running (round-3 verdict: nothing tied the two)."""
+    import glob
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "ringsnark_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "ringsnark_amd", "csrc", "*.hpp")))
+    files += [os.path.join(root, "ringsnark_amd", "csrc", "Makefile"), os.path.join(root, "include", "ringsnark_amd.h")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]

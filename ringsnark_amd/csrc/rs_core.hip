@@ -1015,6 +1015,90 @@ int rs_profile_read(rs_ctx *ctx, rs_kernel_stat *out, int capacity, int *n_out) 
   for (int k = 0; k < capacity && k < (int)agg.size(); k++) out[k] = agg[k];
   RS_API_END
 }
+// ---- measured denominators of the rooflines ("use the measured copy bandwidth as the denominator too",
+// "report achieved modmul/s against a measured modmul micro-benchmark peak"; the reference's own pattern: microbench.cpp:147-205)
+namespace rs {
+// OP 0: v_fma_f64 chains; 1: the six-instruction exact FP64 modular multiply (f64mod.hpp); 2: the Montgomery product on
+// 64-bit integers (intmod.hpp).  Eight independent chains per lane, 2048 workgroups of 256 threads (8 waves per SIMD).
+constexpr int PEAK_ITERS = 2048;
+template <int OP>
+__global__ void __launch_bounds__(256) peak_rate_kernel(uint64_t *out, double a0, double b0, Mod mf, ModI mi) {
+  double x[8];
+  uint64_t y[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    x[i] = a0 + threadIdx.x + i;
+    y[i] = (uint64_t)(threadIdx.x * 8 + i + 3) % mi.p;
+  }
+  const uint64_t c = (uint64_t)(b0 * 1e6) % mi.p;
+  for (int it = 0; it < PEAK_ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      if (OP == 0) x[i] = __builtin_fma(x[i], b0, 0.3333333333333333);
+      if (OP == 1) x[i] = mulmod(x[i], b0, mf);
+      if (OP == 2) y[i] = montmul(y[i], c, mi);
+    }
+  }
+  double sx = 0;
+  uint64_t sy = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) sx += x[i], sy += y[i];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sy + (uint64_t)(long long)sx;
+}
+__global__ void __launch_bounds__(256) peak_copy_kernel(const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+}  // namespace rs
+
+int rs_measure_peaks(rs_ctx *ctx, rs_peaks *out, rs_stream stream) {
+  RS_API_BEGIN_CTX(ctx)
+  RS_REQUIRE(ctx && out, "null argument");
+  hipStream_t st = S(stream);
+  memset(out, 0, sizeof(*out));
+  hipEvent_t e0, e1;
+  RS_HIP(hipEventCreate(&e0));
+  RS_HIP(hipEventCreate(&e1));
+  auto timed = [&](auto &&launch, int reps) {
+    launch();  // warm-up
+    RS_HIP(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; r++) launch();
+    RS_HIP(hipEventRecord(e1, st));
+    RS_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    RS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    return (double)ms * 1e-3 / reps;
+  };
+  // device-to-device copy of 1 GiB (16-byte accesses): read + written bytes per second
+  {
+    const size_t bytes = (size_t)1 << 30;
+    void *a = nullptr, *b = nullptr;
+    RS_HIP(hipMalloc(&a, bytes));
+    RS_HIP(hipMalloc(&b, bytes));
+    RS_HIP(hipMemsetAsync(a, 1, bytes, st));
+    const double sec = timed([&] { hipLaunchKernelGGL(peak_copy_kernel, dim3(256 * 16), dim3(256), 0, st, (const ulonglong2 *)a, (ulonglong2 *)b, bytes / 16); }, 10);
+    out->hbm_copy_gbs = 2.0 * (double)bytes / sec / 1e9;
+    (void)hipFree(a);
+    (void)hipFree(b);
+  }
+  {
+    const unsigned blocks = 256 * 8;
+    uint64_t *d = nullptr;
+    RS_HIP(hipMalloc(&d, (size_t)blocks * 256 * sizeof(uint64_t)));
+    const Mod mf = HostArith<Mod>::make(ctx->Q[0] < (1ull << 50) ? ctx->Q[0] : 1125899906826241ull);
+    const ModI mi = HostArith<ModI>::make(1152921504606830593ull);  // a 60-bit prime (microbench.cpp:35-36 sizes)
+    const double lanes = (double)blocks * 256.0 * PEAK_ITERS * 8.0;  // lane-operations of the inner statement per launch
+    out->fp64_fma_T = lanes / timed([&] { hipLaunchKernelGGL(peak_rate_kernel<0>, dim3(blocks), dim3(256), 0, st, d, 1.5, 1.0000001, mf, mi); }, 3) / 1e12;
+    out->fp64_mulmod_G = lanes / timed([&] { hipLaunchKernelGGL(peak_rate_kernel<1>, dim3(blocks), dim3(256), 0, st, d, 1.5, 12345.0, mf, mi); }, 3) / 1e9;
+    out->int_montmul_G = lanes / timed([&] { hipLaunchKernelGGL(peak_rate_kernel<2>, dim3(blocks), dim3(256), 0, st, d, 1.5, 12345.0, mf, mi); }, 3) / 1e9;
+    (void)hipFree(d);
+  }
+  RS_HIP(hipGetLastError());
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  RS_API_END
+}
+
 int rs_last_timings(rs_ctx *ctx, rs_timings *out) {
   RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && out, "null argument");

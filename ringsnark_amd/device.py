@@ -455,6 +455,12 @@ class Device:
         _lib.check(self.lib.rs_last_timings(self.h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in _lib.Timings._fields_}
 
+    def measure_peaks(self):
+        """{hbm_copy_gbs, fp64_fma_T, fp64_mulmod_G, int_montmul_G} measured on this device now (rs_measure_peaks)"""
+        p = _lib.Peaks()
+        _lib.check(self.lib.rs_measure_peaks(self.h, C.byref(p), self.stream()))
+        return {k: getattr(p, k) for k, _ in _lib.Peaks._fields_}
+
     def profile_read(self):
         """[{name, launches, total_ms, alg_bytes, fp64_ops}] per kernel since profiling was switched on, by time."""
         cap = 64

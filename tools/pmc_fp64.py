@@ -15,6 +15,22 @@ import glob
 import json
 import sys
 
+
+def provenance():
+    """what the counters were collected ON: the hash of the device-library sources of this tree (bench.py refuses to join
+    a file whose hash differs from the tree it runs in) and, where git is at hand, the commit"""
+    import os
+    import subprocess
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from ringsnark_amd._lib import source_hash
+    out = {"source_hash": source_hash()}
+    try:
+        out["commit"] = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
+    except OSError:
+        out["commit"] = None
+    return out
+
+
 mix, stall, out, proofs = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 
 
@@ -30,6 +46,7 @@ def load(d):
 
 
 res = {"units": "per proof (one prover call): wave-level counts as reported by rocprofv3; *_lane_ops = x64", "proofs_in_run": proofs, "kernels": {}}
+res.update(provenance())
 A, nA = load(mix)
 B, nB = load(stall) if stall != "-" else ({}, {})
 for k in sorted(A, key=lambda k: -A[k].get("SQ_INSTS_VALU", 0)):

@@ -6,6 +6,22 @@ FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read,
 Calibration inside the same run: transpose_out_kernel reads S*M*8 bytes and writes m*S*8 bytes of
 known size -- the summary records reported vs expected for both."""
 import csv, glob, json, sys, collections
+
+def provenance():
+    """what the counters were collected ON: the hash of the device-library sources of this tree (bench.py refuses to join
+    a file whose hash differs from the tree it runs in) and, where git is at hand, the commit"""
+    import os
+    import subprocess
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from ringsnark_amd._lib import source_hash
+    out = {"source_hash": source_hash()}
+    try:
+        out["commit"] = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
+    except OSError:
+        out["commit"] = None
+    return out
+
+
 fdir, wdir, out, proofs = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 def load(d, c):
     f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
@@ -16,6 +32,7 @@ def load(d, c):
     return agg
 F, W = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
 res = {"units": "bytes per proof (one prover call)", "proofs_in_run": proofs, "fetch_correction": 2.0, "kernels": {}}
+res.update(provenance())
 for k in sorted(set(F) | set(W)):
     n = max(len(F.get(k, [])), len(W.get(k, [])))
     fetch = sum(F.get(k, [])) * 1024 * 2.0 / proofs

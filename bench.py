@@ -180,7 +180,7 @@ def single_gpu_leg(preset, m, logw, steps, warmup, check):
 
 
 
-def rinocchio_leg(preset, steps=3, logm=None, logw=None, logreg=False):
+def rinocchio_leg(preset, steps=3, logm=None, logw=None, logreg=False, check=True):
     """Rinocchio prover (rinocchio.tcc:75-190) on another BASELINE configuration's shape, one GPU: configs[3]'s ring shape
     (preset C4: N = 16384, 6 ring primes, N_enc = 16384, K = 8) on a chain circuit of 2^logm constraints with a tiled key
     -- the configuration's 2^18 constraints need a 9 TiB key -- or configs[4] exactly as the reference's
@@ -216,14 +216,21 @@ def rinocchio_leg(preset, steps=3, logm=None, logw=None, logreg=False):
     dt = (time.perf_counter() - t0) / steps
     dev.set_profiling(True)
     dev.profile_read()
-    dev.rinocchio_prove(dcs, pk, asg, *ds, window=W)
+    proof = dev.rinocchio_prove(dcs, pk, asg, *ds, window=W)[0]
     torch.cuda.synchronize()
     tm, stats = dev.last_timings(), dev.profile_read()
+    dev.set_profiling(False)
+    chk = None
+    if check:  # untimed: witness-map identities on sampled columns (ZK patch included) + a proof slab by the CPU oracle
+        from tests.proof_check import rinocchio_check
+        ok, info = rinocchio_check(dev, prm, cs, dcs, asg, pk, proof, cs.m, ds)
+        chk = dict(info, ok=ok)
     out = {"preset": prm.name, "shape": "ring N=%d L=%d, encodings N_enc=%d K=%d" % (prm.N, prm.L, prm.N_enc, prm.K), "constraints": cs.m,
            "key_window": W or None, "ms_per_proof": round(dt * 1e3, 3), "value": round(cs.m / dt, 1), "unit": "constraints/s",
            "phase_ms": {"witness_map": round(tm["witness_ms"], 3), "msm": round(tm["msm_ms"], 3)},
            "kernels": [{"name": k["name"], "ms": round(k["total_ms"], 2)} for k in stats[:4]]}
-    del asg, pk, dcs, dev
+    out["check"] = chk if chk is not None else "unchecked"
+    del asg, pk, dcs, dev, proof
     torch.cuda.empty_cache()
     return out
 
@@ -455,9 +462,9 @@ def main():
         from ringsnark_amd import _lib
         reps, blocks = 10, 5
 
-        def ntt_leg(d, p):
+        def ntt_leg(d, p, gib=4):
             """forward / inverse GB/s of the standalone transform of context d on a 4 GiB batch (algorithmic 16 B / coefficient)"""
-            batch = (4 << 30) // (p.N_enc * 8)
+            batch = (gib << 30) // (p.N_enc * 8)
             polys = torch.empty((batch, p.N_enc), dtype=torch.int64, device=d.device).random_(0, int(p.Q[0]))
             res = []
             for inverse in (False, True):
@@ -474,8 +481,8 @@ def main():
                     rates.append(batch * p.N_enc * 16 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9)
                 res.append(sorted(rates)[len(rates) // 2])  # median of the blocks
             del polys
-            o = {"bound": "hbm", "kernel": "forward NTT, %d transforms of %d points per launch (4 GiB in place, preset %s), median of %d blocks of %d launches"
-                                           % (batch, p.N_enc, p.name, blocks, reps),
+            o = {"bound": "hbm", "kernel": "forward NTT, %d transforms of %d points per launch (%d GiB in place, preset %s), median of %d blocks of %d launches"
+                                           % (batch, p.N_enc, gib, p.name, blocks, reps),
                  "achieved": round(res[0], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(res[0] / HBM_PEAK_GBS, 4),
                  "inverse": {"achieved": round(res[1], 1), "frac": round(res[1] / HBM_PEAK_GBS, 4)}}
             if MEASURED.get("hbm_copy_gbs"):
@@ -490,6 +497,21 @@ def main():
         d16 = Device(p16, local_rank)
         ntt_roofline["at_16384_points"] = ntt_leg(d16, p16)
         del d16
+        # ... and on the INTEGER arithmetic: the reference's own micro-benchmark parameters (microbench.cpp:13-14,33-36: N = 16384,
+        # coefficient primes of {59, 60, 60} bits), Montgomery products -- ALU-bound: a butterfly is one Montgomery product, so
+        # beside the HBM fraction the line carries products/s against the rate rs_measure_peaks found for that very product
+        p60 = P.preset("micro60")
+        d60 = Device(p60, local_rank)
+        leg = ntt_leg(d60, p60, gib=1)
+        logn = p60.N_enc.bit_length() - 1
+        for o, gbs in ((leg, leg["achieved"]), (leg["inverse"], leg["inverse"]["achieved"])):
+            prods = gbs * 1e9 / 16.0 * logn / 2.0  # coefficients/s x log2(n)/2 butterflies per coefficient
+            o["montgomery_products_G_per_s"] = round(prods / 1e9, 1)
+            if MEASURED.get("int_montmul_G"):
+                o["frac_of_measured_product_rate"] = round(prods / 1e9 / MEASURED["int_montmul_G"], 4)
+        leg["bound"] = "integer ALU (v_mad_u64_u32: no 64x64 multiplier on gfx950)"
+        ntt_roofline["micro60_integer_arithmetic"] = leg
+        del d60
 
     # ---- untimed post-run check of the timed proof against the CPU oracle
     check = None
@@ -512,8 +534,9 @@ def main():
     # ---- the other BASELINE configurations' shapes, a few seconds each (extra keys, not the metric)
     other = None
     if world == 1 and prm.name == "C3" and recipe is not None and not args.no_other_configs:
-        other = {"configs[3] shape (Rinocchio, N=16384, 6 ring primes, K=8; 2^12 constraints, key window 2^9)": rinocchio_leg("C4", logm=12, logw=9),
-                 "configs[4] (Rinocchio, the reference's logistic-regression circuit and parameters)": rinocchio_leg("C5", steps=10, logreg=True)}
+        other = {"configs[1] (ringGroth16, 2^10 constraints, N=4096 L=2, N_enc=8192 K=4; whole 3 GiB key)": single_gpu_leg("C2", 1 << 10, 11, 20, 3, not args.no_check),
+                 "configs[3] shape (Rinocchio, N=16384, 6 ring primes, K=8; 2^12 constraints, key window 2^9)": rinocchio_leg("C4", logm=12, logw=9, check=not args.no_check),
+                 "configs[4] (Rinocchio, the reference's logistic-regression circuit and parameters)": rinocchio_leg("C5", steps=10, logreg=True, check=not args.no_check)}
 
     if rank == 0:
         key_gib = (3 * m + 2) * prm.enc_words * 8 / 2**30
@@ -536,7 +559,7 @@ def main():
         if MEASURED:
             out["measured_peaks"] = {"hbm_copy_gbs": round(MEASURED["hbm_copy_gbs"], 1), "fp64_fma_T": round(MEASURED["fp64_fma_T"], 2),
                                      "fp64_mulmod_G": round(MEASURED["fp64_mulmod_G"], 1), "int_montmul_G": round(MEASURED["int_montmul_G"], 1),
-                                     "how": "rs_measure_peaks at the start of this run: 1 GiB device-to-device copy (read + written bytes), v_fma_f64 "
+                                     "how": "rs_measure_peaks at the start of this run: 2 GiB device-to-device copy (streaming 16-byte accesses; read + written bytes, best of three grid sizes), v_fma_f64 "
                                             "lane-operations/s, exact-FP64 modular multiplies/s (6 instructions each), Montgomery products/s on a 60-bit prime; "
                                             "`frac_of_measured` in the rooflines divides by these, `frac` by the spec sheet"}
         if timings:
@@ -560,7 +583,10 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    if (check is not None and not check["ok"]) or (recipe is not None and "check" in recipe and not recipe["check"]["ok"]):
+    bad = (check is not None and not check["ok"]) or (recipe is not None and "check" in recipe and not recipe["check"]["ok"])
+    for leg in (other or {}).values():
+        bad = bad or (isinstance(leg.get("check"), dict) and not leg["check"]["ok"])
+    if bad:
         sys.exit(3)
 
 

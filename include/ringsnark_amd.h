@@ -303,7 +303,7 @@ typedef struct rs_timings {
 int rs_last_timings(rs_ctx *ctx, rs_timings *out);
 int rs_set_profiling(rs_ctx *ctx, int enabled);
 /* Measured denominators for the rooflines, on THIS device, now (the reference's micro-benchmark of the same
- * primitives: microbench.cpp:147-205): device-to-device copy bandwidth (GB/s, read + written bytes of a 1 GiB copy with
+ * primitives: microbench.cpp:147-205): device-to-device copy bandwidth (GB/s, read + written bytes of a 2 GiB copy with
  * 16-byte accesses), the v_fma_f64 issue rate (T lane-operations/s), the exact-FP64 modular multiply of f64mod.hpp and the
  * Montgomery product of intmod.hpp on a 60-bit prime (G modular multiplies/s).  About 50 ms.  Synchronises. */
 typedef struct rs_peaks {

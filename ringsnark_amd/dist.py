@@ -136,54 +136,177 @@ def rinocchio_key_ranges(plan: ShardPlan, m, n_aux):
 # ---------------------------------------------------------------------------------------------------
 # slot-sharded witness map -> term-sharded coefficient vectors
 # ---------------------------------------------------------------------------------------------------
-def _p2p_start(ops_send, ops_recv, group):
-    """Launch one batch of point-to-point transfers inside `group`: (tensor, global peer rank) lists; returns a
-    function that waits for it.  RCCL runs the batch as one grouped exchange over the direct xGMI links, on its own
-    stream: whatever the caller launches before waiting overlaps the transfer.  gloo (CPU tests, single-GPU
-    rehearsals) moves host tensors, so device tensors are staged through the host there."""
-    if not ops_send and not ops_recv:
-        return lambda: None
-    stage = dist.get_backend(group) == "gloo" and any(t.is_cuda for t, _ in ops_send + ops_recv)
-    if stage:
-        send_h = [(t.cpu(), p) for t, p in ops_send]
-        recv_h = [(torch.empty(t.shape, dtype=t.dtype), p) for t, p in ops_recv]
-    else:
-        send_h, recv_h = ops_send, ops_recv
-    ops = [dist.P2POp(dist.isend, t.contiguous(), p, group) for t, p in send_h] + [dist.P2POp(dist.irecv, t, p, group) for t, p in recv_h]
-    works = dist.batch_isend_irecv(ops)
-
-    def wait():
-        for r in works:
-            r.wait()
-        if stage:
-            for (dst, _), (src, _) in zip(ops_recv, recv_h):
-                dst.copy_(src)
-    return wait
+# ---------------------------------------------------------------------------------------------------
+# The slot -> term re-shard with RELAYS.  xGMI is point to point: a rank has one link to each of the other ranks of the
+# node, and the re-shard of a limb group only uses the links INSIDE the group (one of seven when two ranks share a limb:
+# 5.4 GiB over a single 76.8 GB/s link at the headline, as long as the witness map it saves).  Every rank outside the group
+# is one more two-hop path a -> c -> b over links the group does not use.  A message of P words from a to b is cut into a
+# direct part d and one part r per outside rank; every rank relays for every other group at the same time, so an
+# inter-group link carries 2 (g - 1) r per direction (g = ranks per group) and an intra-group link d:
+#       d = 2 (g - 1) r,   d + (W - g) r = P       ->   r = P / (2 (g - 1) + W - g)
+# W = 8, g = 2 (the headline): r = P/8, d = P/4 -- the exchange takes a quarter of the single-link time; W = 8, g = 4
+# (configs[3]): d = 0.6 P.  Two phases (first hop + first half of the direct part, then second hop + second half), each one
+# batch of point-to-point operations on the WORLD group; every rank derives the same global list of transfers from the
+# plan alone, so matching sends and receives are issued in the same order on both ends of every link.
+# UNMEASURED on hardware (no multi-GPU node): correctness is covered by the 8-rank gloo tests.
+# ---------------------------------------------------------------------------------------------------
+RELAY = os.environ.get("RINGSNARK_RELAY", "1") != "0"
 
 
-def _p2p(ops_send, ops_recv, group):
-    _p2p_start(ops_send, ops_recv, group)()
+def _split_parts(numel, g, n_rel):
+    """(d1, d2, r): the direct part in two halves and the size of each of the n_rel relayed parts"""
+    if n_rel == 0 or not RELAY:
+        return numel, 0, 0
+    r = numel // (2 * (g - 1) + n_rel)
+    direct = numel - n_rel * r
+    return direct // 2, direct - direct // 2, r
+
+
+class _Exchange:
+    """One re-shard step.  msgs[x] = [(dst, numel), ...] for EVERY rank x of the world (derived from the plan; the same on
+    every rank), send[i] / recv-buffers for this rank's own entries.  start() issues phase 1; finish() completes."""
+
+    def __init__(self, world, rank, groups, msgs, send_tensors, recv_tensors, like):
+        self.world, self.rank, self.msgs = world, rank, msgs
+        self.group_of = {}
+        for g in groups:
+            for x in g:
+                self.group_of[x] = g
+        self.send = [t.contiguous().view(-1) for t in send_tensors]  # this rank's messages, in msgs[rank] order
+        # receive buffers of this rank: for (src, idx) with dst == rank, keyed in the canonical order
+        self.recv = {}
+        it = iter(recv_tensors)
+        for src in range(world):
+            for idx, (dst, numel) in enumerate(msgs[src]):
+                if dst == rank:
+                    t = next(it)
+                    assert t.is_contiguous() and t.numel() == numel, (t.shape, numel)
+                    self.recv[(src, idx)] = t.view(-1)
+        self.relay_buf = {}
+        self.like = like
+        self.stage = dist.get_backend() == "gloo" and like.is_cuda
+        # device transport (RCCL): the two phases are issued on a side stream, so that the compute the caller enqueues on its
+        # own stream in the meantime (the next sub-range's witness map) neither waits for the exchange nor holds it up
+        self.side = torch.cuda.Stream(like.device) if (like.is_cuda and not self.stage) else None
+
+    def _relays(self, src):
+        g = self.group_of[src]
+        return [x for x in range(self.world) if x not in g]
+
+    def _parts(self, src, idx):
+        dst, numel = self.msgs[src][idx]
+        g = self.group_of[src]
+        rel = self._relays(src)
+        d1, d2, r = _split_parts(numel, len(g), len(rel))
+        return dst, rel, d1, d2, r
+
+    def _transfers(self, phase):
+        """global, canonical list of (sender, receiver, kind, src, idx, j, offset, length)"""
+        out = []
+        for src in range(self.world):
+            for idx in range(len(self.msgs[src])):
+                dst, rel, d1, d2, r = self._parts(src, idx)
+                if phase == 1:
+                    if d1:
+                        out.append((src, dst, "direct", src, idx, -1, 0, d1))
+                    for j, c in enumerate(rel):
+                        if r:
+                            out.append((src, c, "hop1", src, idx, j, d1 + d2 + j * r, r))
+                else:
+                    if d2:
+                        out.append((src, dst, "direct", src, idx, -1, d1, d2))
+                    for j, c in enumerate(rel):
+                        if r:
+                            out.append((c, dst, "hop2", src, idx, j, d1 + d2 + j * r, r))
+        return out
+
+    def _issue(self, phase):
+        sends, recvs = [], []
+        for snd, rcv, kind, src, idx, j, off, ln in self._transfers(phase):
+            if snd == self.rank:
+                buf = self.send[idx][off:off + ln] if kind != "hop2" else self.relay_buf[(src, idx, j)]
+                sends.append((buf, rcv))
+            if rcv == self.rank:
+                if kind == "hop1":
+                    dev = "cpu" if self.stage else self.like.device
+                    buf = torch.empty(ln, dtype=self.like.dtype, device=dev)
+                    self.relay_buf[(src, idx, j)] = buf
+                else:
+                    buf = self.recv[(src, idx)][off:off + ln]
+                recvs.append((buf, snd))
+        if not sends and not recvs:
+            return lambda: None
+        if self.stage:  # gloo moves host tensors: stage device tensors through the host (CPU tests / one-GPU rehearsals)
+            send_h = [(t if not t.is_cuda else t.cpu(), p_) for t, p_ in sends]
+            recv_h = [(t if not t.is_cuda else torch.empty(t.shape, dtype=t.dtype), p_) for t, p_ in recvs]
+        else:
+            send_h, recv_h = sends, recvs
+        ops = [dist.P2POp(dist.isend, t, p_) for t, p_ in send_h] + [dist.P2POp(dist.irecv, t, p_) for t, p_ in recv_h]
+        works = dist.batch_isend_irecv(ops)
+
+        def wait():
+            for w in works:
+                w.wait()
+            if self.stage:
+                for (dst_t, _), (src_t, _) in zip(recvs, recv_h):
+                    if dst_t is not src_t:
+                        dst_t.copy_(src_t)
+        return wait
+
+    def start(self):
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream(self.like.device))  # the vectors to send are complete
+            with torch.cuda.stream(self.side):
+                self._wait1 = self._issue(1)
+        else:
+            self._wait1 = self._issue(1)
+        return self
+
+    def finish(self):
+        if self.side is not None:
+            with torch.cuda.stream(self.side):
+                self._wait1()
+                self._issue(2)()
+            torch.cuda.current_stream(self.like.device).wait_stream(self.side)
+        else:
+            self._wait1()           # the relayed parts have arrived at their relays (and the first halves at their owners)
+            self._issue(2)()        # second hop + second halves
+        self.relay_buf.clear()
 
 
 # How the ranks of one limb group (N > L: two ranks per limb at N = 8) share the witness map:
-#   "replicate" (default)  each runs it whole and keeps its term range: no exchange.  Per rank at the headline and N = 8:
-#                          134 ms of witness map + 24 ms of inner products.
-#   "slots"                each maps half the NTT slots (67 ms), then one batch of point-to-point transfers re-shards the
-#                          five coefficient vectors from slots to terms: 5.4 GiB per rank each way over ONE xGMI link
-#                          (>= 75 ms at the link's 76.8 GB/s per direction) -- it pays only if the exchange sustains
-#                          more than ~85 GB/s, which no measurement supports yet.
-WITNESS_SPLIT = os.environ.get("RINGSNARK_WITNESS_SPLIT", "replicate")
+#   "slots" (default)      each maps its share of the NTT slots (rs_witness_map_slots), in SUB-RANGES of slots: the compact
+#                          vectors of one sub-range are re-sharded from slots to terms (the relayed exchange above) while the
+#                          next sub-range is computed, and only one sub-range of compact vectors is alive at a time (the
+#                          four vectors of a configs[3] rank are 96 GiB: they would not fit beside their re-sharded form).
+#                          Headline, N = 8: 67 ms of witness map per rank + 24 ms of inner products, the 5.4 GiB exchange
+#                          behind the witness map of the following sub-range (a quarter of the single-link time with relays).
+#   "replicate"            each runs the whole map and keeps the rows of its term range (rs_witness_map_rows): no exchange,
+#                          the witness map is not divided (134 + 24 ms; configs[3]: 6.7 + 1.15 s per rank, rehearsed at full
+#                          size in profiles/r04_rank_rehearsal_C4_m262144.json).
+WITNESS_SPLIT = os.environ.get("RINGSNARK_WITNESS_SPLIT", "slots")
 if WITNESS_SPLIT not in ("replicate", "slots"):
     raise ValueError("RINGSNARK_WITNESS_SPLIT must be 'replicate' or 'slots', not %r" % WITNESS_SPLIT)
+SLOT_CHUNK_BYTES = int(os.environ.get("RINGSNARK_SLOT_CHUNK_MIB", "8192")) << 20  # compact vectors of one sub-range of slots
+
+
+def _sub_ranges(s0, ns, n_sub):
+    """n_sub contiguous, even-aligned pieces of [s0, s0 + ns) (trailing pieces may be empty)"""
+    per = -(-ns // n_sub)
+    per += per & 1
+    out = []
+    for i in range(n_sub):
+        a = min(ns, i * per)
+        out.append((s0 + a, min(ns, a + per) - a))
+    return out
 
 
 def sharded_witness(backend, plan: ShardPlan, group, cs_local, assignment_local, want, ranges, ds=(None, None, None), defer=False):
     """The witness map of this rank's limbs, returned TERM-sharded: {k: rows [lo_k, hi_k) of vector k, all N
     slots}, plus "Z" (host array [L_local][m+1]).  ranges[k] = function shard -> (lo, hi) of vector k.
-    With one rank per limb group this is the plain witness map; otherwise every rank maps its slot range
-    (rs_witness_map_slots) and one batch of point-to-point transfers re-shards slots -> terms.
+    With one rank per limb group this is the plain witness map; otherwise see WITNESS_SPLIT.
     defer=True: returns (out, finish); the vectors are complete only after finish() -- work that does not read them
-    (the inner product over the auxiliary inputs) goes in between and overlaps the exchange."""
+    (the inner product over the auxiliary inputs) goes in between and overlaps the tail of the exchange."""
     if plan.term_shards == 1 or WITNESS_SPLIT == "replicate":
         # every rank of the limb group runs the whole witness map of its limbs and keeps the rows of its term range
         # (only those rows are written: five full-length vectors of a three-limb configs[3] rank would be 480 GiB)
@@ -191,40 +314,84 @@ def sharded_witness(backend, plan: ShardPlan, group, cs_local, assignment_local,
         out = backend.witness(cs_local, assignment_local, want, ds, rows={k: ranges[k](me) for k in want} if plan.term_shards > 1 else None)
         return (out, lambda: None) if defer else out
     N = backend.N
-    s0, ns = plan.slot_range(N)
-    if ns < 2:  # rs_witness_map_slots takes even, non-empty slot ranges: every shard of the group needs a share
-        raise ValueError("slot split of N = %d slots over %d ranks leaves rank %d without a share; use "
-                         "RINGSNARK_WITNESS_SPLIT=replicate or fewer ranks per limb" % (N, plan.term_shards, plan.rank))
-    wc = backend.witness_slots(cs_local, assignment_local, s0, ns, want, ds)  # compact [rows][L][ns]
-    peers = plan.group_ranks()
+    G = plan.term_shards
     me = plan.term_shard
-    out, sends, recvs, pending = {"Z": wc["Z"]}, [], [], []
+    blocks = [plan.slot_range(N, s) for s in range(G)]
+    if min(b[1] for b in blocks) < 2:  # rs_witness_map_slots takes even, non-empty slot ranges: every shard of the group needs a share
+        raise ValueError("slot split of N = %d slots over %d ranks leaves a rank without a share; use "
+                         "RINGSNARK_WITNESS_SPLIT=replicate or fewer ranks per limb" % (N, G))
+    L_local = len(plan.limbs)
+    rows_of = {k: [ranges[k](s) for s in range(G)] for k in want}
+    total_rows = sum(max(hi for _, hi in rows_of[k]) for k in want)
+    per_slot = total_rows * L_local * 8  # bytes of the compact vectors per slot
+    n_sub = max(1, min(max(b[1] for b in blocks) // 2, -(-(per_slot * max(b[1] for b in blocks)) // SLOT_CHUNK_BYTES)))
+    subs = [_sub_ranges(b[0], b[1], n_sub) for b in blocks]  # subs[shard][i] = (slot0, nslots)
+    groups = [[lg + plan.limb_groups * s for s in range(G)] for lg in range(plan.limb_groups)]
+    out, steps = {}, []
+    like = assignment_local
     for k in want:
-        lo, hi = ranges[k](me)
-        full = torch.empty((hi - lo,) + tuple(wc[k].shape[1:-1]) + (N,), dtype=wc[k].dtype, device=wc[k].device)
-        full[..., s0:s0 + ns] = wc[k][lo:hi]
-        out[k] = full
-        for s, peer in enumerate(peers):
-            if s == me:
+        lo, hi = rows_of[k][me]
+        out[k] = torch.empty((hi - lo, L_local, N), dtype=like.dtype, device=like.device)
+    for i in range(n_sub):
+        a, n = subs[me][i]
+        wc = backend.witness_slots(cs_local, assignment_local, a, n, want, ds) if n else None  # compact [rows][L][n]
+        if wc is not None:
+            out["Z"] = wc["Z"]
+        # the messages of EVERY rank in this step (sizes only), in one canonical order: vector, then destination shard
+        msgs = []
+        for x in range(plan.world):
+            px = make_plan(plan.world, x, plan.L)
+            nx = subs[px.term_shard][i][1]
+            ml = []
+            for k in want:
+                for s in range(G):
+                    if s == px.term_shard:
+                        continue
+                    plo, phi = rows_of[k][s]
+                    if phi > plo and nx > 0:
+                        ml.append((px.limb_group + plan.limb_groups * s, (phi - plo) * L_local * nx))
+            msgs.append(ml)
+        send_t, recv_t, pending = [], [], []
+        for k in want:
+            lo, hi = rows_of[k][me]
+            if n:
+                out[k][..., a:a + n] = wc[k][lo:hi]
+            for s in range(G):
+                if s == me:
+                    continue
+                plo, phi = rows_of[k][s]
+                if phi > plo and n > 0:
+                    send_t.append(wc[k][plo:phi])
+        for x in range(plan.world):  # receive buffers in the canonical order: by source rank, then its message order
+            px = make_plan(plan.world, x, plan.L)
+            if px.limb_group != plan.limb_group or x == plan.rank:
                 continue
-            plo, phi = ranges[k](s)
-            if phi > plo and ns > 0:
-                sends.append((wc[k][plo:phi], peer))
-            ps0, pns = plan.slot_range(N, s)
-            if hi > lo and pns > 0:
-                buf = torch.empty((hi - lo,) + tuple(wc[k].shape[1:-1]) + (pns,), dtype=wc[k].dtype, device=wc[k].device)
-                recvs.append((buf, peer))
-                pending.append((full, ps0, pns, buf))
-    wait = _p2p_start(sends, recvs, group)
+            pa, pn = subs[px.term_shard][i]
+            for k in want:
+                lo, hi = rows_of[k][me]
+                if hi > lo and pn > 0:
+                    buf = torch.empty((hi - lo, L_local, pn), dtype=like.dtype, device=like.device)
+                    recv_t.append(buf)
+                    pending.append((out[k], pa, pn, buf))
+        ex = _Exchange(plan.world, plan.rank, groups, msgs, send_t, recv_t, like).start()
+        if steps:  # the previous sub-range's exchange completes behind this sub-range's witness map
+            _finish_step(steps.pop())
+        steps.append((ex, pending, wc))
 
     def finish():
-        wait()
-        for full, ps0, pns, buf in pending:
-            full[..., ps0:ps0 + pns] = buf
+        while steps:
+            _finish_step(steps.pop())
     if defer:
         return out, finish
     finish()
     return out
+
+
+def _finish_step(step):
+    ex, pending, _wc = step
+    ex.finish()
+    for full, ps0, pns, buf in pending:
+        full[..., ps0:ps0 + pns] = buf
 
 
 def _gather_limbs(plan: ShardPlan, piece, n_elems):

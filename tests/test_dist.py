@@ -112,11 +112,17 @@ def _rinocchio_key(ctx, m, n_aux, zk):
                 beta_rv_ts=ctx.random_enc(84), beta_rw_ts=ctx.random_enc(85), beta_ry_ts=ctx.random_enc(86))
 
 
-def _worker(rank, world, port, preset, m, q_override, tmp, prover="groth16", zk=False, split="slots"):
+def _worker(rank, world, port, preset, m, q_override, tmp, prover="groth16", zk=False, split="slots", chunk_bytes=None, relay=True):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     RD.WITNESS_SPLIT = split  # how the ranks of one limb group share the witness map (dist.py)
+    RD.RELAY = relay
+    if chunk_bytes:
+        RD.SLOT_CHUNK_BYTES = chunk_bytes  # tiny sub-ranges of slots: several pipelined exchange steps at toy scale
     try:
-        prm = P.preset(preset)
+        if preset == "toy4":  # four ring limbs (the headline's limb count) at toy scale
+            prm = P.make_params(32, [30, 30, 30, 30], 64, [40, 40, 41], ring_factor=1 << 12, name="toy4")
+        else:
+            prm = P.preset(preset)
         if q_override:
             prm = P.RingParams(prm.N, prm.q[:q_override], prm.N_enc, prm.Q)
         ctx_full = H.oracle_ctx(prm)
@@ -174,6 +180,33 @@ def test_sharded_groth16_three_ranks_uneven_ranges(tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(3, _free_port(), "toy", 8, 1, out), nprocs=3, join=True)
     assert open(out).read() == "ok"
+
+
+@pytest.mark.parametrize("preset,prover,zk,chunk,relay,desc", [
+    ("toy4", "groth16", False, None, True, "the headline's plan: 4 limb groups x 2 term shards; every rank relays for the other three pairs"),
+    ("toy4", "groth16", False, 2048, True, "the same with the slot range cut into sub-ranges: pipelined exchange steps"),
+    ("toy", "rinocchio", True, 4096, True, "configs[3]'s plan: 2 limb groups x 4 term shards, sub-ranges, relays through the other group"),
+    ("toy", "groth16", False, None, False, "2 x 4 without relays (direct links only)"),
+])
+def test_eight_ranks_relayed_slot_reshard(tmp_path, preset, prover, zk, chunk, relay, desc):
+    """N = 8 over gloo: the slot -> term re-shard of ringsnark_amd/dist.py with its two-hop relays through the ranks of the
+    OTHER limb groups (xGMI is point to point: a pair that shares a limb owns one of its seven links), in sub-ranges of
+    slots.  The sharded proof equals the one-process proof bit for bit."""
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(8, _free_port(), preset, 7, None, out, prover, zk, "slots", chunk, relay), nprocs=8, join=True)
+    assert open(out).read() == "ok", desc
+
+
+def test_relay_parts_cover_every_message():
+    """the split of a message into direct halves and relayed parts: sizes add up, the balance is the one DESIGN.md derives"""
+    for numel in (1, 7, 1000, 12345678):
+        for g, n_rel in ((2, 6), (4, 4), (2, 0), (3, 5)):
+            d1, d2, r = RD._split_parts(numel, g, n_rel)
+            assert d1 + d2 + n_rel * r == numel and min(d1, d2, r) >= 0
+            if n_rel and numel > 1000:
+                assert abs((d1 + d2) - 2 * (g - 1) * r) <= 2 * (g - 1) + n_rel  # d = 2 (g - 1) r up to rounding
+    assert RD._split_parts(800, 2, 6) == (100, 100, 100)  # the headline at N = 8: a quarter direct, an eighth per relay
+    assert RD._sub_ranges(8, 8, 3) == [(8, 4), (12, 4), (16, 0)]
 
 
 def test_shard_plans():

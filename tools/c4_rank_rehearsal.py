@@ -15,7 +15,11 @@ Checks (tests/proof_check.py, the CPU oracle; untimed):
   * inner products: one (limb, component, prime) slab of the rank's PARTIAL sum of <alpha_s_pows, H> and of <beta_prods, aux>
     recomputed by the oracle from the device's rows and the key window.
 
-usage: tools/c4_rank_rehearsal.py [preset=C4] [logm=18] [rank=5] [logw=10] [zk=1] [world=8]
+split = slots (the default plan of dist.py): the rank maps its QUARTER of the slots in sub-ranges; the re-shard to terms has
+no peers here and is stubbed (the rows of the other ranks' slots stay unwritten), so the inner products are timed on
+partly undefined data -- their cost is data independent -- and only the witness map is checked.
+
+usage: tools/c4_rank_rehearsal.py [preset=C4] [logm=18] [rank=5] [logw=10] [zk=1] [world=8] [split=replicate]
 Prints one JSON object (copied to profiles/ by hand)."""
 import json
 import os
@@ -38,6 +42,7 @@ rank = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 logw = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 zk = bool(int(sys.argv[5])) if len(sys.argv) > 5 else True
 world = int(sys.argv[6]) if len(sys.argv) > 6 else 8
+split = sys.argv[7] if len(sys.argv) > 7 else "replicate"
 
 GiB = float(2**30)
 free0, total = torch.cuda.mem_get_info()
@@ -55,7 +60,7 @@ prm = P.preset(preset)
 plan = RD.make_plan(world, rank, prm.L)
 prm_l = P.RingParams(prm.N, [prm.q[i] for i in plan.limbs], prm.N_enc, prm.Q, name=prm.name)
 m, W = 1 << logm, 1 << logw
-out = {"what": "one rank's share of configs[3] on one GPU (collectives stubbed)", "preset": preset, "constraints": m, "world": world, "rank": rank,
+out = {"what": "one rank's share of configs[3] on one GPU (collectives stubbed)", "witness_split": split, "preset": preset, "constraints": m, "world": world, "rank": rank,
        "limbs": plan.limbs, "term_shard": "%d of %d" % (plan.term_shard, plan.term_shards), "key_window": W, "zk": zk,
        "ring_primes_two_adicity": [P.two_adicity(q) for q in prm_l.q], "hbm_total_gib": round(total / GiB, 1)}
 dev = Device(prm_l)
@@ -77,7 +82,18 @@ mem("inputs", out)
 
 # one process: the limb group's all-reduce and the all-gather of the limbs have no peers
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % (29500 + os.getpid() % 2000), rank=0, world_size=1)
-RD.WITNESS_SPLIT = "replicate"
+RD.WITNESS_SPLIT = split
+if split == "slots":
+    class _NoPeers:
+        def __init__(self, *a, **k):
+            pass
+
+        def start(self):
+            return self
+
+        def finish(self):
+            pass
+    RD._Exchange = _NoPeers
 RD._gather_limbs = lambda plan_, piece, n: piece
 _real_all_reduce = dist.all_reduce
 RD.dist.all_reduce = lambda *a, **k: None
@@ -103,6 +119,14 @@ def witness_spy(*a, **k):
 
 
 backend.witness = witness_spy
+if split == "slots":  # keep the term-sharded vectors the sharded prover assembles
+    orig_sw = RD.sharded_witness
+
+    def sw_spy(*a, **k):
+        w = orig_sw(*a, **k)
+        kept.update({n: w[n] for n in ("A_mid", "B_mid", "C_mid", "H")})
+        return w
+    RD.sharded_witness = sw_spy
 proof = None
 for it in range(2):
     kept.clear()  # the previous step's rows (96 GiB at full size) go back to the allocator before the next step asks for its own
@@ -136,6 +160,9 @@ t0 = time.time()
 rng = np.random.RandomState(11)
 octx = H.oracle_ctx(prm_l)
 s0 = 2 * int(rng.randint(prm_l.N // 2 - 1))
+if split == "slots":  # a slot pair this rank mapped itself
+    b0, bn = plan.slot_range(prm_l.N)
+    s0 = b0 + 2 * int(rng.randint(bn // 2 - 1))
 wc = dev.witness_map_slots(dcs, asg, s0, 2, *ds, want=("A_mid", "B_mid", "C_mid", "H"))
 torch.cuda.synchronize()
 errs = []
@@ -156,8 +183,8 @@ for k in ("A_mid", "B_mid", "C_mid", "H"):
 out["check_columns_s"] = round(time.time() - t0, 1)
 t0 = time.time()
 slabs = []
-for idx, kname, vec, Tn in ((7, "alpha_s_pows", kept["H"], hi - lo),) + (((8, "beta_prods", asg[cs.n_inputs:][ranges["beta_prods"][0]:ranges["beta_prods"][1]],
-                                                                          ranges["beta_prods"][1] - ranges["beta_prods"][0]),) if not zk else ()):
+for idx, kname, vec, Tn in (() if split == "slots" else ((7, "alpha_s_pows", kept["H"], hi - lo),) + (((8, "beta_prods", asg[cs.n_inputs:][ranges["beta_prods"][0]:ranges["beta_prods"][1]],
+                                                                          ranges["beta_prods"][1] - ranges["beta_prods"][0]),) if not zk else ())):
     l, c, j = int(rng.randint(prm_l.L)), int(rng.randint(2)), int(rng.randint(prm_l.K))
     acc = np.zeros(prm_l.N_enc, dtype=np.uint64)
     proof_check.slab_inner_product(octx, acc, proof_check.key_slab(pk[kname].store, l, c, j, prm_l.N_enc), vec, l, j, Tn)
@@ -166,7 +193,7 @@ for idx, kname, vec, Tn in ((7, "alpha_s_pows", kept["H"], hi - lo),) + (((8, "b
     slabs.append("elem%d[limb %d][comp %d][prime %d] over %d terms" % (idx, l, c, j, Tn))
 out["check_slabs_s"] = round(time.time() - t0, 1)
 out["check"] = {"ok": not errs, "errors": errs, "columns": "limbs x slots %d,%d: identities at 1 random point each + kept rows == columns" % (s0, s0 + 1),
-                "slabs": slabs}
+                "slabs": slabs if split != "slots" else "skipped: the rows of the peers' slots do not exist in a one-rank rehearsal"}
 print(json.dumps(out))
 dist.destroy_process_group()
 sys.exit(0 if not errs else 1)

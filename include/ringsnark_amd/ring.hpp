@@ -60,6 +60,7 @@ class ChaCha20Rng {
     os_entropy(key, sizeof key);
     rekey(key);
   }
+#ifdef RINGSNARK_AMD_TESTING
   void seed_for_tests(uint64_t seed) {  // deterministic key: splitmix64 expansion of the 64-bit seed
     uint8_t key[32];
     for (int i = 0; i < 4; i++) {
@@ -71,6 +72,7 @@ class ChaCha20Rng {
     }
     rekey(key);
   }
+#endif
   result_type operator()() {
     if (pos_ == 8) refill();
     return buf_[pos_++];
@@ -96,6 +98,7 @@ class ChaCha20Rng {
   static void os_entropy(uint8_t *dst, size_t n) {
     size_t got = 0;
     while (got < n) {
+      errno = 0;  // a stale EINTR from an earlier call must not keep a failing getrandom in this loop
       const ssize_t r = ::getrandom(dst + got, n - got, 0);
       if (r > 0) {
         got += (size_t)r;
@@ -161,14 +164,18 @@ class Context {
   // Host generator behind RingElem::random_* (the secret point s, alpha / beta / delta, the Rinocchio blinding
   // d1..d3), EncodingElem::keygen (the secret key) and the noise seeds of encode.  The reference draws all of these
   // from SEAL's UniformRandomGenerator / seal::random_uint64 (Blake2-based, OS entropy; seal_ring.hpp:27,72-100).
-  // Here: a ChaCha20 keystream keyed with 256 bits from getrandom(2) (/dev/urandom as the fallback).  seed_prng is a
-  // TEST HOOK only: it replaces the key by an expansion of a 64-bit value, which makes every draw reproducible and
-  // therefore every secret guessable.
+  // Here: a ChaCha20 keystream keyed with 256 bits from getrandom(2) (/dev/urandom as the fallback), ONE GENERATOR PER
+  // THREAD (thread_local, each keyed afresh from the OS on first use): the reference's provers draw from OpenMP sections
+  // (rinocchio.tcc:106-163), and two threads on one unlocked generator would share a keystream or corrupt its buffer.
   static ChaCha20Rng &prng() {
-    static ChaCha20Rng g;
+    static thread_local ChaCha20Rng g;
     return g;
   }
+#ifdef RINGSNARK_AMD_TESTING
+  // TEST HOOK, compiled only under -DRINGSNARK_AMD_TESTING: replaces the calling thread's key by an expansion of a 64-bit
+  // value, which makes every draw reproducible and therefore every secret guessable.  Not part of the production header.
   static void seed_prng(uint64_t seed) { prng().seed_for_tests(seed); }
+#endif
   static size_t ring_words() { return (size_t)get_params().L * get_params().N; }
   static size_t enc_words() { return (size_t)get_params().L * 2 * get_params().K * get_params().N_enc; }
 

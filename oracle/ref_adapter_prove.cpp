@@ -16,6 +16,7 @@
 // usage: ref_adapter_prove N L q.. N_enc K Q.. m outdir [poly]
 // poly: the circuit's ring coefficients are general ring elements (random polynomials) instead of the Scalar 5 -- on a
 // primary input and on an auxiliary variable -- as in benchmarks/bench_ntt_SEAL.cpp:46-53 (`row * vars[i]`).
+#define RINGSNARK_AMD_TESTING 1  // Context::seed_prng: reproducible draws for the fixtures (never in production builds)
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>

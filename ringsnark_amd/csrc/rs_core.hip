@@ -91,6 +91,10 @@ uint32_t fwd_reduce_mask(uint64_t p, int logn) {
 }
 // Whether the outputs of a forward transform of length 2^logn (masks as above, inputs |v| <= p) may exceed 2^50: then
 // they are reduced before the pointwise product with a (balanced) table entry; below that the product is exact as is.
+// PRECONDITION on the table: balanced entries, |s| <= p/2 -- then |v s| <= 2^50 p/2 = p 2^49, mulmod's bound (f64mod.hpp;
+// the corner 2^50 x p/2 is case 2 / 3 of tests/f64mod_check.cpp for every preset prime and 2^50 - 27).  A canonical [0, p)
+// table would be a factor of two outside it.  witness.hip build_plan checks the tables it uploads; sub_ntt_wide_kernel
+// MODE 2 callers hand in tables of the same plan.
 bool fwd_end_needs_reduce(uint64_t p, int logn) {
   const double lim = 1125899906842624.0 / (double)p;
   double B = 1.0;

@@ -355,6 +355,21 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
           }
         }
       }
+      // PRECONDITION of the kernels that skip the reduction before the table product (ColPlan::pwmask, fwd_end_needs_reduce in
+      // rs_core.hip; tree_wide_kernel, sub_ntt_wide_kernel MODE 2): the spectrum may be as large as 2^50, so mulmod's
+      // |a b| <= p 2^49 holds only for BALANCED table entries, |s| <= p/2.  Every entry goes through bal(); checked here so
+      // that a future table built any other way fails at plan time, not as a wrong residue.
+      if (!ctx->use_int) {
+        auto balanced_table = [&](const std::vector<uint64_t> &t) {
+          for (uint64_t wd : t) {
+            double d;
+            memcpy(&d, &wd, 8);
+            if (!(d <= 0.5 * (double)p && d >= -0.5 * (double)p)) return false;
+          }
+          return true;
+        };
+        RS_REQUIRE(balanced_table(dhat) && balanced_table(bcd) && balanced_table(b2d), "internal: a spectrum table is not balanced (|s| <= p/2)");
+      }
       lp.d_dhat = up(dhat);
       lp.d_dlow = up(dlow);
       if (!bcd.empty()) lp.d_bc_d = up(bcd);

@@ -287,7 +287,9 @@ class _Exchange:
 WITNESS_SPLIT = os.environ.get("RINGSNARK_WITNESS_SPLIT", "slots")
 if WITNESS_SPLIT not in ("replicate", "slots"):
     raise ValueError("RINGSNARK_WITNESS_SPLIT must be 'replicate' or 'slots', not %r" % WITNESS_SPLIT)
-SLOT_CHUNK_BYTES = int(os.environ.get("RINGSNARK_SLOT_CHUNK_MIB", "8192")) << 20  # compact vectors of one sub-range of slots
+# compact vectors of one sub-range of slots (two sub-ranges are alive at a time, plus their receive and relay buffers: a
+# configs[3] rank at 2^18 constraints peaks at 277 of 288 GiB with 8 GiB, profiles/r04_rank_rehearsal_C4_slots_m262144.json)
+SLOT_CHUNK_BYTES = int(os.environ.get("RINGSNARK_SLOT_CHUNK_MIB", "4096")) << 20
 
 
 def _sub_ranges(s0, ns, n_sub):

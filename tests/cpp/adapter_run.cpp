@@ -5,6 +5,7 @@
 // usage: adapter_run N L q_0..q_{L-1} N_enc K Q_0..Q_{K-1}
 // Checks ring identities, the reference's error messages, and the encoding homomorphism
 //   decode(<E(a_t), r_t>) = sum_t a_t r_t   through encode / operator*= / operator+= / inner_product.
+#define RINGSNARK_AMD_TESTING 1  // Context::seed_prng: reproducible draws for the fixtures (never in production builds)
 #include <cstdio>
 #include <cstdlib>
 #include <random>

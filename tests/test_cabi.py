@@ -102,6 +102,7 @@ def test_adapter_generator_is_chacha20_keyed_from_the_os(tmp_path):
     if gxx is None:
         pytest.skip("no g++")
     src = r"""
+#define RINGSNARK_AMD_TESTING 1  // the reproducible-key hook exists only under this macro
 #include <cstdio>
 #include <ringsnark_amd/ring.hpp>
 int main() {
@@ -131,6 +132,13 @@ int main() {
     assert out[1] == "1 1 1"
     hdr = open(os.path.join(ROOT, "include", "ringsnark_amd", "ring.hpp")).read()
     assert "mt19937" not in hdr and "random_device" not in hdr
+    # a production build (no RINGSNARK_AMD_TESTING) has no way to make the secrets reproducible, and the process generator is
+    # per thread (round-3 advice): the hook must not compile, the generator must be thread_local
+    f2 = tmp_path / "t2.cpp"
+    f2.write_text("#include <ringsnark_amd/ring.hpp>\nint main() { ringsnark::amd::Context::seed_prng(1); return 0; }\n")
+    r2 = subprocess.run([gxx, "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(f2)], capture_output=True, text=True)
+    assert r2.returncode != 0 and "seed_prng" in r2.stderr
+    assert "static thread_local ChaCha20Rng" in hdr
 
 
 @pytest.mark.gpu

@@ -559,7 +559,7 @@ def main():
         if MEASURED:
             out["measured_peaks"] = {"hbm_copy_gbs": round(MEASURED["hbm_copy_gbs"], 1), "fp64_fma_T": round(MEASURED["fp64_fma_T"], 2),
                                      "fp64_mulmod_G": round(MEASURED["fp64_mulmod_G"], 1), "int_montmul_G": round(MEASURED["int_montmul_G"], 1),
-                                     "how": "rs_measure_peaks at the start of this run: 2 GiB device-to-device copy (streaming 16-byte accesses; read + written bytes, best of three grid sizes), v_fma_f64 "
+                                     "how": "rs_measure_peaks at the start of this run: 2 GiB device-to-device copy (streaming 16-byte accesses; read + written bytes, best of four grid sizes, temporal and non-temporal accesses, and hipMemcpyAsync), v_fma_f64 "
                                             "lane-operations/s, exact-FP64 modular multiplies/s (6 instructions each), Montgomery products/s on a 60-bit prime; "
                                             "`frac_of_measured` in the rooflines divides by these, `frac` by the spec sheet"}
         if timings:

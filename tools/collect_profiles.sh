@@ -14,6 +14,8 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
+# what is being profiled: the hash of the device-library sources of THIS tree (bench.py joins a counter file only when it matches)
+python3 -c "from ringsnark_amd._lib import source_hash; print(source_hash())" > "$OUT/source_hash.txt"
 # a failed pass (counter set rejected, bench error) must not leave partial csv files for the summarisers (round-3 advice)
 FAILED=0
 run_pass() {  # run_pass <name> <expected csv glob> <command...>

@@ -16,14 +16,21 @@ import json
 import sys
 
 
-def provenance():
+def provenance(*dirs):
     """what the counters were collected ON: the hash of the device-library sources of this tree (bench.py refuses to join
     a file whose hash differs from the tree it runs in) and, where git is at hand, the commit"""
     import os
     import subprocess
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from ringsnark_amd._lib import source_hash
-    out = {"source_hash": source_hash()}
+    # tools/collect_profiles.sh records the hash of the tree it profiled next to the passes; without that file (older
+    # collections) the hash of the summarising tree is all there is
+    recorded = None
+    for d in dirs:
+        f = os.path.join(os.path.dirname(os.path.normpath(d)), "source_hash.txt")
+        if os.path.exists(f):
+            recorded = open(f).read().strip()
+    out = {"source_hash": recorded or source_hash(), "source_hash_from": "collection" if recorded else "summarising tree"}
     try:
         out["commit"] = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
     except OSError:
@@ -46,7 +53,7 @@ def load(d):
 
 
 res = {"units": "per proof (one prover call): wave-level counts as reported by rocprofv3; *_lane_ops = x64", "proofs_in_run": proofs, "kernels": {}}
-res.update(provenance())
+res.update(provenance(mix))
 A, nA = load(mix)
 B, nB = load(stall) if stall != "-" else ({}, {})
 for k in sorted(A, key=lambda k: -A[k].get("SQ_INSTS_VALU", 0)):

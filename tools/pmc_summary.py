@@ -7,14 +7,21 @@ Calibration inside the same run: transpose_out_kernel reads S*M*8 bytes and writ
 known size -- the summary records reported vs expected for both."""
 import csv, glob, json, sys, collections
 
-def provenance():
+def provenance(*dirs):
     """what the counters were collected ON: the hash of the device-library sources of this tree (bench.py refuses to join
     a file whose hash differs from the tree it runs in) and, where git is at hand, the commit"""
     import os
     import subprocess
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from ringsnark_amd._lib import source_hash
-    out = {"source_hash": source_hash()}
+    # tools/collect_profiles.sh records the hash of the tree it profiled next to the passes; without that file (older
+    # collections) the hash of the summarising tree is all there is
+    recorded = None
+    for d in dirs:
+        f = os.path.join(os.path.dirname(os.path.normpath(d)), "source_hash.txt")
+        if os.path.exists(f):
+            recorded = open(f).read().strip()
+    out = {"source_hash": recorded or source_hash(), "source_hash_from": "collection" if recorded else "summarising tree"}
     try:
         out["commit"] = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
     except OSError:
@@ -32,7 +39,7 @@ def load(d, c):
     return agg
 F, W = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
 res = {"units": "bytes per proof (one prover call)", "proofs_in_run": proofs, "fetch_correction": 2.0, "kernels": {}}
-res.update(provenance())
+res.update(provenance(fdir))
 for k in sorted(set(F) | set(W)):
     n = max(len(F.get(k, [])), len(W.get(k, [])))
     fetch = sum(F.get(k, [])) * 1024 * 2.0 / proofs

@@ -119,6 +119,10 @@ def kernel_roofline(k, pmc, fp64_pmc=None, stale=None):
         if fam:
             traffic = int(sum(v["hbm_bytes"] for v in fam) / max(1, sum(v["launches_per_proof"] for v in fam)))
     out["traffic"] = traffic
+    if traffic is not None:  # what the memory system actually moved per second (counter traffic over the live launch time)
+        out["traffic_gbs"] = round(traffic * max(1, k["launches"]) / sec / 1e9, 1)
+        if MEASURED.get("hbm_copy_gbs"):
+            out["traffic_frac_of_measured_copy"] = round(out["traffic_gbs"] / MEASURED["hbm_copy_gbs"], 4)
     if traffic is None:
         out["traffic_reason"] = (stale or {}).get("traffic") or "kernel not in the counter file"
     return out

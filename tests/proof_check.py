@@ -129,9 +129,10 @@ def groth16_check(dev, prm, cs, dcs, asg, pk, proof, m, W=None, seed=5, n_cols=4
     rng = np.random.RandomState(seed)
     slabs = [("A", int(rng.randint(prm.L)), int(rng.randint(2)), int(rng.randint(prm.K))),
              ("C", int(rng.randint(prm.L)), int(rng.randint(2)), int(rng.randint(prm.K)))]
+    slabs.append(("B", int(rng.randint(prm.L)), int(rng.randint(2)), int(rng.randint(prm.K))))  # drawn last: A and C keep their round-3 slabs
     key = {}
     for elem, l, c, j in slabs:
-        for nme in (("s_pows", "alpha") if elem == "A" else ("delta_ts", "delta_mid")):
+        for nme in {"A": ("s_pows", "alpha"), "B": ("s_pows", "beta"), "C": ("delta_ts", "delta_mid")}[elem]:
             key[(nme, l, c, j)] = key_slab(pk[nme], l, c, j, prm.N_enc)
     proof_h = {(e, l, c, j): to_host(proof[{"A": 0, "B": 1, "C": 2}[e], l, c, j].contiguous()) for e, l, c, j in slabs}
     for k in list(pk.keys()):
@@ -147,16 +148,19 @@ def groth16_check(dev, prm, cs, dcs, asg, pk, proof, m, W=None, seed=5, n_cols=4
     t_cols = time.perf_counter() - t_start
     for elem, l, c, j in slabs:
         acc = np.zeros(prm.N_enc, dtype=np.uint64)
-        if elem == "A":  # groth16.tcc:89-95
-            slab_inner_product(octx, acc, key[("s_pows", l, c, j)], w["A_io"], l, j, m)
-            slab_inner_product(octx, acc, key[("s_pows", l, c, j)], w["A_mid"], l, j, m)
-            acc = (acc + key[("alpha", l, c, j)][0]) % np.uint64(prm.Q[j])
+        if elem in ("A", "B"):  # groth16.tcc:89-95, 97-103
+            slab_inner_product(octx, acc, key[("s_pows", l, c, j)], w[elem + "_io"], l, j, m)
+            slab_inner_product(octx, acc, key[("s_pows", l, c, j)], w[elem + "_mid"], l, j, m)
+            acc = (acc + key[("alpha" if elem == "A" else "beta", l, c, j)][0]) % np.uint64(prm.Q[j])
         else:  # groth16.tcc:105-112
             slab_inner_product(octx, acc, key[("delta_ts", l, c, j)], w["H"], l, j, m + 1)
             slab_inner_product(octx, acc, key[("delta_mid", l, c, j)], asg[cs.n_inputs:], l, j, cs.n_aux)
         if not (acc == proof_h[(elem, l, c, j)]).all():
             return False, {"error": "proof element %s slab (limb %d, component %d, prime %d) differs from the CPU oracle" % (elem, l, c, j)}
-    return True, {"columns": len(cols), "points_per_column": 2,
+    return True, {"kind": "SAMPLED check (not every column, not every slab)",
+                  "sample": "%d of %d witness-map columns x 2 random points; %d of %d (element, limb, component, prime) slabs of the proof" % (
+                      len(cols), prm.L * prm.N, len(slabs), 3 * prm.L * 2 * prm.K),
+                  "columns": len(cols), "points_per_column": 2,
                   "slabs": ["%s[limb %d][comp %d][prime %d]" % s for s in slabs],
                   "seconds": round(time.perf_counter() - t_start, 1), "columns_seconds": round(t_cols, 1)}
 
@@ -192,4 +196,7 @@ def rinocchio_check(dev, prm, cs, dcs, asg, pk, proof, m, ds=(None, None, None),
         if not (acc == to_host(proof[idx, l, c, j].contiguous())).all():
             return False, {"error": "proof element %d slab (limb %d, component %d, prime %d) differs from the CPU oracle" % (idx, l, c, j)}
         done.append("elem%d[limb %d][comp %d][prime %d]" % (idx, l, c, j))
-    return True, {"columns": len(cols), "slabs": done}
+    return True, {"kind": "SAMPLED check (not every column, not every slab)",
+                  "sample": "%d of %d witness-map columns; %d of %d (element, limb, component, prime) slabs of the proof" % (
+                      len(cols), prm.L * prm.N, len(done), 9 * prm.L * 2 * prm.K),
+                  "columns": len(cols), "slabs": done}

@@ -112,7 +112,8 @@ def _rinocchio_key(ctx, m, n_aux, zk):
                 beta_rv_ts=ctx.random_enc(84), beta_rw_ts=ctx.random_enc(85), beta_ry_ts=ctx.random_enc(86))
 
 
-def _worker(rank, world, port, preset, m, q_override, tmp, prover="groth16", zk=False, split="slots", chunk_bytes=None, relay=True):
+def _worker(rank, world, port, preset, m, q_override, tmp, prover="groth16", zk=False, split="slots", chunk_bytes=None, relay=True,
+            scalar_wires=False):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     RD.WITNESS_SPLIT = split  # how the ranks of one limb group share the witness map (dist.py)
     RD.RELAY = relay
@@ -134,6 +135,15 @@ def _worker(rank, world, port, preset, m, q_override, tmp, prover="groth16", zk=
         else:
             pk = _rinocchio_key(ctx_full, m, cs_full.n_aux, zk)
         ds = [ctx_full.random_ring(60 + k) for k in range(3)] if zk else [None] * 3
+        kinds = aux_kinds = None
+        if scalar_wires:  # auxiliary wires held as RingElem Scalars: 1 (passes the key element through), 0 (skipped), 7 (flattened)
+            asg = asg.copy()
+            a0 = cs_full.n_inputs
+            kinds = np.zeros(cs_full.n_vars, dtype=np.uint8)
+            for k, (val, kind) in enumerate(((1, O.KIND_ONE), (0, O.KIND_POLY), (7, O.KIND_POLY), (1, O.KIND_ONE))):
+                asg[a0 + 2 * k] = val
+                kinds[a0 + 2 * k] = kind
+            aux_kinds = kinds[a0:]
         plan = RD.make_plan(world, rank, prm.L)
         tg = RD.groups_for(plan)
         prm_local = P.RingParams(prm.N, [prm.q[i] for i in plan.limbs], prm.N_enc, prm.Q)
@@ -143,13 +153,14 @@ def _worker(rank, world, port, preset, m, q_override, tmp, prover="groth16", zk=
         pk_local = {k: t(v[:, plan.limbs] if v.ndim == 5 else v[plan.limbs]) for k, v in pk.items()}
         asg_local = t(asg[:, plan.limbs])
         if prover == "groth16":
-            got = RD.groth16_prove_sharded(backend, plan, tg, cs_local, pk_local, asg_local, m, cs_full.n_inputs, cs_full.n_aux)
-            exp, exp_empty, got_empty = O.groth16_prove(ctx_full, H.oracle_cs(cs_full), pk, asg)[0], None, None
+            got = RD.groth16_prove_sharded(backend, plan, tg, cs_local, pk_local, asg_local, m, cs_full.n_inputs, cs_full.n_aux,
+                                           aux_kinds=aux_kinds)
+            exp, exp_empty, got_empty = O.groth16_prove(ctx_full, H.oracle_cs(cs_full), pk, asg, kinds)[0], None, None
         else:
             dl = [None if d is None else t(d[plan.limbs]) for d in ds]
             got, got_empty = RD.rinocchio_prove_sharded(backend, plan, tg, cs_local, pk_local, asg_local, m, cs_full.n_inputs,
-                                                        cs_full.n_aux, *dl)
-            exp, exp_empty = O.rinocchio_prove(ctx_full, H.oracle_cs(cs_full), pk, asg, *ds)
+                                                        cs_full.n_aux, *dl, aux_kinds=aux_kinds)
+            exp, exp_empty = O.rinocchio_prove(ctx_full, H.oracle_cs(cs_full), pk, asg, *ds, kinds=kinds)
         if rank == 0:
             ok = bool((OracleBackend._np(got) == exp).all()) and got_empty == exp_empty
             open(tmp, "w").write("ok" if ok else "mismatch")
@@ -195,6 +206,15 @@ def test_eight_ranks_relayed_slot_reshard(tmp_path, preset, prover, zk, chunk, r
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(8, _free_port(), preset, 7, None, out, prover, zk, "slots", chunk, relay), nprocs=8, join=True)
     assert open(out).read() == "ok", desc
+
+
+@pytest.mark.parametrize("prover,q_override,zk", [("groth16", 1, False), ("groth16", None, False), ("rinocchio", 1, True)])
+def test_sharded_provers_pass_scalar_one_wires_through(tmp_path, prover, q_override, zk):
+    """Scalar-1 auxiliary wires (seal_ring.tcc:525-527) across the term split (the kinds are sliced with the terms) and the
+    limb split (a property of the wire: the same on every limb): the sharded proof equals the oracle's proof WITH kinds."""
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(2, _free_port(), "toy", 9, q_override, out, prover, zk, "slots", None, True, True), nprocs=2, join=True)
+    assert open(out).read() == "ok"
 
 
 def test_relay_parts_cover_every_message():

@@ -844,6 +844,45 @@ def test_witness_map_row_ranges_equal_slices_of_the_whole(name, m, kind, zk):
     assert (host(sub["A_mid"]) == full["A_mid"][3:9]).all() and (host(sub["H"]) == full["H"][1:]).all() and sub["B_mid"] is None
 
 
+def test_witness_map_row_ranges_are_validated():
+    """rs_witness_map_rows refuses ranges outside a vector and different ranges for the io and mid vectors of one matrix
+    (one pass writes both)."""
+    import ctypes as C
+    from ringsnark_amd import _lib
+    from ringsnark_amd.device import _ptr
+    dev = dev_for("toy")
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    m = 12
+    cs = R.wide_r1cs(m, prm.q)
+    asg = dev.put(H.make_assignment(ctx, cs))
+    dcs = dev.r1cs(cs)
+    outs = [dev.ring_empty(m + 1) for _ in range(7)]
+    Z = np.zeros((prm.L, m + 1), dtype=np.uint64)
+
+    def call(rows):
+        flat = (C.c_size_t * 14)(*[x for r in rows for x in r])
+        return dev.lib.rs_witness_map_rows(dev.h, dcs.h, _ptr(asg), None, None, None, flat, *[_ptr(o) for o in outs],
+                                           Z.ctypes.data_as(_lib.u64p), dev.stream())
+    full = [(0, m)] * 6 + [(0, m + 1)]
+    assert call(full) == _lib.RS_OK
+    assert call(full[:6] + [(0, m + 2)]) == _lib.RS_ERR_INVALID and b"row range" in dev.lib.rs_last_error()
+    assert call([(0, m + 1)] + full[1:]) == _lib.RS_ERR_INVALID
+    assert call([(5, 3)] + full[1:]) == _lib.RS_ERR_INVALID
+    assert call([(0, 4)] + full[1:]) == _lib.RS_ERR_INVALID and b"same row range" in dev.lib.rs_last_error()  # A_io != A_mid
+
+
+def test_measured_peaks_are_plausible():
+    """rs_measure_peaks (the second denominators of bench.py's rooflines): a device-to-device copy between 2 and 8 TB/s
+    (8 TB/s is the HBM3E spec), v_fma_f64 between 15 and 39.3 T lane-operations/s (the spec at 2.4 GHz), the exact-FP64
+    modular multiply at a sixth of the FMA rate give or take, the Montgomery product several times slower than that."""
+    p = dev_for("toy").measure_peaks()
+    assert 2000 < p["hbm_copy_gbs"] < 8000, p
+    assert 15 < p["fp64_fma_T"] < 39.4, p
+    assert 0.10 < p["fp64_mulmod_G"] / 1e3 / p["fp64_fma_T"] < 0.25, p
+    assert 2 < p["fp64_mulmod_G"] / p["int_montmul_G"] < 12, p
+
+
 def test_msm_with_a_tiled_key_equals_the_explicit_key():
     """crs_window (ringsnark_amd.h): logical element t is read from index t % window."""
     import torch

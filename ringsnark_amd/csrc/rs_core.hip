@@ -952,7 +952,10 @@ int rs_set_tuning(const char *key, int value) {
     g_mac_share_keys = value != 0;
   else if (std::string(key) == "ntt_wide_grid")
     g_ntt_wide_grid = std::max(1, value);
-  else if (std::string(key) == "witness_force_bc") {
+  else if (std::string(key) == "witness_cross_maxr") {
+    RS_REQUIRE(value >= 1 && value <= 6, "witness_cross_maxr must be in [1, 6]");
+    g_witness_cross_maxr = value;
+  } else if (std::string(key) == "witness_force_bc") {
     RS_REQUIRE(value == 0 || (value >= 5 && value <= 20), "witness_force_bc must be 0 or in [5, 20]");
     g_witness_force_bc = value;  // takes effect for plans built afterwards (plans are cached per context and size)
   } else if (std::string(key) == "witness_bc2") {

@@ -273,6 +273,7 @@ inline hipStream_t S(rs_stream s) { return (hipStream_t)s; }
 // launch helpers implemented in the .hip files
 void msm_scratch_release(rs_ctx *ctx);  // msm.hip
 extern int g_mac_variant, g_mac_ablate, g_plain_variant, g_mac_chunk_units, g_msm_host_tile, g_mac_share_keys;  // msm.hip tuning knobs
+extern int g_witness_cross_maxr;           // witness.hip: stages per cross pass of the multi-pass transforms
 extern int g_witness_force_bc;             // witness.hip: cap on the transform length (block-convolution path)
 extern int g_witness_bc2;                  // witness.hip: two-dimensional block convolutions where they apply
 extern int g_prover_lin_io;               // prover.hip: io vectors as linear forms in groth16::prover

@@ -219,6 +219,7 @@ static uint64_t plain_word(const rs_ctx *ctx, uint64_t v, uint64_t p) {
   return ctx->use_int ? word_of(HostArith<ModI>::plain(v, p)) : word_of(HostArith<Mod>::plain(v, p));
 }
 
+int g_witness_cross_maxr = 6;  // tuning knob "witness_cross_maxr": most stages of one cross pass (FP64 arithmetic; 4 = the round-3 passes)
 int g_witness_force_bc = 0;  // tuning knob "witness_force_bc": pretend the ring primes have only this 2-adicity (tests)
 int g_witness_bc2 = 1;       // tuning knob "witness_bc2": two-dimensional block convolutions where they apply (0: the pairwise form)
 
@@ -638,6 +639,16 @@ static void launch_tree_tiles_generic(rs_ctx *ctx, typename ArithOf<M>::T *cols,
 template <bool INV, int MODE, class M>
 static void launch_cross_pass(int R, const dim3 &grid, const CrossArgs &a, const ColPlansT<M> &cp, hipStream_t st) {
   using CPS = ColPlansT<M>;
+  if constexpr (std::is_same<M, Mod>::value) {  // radix 32 / 64 passes: six cross stages (M = 2^18) in ONE pass over the workspace instead of two
+    if (R == 6) {
+      hipLaunchKernelGGL((cross_kernel<INV, 6, MODE, CPS>), grid, dim3(256), 0, st, a, cp);
+      return;
+    }
+    if (R == 5) {
+      hipLaunchKernelGGL((cross_kernel<INV, 5, MODE, CPS>), grid, dim3(256), 0, st, a, cp);
+      return;
+    }
+  }
   switch (R) {
     case 4: hipLaunchKernelGGL((cross_kernel<INV, 4, MODE, CPS>), grid, dim3(256), 0, st, a, cp); break;
     case 3: hipLaunchKernelGGL((cross_kernel<INV, 3, MODE, CPS>), grid, dim3(256), 0, st, a, cp); break;
@@ -674,7 +685,9 @@ static void launch_cross(rs_ctx *ctx, CrossArgs a, size_t ncols, int logB, const
   const size_t groups = ((size_t)1 << a.logtot);
   int done = 0;
   while (done < ncross) {
-    const int R = pick_radix(ncross - done, 4);
+    // FP64: up to six stages per pass (64 strided elements per thread: the pass is HBM bound, the registers are idle) --
+    // a transform with five or six cross stages (M = 2^17, 2^18) crosses the workspace once instead of twice
+    const int R = pick_radix(ncross - done, std::is_same<M, Mod>::value ? std::max(1, std::min(6, g_witness_cross_maxr)) : 4);
     a.s0 = INV ? logB + done : done;
     const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>((groups >> R) / 256, 1024));
     const dim3 grid(gx, (unsigned)ncols);

@@ -106,6 +106,27 @@ def test_block_convolutions_equal_full_length_transforms_beyond_2_16(m):
         assert (runs[0][k] == runs[14][k]).all(), k
 
 
+@pytest.mark.parametrize("m", [70000, 262144])
+def test_wide_cross_passes_equal_the_radix_16_ones(m):
+    """witness_cross_maxr: five or six cross stages in ONE pass over the workspace (radix 32 / 64; M = 2^17, 2^18) against
+    the round-3 passes of at most four stages -- the same stages with the same reduction points, so the vectors are identical."""
+    from ringsnark_amd.device import to_host
+    prm = P.preset("toy44")
+    runs = {}
+    for maxr in (4, 6):
+        _set_tuning(b"witness_cross_maxr", maxr)
+        try:
+            dev, cs, asg, ds, w, names = _run(prm, m, True, 0)
+        finally:
+            _set_tuning(b"witness_cross_maxr", 6)
+        wide = [n for n in names if n.startswith("cross_kernel<") and n.split(",")[1].strip() in ("5", "6")]
+        assert bool(wide) == (maxr == 6), names
+        runs[maxr] = {k: to_host(w[k]) for k in KEYS}
+        del dev, asg, w
+    for k in KEYS:
+        assert (runs[4][k] == runs[6][k]).all(), k
+
+
 def test_integer_arithmetic_at_2_17():
     """The Montgomery-integer contexts (moduli >= 2^50: microbench.cpp:33-36, BFVDefault(2048)) run the generic kernels of
     the multi-pass path; M = 2^17 forced on toy44's primes, equal to the FP64 context bit for bit."""

@@ -143,10 +143,15 @@ int rs_inner_product(rs_ctx *ctx, const uint64_t *d_encs, const uint64_t *d_ring
  * adding their separate inner products (the ciphertext ring is distributive; DESIGN.md "MSM").
  *   d_out[c][g] = sum_{v in group g} sum_{t < vec[v].T} d_crs[c][t] * vec[v].d_coeff[t]      */
 typedef struct rs_msm_vec {
-  const uint64_t *d_coeff; /* [T][L][N] */
+  const uint64_t *d_coeff; /* [T][L][N]; slot_const: [T][L] */
   const uint8_t *h_kinds;  /* host [T] or NULL */
   size_t T;                /* terms (<= crs_len) */
   int group;               /* output group index */
+  int slot_const;          /* 1: every ring element of the vector holds ONE value per limb in all its slots and d_coeff is the
+                            * compact [T][L] array of those values -- coefficients_for_Z (util/evaluation_domain.tcc:54-60: slot
+                            * constant by construction), which Rinocchio multiplies into both key vectors (rinocchio.tcc:150-160).
+                            * Same result as the expanded [T][L][N] vector (the plaintext of such an element is value x
+                            * encode(1,...,1)); (m+1) ring elements -- 24 GiB on a configs[3] rank -- are never materialised. */
 } rs_msm_vec;
 /* crs_window: 0, or the number of elements actually stored per CRS vector -- logical element t
  * is then read from index t % crs_window ("tiled" key: how a proving key larger than HBM, e.g. the

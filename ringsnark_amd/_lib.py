@@ -28,7 +28,7 @@ class RsError(RuntimeError):
 
 
 class MsmVec(C.Structure):
-    _fields_ = [("d_coeff", vp), ("h_kinds", u8p), ("T", C.c_size_t), ("group", C.c_int)]
+    _fields_ = [("d_coeff", vp), ("h_kinds", u8p), ("T", C.c_size_t), ("group", C.c_int), ("slot_const", C.c_int)]
 
 
 class Groth16PK(C.Structure):

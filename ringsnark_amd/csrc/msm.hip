@@ -41,6 +41,7 @@ static int tile_threads(int logn) { return std::max(64, std::min(1024, (1 << log
 struct MsmScratch {
   void *d_plain_tabs = nullptr, *d_coeff_tabs = nullptr;  // device copies of the context's tables (NttTable or NttTableI)
   uint64_t *d_Qint = nullptr;
+  uint64_t *d_ones_plain = nullptr;  // [L][N_enc]: batch encoding of the ring element (1, ..., 1), built at first use (slot-constant vectors)
   void *d_coeff_tabs_f64 = nullptr;  // hybrid contexts: FP64 tables of the data primes beside the integer ones
   // host-resident keys: copy stream and the events of the two staging buffers (copied: data landed; freed: its readers ran)
   hipStream_t copy_stream = nullptr;
@@ -89,6 +90,7 @@ void msm_scratch_release(rs_ctx *ctx) {
   (void)hipFree(it->second.d_plain_tabs);
   (void)hipFree(it->second.d_coeff_tabs);
   (void)hipFree(it->second.d_Qint);
+  if (it->second.d_ones_plain) (void)hipFree(it->second.d_ones_plain);
   if (it->second.d_coeff_tabs_f64) (void)hipFree(it->second.d_coeff_tabs_f64);
   if (it->second.copy_stream) {
     (void)hipStreamDestroy(it->second.copy_stream);
@@ -203,6 +205,17 @@ static void launch_mac_v4(rs_ctx *ctx, const MacArgs4 &a, bool paired, const Msm
   RS_HIP(hipGetLastError());
 }
 
+__global__ void __launch_bounds__(256) fill_value_kernel(uint64_t *p, size_t n, uint64_t v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+// [T][L] values -> [T][L][N] ring elements with the value in every slot
+__global__ void __launch_bounds__(256) broadcast_rows_kernel(const uint64_t *__restrict__ vals, uint64_t *__restrict__ out, size_t total, int N) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) out[i] = vals[i / (size_t)N];
+}
+void batch_encode_run(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, size_t count, hipStream_t st);
+
 int g_mac_ablate = 0;
 int g_mac_share_keys = 1;  // tuning knob "mac_share_keys": two key vectors share the plaintext spectrum (mac_kernel_v4; 8192 and 16384 points)
 int g_msm_host_tile = 1024;  // tuning knob "msm_host_tile": terms per staging buffer of a host-resident key
@@ -250,12 +263,43 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     RS_HIP(hipMemsetAsync(d_nz, 0, nz_total * sizeof(unsigned), st));
   }
   if (kinds_total) d_kinds = (uint8_t *)ws_get(ctx, 3, kinds_total);
+  // Slot-constant vectors (rs_msm_vec::slot_const: [T][L] values).  The generic plaintext kernel multiplies the value into
+  // the plaintext of (1, ..., 1); the wide 8192-point kernel has no such path: there the rows are expanded into a workspace.
+  bool any_sc = false;
+  for (int v = 0; v < n_vecs; v++) any_sc = any_sc || vecs[v].slot_const;
+  const bool sc_native = !(std::is_same<M, Mod>::value && g_plain_variant == 1 && n == 8192 && (ctx->N == 8192 || ctx->N == 4096));
+  std::vector<const uint64_t *> coeff_ptr(n_vecs);
+  for (int v = 0; v < n_vecs; v++) coeff_ptr[v] = vecs[v].d_coeff;
+  if (any_sc && sc_native && !sc.d_ones_plain) {
+    const size_t rw = ctx->ring_words();
+    uint64_t *ones = (uint64_t *)ws_get(ctx, 14, rw * sizeof(uint64_t));
+    hipLaunchKernelGGL(fill_value_kernel, dim3((unsigned)((rw + 255) / 256)), dim3(256), 0, st, ones, rw, 1ull);
+    RS_HIP(hipMalloc(&sc.d_ones_plain, (size_t)L * n * sizeof(uint64_t)));
+    batch_encode_run(ctx, ones, sc.d_ones_plain, 1, st);  // sc is the context's entry itself (scratch_for returns a reference)
+  }
+  if (any_sc && !sc_native) {
+    size_t rows = 0;
+    for (int v = 0; v < n_vecs; v++) rows += vecs[v].slot_const ? vecs[v].T : 0;
+    uint64_t *buf = (uint64_t *)ws_get(ctx, 14, std::max<size_t>(1, rows) * ctx->ring_words() * sizeof(uint64_t));
+    size_t at = 0;
+    for (int v = 0; v < n_vecs; v++)
+      if (vecs[v].slot_const && vecs[v].T) {
+        const size_t total = vecs[v].T * ctx->ring_words();
+        hipLaunchKernelGGL(broadcast_rows_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, st, vecs[v].d_coeff,
+                           buf + at, total, ctx->N);
+        coeff_ptr[v] = buf + at;
+        at += total;
+      }
+    RS_HIP(hipGetLastError());
+  }
+  pa.ones_plain = sc.d_ones_plain;
   {
     size_t nzo = 0, ko = 0;
     for (int v = 0; v < n_vecs; v++) {
       PlainGroup &G = pa.g[vecs[v].group];
       RS_REQUIRE(G.n < MAX_GROUP_VECS, "too many vectors in one group");
-      G.coeff[G.n] = vecs[v].d_coeff;
+      G.coeff[G.n] = coeff_ptr[v];
+      G.slot_const[G.n] = (vecs[v].slot_const && sc_native) ? 1 : 0;
       G.T[G.n] = vecs[v].T;
       if (h_used) {
         nz_ptr[v] = d_nz + nzo;

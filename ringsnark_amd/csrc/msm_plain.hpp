@@ -19,11 +19,13 @@ struct PlainGroup {
   const uint8_t *kinds[MAX_GROUP_VECS];
   unsigned *nz[MAX_GROUP_VECS];
   unsigned long long T[MAX_GROUP_VECS];
+  unsigned char slot_const[MAX_GROUP_VECS];  // coeff[v] is [T][L]: one value per (term, limb), in every slot (rs_msm_vec::slot_const)
   int n;
   MsmLin lin;  // optional extra vector in linear form (count == 0: none); wide plaintext kernel only
 };
 struct PlainArgs {
   PlainGroup g[MAX_GROUPS];
+  const uint64_t *ones_plain;  // [L][N_enc] canonical plaintext of the ring element (1, ..., 1): slot-constant vectors are value x this
 };
 
 // radix of the wave-private rounds: 3 keeps the accumulators + a round inside 128 VGPRs (no scratch)
@@ -64,6 +66,21 @@ plain_center_kernel(PlainArgs args, typename ArithOf<M>::Lift *__restrict__ C, u
       if (threadIdx.x == 0) {
         acc[0] += Lift(1);
         if (G.nz[v]) atomicOr(&G.nz[v][t], 1u);
+      }
+      continue;
+    }
+    if (G.slot_const[v]) {
+      // a slot-constant ring element c: its batch encoding is c x encode(1, ..., 1) (the inverse transform is linear), so the
+      // plaintext needs no transform -- one modular product per coefficient against the context's table; c = 0 is_zero()
+      const uint64_t cres = G.coeff[v][(size_t)t * L + limb];
+      if (cres == 0) continue;  // uniform over the workgroup
+      if (threadIdx.x == 0 && G.nz[v]) atomicOr(&G.nz[v][t], 1u);
+      const T c = center(from_res<T>(cres), mod);
+      const uint64_t *ones = args.ones_plain + (size_t)limb * n;
+#pragma unroll
+      for (int k = 0; k < EPT; k++) {
+        const int p = threadIdx.x + k * blockDim.x;
+        if (p < n) acc[k] += lift_centered(canon(mulmod_dd(c, from_res<T>(ones[p]), mod), mod), mod);
       }
       continue;
     }

@@ -53,17 +53,6 @@ struct PhaseTimer {
   }
 };
 
-// z[t][limb][x] = Z_limb[t]: coefficients_for_Z as ring elements (slot-constant)
-__global__ void __launch_bounds__(256)
-broadcast_z_kernel(const uint64_t *__restrict__ Z /* [L][rows] */, uint64_t *__restrict__ out, size_t rows, int N, int L) {
-  const size_t total = rows * (size_t)L * N, stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const size_t t = i / ((size_t)L * N);
-    const int limb = (int)((i / (size_t)N) % (size_t)L);
-    out[i] = Z[(size_t)limb * rows + t];
-  }
-}
-
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   z += 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -209,19 +198,20 @@ int rs_rinocchio_prove_kinds(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_
   memset(&ctx->timings, 0, sizeof(ctx->timings));
   PhaseTimer pt(ctx, st);
   pt.mark(0);
-  uint64_t *wbuf = (uint64_t *)ws_get(ctx, 8, (5 * m + 2) * rw * sizeof(uint64_t));
+  uint64_t *wbuf = (uint64_t *)ws_get(ctx, 8, (4 * m + 1) * rw * sizeof(uint64_t));
   uint64_t *A_mid = wbuf, *B_mid = wbuf + m * rw, *C_mid = wbuf + 2 * m * rw, *H = wbuf + 3 * m * rw;
-  uint64_t *Zr = wbuf + (4 * m + 1) * rw;  // (m+1) ring elements
   uint64_t *outs[7] = {nullptr, nullptr, nullptr, A_mid, B_mid, C_mid, H};
   std::vector<uint64_t> hZ((size_t)ctx->L * (m + 1));
   witness_run(ctx, cs, d_assignment, d_d1, d_d2, d_d3, outs, hZ.data(), st);
+  // coefficients_for_Z are slot constant: they go to the inner products as the compact [m+1][L] array of their values
+  // (rs_msm_vec::slot_const) -- round 3 materialised m + 1 ring elements for them (a fifth of the prover's vectors)
+  uint64_t *dZ = (uint64_t *)ws_get(ctx, 9, hZ.size() * sizeof(uint64_t));
   {
-    uint64_t *dZ = (uint64_t *)ws_get(ctx, 9, hZ.size() * sizeof(uint64_t));
-    RS_HIP(hipMemcpyAsync(dZ, hZ.data(), hZ.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    const size_t total = (m + 1) * rw;
-    hipLaunchKernelGGL(broadcast_z_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, st,
-                       dZ, Zr, m + 1, ctx->N, ctx->L);
-    RS_HIP(hipStreamSynchronize(st));  // hZ is a host temporary
+    std::vector<uint64_t> hZt(hZ.size());
+    for (int i = 0; i < ctx->L; i++)
+      for (size_t t = 0; t <= m; t++) hZt[t * ctx->L + i] = hZ[(size_t)i * (m + 1) + t];
+    RS_HIP(hipMemcpyAsync(dZ, hZt.data(), hZt.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    RS_HIP(hipStreamSynchronize(st));  // hZt is a host temporary
   }
   pt.mark(1);
   // the ten inner products of rinocchio.tcc:106-163 in one grouped pass over both CRS vectors
@@ -233,7 +223,7 @@ int rs_rinocchio_prove_kinds(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_
   {
     const uint64_t *crs[2] = {pk->d_s_pows, pk->d_alpha_s_pows};
     rs_msm_vec v[5] = {{A_mid, nullptr, m, 0}, {B_mid, nullptr, m, 1}, {C_mid, nullptr, m, 2}, {H, nullptr, m + 1, 3},
-                       {Zr, zkinds.data(), m + 1, 4}};
+                       {dZ, zkinds.data(), m + 1, 4, 1}};
     msm_run(ctx, crs, 2, m + 1, v, 5, 5, mo, nullptr, used, st, pk->window, nullptr, pk->host_key != 0);
   }
   auto slot = [&](int c, int g) { return mo + ((size_t)c * 5 + g) * ew; };

@@ -288,7 +288,8 @@ class Device:
         return out, int(used.value)
 
     def msm(self, crs_list, vecs, n_groups, want_used=False, crs_len=None, window=0):
-        """vecs: list of (coeff tensor [T][L][N], kinds or None, group).  window != 0: the CRS tensors hold
+        """vecs: list of (coeff tensor [T][L][N], kinds or None, group) or, for a SLOT-CONSTANT vector (one value per
+        (term, limb) in every slot: coefficients_for_Z), (tensor [T][L], kinds, group, True).  window != 0: the CRS tensors hold
         `window` elements and logical element t is read from t % window (crs_len = logical length).
         CRS vectors given as HostWords (host_alloc) are streamed from host memory (rs_msm_hostkey)."""
         n_crs = len(crs_list)
@@ -299,10 +300,14 @@ class Device:
         crs = (C.c_void_p * n_crs)(*[(c.ptr if on_host else c.data_ptr()) for c in crs_list])
         mv = (_lib.MsmVec * len(vecs))()
         keep = []
-        for k, (coeff, kinds, group) in enumerate(vecs):
+        for k, vec in enumerate(vecs):
+            coeff, kinds, group = vec[:3]
+            slot_const = len(vec) > 3 and bool(vec[3])
+            assert coeff.is_contiguous()
             mv[k].d_coeff = coeff.data_ptr()
-            mv[k].T = self._count(coeff, self.ring_words)
+            mv[k].T = self._count(coeff, self.L if slot_const else self.ring_words)
             mv[k].group = group
+            mv[k].slot_const = 1 if slot_const else 0
             if kinds is not None:
                 kk = np.ascontiguousarray(kinds, dtype=np.uint8)
                 keep.append(kk)

@@ -474,12 +474,13 @@ def rinocchio_prove_sharded(backend, plan: ShardPlan, term_group, cs_local, pk_l
     lo, hi = ranges["s_pows"]
     # coefficients_for_Z as ring elements (slot constant); its monic leading coefficient is the RingElem
     # Scalar 1 (evaluation_domain.tcc:55-58), which passes the ciphertext through (seal_ring.tcc:525-527)
-    zrows = backend.broadcast_scalars(w["Z"][:, lo:hi])
+    # slot constant: handed over as the compact [rows][L] array of values (rs_msm_vec::slot_const), never as ring elements
+    zvals = backend.scalar_rows(w["Z"][:, lo:hi])
     zkinds = np.full(hi - lo, RS_KIND_POLY, dtype=np.uint8)
     if hi == m + 1 and hi > lo:
         zkinds[-1] = RS_KIND_ONE
     mo, used = backend.msm([key_slice(pk_local["s_pows"], lo, hi), key_slice(pk_local["alpha_s_pows"], lo, hi)],
-                           [(w["A_mid"], None, 0), (w["B_mid"], None, 1), (w["C_mid"], None, 2), (w["H"], None, 3), (zrows, zkinds, 4)], 5,
+                           [(w["A_mid"], None, 0), (w["B_mid"], None, 1), (w["C_mid"], None, 2), (w["H"], None, 3), (zvals, zkinds, 4, True)], 5,
                            want_used=True)
     enc_shape = tuple(mo.shape[-4:])
     used_f = 0
@@ -568,7 +569,7 @@ class DeviceBackend:
         """crs_list: KeySlice per key vector (same length / window).  Returns ([n_crs][n_groups] encodings, used)."""
         ks = crs_list[0]
         assert all(k.length == ks.length and k.window == ks.window for k in crs_list)
-        out, used = self.dev.msm([k.tensor for k in crs_list], [(v.contiguous(), kinds, g) for v, kinds, g in vecs], n_groups,
+        out, used = self.dev.msm([k.tensor for k in crs_list], [(v[0].contiguous(),) + tuple(v[1:]) for v in vecs], n_groups,
                                  want_used=want_used, crs_len=ks.length, window=ks.window)
         if addends is not None:
             out = torch.stack([torch.stack([self.dev.enc_add(out[c][g], addends[g]) for g in range(n_groups)]) for c in range(len(crs_list))])
@@ -597,7 +598,6 @@ class DeviceBackend:
         """The all-reduce adds `shards` canonical residues as int64: needs shards * max(Q_j) < 2^63."""
         assert shards * max(int(x) for x in self.dev.prm.Q) < 2**63, "too many term shards for these moduli"
 
-    def broadcast_scalars(self, z):
-        """[L][rows] host residues -> ring elements [rows][L][N] with the value in every slot."""
-        t = self.dev.put(np.ascontiguousarray(z.T))  # [rows][L]
-        return t.unsqueeze(-1).expand(t.shape[0], t.shape[1], self.N).contiguous()
+    def scalar_rows(self, z):
+        """[L][rows] host residues -> the compact [rows][L] device array a slot-constant vector is handed over as."""
+        return self.dev.put(np.ascontiguousarray(z.T))

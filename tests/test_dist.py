@@ -65,9 +65,12 @@ class OracleBackend:
             row = []
             for g in range(n_groups):
                 acc = np.zeros(self.ctx.enc_shape(), dtype=np.uint64)
-                for vi, (v, kinds, gg) in enumerate(vecs):
+                for vi, vec in enumerate(vecs):
+                    v, kinds, gg = vec[:3]
                     if gg != g or v.shape[0] == 0:
                         continue
+                    if len(vec) > 3 and vec[3]:  # slot-constant vector [rows][L]: the ring elements with the value in every slot
+                        v = self._t(np.repeat(self._np(v)[:, :, None], self.ctx.N, axis=2))
                     ip, u = self.ctx.inner_product(crs[:v.shape[0]], self._np(v), kinds)
                     if ci == 0:
                         used[vi] = u
@@ -94,9 +97,8 @@ class OracleBackend:
             a[..., j, :] %= np.uint64(Q)
         return self._t(a)
 
-    def broadcast_scalars(self, z):
-        z = np.ascontiguousarray(z.T)  # [rows][L]
-        return self._t(np.repeat(z[:, :, None], self.ctx.N, axis=2))
+    def scalar_rows(self, z):
+        return self._t(np.ascontiguousarray(z.T))  # [rows][L]
 
 
 def _free_port():

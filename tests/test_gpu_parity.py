@@ -844,6 +844,39 @@ def test_witness_map_row_ranges_equal_slices_of_the_whole(name, m, kind, zk):
     assert (host(sub["A_mid"]) == full["A_mid"][3:9]).all() and (host(sub["H"]) == full["H"][1:]).all() and sub["B_mid"] is None
 
 
+@pytest.mark.parametrize("name,T", [("toy", 9), ("toy49", 20), ("toy60", 9), ("C2", 6), ("C5s", 4), ("C4", 3), ("C5", 5)])
+def test_slot_constant_vectors_equal_their_expanded_rows(name, T):
+    """rs_msm_vec::slot_const: a vector whose ring elements hold one value per limb in every slot (coefficients_for_Z,
+    util/evaluation_domain.tcc:54-60) handed over as the compact [T][L] array of values -- the plaintext is value x
+    encode(1, ..., 1), no transform -- gives the inner products of the expanded [T][L][N] vector: against the oracle (toy
+    presets), on both arithmetics, the hybrid context (C5), the 16384-point shapes, and the wide 8192-point plaintext kernel
+    (C2), which expands the rows inside the library.  A zero value is skipped like a zero polynomial (used-term counts), a
+    Scalar-1 term (the leading coefficient of Z) still passes its key element through, and the vector may share a group
+    with an ordinary one."""
+    import torch
+    dev = dev_for(name)
+    prm = dev.prm
+    ctx = H.oracle_ctx(prm)
+    rng = np.random.RandomState(T)
+    vals = np.stack([rng.randint(0, 2**62, size=T, dtype=np.int64).astype(np.uint64) % np.uint64(q) for q in prm.q], axis=1)  # [T][L]
+    vals[1] = 0
+    vals[T - 1] = 1
+    kinds = np.zeros(T, dtype=np.uint8)
+    kinds[T - 1] = O.KIND_ONE
+    rows = np.ascontiguousarray(np.repeat(vals[:, :, None], prm.N, axis=2))
+    other = ctx.random_ring(5, T)
+    keys = [ctx.random_enc(31, T), ctx.random_enc(32, T)]
+    dkeys = [dev.put(k) for k in keys]
+    compact, used_c = dev.msm(dkeys, [(dev.put(vals), kinds, 0, True), (dev.put(other), None, 1), (dev.put(vals), None, 1, True)], 2, want_used=True)
+    expanded, used_e = dev.msm(dkeys, [(dev.put(rows), kinds, 0), (dev.put(other), None, 1), (dev.put(rows), None, 1)], 2, want_used=True)
+    assert used_c == used_e and used_c[0] == T - 1 and used_c[2] == T - 1
+    assert torch.equal(compact, expanded)
+    if prm.N_enc <= 128:
+        for c in range(2):
+            exp, _ = ctx.inner_product(keys[c], rows, kinds)
+            assert (host(compact)[c, 0] == exp).all()
+
+
 def test_witness_map_row_ranges_are_validated():
     """rs_witness_map_rows refuses ranges outside a vector and different ranges for the io and mid vectors of one matrix
     (one pass writes both)."""

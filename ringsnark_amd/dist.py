@@ -134,10 +134,7 @@ def rinocchio_key_ranges(plan: ShardPlan, m, n_aux):
 
 
 # ---------------------------------------------------------------------------------------------------
-# slot-sharded witness map -> term-sharded coefficient vectors
-# ---------------------------------------------------------------------------------------------------
-# ---------------------------------------------------------------------------------------------------
-# The slot -> term re-shard with RELAYS.  xGMI is point to point: a rank has one link to each of the other ranks of the
+# slot-sharded witness map -> term-sharded coefficient vectors: the slot -> term re-shard, with RELAYS.  xGMI is point to point: a rank has one link to each of the other ranks of the
 # node, and the re-shard of a limb group only uses the links INSIDE the group (one of seven when two ranks share a limb:
 # 5.4 GiB over a single 76.8 GB/s link at the headline, as long as the witness map it saves).  Every rank outside the group
 # is one more two-hop path a -> c -> b over links the group does not use.  A message of P words from a to b is cut into a
@@ -282,8 +279,8 @@ class _Exchange:
 #                          Headline, N = 8: 67 ms of witness map per rank + 24 ms of inner products, the 5.4 GiB exchange
 #                          behind the witness map of the following sub-range (a quarter of the single-link time with relays).
 #   "replicate"            each runs the whole map and keeps the rows of its term range (rs_witness_map_rows): no exchange,
-#                          the witness map is not divided (134 + 24 ms; configs[3]: 6.7 + 1.15 s per rank, rehearsed at full
-#                          size in profiles/r04_rank_rehearsal_C4_m262144.json).
+#                          the witness map is not divided (134 + 24 ms; configs[3]: 6.2 + 1.14 s per rank against 1.6 + 1.15 s
+#                          for "slots", both rehearsed at full size: profiles/r04_rank_rehearsal_C4*_m262144.json).
 WITNESS_SPLIT = os.environ.get("RINGSNARK_WITNESS_SPLIT", "slots")
 if WITNESS_SPLIT not in ("replicate", "slots"):
     raise ValueError("RINGSNARK_WITNESS_SPLIT must be 'replicate' or 'slots', not %r" % WITNESS_SPLIT)

@@ -425,9 +425,57 @@ __global__ void __launch_bounds__(1024) ntt_generic_kernel(uint64_t *__restrict_
     poly[i] = to_res(canon(v, mod));
   }
 }
+// The same transform with the first round reading the polynomial straight from global memory and the last round writing the
+// canonical result straight back (no staging passes), radix-16 rounds: three tile exchanges at 16384 points instead of the
+// generic kernel's five + two (round 4; the integer contexts -- microbench.cpp:33-36's 59/60-bit primes).
+template <class T>
+struct GlobalResIn {
+  const uint64_t *p;
+  __device__ __forceinline__ int pbase(int) const { return 0; }
+  __device__ __forceinline__ T load(int base, int, int eoff, int) const { return from_res<T>(p[base + eoff]); }
+  __device__ __forceinline__ void store(int, int, int, int, T) const {}
+};
+template <bool SCALE, class T, class M>
+struct GlobalResOut {
+  uint64_t *p;
+  M mod;
+  T ninv;
+  __device__ __forceinline__ int pbase(int) const { return 0; }
+  __device__ __forceinline__ T load(int, int, int, int) const { return T(0); }
+  __device__ __forceinline__ void store(int base, int, int eoff, int, T v) const {
+    if (SCALE) v = mulmod(reduce(v, mod), ninv, mod);
+    p[base + eoff] = to_res(canon(v, mod));
+  }
+};
+template <bool INV, class T, class M>
+__global__ void __launch_bounds__(1024) ntt_io_kernel(uint64_t *__restrict__ data, int logn, const T *__restrict__ tw, M mod, T ninv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T *s = reinterpret_cast<T *>(smem);
+  uint64_t *poly = data + ((size_t)blockIdx.x << logn);
+  const GlobalResIn<T> gin{poly};
+  const GlobalResOut<INV, T, M> gout{poly, mod, ninv};
+  if (INV)
+    lds_ntt_inv_io<4>(s, gin, gout, logn, logn, tw, 1, mod, 0u);
+  else
+    lds_ntt_fwd_io<4>(s, gin, gout, logn, logn, tw, 1, mod, 0u);
+}
+int g_int_ntt_variant = 1;  // tuning knob "int_ntt_variant": 1 = ntt_io_kernel (lengths >= 2^10), 0 = ntt_generic_kernel
 void launch_ntt_int(rs_ctx *ctx, const NttTableI &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st) {
   (void)ctx;
   if (batch == 0) return;
+  if (g_int_ntt_variant == 1 && t.logn >= 10) {  // at least two rounds, so that the in-place global reads all precede the writes
+    const size_t lds = padded_len((size_t)1 << t.logn) * sizeof(uint64_t);
+    const int thr = std::max(64, std::min(1024, (1 << t.logn) >> 4));
+    if (inverse) {
+      RS_HIP(hipFuncSetAttribute((const void *)ntt_io_kernel<true, uint64_t, ModI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((ntt_io_kernel<true, uint64_t, ModI>), dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, t.d_itw, t.mod, t.ninv);
+    } else {
+      RS_HIP(hipFuncSetAttribute((const void *)ntt_io_kernel<false, uint64_t, ModI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((ntt_io_kernel<false, uint64_t, ModI>), dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, t.d_tw, t.mod, t.ninv);
+    }
+    RS_HIP(hipGetLastError());
+    return;
+  }
   const size_t lds = padded_len((size_t)1 << t.logn) * sizeof(uint64_t);
   const int thr = std::max(64, std::min(1024, (1 << t.logn) >> 3));
   if (inverse) {
@@ -952,6 +1000,8 @@ int rs_set_tuning(const char *key, int value) {
     g_mac_share_keys = value != 0;
   else if (std::string(key) == "ntt_wide_grid")
     g_ntt_wide_grid = std::max(1, value);
+  else if (std::string(key) == "int_ntt_variant")
+    g_int_ntt_variant = value;
   else if (std::string(key) == "witness_cross_maxr") {
     RS_REQUIRE(value >= 1 && value <= 6, "witness_cross_maxr must be in [1, 6]");
     g_witness_cross_maxr = value;

@@ -313,6 +313,8 @@ int rs_set_profiling(rs_ctx *ctx, int enabled);
  * Montgomery product of intmod.hpp on a 60-bit prime (G modular multiplies/s).  About 50 ms.  Synchronises. */
 typedef struct rs_peaks {
   double hbm_copy_gbs, fp64_fma_T, fp64_mulmod_G, int_montmul_G;
+  double hbm_read_gbs;    /* read-only stream of 2 GiB (the shape of the inner products' key traffic) */
+  double hbm_inplace_gbs; /* every word of 2 GiB read and written back in place (read + written bytes; the shape of the workspace passes) */
 } rs_peaks;
 int rs_measure_peaks(rs_ctx *ctx, rs_peaks *out, rs_stream stream);
 /* Per-kernel device time of everything launched on the context since profiling was enabled (or

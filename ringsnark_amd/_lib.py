@@ -46,7 +46,8 @@ class Timings(C.Structure):
 
 
 class Peaks(C.Structure):
-    _fields_ = [("hbm_copy_gbs", C.c_double), ("fp64_fma_T", C.c_double), ("fp64_mulmod_G", C.c_double), ("int_montmul_G", C.c_double)]
+    _fields_ = [("hbm_copy_gbs", C.c_double), ("fp64_fma_T", C.c_double), ("fp64_mulmod_G", C.c_double), ("int_montmul_G", C.c_double),
+                ("hbm_read_gbs", C.c_double), ("hbm_inplace_gbs", C.c_double)]
 
 
 class KernelStat(C.Structure):

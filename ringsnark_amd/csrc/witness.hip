@@ -219,6 +219,9 @@ static uint64_t plain_word(const rs_ctx *ctx, uint64_t v, uint64_t p) {
   return ctx->use_int ? word_of(HostArith<ModI>::plain(v, p)) : word_of(HostArith<Mod>::plain(v, p));
 }
 
+int g_witness_sub_log = 12;     // tuning knob "witness_sub_log": 12 = rooted sub-transforms on blocks of 2^12 (sub_ntt_w12_kernel) where sub_block_log says so; 13: never
+int g_witness_sub12_cross = 4;  // tuning knob "witness_sub12_cross": most cross stages of a transform that takes 2^12 blocks
+int g_witness_cross_pair = 1;  // tuning knob "witness_cross_pair": two groups per thread and 16-byte accesses in the cross passes (0: the round-3 form)
 int g_witness_cross_maxr = 6;  // tuning knob "witness_cross_maxr": most stages of one cross pass (FP64 arithmetic; 4 = the round-3 passes)
 int g_witness_force_bc = 0;  // tuning knob "witness_force_bc": pretend the ring primes have only this 2-adicity (tests)
 int g_witness_bc2 = 1;       // tuning knob "witness_bc2": two-dimensional block convolutions where they apply (0: the pairwise form)
@@ -636,24 +639,24 @@ static void launch_tree_tiles_generic(rs_ctx *ctx, typename ArithOf<M>::T *cols,
   RS_HIP(hipGetLastError());
 }
 
-template <bool INV, int MODE, class M>
+template <bool INV, int MODE, class M, int V>
 static void launch_cross_pass(int R, const dim3 &grid, const CrossArgs &a, const ColPlansT<M> &cp, hipStream_t st) {
   using CPS = ColPlansT<M>;
   if constexpr (std::is_same<M, Mod>::value) {  // radix 32 / 64 passes: six cross stages (M = 2^18) in ONE pass over the workspace instead of two
     if (R == 6) {
-      hipLaunchKernelGGL((cross_kernel<INV, 6, MODE, CPS>), grid, dim3(256), 0, st, a, cp);
+      hipLaunchKernelGGL((cross_kernel<INV, 6, MODE, CPS, 1>), grid, dim3(256), 0, st, a, cp);  // 64 elements per thread already
       return;
     }
     if (R == 5) {
-      hipLaunchKernelGGL((cross_kernel<INV, 5, MODE, CPS>), grid, dim3(256), 0, st, a, cp);
+      hipLaunchKernelGGL((cross_kernel<INV, 5, MODE, CPS, V>), grid, dim3(256), 0, st, a, cp);
       return;
     }
   }
   switch (R) {
-    case 4: hipLaunchKernelGGL((cross_kernel<INV, 4, MODE, CPS>), grid, dim3(256), 0, st, a, cp); break;
-    case 3: hipLaunchKernelGGL((cross_kernel<INV, 3, MODE, CPS>), grid, dim3(256), 0, st, a, cp); break;
-    case 2: hipLaunchKernelGGL((cross_kernel<INV, 2, MODE, CPS>), grid, dim3(256), 0, st, a, cp); break;
-    default: hipLaunchKernelGGL((cross_kernel<INV, 1, MODE, CPS>), grid, dim3(256), 0, st, a, cp); break;
+    case 4: hipLaunchKernelGGL((cross_kernel<INV, 4, MODE, CPS, V>), grid, dim3(256), 0, st, a, cp); break;
+    case 3: hipLaunchKernelGGL((cross_kernel<INV, 3, MODE, CPS, V>), grid, dim3(256), 0, st, a, cp); break;
+    case 2: hipLaunchKernelGGL((cross_kernel<INV, 2, MODE, CPS, V>), grid, dim3(256), 0, st, a, cp); break;
+    default: hipLaunchKernelGGL((cross_kernel<INV, 1, MODE, CPS, V>), grid, dim3(256), 0, st, a, cp); break;
   }
 }
 
@@ -689,18 +692,35 @@ static void launch_cross(rs_ctx *ctx, CrossArgs a, size_t ncols, int logB, const
     // a transform with five or six cross stages (M = 2^17, 2^18) crosses the workspace once instead of twice
     const int R = pick_radix(ncross - done, std::is_same<M, Mod>::value ? std::max(1, std::min(6, g_witness_cross_maxr)) : 4);
     a.s0 = INV ? logB + done : done;
-    const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>((groups >> R) / 256, 1024));
-    const dim3 grid(gx, (unsigned)ncols);
     const bool special = INV ? (done + R >= ncross) : (done == 0);
+    // two adjacent groups per thread, 16-byte accesses (cross_kernel<..., 2>): needs wave-uniform twiddles for 128
+    // consecutive groups (smallest gap >= 2^7) and 16-byte aligned columns
+    const bool paired = g_witness_cross_pair && R <= 5 && logB >= 8 && a.logM >= 2 &&
+                        (((uintptr_t)a.W | (uintptr_t)a.src | (uintptr_t)a.dst) & 15) == 0;
+    const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>((groups >> R) / (paired ? 512 : 256), 1024));
+    const dim3 grid(gx, (unsigned)ncols);
     ProfScope prof(ctx, st, cross_name(INV, R, special ? MODE : 0), (double)ncols * 8.0 * cross_words<INV, MODE>(a, special),
-                   (double)ncols * ntt_fp64((double)groups, R));
-    if (special)
-      launch_cross_pass<INV, MODE, M>(R, grid, a, cp, st);
+                   (double)ncols * ntt_fp64((double)groups, (special && !INV) ? R - 1 : R));  // a source pass: stage 0 meets zero padding, a copy
+    if (special && paired)
+      launch_cross_pass<INV, MODE, M, 2>(R, grid, a, cp, st);
+    else if (special)
+      launch_cross_pass<INV, MODE, M, 1>(R, grid, a, cp, st);
+    else if (paired)
+      launch_cross_pass<INV, 0, M, 2>(R, grid, a, cp, st);
     else
-      launch_cross_pass<INV, 0, M>(R, grid, a, cp, st);
+      launch_cross_pass<INV, 0, M, 1>(R, grid, a, cp, st);
     done += R;
   }
   RS_HIP(hipGetLastError());
+}
+
+// Block of the rooted sub-transforms of a multi-pass transform of length 2^logsub: the LDS tile (2^13), or 2^12 for the
+// FP64 contexts (knob witness_sub_log = 12; sub_ntt_w12_kernel, four workgroups per CU: 14 % faster per coefficient)
+// where the extra cross stage keeps the cross pass at four stages or fewer (knob witness_sub12_cross) -- a five-stage
+// FORWARD pass from a source costs more than the smaller block saves (measured on the headline).
+template <class M>
+static int sub_block_log(int logT, int logsub) {
+  return (std::is_same<M, Mod>::value && g_witness_sub_log == 12 && logT == 13 && logsub - 12 <= g_witness_sub12_cross) ? 12 : logT;
 }
 
 template <int MODE, class M>
@@ -719,11 +739,21 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
 #endif
   const double Bn = (double)((size_t)1 << logB), blocks = (double)(ncols * bpc);
   static const char *const names_w16[4] = {"sub_ntt_wide16_kernel<0>", "sub_ntt_wide16_kernel<1>", "sub_ntt_wide16_kernel<2>", "sub_ntt_wide16_kernel<3>"};
-  ProfScope prof(ctx, st, ct ? (g_witness_sub_ct == 3 ? names_w16[MODE] : g_witness_sub_ct == 2 ? names_wide[MODE] : names_ct[MODE]) : names[MODE], blocks * Bn * (MODE == 3 ? 24.0 : 16.0),
+  static const char *const names_w12[4] = {"sub_ntt_w12_kernel<0>", "sub_ntt_w12_kernel<1>", "sub_ntt_w12_kernel<2>", "sub_ntt_w12_kernel<3>"};
+  const bool w12 = FP && logB == 12 && MODE != 1 && g_witness_sub_log == 12;
+  ProfScope prof(ctx, st, w12 ? names_w12[MODE] : ct ? (g_witness_sub_ct == 3 ? names_w16[MODE] : g_witness_sub_ct == 2 ? names_wide[MODE] : names_ct[MODE]) : names[MODE], blocks * Bn * (MODE == 3 ? 24.0 : 16.0),
                  blocks * ((MODE >= 2 ? 2.0 : 1.0) * ntt_fp64(Bn, logB) + (MODE >= 2 ? 7.0 * Bn : 0.0)));
   static TabPtrs none{};
   const TabPtrs &tp = tabs ? *tabs : none;
   if constexpr (FP) {
+    if (logB == 12 && MODE != 1 && g_witness_sub_log == 12) {
+      const int wl = 4352 * (int)sizeof(double);
+      const unsigned long long nb = (unsigned long long)(ncols * bpc);
+      hipLaunchKernelGGL((sub_ntt_w12_kernel<MODE>), dim3((unsigned)std::min<unsigned long long>(nb, 1024)), dim3(256), wl, st, X,
+                         logsub - logB, tp, (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp, nb);
+      RS_HIP(hipGetLastError());
+      return;
+    }
 #ifdef RS_EXPERIMENTS
     if (logB == 13 && MODE != 1 && g_witness_sub_ct == 3) {
       const int wl = (int)(WideShape<13>::TILE * sizeof(double));
@@ -838,7 +868,8 @@ static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp
                        size_t ncols, size_t col0, size_t S, size_t spl, int limb0, hipStream_t st) {
   using T = typename ArithOf<M>::T;
   constexpr bool FP = std::is_same<M, Mod>::value;
-  const int logM = P->logM, logB = std::min(g_witness_lds_logM, logM);
+  const int logM = P->logM, logT = std::min(g_witness_lds_logM, logM);
+  int logB = sub_block_log<M>(logT, logM + 1);  // block of the rooted sub-transforms
   const size_t Mlen = P->M;
   CrossArgs a{};
   a.W = W;
@@ -858,18 +889,19 @@ static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp
   launch_sub<2, M>(ctx, W, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * Mlen) >> logB, S, spl, cp, st);
   launch_cross<true, CD_TAKE_LOW, M>(ctx, a, ncols, logB, cp, st);
   // product tree: levels <= logTree inside LDS tiles (the wide kernel takes 2^14 tiles: one multi-pass level less)
-  int logTree = logB;
+  int logTree = logT;
   if constexpr (FP) {
-    if (logB == 13 && logM >= 15 && g_witness_tree_ct == 2 && g_witness_tree_log >= 14) logTree = 14;
+    if (logT == 13 && logM >= 15 && g_witness_tree_ct == 2 && g_witness_tree_log >= 14) logTree = 14;
     launch_tree_tiles(ctx, X, ncols, col0, logM, logTree, S, spl, cp, st);
   } else {
-    launch_tree_tiles_generic<M>(ctx, X, ncols, col0, logM, logB, S, spl, cp, st);
+    launch_tree_tiles_generic<M>(ctx, X, ncols, col0, logM, logT, S, spl, cp, st);
   }
   // levels above: F_node = F_left + D_left * F_right with multi-pass transforms of length 2^l
   a.logtot = logM;
   for (int l = logTree + 1; l <= logM; l++) {
     a.l = l;
     a.logsub = l;
+    logB = sub_block_log<M>(logT, l);
     launch_cross<false, CS_FILL_RIGHT, M>(ctx, a, ncols, logB, cp, st);
     for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = static_cast<const T *>(P->limb[i].d_dhat) + (size_t)l * Mlen;
     launch_sub<2, M>(ctx, W, ncols, col0, logM, l, logB, &tp, Mlen >> logB, S, spl, cp, st);
@@ -886,7 +918,7 @@ static void big_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, con
                   const typename ArithOf<M>::T *B, typename ArithOf<M>::T *H, typename ArithOf<M>::T *W1, typename ArithOf<M>::T *W2,
                   size_t ncols, size_t col0, size_t S, size_t spl, const uint64_t *d1, const uint64_t *d2, const uint64_t *d3,
                   const ColMap &cm, int limb0, hipStream_t st) {
-  const int logM = P->logM, logB = std::min(g_witness_lds_logM, logM);
+  const int logM = P->logM, logB = sub_block_log<M>(std::min(g_witness_lds_logM, logM), logM + 1);
   const size_t Mlen = P->M;
   CrossArgs a{};
   a.logM = logM;

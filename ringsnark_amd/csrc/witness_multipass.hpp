@@ -18,10 +18,49 @@ struct TabPtrs {
 #ifndef RS_WORKSPACE_NT
 #define RS_WORKSPACE_NT 1
 #endif
+// two adjacent words moved by one 16-byte access (the paired cross passes below)
+template <class T>
+struct Pair {
+  T x, y;
+};
+template <class T>
+__device__ __forceinline__ Pair<T> ld_pair(const T *p) {
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  const V2 v = *reinterpret_cast<const V2 *>(p);
+  return Pair<T>{v.x, v.y};
+}
+template <class T>
+__device__ __forceinline__ void st_pair(T *p, T x, T y) {
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  V2 v;
+  v.x = x;
+  v.y = y;
+  *reinterpret_cast<V2 *>(p) = v;
+}
 template <class T>
 struct GlobalIOT {
   T *p;
   __device__ __forceinline__ int pbase(int) const { return 0; }
+  __device__ __forceinline__ Pair<T> load2(int k) const {
+    typedef T V2 __attribute__((ext_vector_type(2)));
+#if RS_WORKSPACE_NT
+    const V2 v = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(p + k));
+#else
+    const V2 v = *reinterpret_cast<const V2 *>(p + k);
+#endif
+    return Pair<T>{v.x, v.y};
+  }
+  __device__ __forceinline__ void store2(int k, T x, T y) const {
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    V2 v;
+    v.x = x;
+    v.y = y;
+#if RS_WORKSPACE_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<V2 *>(p + k));
+#else
+    *reinterpret_cast<V2 *>(p + k) = v;
+#endif
+  }
 #if RS_WORKSPACE_NT  // the multi-pass workspaces are streamed once per pass and are far larger than L2 and the Infinity Cache
   __device__ __forceinline__ T load(int base, int, int eoff, int) const { return __builtin_nontemporal_load(p + base + eoff); }
   __device__ __forceinline__ void store(int base, int, int eoff, int, T v) const { __builtin_nontemporal_store(v, p + base + eoff); }
@@ -51,6 +90,9 @@ struct CrossArgs {
 template <int SRC, class Mt>
 struct CrossIn {
   using T = typename ArithOf<Mt>::T;
+  // Every source feeds the FIRST round of a transform whose upper half is zero padding (length-2M transforms of M
+  // inputs; per tree node (F_right, 0)): the round skips those loads and its first stage is a copy (ntt_core.hpp)
+  static constexpr bool zero_upper = true;
   const T *p;  // this column of the source
   const T *invfact;
   Mt mod;
@@ -63,6 +105,27 @@ struct CrossIn {
     if (SRC == CS_PAD_CENTER) return k < M ? center(p[k], mod) : T(0);
     if (SRC == CS_REV_TRUNC) return k < m - 1 ? reduce(p[2 * m - 2 - k], mod) : T(0);  // T_k = P_{2m-2-k}, k < m-1
     return p[k];
+  }
+  // elements k, k + 1 (k even; M, n/2 even: both fall on the same side of every boundary but CS_REV_TRUNC's)
+  __device__ __forceinline__ Pair<T> load2(int k) const {
+    if (SRC == CS_REV_TRUNC) return Pair<T>{load(k, 0, 0, 0), load(k + 1, 0, 0, 0)};  // reversed, odd-aligned: two words
+    Pair<T> r{T(0), T(0)};
+    if (SRC == CS_SCALE_PAD) {
+      if (k < M) {
+        const Pair<T> a = ld_pair(p + k), f = ld_pair(invfact + k);
+        r = Pair<T>{mulmod(a.x, f.x, mod), mulmod(a.y, f.y, mod)};
+      }
+    } else if (SRC == CS_FILL_RIGHT) {
+      if ((k & (n - 1)) < h) r = ld_pair(p + k + h);
+    } else if (SRC == CS_PAD_CENTER) {
+      if (k < M) {
+        const Pair<T> a = ld_pair(p + k);
+        r = Pair<T>{center(a.x, mod), center(a.y, mod)};
+      }
+    } else {
+      r = ld_pair(p + k);
+    }
+    return r;
   }
 };
 template <int DST, class Mt>
@@ -91,11 +154,140 @@ struct CrossOut {
       p[k] = v;
     }
   }
+  __device__ __forceinline__ void store2(int k, T x, T y) const {
+    if (DST == CD_TAKE_LOW) {
+      if (k < M) {
+        const Pair<T> f = ld_pair(invfact + k);
+        st_pair(p + k, (f.x != T(0)) ? reduce(x, mod) : T(0), (f.y != T(0)) ? reduce(y, mod) : T(0));
+      }
+    } else if (DST == CD_COMBINE || DST == CD_COMBINE_CANON) {
+      Pair<T> a{T(0), T(0)};
+      if ((k & (n - 1)) < h) a = ld_pair(p + k);
+      const T f0 = reduce(addm(x, a.x, mod), mod), f1 = reduce(addm(y, a.y, mod), mod);
+      st_pair(p + k, DST == CD_COMBINE_CANON ? canon(f0, mod) : f0, DST == CD_COMBINE_CANON ? canon(f1, mod) : f1);
+    } else if (DST == CD_H_FINISH || DST == CD_H_FINISH_CANON) {  // reversed, odd-aligned: two words
+      store(k, 0, 0, 0, x);
+      store(k + 1, 0, 0, 0, y);
+    } else {
+      st_pair(p + k, x, y);
+    }
+  }
 };
+
+// The rounds of ntt_core.hpp (fwd_round / inv_round) for the cross passes, TWO adjacent groups per thread: the two share
+// every twiddle, and every access to the workspace, the source and the sink is a 16-byte one (a wave moves 1 KiB per
+// instruction instead of 512 B).  Same stages, same reduction points per coefficient: the stored values are identical.
+template <int R, class In, class Out, class T, class M>
+__device__ __forceinline__ void fwd_round2(const In in, const Out out, int logtot, int logsub, int s0, const T *__restrict__ tw,
+                                           const M mod, uint32_t red_mask, const Lanes ln) {
+  constexpr int E = 1 << R;
+  const int lstep = logsub - s0 - R, sstep = 1 << lstep;  // lstep >= 6: the wave's groups share hi_all
+  const int npairs = (1 << logtot) >> (R + 1);
+  for (int gp = ln.tid; gp < npairs; gp += ln.nthr) {
+    const int grp = 2 * gp;
+    const int lo = grp & (sstep - 1);
+    const int hi_all = __builtin_amdgcn_readfirstlane(grp >> lstep);
+    const int hi = hi_all & ((1 << s0) - 1);
+    const int base = (hi_all << (logsub - s0)) + lo;
+    T v[2][E];
+    constexpr bool ZU = zero_upper_of<In>::value;  // elements e >= E/2 are known zeros: no loads, stage 0 is a copy
+#pragma unroll
+    for (int e = 0; e < (ZU ? E / 2 : E); e++) {
+      const Pair<T> x = in.load2(base + e * sstep);
+      v[0][e] = x.x;
+      v[1][e] = x.y;
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      if ((red_mask >> (s0 + k)) & 1u) {
+#pragma unroll
+        for (int e = 0; e < ((ZU && k == 0) ? E / 2 : E); e++) {
+          v[0][e] = reduce(v[0][e], mod);
+          v[1][e] = reduce(v[1][e], mod);
+        }
+      }
+      if (ZU && k == 0) {
+#pragma unroll
+        for (int e = 0; e < E / 2; e++) {
+          v[0][e + E / 2] = v[0][e];
+          v[1][e + E / 2] = v[1][e];
+        }
+        continue;
+      }
+      const int half = E >> (k + 1);
+      const int twbase = (1 << (s0 + k)) + (hi << k);
+#pragma unroll
+      for (int blk = 0; blk < (1 << k); blk++) {
+        const T w = tw[twbase + blk];
+#pragma unroll
+        for (int e0 = 0; e0 < half; e0++) {
+          const int ia = blk * 2 * half + e0, ib = ia + half;
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            const T t = mulmod(v[c][ib], w, mod);
+            const T a = v[c][ia];
+            v[c][ia] = addm(a, t, mod);
+            v[c][ib] = subm(a, t, mod);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) out.store2(base + e * sstep, v[0][e], v[1][e]);
+  }
+}
+template <int R, class In, class Out, class T, class M>
+__device__ __forceinline__ void inv_round2(const In in, const Out out, int logtot, int logsub, int u0, const T *__restrict__ itw,
+                                           const M mod, uint32_t red_mask, const Lanes ln) {
+  constexpr int E = 1 << R;
+  const int g0 = 1 << u0;  // u0 >= 6
+  const int npairs = (1 << logtot) >> (R + 1);
+  const int gpb_log = logsub - u0 - R;
+  for (int gp = ln.tid; gp < npairs; gp += ln.nthr) {
+    const int grp = 2 * gp;
+    const int lo = grp & (g0 - 1);
+    const int hi_all = __builtin_amdgcn_readfirstlane(grp >> u0);
+    const int hi = hi_all & ((1 << gpb_log) - 1);
+    const int base = (hi_all << (u0 + R)) + lo;
+    T v[2][E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const Pair<T> x = in.load2(base + e * g0);
+      v[0][e] = x.x;
+      v[1][e] = x.y;
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      if ((red_mask >> (u0 + k)) & 1u) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          v[0][e] = reduce(v[0][e], mod);
+          v[1][e] = reduce(v[1][e], mod);
+        }
+      }
+      const int Mg = (1 << logsub) >> (u0 + k + 1);
+      const int twbase = Mg + (hi << (R - 1 - k));
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        if (e & (1 << k)) continue;
+        const T w = itw[twbase + (e >> (k + 1))];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          const T a = v[c][e], b = v[c][e + (1 << k)];
+          v[c][e] = addm(a, b, mod);
+          v[c][e + (1 << k)] = mulmod(subm(a, b, mod), w, mod);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) out.store2(base + e * g0, v[0][e], v[1][e]);
+  }
+}
 
 // cross stages [s0, s0+R) of batched length-2^logsub transforms inside columns of length 2^logtot.
 // grid (x, columns).  MODE: CrossSrc for forward passes, CrossDst for inverse passes.
-template <bool INV, int R, int MODE, class CPS>
+// V = 2: the paired rounds (16-byte accesses; launch_cross checks the alignment of the buffers).
+template <bool INV, int R, int MODE, class CPS, int V = 1>
 __global__ void __launch_bounds__(256) cross_kernel(CrossArgs a, CPS plans) {
   using T = typename CPS::T;
   using Mt = typename CPS::M;
@@ -106,18 +298,30 @@ __global__ void __launch_bounds__(256) cross_kernel(CrossArgs a, CPS plans) {
   const int M = 1 << a.logM, n = 1 << a.l;
   if (INV) {
     if (MODE == CD_PLAIN) {
-      inv_round<R>(io, io, a.logtot, a.logsub, a.s0, P.itw, 1, P.mod, P.imask[a.logsub], ln);
+      if (V == 2)
+        inv_round2<R>(io, io, a.logtot, a.logsub, a.s0, P.itw, P.mod, P.imask[a.logsub], ln);
+      else
+        inv_round<R>(io, io, a.logtot, a.logsub, a.s0, P.itw, 1, P.mod, P.imask[a.logsub], ln);
     } else {
       const CrossOut<MODE, Mt> out{static_cast<T *>(a.dst) + (col << a.logM), P.invfact, P.mod, M, a.m, n, n >> 1};
-      inv_round<R>(io, out, a.logtot, a.logsub, a.s0, P.itw, 1, P.mod, P.imask[a.logsub], ln);
+      if (V == 2)
+        inv_round2<R>(io, out, a.logtot, a.logsub, a.s0, P.itw, P.mod, P.imask[a.logsub], ln);
+      else
+        inv_round<R>(io, out, a.logtot, a.logsub, a.s0, P.itw, 1, P.mod, P.imask[a.logsub], ln);
     }
   } else {
     if (MODE == CS_PLAIN) {
-      fwd_round<R>(io, io, a.logtot, a.logsub, a.s0, P.tw, 1, P.mod, P.fmask[a.logsub], ln);
+      if (V == 2)
+        fwd_round2<R>(io, io, a.logtot, a.logsub, a.s0, P.tw, P.mod, P.fmask[a.logsub], ln);
+      else
+        fwd_round<R>(io, io, a.logtot, a.logsub, a.s0, P.tw, 1, P.mod, P.fmask[a.logsub], ln);
     } else {
       const size_t stride = MODE == CS_REV_TRUNC ? (size_t)2 << a.logM : (size_t)1 << a.logM;
       const CrossIn<MODE, Mt> in{static_cast<const T *>(a.src) + col * stride, P.invfact, P.mod, M, a.m, n, n >> 1};
-      fwd_round<R>(in, io, a.logtot, a.logsub, a.s0, P.tw, 1, P.mod, P.fmask[a.logsub], ln);
+      if (V == 2)
+        fwd_round2<R>(in, io, a.logtot, a.logsub, a.s0, P.tw, P.mod, P.fmask[a.logsub], ln);
+      else
+        fwd_round<R>(in, io, a.logtot, a.logsub, a.s0, P.tw, 1, P.mod, P.fmask[a.logsub], ln);
     }
   }
 }
@@ -462,6 +666,136 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
 #pragma unroll
       for (int e = 0; e < 16; e++) dst[(S::S / 2) * e] = make_double2(v[0][e], v[1][e]);
     }
+  }
+}
+
+// sub_ntt_wide_kernel on blocks of 2^12 (knob witness_sub_log = 12): 256 threads x 16 coefficients, <= 128 registers,
+// a 34 KiB tile -- FOUR workgroups (16 waves, four per SIMD) per CU instead of two of 2^13 at two waves per SIMD, with the
+// same four tile exchanges per fused forward-multiply-inverse (rounds of 4 | 4 | 4 stages each way; the last forward round
+// leaves 16 consecutive spectrum points per thread, the operand set of the inverse's first round).  The transform one
+// level up gets one more cross stage (still one pass over the workspace).  Stage arithmetic, reduction points and table
+// products per coefficient are those of the 2^13 kernel: the stored values are identical.
+template <int MODE>
+__global__ void __launch_bounds__(256, 4)
+sub_ntt_w12_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab_period, unsigned blocks_per_col, size_t col0,
+                   unsigned S_, unsigned slots_per_limb, ColPlans plans, unsigned long long nblocks) {
+  constexpr int N = 4096, SP = 272;  // px(i) = i + (i >> 4); elements 256 apart are 272 slots apart
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *s = reinterpret_cast<double *>(smem);
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int pt = t + (t >> 4);
+  for (unsigned long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const size_t col = blk / blocks_per_col;
+    const int limb = (int)(((col0 + col) % S_) / slots_per_limb);
+    const ColPlan &P = plans.l[limb];
+    const Mod mod = P.mod;
+    const int root = (1 << log_n1) + (int)(blk & ((1u << log_n1) - 1));
+    const int logn = 12 + log_n1;
+    const uint32_t fmask = P.fmask[logn] >> log_n1, imask = P.imask[logn];
+    const double *__restrict__ tw = P.tw;
+    const double *__restrict__ itw = P.itw;
+    double *xb = X + blk * (size_t)N;
+    double v[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = __builtin_nontemporal_load(xb + t + 256 * e);
+    // ---- forward round 1: stages 0..3 on elements t + 256 e (uniform twiddles)
+    reg_fwd_stages<4, true>(v, mod, fmask, [&](int k, int b) { return tw[(root << k) + b]; });
+    __syncthreads();  // the previous block's last-round reads of the tile are done
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[pt + SP * e] = v[e];
+    __syncthreads();
+    // ---- forward round 2: stages 4..7 on hi*256 + lo + 16 e
+    {
+      const int lo = t & 15, hi = t >> 4;
+      const int pb = hi * SP + lo;
+      double w[15];
+      SubTw::run<1>(tw + (root << 4) + hi, w);
+      SubTw::run<2>(tw + (root << 5) + (hi << 1), w + 1);
+      SubTw::run<4>(tw + (root << 6) + (hi << 2), w + 3);
+      SubTw::run<8>(tw + (root << 7) + (hi << 3), w + 7);
+#pragma unroll
+      for (int e = 0; e < 16; e++) v[e] = s[pb + 17 * e];
+      reg_fwd_stages<4, true>(v, mod, fmask >> 4, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[pb + 17 * e] = v[e];
+    }
+    __syncthreads();
+    // ---- forward round 3 (stages 8..11) on the 16 consecutive points 16 t .., table product, inverse round 1 (stages 0..3)
+    const int pb3 = 17 * t;
+    {
+      double w[15];
+      SubTw::run<1>(tw + (root << 8) + t, w);
+      SubTw::run<2>(tw + (root << 9) + (t << 1), w + 1);
+      SubTw::run<4>(tw + (root << 10) + (t << 2), w + 3);
+      SubTw::run<8>(tw + (root << 11) + (t << 3), w + 7);
+#pragma unroll
+      for (int e = 0; e < 16; e++) v[e] = s[pb3 + e];
+      reg_fwd_stages<4, true>(v, mod, fmask >> 8, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
+      const int r0 = wave * 1024;                      // the wave's 64 groups: 1024 consecutive points
+      const int p0 = r0 + (r0 >> 4) + 2 * lane + (lane >> 3);  // px(r0 + 2 lane)
+      if (MODE == 0) {  // forward only: the wave streams its own range out
+#pragma unroll
+        for (int e = 0; e < 16; e++) s[pb3 + e] = v[e];
+        wave_sync();
+        double2 *d2 = reinterpret_cast<double2 *>(xb + r0) + lane;
+#pragma unroll
+        for (int i = 0; i < 8; i++) d2[64 * i] = make_double2(s[p0 + 136 * i], s[p0 + 136 * i + 1]);
+        continue;
+      }
+      {  // table entries of the wave's range: coalesced 16-byte loads, handed to their owners through the wave's part of the tile
+        const double *tab = (MODE == 2) ? static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * N
+                                        : static_cast<const double *>(tabs.t[0]) + blk * (size_t)N;
+        const double2 *t2 = reinterpret_cast<const double2 *>(tab + r0) + lane;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const double2 v2 = t2[64 * i];
+          s[p0 + 136 * i] = v2.x;
+          s[p0 + 136 * i + 1] = v2.y;
+        }
+        wave_sync();
+        if (MODE == 2) {
+          if ((P.pwmask >> logn) & 1u) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) v[e] = reduce(v[e], mod);
+          }
+#pragma unroll
+          for (int e = 0; e < 16; e++) v[e] = mulmod(v[e], s[pb3 + e], mod);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; e++) v[e] = mulmod(reduce(v[e], mod), reduce(s[pb3 + e], mod), mod);
+        }
+      }
+      SubTw::run<8>(itw + ((size_t)root << 11) + (t << 3), w);
+      SubTw::run<4>(itw + ((size_t)root << 10) + (t << 2), w + 8);
+      SubTw::run<2>(itw + ((size_t)root << 9) + (t << 1), w + 12);
+      SubTw::run<1>(itw + ((size_t)root << 8) + t, w + 14);
+      reg_inv_stages<4, true>(v, mod, imask, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[pb3 + e] = v[e];
+    }
+    __syncthreads();
+    // ---- inverse round 2: stages 4..7; block of stage 4+k: (hi << (3-k)) + (e >> (k+1))
+    {
+      const int lo = t & 15, hi = t >> 4;
+      const int pb = hi * SP + lo;
+      double w[15];
+      SubTw::run<8>(itw + ((size_t)root << 7) + (hi << 3), w);
+      SubTw::run<4>(itw + ((size_t)root << 6) + (hi << 2), w + 8);
+      SubTw::run<2>(itw + ((size_t)root << 5) + (hi << 1), w + 12);
+      SubTw::run<1>(itw + ((size_t)root << 4) + hi, w + 14);
+#pragma unroll
+      for (int e = 0; e < 16; e++) v[e] = s[pb + 17 * e];
+      reg_inv_stages<4, true>(v, mod, imask >> 4, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[pb + 17 * e] = v[e];
+    }
+    __syncthreads();
+    // ---- inverse round 3: stages 8..11 on elements t + 256 e; block of stage 8+k: e >> (k+1) of 8 >> k
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = s[pt + SP * e];
+    reg_inv_stages<4, true>(v, mod, imask >> 8, [&](int k, int i) { return itw[((8 >> k) * root) + i]; });
+#pragma unroll
+    for (int e = 0; e < 16; e++) __builtin_nontemporal_store(v[e], xb + t + 256 * e);
   }
 }
 

@@ -461,7 +461,7 @@ class Device:
         return {k: getattr(t, k) for k, _ in _lib.Timings._fields_}
 
     def measure_peaks(self):
-        """{hbm_copy_gbs, fp64_fma_T, fp64_mulmod_G, int_montmul_G} measured on this device now (rs_measure_peaks)"""
+        """{hbm_copy_gbs, hbm_read_gbs, hbm_inplace_gbs, fp64_fma_T, fp64_mulmod_G, int_montmul_G} measured on this device now (rs_measure_peaks)"""
         p = _lib.Peaks()
         _lib.check(self.lib.rs_measure_peaks(self.h, C.byref(p), self.stream()))
         return {k: getattr(p, k) for k, _ in _lib.Peaks._fields_}

@@ -911,6 +911,7 @@ def test_measured_peaks_are_plausible():
     modular multiply at a sixth of the FMA rate give or take, the Montgomery product several times slower than that."""
     p = dev_for("toy").measure_peaks()
     assert 2000 < p["hbm_copy_gbs"] < 8000, p
+    assert 2000 < p["hbm_read_gbs"] < 8000 and 2000 < p["hbm_inplace_gbs"] < 8000, p
     assert 15 < p["fp64_fma_T"] < 39.4, p
     assert 0.10 < p["fp64_mulmod_G"] / 1e3 / p["fp64_fma_T"] < 0.25, p
     assert 2 < p["fp64_mulmod_G"] / p["int_montmul_G"] < 12, p

@@ -19,6 +19,7 @@ from tests import proof_check
 
 pytestmark = pytest.mark.gpu
 
+SUB_LOG_DEFAULT = 12  # the library default of the knob witness_sub_log
 KEYS = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
 
 
@@ -125,6 +126,32 @@ def test_wide_cross_passes_equal_the_radix_16_ones(m):
         del dev, asg, w
     for k in KEYS:
         assert (runs[4][k] == runs[6][k]).all(), k
+
+
+@pytest.mark.parametrize("m,cross", [(20000, 4), (70000, 4), (70000, 8), (262144, 4), (262144, 8)])
+def test_sub_transform_blocks_of_2_12_equal_2_13(m, cross):
+    """witness_sub_log = 12 (the default): the rooted sub-transforms on blocks of 2^12 (sub_ntt_w12_kernel, four workgroups per
+    CU, one more cross stage per transform) against blocks of 2^13 -- the same stages, reduction points and table products
+    per coefficient, so every vector is identical.  witness_sub12_cross = 4 (default): only the transforms whose cross pass
+    stays within four stages take the small blocks; 8: every transform.  m = 20000: M = 2^15, the smallest multi-pass size."""
+    from ringsnark_amd.device import to_host
+    prm = P.preset("toy44")
+    runs = {}
+    for logb in (13, 12):
+        _set_tuning(b"witness_sub_log", logb)
+        _set_tuning(b"witness_sub12_cross", cross)
+        try:
+            dev, cs, asg, ds, w, names = _run(prm, m, True, 0)
+        finally:
+            _set_tuning(b"witness_sub_log", SUB_LOG_DEFAULT)
+            _set_tuning(b"witness_sub12_cross", 4)
+        assert any(n.startswith("sub_ntt_w12_kernel") for n in names) == (logb == 12), names
+        if logb == 12:
+            assert any(n.startswith("sub_ntt_wide_kernel") for n in names) == (cross == 4 and m > 32768), names
+        runs[logb] = {k: to_host(w[k]) for k in KEYS}
+        del dev, asg, w
+    for k in KEYS:
+        assert (runs[13][k] == runs[12][k]).all(), k
 
 
 def test_integer_arithmetic_at_2_17():

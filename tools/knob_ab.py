@@ -1,6 +1,6 @@
 """A/B of one rs_set_tuning knob on one GPU: the headline ringGroth16 proof (C3, 2^16 constraints, window 2^13) and the
 configs[3]-shape Rinocchio proof (C4, 2^12 constraints, window 2^9), per-kernel times of the inner products.
-usage: tools/knob_ab.py <knob> <value,value,...> [groth16|rinocchio|both]"""
+usage: tools/knob_ab.py <knob> <value,value,...> [groth16|rinocchio|both]      KNOB_AB_KERNELS=prefix,prefix: the kernels listed"""
 import os
 import sys
 import time
@@ -13,7 +13,10 @@ from ringsnark_amd.device import Device
 
 knob, values = sys.argv[1].encode(), [int(v) for v in sys.argv[2].split(",")]
 which = sys.argv[3] if len(sys.argv) > 3 else "both"
+PREFIXES = tuple(os.environ.get("KNOB_AB_KERNELS", "mac_,plain_").split(","))
 lib = _lib.load()
+for kv in filter(None, os.environ.get("KNOB_AB_SET", "").split(",")):  # other knobs held fixed: KNOB_AB_SET=key=value,key=value
+    _lib.check(lib.rs_set_tuning(kv.split("=")[0].encode(), int(kv.split("=")[1])))
 
 
 def run(tag, dev, prove, m):
@@ -32,7 +35,7 @@ def run(tag, dev, prove, m):
         ks = dev.profile_read()
         dev.set_profiling(False)
         print("%s %s=%d: %.1f ms/proof (%.0f constraints/s)  " % (tag, knob.decode(), v, dt * 1e3, m / dt) +
-              "  ".join("%s %.1f" % (k["name"][:28], k["total_ms"] / 3) for k in ks if k["name"].startswith(("mac_", "plain_"))), flush=True)
+              "  ".join("%s %.1f" % (k["name"][:28], k["total_ms"] / 3) for k in ks if k["name"].startswith(PREFIXES)), flush=True)
 
 
 if which in ("groth16", "both"):

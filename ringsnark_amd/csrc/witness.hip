@@ -828,11 +828,13 @@ static void bc2_conv(rs_ctx *ctx, Bc2Args a, int logY, size_t ncols, const TabPt
     TabPtrs tp{};
     if (MODE == 2) tp = *tab;
     if (MODE == 3) tp.t[0] = other;
-    const int wl = (int)(WideShape<13>::TILE * sizeof(double));
-    RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_wide_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
-    hipLaunchKernelGGL((sub_ntt_wide_kernel<MODE>), dim3((unsigned)std::min<unsigned long long>(nb, 512)), dim3(256), wl, st, a.Ws, 1, tp,
-                       (unsigned)((size_t)a.units * Y * 2), (unsigned)((size_t)a.units * Y * 2), a.col0, a.S, a.slots_per_limb, cp, nb,
-                       (const double *)a.Wy);
+    {
+      const int wl = (int)(WideShape<13>::TILE * sizeof(double));
+      RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_wide_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+      hipLaunchKernelGGL((sub_ntt_wide_kernel<MODE>), dim3((unsigned)std::min<unsigned long long>(nb, 512)), dim3(256), wl, st, a.Ws, 1, tp,
+                         (unsigned)((size_t)a.units * Y * 2), (unsigned)((size_t)a.units * Y * 2), a.col0, a.S, a.slots_per_limb, cp, nb,
+                         (const double *)a.Wy);
+    }
   }
   if (MODE != 0 && logY <= 5) {
     ProfScope prof(ctx, st, "bc2_yinv_kernel", (double)cu * (double)Y * BC2_B * 24.0, (double)cu * 2.0 * BC2_B * ntt_fp64((double)Y, logY));

@@ -669,131 +669,143 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
   }
 }
 
-// sub_ntt_wide_kernel on blocks of 2^12 (knob witness_sub_log = 12): 256 threads x 16 coefficients, <= 128 registers,
-// a 34 KiB tile -- FOUR workgroups (16 waves, four per SIMD) per CU instead of two of 2^13 at two waves per SIMD, with the
-// same four tile exchanges per fused forward-multiply-inverse (rounds of 4 | 4 | 4 stages each way; the last forward round
-// leaves 16 consecutive spectrum points per thread, the operand set of the inverse's first round).  The transform one
-// level up gets one more cross stage (still one pass over the workspace).  Stage arithmetic, reduction points and table
-// products per coefficient are those of the 2^13 kernel: the stored values are identical.
+// ---- rooted sub-transforms on blocks of 2^12: 256 threads x 16 coefficients -------------------------------------------
+// One block of 2^12 in the wide form with 16 coefficients per thread: rounds of 4 | 4 | 4 stages each way; the last
+// forward round leaves 16 consecutive spectrum points per thread, the operand set of the inverse's first round, so the
+// fused forward-multiply-inverse exchanges the 34 KiB tile four times, like the 2^13 kernel's 4 | 5 | 4.  In: v[e] =
+// element t + 256 e.  Out (MODE >= 2): v[e] = element t + 256 e after the 12 inverse stages; MODE 0: the spectrum is
+// written to fwd_out (the wave that finished a range streams it out) and v is dead.  `root`: tree node of the block in
+// the long transform; fmask / imask: reduction bits of its 12 stages; tab: the 4096 table entries of this block.
+template <int MODE>
+__device__ __forceinline__ void w12_block(double (&v)[16], double *s, const double *__restrict__ tw, const double *__restrict__ itw,
+                                          const Mod mod, int root, uint32_t fmask, uint32_t imask, bool pw_reduce,
+                                          const double *__restrict__ tab, double *__restrict__ fwd_out) {
+  constexpr int SP = 272;  // px(i) = i + (i >> 4); elements 256 apart are 272 slots apart
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int pt = t + (t >> 4);
+  // ---- forward round 1: stages 0..3 on elements t + 256 e (uniform twiddles)
+  reg_fwd_stages<4, true>(v, mod, fmask, [&](int k, int b) { return tw[(root << k) + b]; });
+  __syncthreads();  // the previous block's last-round reads of the tile are done
+#pragma unroll
+  for (int e = 0; e < 16; e++) s[pt + SP * e] = v[e];
+  __syncthreads();
+  // ---- forward round 2: stages 4..7 on hi*256 + lo + 16 e
+  {
+    const int lo = t & 15, hi = t >> 4;
+    const int pb = hi * SP + lo;
+    double w[15];
+    SubTw::run<1>(tw + (root << 4) + hi, w);
+    SubTw::run<2>(tw + (root << 5) + (hi << 1), w + 1);
+    SubTw::run<4>(tw + (root << 6) + (hi << 2), w + 3);
+    SubTw::run<8>(tw + (root << 7) + (hi << 3), w + 7);
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = s[pb + 17 * e];
+    reg_fwd_stages<4, true>(v, mod, fmask >> 4, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[pb + 17 * e] = v[e];
+  }
+  __syncthreads();
+  // ---- forward round 3 (stages 8..11) on the 16 consecutive points 16 t .., table product, inverse round 1 (stages 0..3)
+  const int pb3 = 17 * t;
+  {
+    double w[15];
+    SubTw::run<1>(tw + (root << 8) + t, w);
+    SubTw::run<2>(tw + (root << 9) + (t << 1), w + 1);
+    SubTw::run<4>(tw + (root << 10) + (t << 2), w + 3);
+    SubTw::run<8>(tw + (root << 11) + (t << 3), w + 7);
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = s[pb3 + e];
+    reg_fwd_stages<4, true>(v, mod, fmask >> 8, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
+    const int r0 = wave * 1024;                              // the wave's 64 groups: 1024 consecutive points
+    const int p0 = r0 + (r0 >> 4) + 2 * lane + (lane >> 3);  // px(r0 + 2 lane)
+    if (MODE == 0) {  // forward only: the wave streams its own range out
+#pragma unroll
+      for (int e = 0; e < 16; e++) s[pb3 + e] = v[e];
+      wave_sync();
+      double2 *d2 = reinterpret_cast<double2 *>(fwd_out + r0) + lane;
+#pragma unroll
+      for (int i = 0; i < 8; i++) d2[64 * i] = make_double2(s[p0 + 136 * i], s[p0 + 136 * i + 1]);
+      return;
+    }
+    {  // table entries of the wave's range: coalesced 16-byte loads, handed to their owners through the wave's part of the tile
+      const double2 *t2 = reinterpret_cast<const double2 *>(tab + r0) + lane;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const double2 v2 = t2[64 * i];
+        s[p0 + 136 * i] = v2.x;
+        s[p0 + 136 * i + 1] = v2.y;
+      }
+      wave_sync();
+      if (MODE == 2) {
+        if (pw_reduce) {  // primes above ~2^46 only (a guarded pass, not a select)
+#pragma unroll
+          for (int e = 0; e < 16; e++) v[e] = reduce(v[e], mod);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e++) v[e] = mulmod(v[e], s[pb3 + e], mod);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) v[e] = mulmod(reduce(v[e], mod), reduce(s[pb3 + e], mod), mod);
+      }
+    }
+    SubTw::run<8>(itw + ((size_t)root << 11) + (t << 3), w);
+    SubTw::run<4>(itw + ((size_t)root << 10) + (t << 2), w + 8);
+    SubTw::run<2>(itw + ((size_t)root << 9) + (t << 1), w + 12);
+    SubTw::run<1>(itw + ((size_t)root << 8) + t, w + 14);
+    reg_inv_stages<4, true>(v, mod, imask, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[pb3 + e] = v[e];
+  }
+  __syncthreads();
+  // ---- inverse round 2: stages 4..7; block of stage 4+k: (hi << (3-k)) + (e >> (k+1))
+  {
+    const int lo = t & 15, hi = t >> 4;
+    const int pb = hi * SP + lo;
+    double w[15];
+    SubTw::run<8>(itw + ((size_t)root << 7) + (hi << 3), w);
+    SubTw::run<4>(itw + ((size_t)root << 6) + (hi << 2), w + 8);
+    SubTw::run<2>(itw + ((size_t)root << 5) + (hi << 1), w + 12);
+    SubTw::run<1>(itw + ((size_t)root << 4) + hi, w + 14);
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = s[pb + 17 * e];
+    reg_inv_stages<4, true>(v, mod, imask >> 4, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
+#pragma unroll
+    for (int e = 0; e < 16; e++) s[pb + 17 * e] = v[e];
+  }
+  __syncthreads();
+  // ---- inverse round 3: stages 8..11 on elements t + 256 e; block of stage 8+k: e >> (k+1) of 8 >> k
+#pragma unroll
+  for (int e = 0; e < 16; e++) v[e] = s[pt + SP * e];
+  reg_inv_stages<4, true>(v, mod, imask >> 8, [&](int k, int i) { return itw[((8 >> k) * root) + i]; });
+}
+
+// sub_ntt_wide_kernel on blocks of 2^12 (knob witness_sub_log = 12): 116-128 registers, a 34 KiB tile -- FOUR workgroups
+// (16 waves, four per SIMD) per CU instead of two of 2^13 at two waves per SIMD.  The transform one level up gets one more
+// cross stage (still one pass over the workspace).  Stage arithmetic, reduction points and table products per coefficient
+// are those of the 2^13 kernel: the stored values are identical.
 template <int MODE>
 __global__ void __launch_bounds__(256, 4)
 sub_ntt_w12_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab_period, unsigned blocks_per_col, size_t col0,
                    unsigned S_, unsigned slots_per_limb, ColPlans plans, unsigned long long nblocks) {
-  constexpr int N = 4096, SP = 272;  // px(i) = i + (i >> 4); elements 256 apart are 272 slots apart
+  constexpr int N = 4096;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int pt = t + (t >> 4);
+  const int t = threadIdx.x;
   for (unsigned long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const size_t col = blk / blocks_per_col;
     const int limb = (int)(((col0 + col) % S_) / slots_per_limb);
     const ColPlan &P = plans.l[limb];
-    const Mod mod = P.mod;
     const int root = (1 << log_n1) + (int)(blk & ((1u << log_n1) - 1));
     const int logn = 12 + log_n1;
-    const uint32_t fmask = P.fmask[logn] >> log_n1, imask = P.imask[logn];
-    const double *__restrict__ tw = P.tw;
-    const double *__restrict__ itw = P.itw;
     double *xb = X + blk * (size_t)N;
     double v[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) v[e] = __builtin_nontemporal_load(xb + t + 256 * e);
-    // ---- forward round 1: stages 0..3 on elements t + 256 e (uniform twiddles)
-    reg_fwd_stages<4, true>(v, mod, fmask, [&](int k, int b) { return tw[(root << k) + b]; });
-    __syncthreads();  // the previous block's last-round reads of the tile are done
-#pragma unroll
-    for (int e = 0; e < 16; e++) s[pt + SP * e] = v[e];
-    __syncthreads();
-    // ---- forward round 2: stages 4..7 on hi*256 + lo + 16 e
-    {
-      const int lo = t & 15, hi = t >> 4;
-      const int pb = hi * SP + lo;
-      double w[15];
-      SubTw::run<1>(tw + (root << 4) + hi, w);
-      SubTw::run<2>(tw + (root << 5) + (hi << 1), w + 1);
-      SubTw::run<4>(tw + (root << 6) + (hi << 2), w + 3);
-      SubTw::run<8>(tw + (root << 7) + (hi << 3), w + 7);
-#pragma unroll
-      for (int e = 0; e < 16; e++) v[e] = s[pb + 17 * e];
-      reg_fwd_stages<4, true>(v, mod, fmask >> 4, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
-#pragma unroll
-      for (int e = 0; e < 16; e++) s[pb + 17 * e] = v[e];
-    }
-    __syncthreads();
-    // ---- forward round 3 (stages 8..11) on the 16 consecutive points 16 t .., table product, inverse round 1 (stages 0..3)
-    const int pb3 = 17 * t;
-    {
-      double w[15];
-      SubTw::run<1>(tw + (root << 8) + t, w);
-      SubTw::run<2>(tw + (root << 9) + (t << 1), w + 1);
-      SubTw::run<4>(tw + (root << 10) + (t << 2), w + 3);
-      SubTw::run<8>(tw + (root << 11) + (t << 3), w + 7);
-#pragma unroll
-      for (int e = 0; e < 16; e++) v[e] = s[pb3 + e];
-      reg_fwd_stages<4, true>(v, mod, fmask >> 8, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
-      const int r0 = wave * 1024;                      // the wave's 64 groups: 1024 consecutive points
-      const int p0 = r0 + (r0 >> 4) + 2 * lane + (lane >> 3);  // px(r0 + 2 lane)
-      if (MODE == 0) {  // forward only: the wave streams its own range out
-#pragma unroll
-        for (int e = 0; e < 16; e++) s[pb3 + e] = v[e];
-        wave_sync();
-        double2 *d2 = reinterpret_cast<double2 *>(xb + r0) + lane;
-#pragma unroll
-        for (int i = 0; i < 8; i++) d2[64 * i] = make_double2(s[p0 + 136 * i], s[p0 + 136 * i + 1]);
-        continue;
-      }
-      {  // table entries of the wave's range: coalesced 16-byte loads, handed to their owners through the wave's part of the tile
-        const double *tab = (MODE == 2) ? static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * N
-                                        : static_cast<const double *>(tabs.t[0]) + blk * (size_t)N;
-        const double2 *t2 = reinterpret_cast<const double2 *>(tab + r0) + lane;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const double2 v2 = t2[64 * i];
-          s[p0 + 136 * i] = v2.x;
-          s[p0 + 136 * i + 1] = v2.y;
-        }
-        wave_sync();
-        if (MODE == 2) {
-          if ((P.pwmask >> logn) & 1u) {
-#pragma unroll
-            for (int e = 0; e < 16; e++) v[e] = reduce(v[e], mod);
-          }
-#pragma unroll
-          for (int e = 0; e < 16; e++) v[e] = mulmod(v[e], s[pb3 + e], mod);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 16; e++) v[e] = mulmod(reduce(v[e], mod), reduce(s[pb3 + e], mod), mod);
-        }
-      }
-      SubTw::run<8>(itw + ((size_t)root << 11) + (t << 3), w);
-      SubTw::run<4>(itw + ((size_t)root << 10) + (t << 2), w + 8);
-      SubTw::run<2>(itw + ((size_t)root << 9) + (t << 1), w + 12);
-      SubTw::run<1>(itw + ((size_t)root << 8) + t, w + 14);
-      reg_inv_stages<4, true>(v, mod, imask, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
-#pragma unroll
-      for (int e = 0; e < 16; e++) s[pb3 + e] = v[e];
-    }
-    __syncthreads();
-    // ---- inverse round 2: stages 4..7; block of stage 4+k: (hi << (3-k)) + (e >> (k+1))
-    {
-      const int lo = t & 15, hi = t >> 4;
-      const int pb = hi * SP + lo;
-      double w[15];
-      SubTw::run<8>(itw + ((size_t)root << 7) + (hi << 3), w);
-      SubTw::run<4>(itw + ((size_t)root << 6) + (hi << 2), w + 8);
-      SubTw::run<2>(itw + ((size_t)root << 5) + (hi << 1), w + 12);
-      SubTw::run<1>(itw + ((size_t)root << 4) + hi, w + 14);
-#pragma unroll
-      for (int e = 0; e < 16; e++) v[e] = s[pb + 17 * e];
-      reg_inv_stages<4, true>(v, mod, imask >> 4, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
-#pragma unroll
-      for (int e = 0; e < 16; e++) s[pb + 17 * e] = v[e];
-    }
-    __syncthreads();
-    // ---- inverse round 3: stages 8..11 on elements t + 256 e; block of stage 8+k: e >> (k+1) of 8 >> k
-#pragma unroll
-    for (int e = 0; e < 16; e++) v[e] = s[pt + SP * e];
-    reg_inv_stages<4, true>(v, mod, imask >> 8, [&](int k, int i) { return itw[((8 >> k) * root) + i]; });
+    const double *tab = MODE == 2   ? static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * N
+                        : MODE == 3 ? static_cast<const double *>(tabs.t[0]) + blk * (size_t)N
+                                    : nullptr;
+    w12_block<MODE>(v, s, P.tw, P.itw, P.mod, root, P.fmask[logn] >> log_n1, P.imask[logn], (P.pwmask >> logn) & 1u, tab, xb);
+    if (MODE == 0) continue;
 #pragma unroll
     for (int e = 0; e < 16; e++) __builtin_nontemporal_store(v[e], xb + t + 256 * e);
   }

@@ -39,7 +39,7 @@ def run(tag, dev, prove, m):
 
 
 if which in ("groth16", "both"):
-    prm = P.preset("C3")
+    prm = P.preset(os.environ.get("KNOB_AB_PRESET", "C3"))  # C3R: the recipe primes (two-dimensional block convolutions)
     dev = Device(prm)
     m, W = 1 << 16, 1 << 13
     dcs = dev.r1cs(R.chain_r1cs(m, prm.q))
@@ -48,7 +48,7 @@ if which in ("groth16", "both"):
     dev.chain_assignment(asg, m)
     pk = {k: dev.fill_uniform(dev.enc_empty(W), 1, 13 + i) for i, k in enumerate(("s_pows", "delta_ts", "delta_mid"))}
     pk["alpha"], pk["beta"] = dev.fill_uniform(dev.enc_empty(), 1, 16), dev.fill_uniform(dev.enc_empty(), 1, 17)
-    run("C3 groth16 2^16", dev, lambda: dev.groth16_prove(dcs, pk, asg, want_empty=False, window=W), m)
+    run(prm.name + " groth16 2^16", dev, lambda: dev.groth16_prove(dcs, pk, asg, want_empty=False, window=W), m)
     del dev, dcs, asg, pk
     torch.cuda.empty_cache()
 if which in ("rinocchio", "both"):

@@ -309,7 +309,7 @@ int rs_last_timings(rs_ctx *ctx, rs_timings *out);
 int rs_set_profiling(rs_ctx *ctx, int enabled);
 /* Measured denominators for the rooflines, on THIS device, now (the reference's micro-benchmark of the same
  * primitives: microbench.cpp:147-205): device-to-device copy bandwidth (GB/s, read + written bytes of a 2 GiB copy with
- * 16-byte accesses), the v_fma_f64 issue rate (T lane-operations/s), the exact-FP64 modular multiply of f64mod.hpp and the
+ * 16-byte accesses; also as a read-only stream and as an in-place update), the v_fma_f64 issue rate (T lane-operations/s), the exact-FP64 modular multiply of f64mod.hpp and the
  * Montgomery product of intmod.hpp on a 60-bit prime (G modular multiplies/s).  About 50 ms.  Synchronises. */
 typedef struct rs_peaks {
   double hbm_copy_gbs, fp64_fma_T, fp64_mulmod_G, int_montmul_G;
@@ -332,7 +332,8 @@ int rs_profile_read(rs_ctx *ctx, rs_kernel_stat *out, int capacity, int *n_out);
 /* process-wide kernel-shape knobs; results are identical for every accepted value:
  *   "ntt_variant" (14: wide kernels of ntt_wide.hpp, default), "ntt_wide_grid", "mac_variant" (5: mac_kernel_v3),
  *   "plain_variant" (1: plain_center_wide_kernel), "witness_lds_logM", "witness_sub_ct" (2: sub_ntt_wide_kernel),
- *   "witness_tree_ct" (2: tree_wide_kernel), "witness_tree_log" (14), "mac_chunk_units", "mac_share_keys" (1: mac_kernel_v4, one plaintext spectrum for two key vectors), "prover_lin_io" (1), "witness_col_budget_mib", "witness_force_bc", "witness_bc2" (1), "msm_host_tile" (1024 terms per staging buffer), "force_int_arith".
+ *   "witness_tree_ct" (2: tree_wide_kernel), "witness_tree_log" (14), "mac_chunk_units", "mac_share_keys" (1: mac_kernel_v4, one plaintext spectrum for two key vectors), "prover_lin_io" (1), "witness_col_budget_mib", "witness_force_bc", "witness_bc2" (1), "msm_host_tile" (1024 terms per staging buffer), "force_int_arith",
+ *   "witness_cross_maxr" (6: most stages of one cross pass), "witness_cross_pair" (1: two groups per thread, 16-byte accesses), "witness_sub_log" (12: rooted sub-transforms on 2^12 blocks, sub_ntt_w12_kernel, where the cross pass stays within "witness_sub12_cross" = 4 stages; 13: never), "int_ntt_variant" (1: ntt_io_kernel).
  * (Variants that alter results -- timing ablations -- exist only as compile-time macros / the separate experiments
  * build, `make -C ringsnark_amd/csrc experiments`; never in the release library.) */
 int rs_set_tuning(const char *key, int value);

@@ -1005,6 +1005,8 @@ int rs_set_tuning(const char *key, int value) {
   else if (std::string(key) == "witness_sub_log") {
     RS_REQUIRE(value == 12 || value == 13, "witness_sub_log must be 12 or 13");
     g_witness_sub_log = value;
+  } else if (std::string(key) == "witness_h_coset") {
+    g_witness_h_coset = value ? 1 : 0;
   } else if (std::string(key) == "witness_sub12_cross") {
     RS_REQUIRE(value >= 1 && value <= 8, "witness_sub12_cross must be in [1, 8]");
     g_witness_sub12_cross = value;

@@ -56,6 +56,8 @@ struct LimbPlan {
   void *d_dlow = nullptr;                  // [SCHOOL_LEVELS+1][M/2] low coefficients of D_left
   void *d_shat = nullptr;                  // [2M] spectrum of rev(Z)^-1 mod x^(m-1), scaled 1/(2M)^2
   void *d_ztab = nullptr;                  // [M] Z_k (0 beyond m)
+  // coset form of H (big_h_coset; full-length plans): g^k; g^-k / M; 1 / Z(g w^i) in the forward transform's output order
+  void *d_cos_g = nullptr, *d_cos_h = nullptr, *d_cos_z = nullptr;  // [M] each
   // block-convolution path (WitnessPlan::bcLog != 0): spectra of the B-coefficient blocks of the same polynomials,
   // transform length 2B = 2^bcLog, scaled by 1/(2B)
   void *d_bc_e = nullptr;                  // [M/B][2B] blocks of (-1)^k/k!
@@ -219,6 +221,7 @@ static uint64_t plain_word(const rs_ctx *ctx, uint64_t v, uint64_t p) {
   return ctx->use_int ? word_of(HostArith<ModI>::plain(v, p)) : word_of(HostArith<Mod>::plain(v, p));
 }
 
+int g_witness_h_coset = 1;      // tuning knob "witness_h_coset": H on a coset (four length-M transforms) when the call interpolates C; 0: always big_h
 int g_witness_sub_log = 12;     // tuning knob "witness_sub_log": 12 = rooted sub-transforms on blocks of 2^12 (sub_ntt_w12_kernel) where sub_block_log says so; 13: never
 int g_witness_sub12_cross = 4;  // tuning knob "witness_sub12_cross": most cross stages of a transform that takes 2^12 blocks
 int g_witness_cross_pair = 1;  // tuning knob "witness_cross_pair": two groups per thread and 16-byte accesses in the cross passes (0: the round-3 form)
@@ -401,6 +404,48 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
       std::vector<uint64_t> zt(M, 0);
       for (size_t k = 0; k < M && k <= m; k++) zt[k] = bal(Z[k]);
       lp.d_ztab = up(zt);
+      if (!blocked && M >= 2) {
+        // H on a coset (Rinocchio, where C is interpolated anyway): H(g w^i) = (A B - C)(g w^i) / Z(g w^i) at the M points
+        // g w^i, none of which may be a root of Z (an integer 0 .. m-1; the point g w^0 = g itself is one for g < m): try
+        // g = m + 1, m + 2, ... until Z has no zero there (a given g fails with probability ~ m M / q)
+        const uint64_t mi = invmod((uint64_t)M % p, p);
+        for (uint64_t g = (uint64_t)m + 1;; g++) {
+          RS_REQUIRE(g < (uint64_t)m + 1000, "internal: no coset for the vanishing polynomial");
+          std::vector<uint64_t> gp(M), zc(M, 0);
+          gp[0] = 1;
+          for (size_t k = 1; k < M; k++) gp[k] = mulmod(gp[k - 1], g % p, p);
+          for (size_t k = 0; k < M && k <= m; k++) zc[k] = mulmod(Z[k], gp[k], p);
+          if (m == M) zc[0] = addmod(zc[0], mulmod(gp[M - 1], g % p, p), p);  // x^M = g^M on the coset
+          ntt_fwd(zc, logM, T);
+          bool ok = true;
+          for (size_t k = 0; k < M && ok; k++) ok = zc[k] != 0;
+          if (!ok) continue;
+          // batch inversion of the M values
+          std::vector<uint64_t> pre(M);
+          uint64_t acc = 1;
+          for (size_t k = 0; k < M; k++) {
+            pre[k] = acc;
+            acc = mulmod(acc, zc[k], p);
+          }
+          uint64_t inv = invmod(acc, p);
+          std::vector<uint64_t> zi(M), gh(M), gg(M);
+          for (size_t k = M; k-- > 0;) {
+            zi[k] = bal(mulmod(inv, pre[k], p));
+            inv = mulmod(inv, zc[k], p);
+          }
+          const uint64_t ginv = invmod(g % p, p);
+          uint64_t gi = mi;  // g^-k / M
+          for (size_t k = 0; k < M; k++) {
+            gg[k] = bal(gp[k]);
+            gh[k] = bal(gi);
+            gi = mulmod(gi, ginv, p);
+          }
+          lp.d_cos_g = up(gg);
+          lp.d_cos_h = up(gh);
+          lp.d_cos_z = up(zi);
+          break;
+        }
+      }
       // S = rev(Z)^-1 mod x^(m-1) (Newton iteration): quo(P, Z) = rev(rev(P) * S mod x^(m-1)) for
       // deg P = 2m-2.  Spectrum at length 2M, scaled by 1/(2M)^2 (two unscaled inverse transforms).
       std::vector<uint64_t> shat(2 * M, 0);
@@ -472,7 +517,7 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
 static void free_plan_tables(WitnessPlan *P) {
   for (auto &lp : P->limb) {
     void *ptrs[] = {lp.d_tw, lp.d_itw, lp.d_invfact, lp.d_ehat, lp.d_dhat, lp.d_dlow, lp.d_shat, lp.d_ztab, lp.d_bc_e, lp.d_bc_s, lp.d_bc_d,
-                    lp.d_b2_e, lp.d_b2_s, lp.d_b2_d};
+                    lp.d_b2_e, lp.d_b2_s, lp.d_b2_d, lp.d_cos_g, lp.d_cos_h, lp.d_cos_z};
     for (void *q : ptrs)
       if (q) (void)hipFree(q);
   }
@@ -516,6 +561,9 @@ static ColPlansT<M> make_colplans(rs_ctx *ctx, const WitnessPlan *P, int limb0 =
     c.b2_e = static_cast<const T *>(lp.d_b2_e);
     c.b2_s = static_cast<const T *>(lp.d_b2_s);
     c.b2_d = static_cast<const T *>(lp.d_b2_d);
+    c.cos_g = static_cast<const T *>(lp.d_cos_g);
+    c.cos_h = static_cast<const T *>(lp.d_cos_h);
+    c.cos_z = static_cast<const T *>(lp.d_cos_z);
     c.bc_inv2b = P->bcLog ? HostArith<M>::konst(host::invmod(((uint64_t)1 << P->bcLog) % lp.p, lp.p), lp.p) : T(0);
     c.b2_inv = P->bc2 ? HostArith<M>::konst(host::invmod((uint64_t)(4 * P->M) % lp.p, lp.p), lp.p) : T(0);
     c.fwd_mask2 = lp.fwd_mask2;
@@ -729,20 +777,20 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
   constexpr bool FP = std::is_same<M, Mod>::value;
   const size_t lds = padded_len((size_t)1 << logB) * sizeof(double);
   const size_t bpc = (size_t)1 << (logtot - logB);
-  static const char *const names[4] = {"sub_ntt_kernel<0", "sub_ntt_kernel<1", "sub_ntt_kernel<2", "sub_ntt_kernel<3"};
-  static const char *const names_ct[4] = {"sub_ntt_ct_kernel<0, 13>", "sub_ntt_ct_kernel<1, 13>", "sub_ntt_ct_kernel<2, 13>", "sub_ntt_ct_kernel<3, 13>"};
-  static const char *const names_wide[4] = {"sub_ntt_wide_kernel<0>", "sub_ntt_wide_kernel<1>", "sub_ntt_wide_kernel<2>", "sub_ntt_wide_kernel<3>"};
+  static const char *const names[5] = {"sub_ntt_kernel<0", "sub_ntt_kernel<1", "sub_ntt_kernel<2", "sub_ntt_kernel<3", "sub_ntt_kernel<4"};
+  static const char *const names_ct[5] = {"sub_ntt_ct_kernel<0, 13>", "sub_ntt_ct_kernel<1, 13>", "sub_ntt_ct_kernel<2, 13>", "sub_ntt_ct_kernel<3, 13>", "sub_ntt_ct_kernel<4, 13>"};
+  static const char *const names_wide[5] = {"sub_ntt_wide_kernel<0>", "sub_ntt_wide_kernel<1>", "sub_ntt_wide_kernel<2>", "sub_ntt_wide_kernel<3>", "sub_ntt_wide_kernel<4>"};
 #ifdef RS_EXPERIMENTS
-  const bool ct = FP && logB == 13 && MODE != 1 && g_witness_sub_ct;
+  const bool ct = FP && logB == 13 && MODE != 1 && g_witness_sub_ct && (MODE != 4 || g_witness_sub_ct == 2);  // MODE 4: generic, wide and 2^12 kernels only
 #else
   const bool ct = FP && logB == 13 && MODE != 1 && g_witness_sub_ct == 2;  // 0: the generic kernel; 1 and 3 exist in the experiments build only
 #endif
   const double Bn = (double)((size_t)1 << logB), blocks = (double)(ncols * bpc);
-  static const char *const names_w16[4] = {"sub_ntt_wide16_kernel<0>", "sub_ntt_wide16_kernel<1>", "sub_ntt_wide16_kernel<2>", "sub_ntt_wide16_kernel<3>"};
-  static const char *const names_w12[4] = {"sub_ntt_w12_kernel<0>", "sub_ntt_w12_kernel<1>", "sub_ntt_w12_kernel<2>", "sub_ntt_w12_kernel<3>"};
+  static const char *const names_w16[5] = {"sub_ntt_wide16_kernel<0>", "sub_ntt_wide16_kernel<1>", "sub_ntt_wide16_kernel<2>", "sub_ntt_wide16_kernel<3>", "sub_ntt_wide16_kernel<4>"};
+  static const char *const names_w12[5] = {"sub_ntt_w12_kernel<0>", "sub_ntt_w12_kernel<1>", "sub_ntt_w12_kernel<2>", "sub_ntt_w12_kernel<3>", "sub_ntt_w12_kernel<4>"};
   const bool w12 = FP && logB == 12 && MODE != 1 && g_witness_sub_log == 12;
-  ProfScope prof(ctx, st, w12 ? names_w12[MODE] : ct ? (g_witness_sub_ct == 3 ? names_w16[MODE] : g_witness_sub_ct == 2 ? names_wide[MODE] : names_ct[MODE]) : names[MODE], blocks * Bn * (MODE == 3 ? 24.0 : 16.0),
-                 blocks * ((MODE >= 2 ? 2.0 : 1.0) * ntt_fp64(Bn, logB) + (MODE >= 2 ? 7.0 * Bn : 0.0)));
+  ProfScope prof(ctx, st, w12 ? names_w12[MODE] : ct ? (g_witness_sub_ct == 3 ? names_w16[MODE] : g_witness_sub_ct == 2 ? names_wide[MODE] : names_ct[MODE]) : names[MODE], blocks * Bn * (MODE == 4 ? 32.0 : MODE == 3 ? 24.0 : 16.0),
+                 blocks * ((MODE >= 2 ? 2.0 : 1.0) * ntt_fp64(Bn, logB) + (MODE == 4 ? 24.0 * Bn : MODE >= 2 ? 7.0 * Bn : 0.0)));
   static TabPtrs none{};
   const TabPtrs &tp = tabs ? *tabs : none;
   if constexpr (FP) {
@@ -755,7 +803,7 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
       return;
     }
 #ifdef RS_EXPERIMENTS
-    if (logB == 13 && MODE != 1 && g_witness_sub_ct == 3) {
+    if (logB == 13 && MODE != 1 && MODE != 4 && g_witness_sub_ct == 3) {
       const int wl = (int)(WideShape<13>::TILE * sizeof(double));
       const unsigned long long nb = (unsigned long long)(ncols * bpc);
       RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_wide16_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
@@ -776,7 +824,7 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
       return;
     }
 #ifdef RS_EXPERIMENTS
-    if (logB == 13 && MODE != 1 && g_witness_sub_ct) {
+    if (logB == 13 && MODE != 1 && MODE != 4 && g_witness_sub_ct) {
       RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_ct_kernel<MODE, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL((sub_ntt_ct_kernel<MODE, 13>), dim3((unsigned)(ncols * bpc)), dim3(512), lds, st, X, logsub - logB, tp,
                          (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp);
@@ -956,6 +1004,57 @@ static void big_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, con
   launch_cross<true, CD_H_FINISH, M>(ctx, a, ncols, logB, cp, st);
   const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((ncols * Mlen + 255) / 256, 256 * 16));
   ProfScope prof(ctx, st, "h_patch_kernel", (double)ncols * (double)Mlen * (d1 ? 32.0 : 16.0), d1 ? 24.0 * (double)ncols * (double)Mlen : 0.0);
+  hipLaunchKernelGGL(h_patch_kernel<ColPlansT<M>>, dim3(blocks), dim3(256), 0, st, H, A, B, logM, (int)P->m, ncols, col0, (unsigned)S,
+                     (unsigned)spl, cp, d1, d2, d3, cm);
+  RS_HIP(hipGetLastError());
+}
+
+// H on a coset, when C's coefficients are at hand (Rinocchio keeps C_mid, rinocchio.tcc:75-190; ringGroth16 never
+// interpolates C and takes big_h): with the M points g w^i, none a root of Z,
+//     H(g w^i) = (A(g w^i) B(g w^i) - C(g w^i)) / Z(g w^i),   deg H <= m - 2 < M,
+// so H is the inverse coset transform of that quotient: FOUR transforms of length M (three forward, one inverse, the
+// pointwise step inside the sub-transform kernel of B) instead of big_h's five of length 2M.  The division is exact in
+// Z_q, so H is the polynomial the reference's long division (util/polynomials.tcc:62-81) returns; the ZK patch follows as
+// in big_h.  W1, W2: workspaces [ncols][2M] (W1 holds the spectra of A and of C, W2 that of B and the result).
+template <class M>
+static void big_h_coset(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, const typename ArithOf<M>::T *A,
+                        const typename ArithOf<M>::T *B, const typename ArithOf<M>::T *Cc, typename ArithOf<M>::T *H,
+                        typename ArithOf<M>::T *W1, typename ArithOf<M>::T *W2, size_t ncols, size_t col0, size_t S, size_t spl,
+                        const uint64_t *d1, const uint64_t *d2, const uint64_t *d3, const ColMap &cm, int limb0, hipStream_t st) {
+  using T = typename ArithOf<M>::T;
+  const int logM = P->logM, logB = sub_block_log<M>(std::min(g_witness_lds_logM, logM), logM);
+  const size_t Mlen = P->M;
+  T *W3 = W1 + ncols * Mlen;  // the second half of the [ncols][2M] workspace
+  CrossArgs a{};
+  a.logM = logM;
+  a.l = 1;
+  a.m = (int)P->m;
+  a.S = (unsigned)S;
+  a.slots_per_limb = (unsigned)spl;
+  a.col0 = col0;
+  a.logtot = a.logsub = logM;
+  TabPtrs tp{};
+  const T *srcs[3] = {A, Cc, B};
+  T *dsts[3] = {W1, W3, W2};
+  for (int k = 0; k < 3; k++) {
+    a.W = dsts[k];
+    a.src = srcs[k];
+    launch_cross<false, CS_COSET, M>(ctx, a, ncols, logB, cp, st);
+    if (k < 2) launch_sub<0, M>(ctx, dsts[k], ncols, col0, logM, logM, logB, nullptr, 1, S, spl, cp, st);
+  }
+  for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_cos_z;
+  tp.w1 = W1;
+  tp.w3 = W3;
+  launch_sub<4, M>(ctx, W2, ncols, col0, logM, logM, logB, &tp, Mlen >> logB, S, spl, cp, st);
+  a.W = W2;
+  a.dst = H;
+  if (!d1) {
+    launch_cross<true, CD_H_COSET_CANON, M>(ctx, a, ncols, logB, cp, st);
+    return;
+  }
+  launch_cross<true, CD_H_COSET, M>(ctx, a, ncols, logB, cp, st);
+  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((ncols * Mlen + 255) / 256, 256 * 16));
+  ProfScope prof(ctx, st, "h_patch_kernel", (double)ncols * (double)Mlen * 32.0, 24.0 * (double)ncols * (double)Mlen);
   hipLaunchKernelGGL(h_patch_kernel<ColPlansT<M>>, dim3(blocks), dim3(256), 0, st, H, A, B, logM, (int)P->m, ncols, col0, (unsigned)S,
                      (unsigned)spl, cp, d1, d2, d3, cm);
   RS_HIP(hipGetLastError());
@@ -1234,7 +1333,8 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> 
 template <class M>
 static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, const typename ArithOf<M>::T *A,
                      const typename ArithOf<M>::T *B, typename ArithOf<M>::T *H, size_t S, size_t spl, const uint64_t *d1,
-                     const uint64_t *d2, const uint64_t *d3, const ColMap &cm, hipStream_t st) {
+                     const uint64_t *d2, const uint64_t *d3, const ColMap &cm, hipStream_t st,
+                     const typename ArithOf<M>::T *Cc = nullptr /* coefficients of C when the call interpolates them: the coset form */) {
   using T = typename ArithOf<M>::T;
   constexpr bool FP = std::is_same<M, Mod>::value;
   const size_t Mlen = P->M;
@@ -1290,7 +1390,10 @@ static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, 
   T *W2 = (T *)ws_get(ctx, 13, chunk * 2 * Mlen * sizeof(double));
   for (size_t c0 = 0; c0 < S; c0 += chunk) {
     const size_t nc = std::min(chunk, S - c0);
-    big_h<M>(ctx, P, cp, A + c0 * Mlen, B + c0 * Mlen, H + c0 * Mlen, W1, W2, nc, c0, S, spl, d1, d2, d3, cm, cm.limb0, st);
+    if (Cc && g_witness_h_coset && P->limb[cm.limb0].d_cos_z)
+      big_h_coset<M>(ctx, P, cp, A + c0 * Mlen, B + c0 * Mlen, Cc + c0 * Mlen, H + c0 * Mlen, W1, W2, nc, c0, S, spl, d1, d2, d3, cm, cm.limb0, st);
+    else
+      big_h<M>(ctx, P, cp, A + c0 * Mlen, B + c0 * Mlen, H + c0 * Mlen, W1, W2, nc, c0, S, spl, d1, d2, d3, cm, cm.limb0, st);
   }
 }
 
@@ -1438,7 +1541,7 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
     for (int k = 0; k < 10; k++) n9 += (k != 6) && needed(k);
     if (n9) launch_interp<M_>(ctx, P, cp, colbuf, (size_t)n9 * C, C, (size_t)cm.ns, cm.limb0, st);
   }
-  if (needH) launch_h<M_>(ctx, P, cp, colv(3), colv(4), colv(6), C, (size_t)cm.ns, d1, d2, d3, cm, st);
+  if (needH) launch_h<M_>(ctx, P, cp, colv(3), colv(4), colv(6), C, (size_t)cm.ns, d1, d2, d3, cm, st, need_full[2] ? colv(5) : (const T *)nullptr);
   const unsigned eb = (unsigned)std::min<size_t>((vec + 255) / 256, 256 * 16);
   if (!shortcut) {
     // fallback: X_mid = interp(full) - interp(io) + interp(constant part), combined in column-major form

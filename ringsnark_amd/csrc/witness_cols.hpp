@@ -18,6 +18,7 @@ struct ColPlanT {
   const T *tw, *itw, *invfact, *ehat, *dhat, *dlow, *shat, *ztab;
   const T *bc_e, *bc_s, *bc_d;  // block-convolution path (LimbPlan)
   const T *b2_e, *b2_s, *b2_d;  // ... in its two-dimensional form
+  const T *cos_g, *cos_h, *cos_z;  // coset form of H (big_h_coset): g^k, g^-k / M, 1 / Z(g w^i) in transform order
   T bc_inv2b;                   // 1 / (2B) as a table constant
   T b2_inv;                     // 1 / (2B * 2M/B) = 1 / (4M): both unscaled inverse transforms of a two-dimensional data x data product
   uint32_t fwd_mask2, inv_mask2;

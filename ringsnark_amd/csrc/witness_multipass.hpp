@@ -14,6 +14,7 @@ namespace rs {
 // =============================================================================================
 struct TabPtrs {
   const void *t[RS_MAX_L];  // tables of the context's arithmetic (8-byte words)
+  const void *w1, *w3;      // MODE 4: two other workspaces of the same shape (spectra, lazily reduced)
 };
 #ifndef RS_WORKSPACE_NT
 #define RS_WORKSPACE_NT 1
@@ -77,8 +78,8 @@ using GlobalF64IO = GlobalIOT<double>;
 // last inverse pass hands its output to a sink functor (truncation, node recombination, H
 // extraction).  Every other pass works in place on the workspace.  This removes the separate
 // element-wise launches (and their HBM round trips) around every multi-pass transform.
-enum CrossSrc { CS_PLAIN = 0, CS_SCALE_PAD, CS_FILL_RIGHT, CS_PAD_CENTER, CS_REV_TRUNC };
-enum CrossDst { CD_PLAIN = 0, CD_TAKE_LOW, CD_COMBINE, CD_COMBINE_CANON, CD_H_FINISH, CD_H_FINISH_CANON };
+enum CrossSrc { CS_PLAIN = 0, CS_SCALE_PAD, CS_FILL_RIGHT, CS_PAD_CENTER, CS_REV_TRUNC, CS_COSET };
+enum CrossDst { CD_PLAIN = 0, CD_TAKE_LOW, CD_COMBINE, CD_COMBINE_CANON, CD_H_FINISH, CD_H_FINISH_CANON, CD_H_COSET, CD_H_COSET_CANON };
 struct CrossArgs {
   void *W;          // workspace columns [ncols][2^logtot]   (8-byte words of the context's arithmetic)
   const void *src;  // source columns (CS_*): [ncols][M] (CS_REV_TRUNC: [ncols][2M])
@@ -92,7 +93,8 @@ struct CrossIn {
   using T = typename ArithOf<Mt>::T;
   // Every source feeds the FIRST round of a transform whose upper half is zero padding (length-2M transforms of M
   // inputs; per tree node (F_right, 0)): the round skips those loads and its first stage is a copy (ntt_core.hpp)
-  static constexpr bool zero_upper = true;
+  // (CS_COSET: a full-length transform of M coefficients times g^k -- `invfact` points at that table; no padding)
+  static constexpr bool zero_upper = SRC != CS_COSET;
   const T *p;  // this column of the source
   const T *invfact;
   Mt mod;
@@ -104,6 +106,7 @@ struct CrossIn {
     if (SRC == CS_FILL_RIGHT) return (k & (n - 1)) < h ? p[k + h] : T(0);         // per node: (F_right, 0)
     if (SRC == CS_PAD_CENTER) return k < M ? center(p[k], mod) : T(0);
     if (SRC == CS_REV_TRUNC) return k < m - 1 ? reduce(p[2 * m - 2 - k], mod) : T(0);  // T_k = P_{2m-2-k}, k < m-1
+    if (SRC == CS_COSET) return mulmod(center(p[k], mod), invfact[k], mod);            // a_k g^k
     return p[k];
   }
   // elements k, k + 1 (k even; M, n/2 even: both fall on the same side of every boundary but CS_REV_TRUNC's)
@@ -122,6 +125,9 @@ struct CrossIn {
         const Pair<T> a = ld_pair(p + k);
         r = Pair<T>{center(a.x, mod), center(a.y, mod)};
       }
+    } else if (SRC == CS_COSET) {
+      const Pair<T> a = ld_pair(p + k), f = ld_pair(invfact + k);
+      r = Pair<T>{mulmod(center(a.x, mod), f.x, mod), mulmod(center(a.y, mod), f.y, mod)};
     } else {
       r = ld_pair(p + k);
     }
@@ -150,6 +156,10 @@ struct CrossOut {
         p[m - 2 - k] = canon(v, mod);
       else if (k < M)
         p[k] = T(0);
+    } else if (DST == CD_H_COSET) {  // H_k = v_k g^-k / M (`invfact` points at that table); positions above m-2: h_patch_kernel
+      if (k <= m - 2) p[k] = reduce(mulmod(reduce(v, mod), invfact[k], mod), mod);
+    } else if (DST == CD_H_COSET_CANON) {
+      p[k] = k <= m - 2 ? canon(mulmod(reduce(v, mod), invfact[k], mod), mod) : T(0);
     } else {
       p[k] = v;
     }
@@ -165,8 +175,8 @@ struct CrossOut {
       if ((k & (n - 1)) < h) a = ld_pair(p + k);
       const T f0 = reduce(addm(x, a.x, mod), mod), f1 = reduce(addm(y, a.y, mod), mod);
       st_pair(p + k, DST == CD_COMBINE_CANON ? canon(f0, mod) : f0, DST == CD_COMBINE_CANON ? canon(f1, mod) : f1);
-    } else if (DST == CD_H_FINISH || DST == CD_H_FINISH_CANON) {  // reversed, odd-aligned: two words
-      store(k, 0, 0, 0, x);
+    } else if (DST == CD_H_FINISH || DST == CD_H_FINISH_CANON || DST == CD_H_COSET || DST == CD_H_COSET_CANON) {
+      store(k, 0, 0, 0, x);  // reversed and odd-aligned (H_FINISH), or a limit (m - 2) of either parity: two words
       store(k + 1, 0, 0, 0, y);
     } else {
       st_pair(p + k, x, y);
@@ -303,7 +313,8 @@ __global__ void __launch_bounds__(256) cross_kernel(CrossArgs a, CPS plans) {
       else
         inv_round<R>(io, io, a.logtot, a.logsub, a.s0, P.itw, 1, P.mod, P.imask[a.logsub], ln);
     } else {
-      const CrossOut<MODE, Mt> out{static_cast<T *>(a.dst) + (col << a.logM), P.invfact, P.mod, M, a.m, n, n >> 1};
+      const CrossOut<MODE, Mt> out{static_cast<T *>(a.dst) + (col << a.logM), (MODE == CD_H_COSET || MODE == CD_H_COSET_CANON) ? P.cos_h : P.invfact,
+                                   P.mod, M, a.m, n, n >> 1};
       if (V == 2)
         inv_round2<R>(io, out, a.logtot, a.logsub, a.s0, P.itw, P.mod, P.imask[a.logsub], ln);
       else
@@ -317,7 +328,7 @@ __global__ void __launch_bounds__(256) cross_kernel(CrossArgs a, CPS plans) {
         fwd_round<R>(io, io, a.logtot, a.logsub, a.s0, P.tw, 1, P.mod, P.fmask[a.logsub], ln);
     } else {
       const size_t stride = MODE == CS_REV_TRUNC ? (size_t)2 << a.logM : (size_t)1 << a.logM;
-      const CrossIn<MODE, Mt> in{static_cast<const T *>(a.src) + col * stride, P.invfact, P.mod, M, a.m, n, n >> 1};
+      const CrossIn<MODE, Mt> in{static_cast<const T *>(a.src) + col * stride, MODE == CS_COSET ? P.cos_g : P.invfact, P.mod, M, a.m, n, n >> 1};
       if (V == 2)
         fwd_round2<R>(in, io, a.logtot, a.logsub, a.s0, P.tw, P.mod, P.fmask[a.logsub], ln);
       else
@@ -373,6 +384,15 @@ sub_ntt_kernel(typename CPS::T *__restrict__ X, int logB, int log_n1, TabPtrs ta
     const T *tab = static_cast<const T *>(tabs.t[0]) + blk * (size_t)Bn;
     for (int i = threadIdx.x; i < Bn; i += blockDim.x)
       s[pidx(i)] = mulmod_dd(reduce(s[pidx(i)], mod), reduce(tab[i], mod), mod);
+    __syncthreads();
+  }
+  if (MODE == 4) {  // coset form of H: (spectrum * spectrum of A - spectrum of C) / Z on the coset (big_h_coset)
+    const T *w1 = static_cast<const T *>(tabs.w1) + blk * (size_t)Bn, *w3 = static_cast<const T *>(tabs.w3) + blk * (size_t)Bn;
+    const T *zi = static_cast<const T *>(tabs.t[limb]) + (size_t)(blk % tab_period) * Bn;
+    for (int i = threadIdx.x; i < Bn; i += blockDim.x) {
+      const T ab = mulmod_dd(reduce(s[pidx(i)], mod), reduce(w1[i], mod), mod);
+      s[pidx(i)] = mulmod(reduce(subm(ab, reduce(w3[i], mod), mod), mod), zi[i], mod);
+    }
     __syncthreads();
   }
   if (MODE >= 1) {
@@ -579,33 +599,49 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
         // The table entries of the wave's 64 groups are 1024 consecutive words: fetched with coalesced 16-byte loads
         // and handed to their owners through the wave's range of the tile, which is free once x has been read (a
         // thread fetching its own 128-byte run touches 64 different lines per instruction).
-        const double *tab = (MODE == 2) ? static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * S::N
-                                        : static_cast<const double *>(tabs.t[0]) + blk * (size_t)S::N;
         const int wave = t >> 6, lane = t & 63;
         const int r0 = (j * 256 + wave * 64) * 16;
         const int p0 = S::px(r0 + 2 * lane);
-        const double2 *t2 = reinterpret_cast<const double2 *>(tab + r0) + lane;
+        auto stage = [&](const double *tab) {  // the wave's 1024 entries of `tab` -> its range of the tile
+          const double2 *t2 = reinterpret_cast<const double2 *>(tab + r0) + lane;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+          for (int i = 0; i < 8; i++) {
 #ifdef RS_SUBW_ABLATE_TW
-          const double2 v2 = make_double2(3.0 + i, 5.0 + lane);
+            const double2 v2 = make_double2(3.0 + i, 5.0 + lane);
 #else
-          const double2 v2 = t2[64 * i];
+            const double2 v2 = t2[64 * i];
 #endif
-          s[p0 + S::px128(i)] = v2.x;
-          s[p0 + S::px128(i) + 1] = v2.y;
-        }
-        wave_sync();
-        if (MODE == 2) {
-          if ((P.pwmask >> logn) & 1u) {  // primes above ~2^46 only (a guarded pass, not a select)
-#pragma unroll
-            for (int e = 0; e < 16; e++) x[e] = reduce(x[e], mod);
+            s[p0 + S::px128(i)] = v2.x;
+            s[p0 + S::px128(i) + 1] = v2.y;
           }
+          wave_sync();
+        };
+        if (MODE == 4) {  // (x * spectrum of A - spectrum of C) / Z on the coset: three staged operands
+          stage(static_cast<const double *>(tabs.w1) + blk * (size_t)S::N);
+#pragma unroll
+          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), reduce(s[pb + e], mod), mod);
+          wave_sync();
+          stage(static_cast<const double *>(tabs.w3) + blk * (size_t)S::N);
+#pragma unroll
+          for (int e = 0; e < 16; e++) x[e] = reduce(x[e] - reduce(s[pb + e], mod), mod);
+          wave_sync();
+          stage(static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * S::N);
 #pragma unroll
           for (int e = 0; e < 16; e++) x[e] = mulmod(x[e], s[pb + e], mod);
         } else {
+          stage((MODE == 2) ? static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * S::N
+                            : static_cast<const double *>(tabs.t[0]) + blk * (size_t)S::N);
+          if (MODE == 2) {
+            if ((P.pwmask >> logn) & 1u) {  // primes above ~2^46 only (a guarded pass, not a select)
 #pragma unroll
-          for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), reduce(s[pb + e], mod), mod);
+              for (int e = 0; e < 16; e++) x[e] = reduce(x[e], mod);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++) x[e] = mulmod(x[e], s[pb + e], mod);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) x[e] = mulmod(reduce(x[e], mod), reduce(s[pb + e], mod), mod);
+          }
         }
       }
       // inverse stage k of the block: twiddle itw[(n >> (k+1)) root + (position >> (k+1))]
@@ -679,7 +715,8 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
 template <int MODE>
 __device__ __forceinline__ void w12_block(double (&v)[16], double *s, const double *__restrict__ tw, const double *__restrict__ itw,
                                           const Mod mod, int root, uint32_t fmask, uint32_t imask, bool pw_reduce,
-                                          const double *__restrict__ tab, double *__restrict__ fwd_out) {
+                                          const double *__restrict__ tab, double *__restrict__ fwd_out,
+                                          const double *__restrict__ w1 = nullptr, const double *__restrict__ w3 = nullptr) {
   constexpr int SP = 272;  // px(i) = i + (i >> 4); elements 256 apart are 272 slots apart
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int pt = t + (t >> 4);
@@ -728,24 +765,41 @@ __device__ __forceinline__ void w12_block(double (&v)[16], double *s, const doub
       return;
     }
     {  // table entries of the wave's range: coalesced 16-byte loads, handed to their owners through the wave's part of the tile
-      const double2 *t2 = reinterpret_cast<const double2 *>(tab + r0) + lane;
+      auto stage = [&](const double *__restrict__ tb) {
+        const double2 *t2 = reinterpret_cast<const double2 *>(tb + r0) + lane;
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const double2 v2 = t2[64 * i];
-        s[p0 + 136 * i] = v2.x;
-        s[p0 + 136 * i + 1] = v2.y;
-      }
-      wave_sync();
-      if (MODE == 2) {
-        if (pw_reduce) {  // primes above ~2^46 only (a guarded pass, not a select)
-#pragma unroll
-          for (int e = 0; e < 16; e++) v[e] = reduce(v[e], mod);
+        for (int i = 0; i < 8; i++) {
+          const double2 v2 = t2[64 * i];
+          s[p0 + 136 * i] = v2.x;
+          s[p0 + 136 * i + 1] = v2.y;
         }
+        wave_sync();
+      };
+      if (MODE == 4) {  // (x * spectrum of A - spectrum of C) / Z on the coset: three staged operands
+        stage(w1);
+#pragma unroll
+        for (int e = 0; e < 16; e++) v[e] = mulmod(reduce(v[e], mod), reduce(s[pb3 + e], mod), mod);
+        wave_sync();
+        stage(w3);
+#pragma unroll
+        for (int e = 0; e < 16; e++) v[e] = reduce(v[e] - reduce(s[pb3 + e], mod), mod);
+        wave_sync();
+        stage(tab);
 #pragma unroll
         for (int e = 0; e < 16; e++) v[e] = mulmod(v[e], s[pb3 + e], mod);
       } else {
+        stage(tab);
+        if (MODE == 2) {
+          if (pw_reduce) {  // primes above ~2^46 only (a guarded pass, not a select)
 #pragma unroll
-        for (int e = 0; e < 16; e++) v[e] = mulmod(reduce(v[e], mod), reduce(s[pb3 + e], mod), mod);
+            for (int e = 0; e < 16; e++) v[e] = reduce(v[e], mod);
+          }
+#pragma unroll
+          for (int e = 0; e < 16; e++) v[e] = mulmod(v[e], s[pb3 + e], mod);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; e++) v[e] = mulmod(reduce(v[e], mod), reduce(s[pb3 + e], mod), mod);
+        }
       }
     }
     SubTw::run<8>(itw + ((size_t)root << 11) + (t << 3), w);
@@ -801,10 +855,12 @@ sub_ntt_w12_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned ta
     double v[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) v[e] = __builtin_nontemporal_load(xb + t + 256 * e);
-    const double *tab = MODE == 2   ? static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * N
-                        : MODE == 3 ? static_cast<const double *>(tabs.t[0]) + blk * (size_t)N
-                                    : nullptr;
-    w12_block<MODE>(v, s, P.tw, P.itw, P.mod, root, P.fmask[logn] >> log_n1, P.imask[logn], (P.pwmask >> logn) & 1u, tab, xb);
+    const double *tab = (MODE == 2 || MODE == 4) ? static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * N
+                        : MODE == 3              ? static_cast<const double *>(tabs.t[0]) + blk * (size_t)N
+                                                 : nullptr;
+    w12_block<MODE>(v, s, P.tw, P.itw, P.mod, root, P.fmask[logn] >> log_n1, P.imask[logn], (P.pwmask >> logn) & 1u, tab, xb,
+                    MODE == 4 ? static_cast<const double *>(tabs.w1) + blk * (size_t)N : nullptr,
+                    MODE == 4 ? static_cast<const double *>(tabs.w3) + blk * (size_t)N : nullptr);
     if (MODE == 0) continue;
 #pragma unroll
     for (int e = 0; e < 16; e++) __builtin_nontemporal_store(v[e], xb + t + 256 * e);

@@ -154,6 +154,34 @@ def test_sub_transform_blocks_of_2_12_equal_2_13(m, cross):
         assert (runs[13][k] == runs[12][k]).all(), k
 
 
+@pytest.mark.parametrize("m,zk,int_arith", [(20000, True, False), (32768, False, False), (65536, True, False), (70000, False, False),
+                                             (262144, True, False), (40000, True, True)])
+def test_h_on_a_coset_equals_the_long_division_form(m, zk, int_arith):
+    """witness_h_coset (default on; taken when the call interpolates C -- Rinocchio): H as the inverse coset transform of
+    (A B - C) / Z at M points g w^i (four length-M transforms) against big_h's quotient by rev(Z)^-1 (five of length 2M).
+    The division is exact in Z_q, so the two are the same polynomial: bit-equal H, every other vector untouched, and the
+    identity H Z = A B - C (+ ZK patch) at random points.  m = 32768, 65536: m = M, where Z has M + 1 coefficients and
+    x^M folds onto g^M."""
+    from ringsnark_amd.device import to_host
+    prm = P.preset("toy44")
+    runs = {}
+    for coset in (0, 1):
+        _set_tuning(b"witness_h_coset", coset)
+        try:
+            dev, cs, asg, ds, w, names = _run(prm, m, zk, 0, int_arith=int_arith)
+        finally:
+            _set_tuning(b"witness_h_coset", 1)
+        assert any("<4" in n and n.startswith("sub_ntt") for n in names) == (coset == 1), names
+        if coset:
+            rng = np.random.RandomState(m % 1000)
+            err = proof_check.check_columns(prm, cs, asg, {k: w[k] for k in KEYS}, [(0, 1), (prm.L - 1, prm.N - 2)], rng, tuple(ds))
+            assert err is None, err
+        runs[coset] = {k: to_host(w[k]) for k in KEYS}
+        del dev, asg, w
+    for k in KEYS:
+        assert (runs[0][k] == runs[1][k]).all(), k
+
+
 def test_integer_arithmetic_at_2_17():
     """The Montgomery-integer contexts (moduli >= 2^50: microbench.cpp:33-36, BFVDefault(2048)) run the generic kernels of
     the multi-pass path; M = 2^17 forced on toy44's primes, equal to the FP64 context bit for bit."""

@@ -182,7 +182,7 @@ def single_gpu_leg(preset, m, logw, steps, warmup, check):
            "phase_ms": {"witness_map": round(timings["witness_ms"], 3), "msm": round(timings["msm_ms"], 3)},
            "kernels": [{"name": k["name"], "ms": round(k["total_ms"], 2), "launches": k["launches"]} for k in stats[:6]]}
     if check:
-        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk, proof, m, window or None, n_cols=10)
+        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk, proof, m, window or None, n_slabs=6)
         out["check"] = dict(info, ok=ok)
     del proof, asg, pk, dcs, dev
     torch.cuda.empty_cache()
@@ -527,7 +527,7 @@ def main():
     check = None
     if world == 1 and not args.no_check:
         pk.clear()  # the check releases the key (pk1 holds the last references) before it re-runs the witness map
-        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk1, proof[0], m, window1 or pk1["s_pows"].shape[0], n_cols=10)
+        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk1, proof[0], m, window1 or pk1["s_pows"].shape[0], n_slabs=6)
         check = dict(info, ok=ok)
 
     # ---- the same statement on the ring primes the reference's own recipe yields (preset C3R), one GPU

@@ -21,8 +21,8 @@ u8p = C.POINTER(C.c_uint8)
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "rs_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("rs_oracle.c", "rs_identities.c", "rs_oracle.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "librs_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -42,6 +42,10 @@ class R1CS(C.Structure):
         ("ptab_N", C.c_size_t),
         ("ptab_slot0", C.c_size_t),
     ]
+
+
+class WMVectors(C.Structure):
+    _fields_ = [(k, u64p) for k in ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")] + [("stride", C.c_size_t * 7), ("Z", u64p)]
 
 
 class Groth16PK(C.Structure):
@@ -128,6 +132,9 @@ def lib():
         L.rso_rinocchio_prove_kinds.argtypes = [C.c_void_p, C.POINTER(R1CS), C.POINTER(RinocchioPK), u64p, u8p] + [u64p] * 4 + [C.POINTER(C.c_int)]
         L.rso_rinocchio_prove_kinds.restype = None
         L.rso_fill_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, u64p]
+        L.rso_witness_identities.restype = C.c_size_t
+        L.rso_witness_identities.argtypes = [C.c_uint64, C.c_size_t, C.POINTER(R1CS), C.c_int, u64p, C.c_size_t, u64p, u64p, u64p,
+                                             C.POINTER(WMVectors), u64p, C.c_int, u8p, C.c_int]
         _lib = L
     return _lib
 
@@ -475,6 +482,45 @@ def witness_map(q, cs, limb, assignment, d1=None, d2=None, d3=None, threads=1):
     else:
         lib().rso_witness_map_mt(*args, threads)
     return o
+
+
+IDENTITY_NAMES = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
+
+
+def witness_identities(q, cs, limb, assignment, vectors, points, d1=None, d2=None, d3=None, Z=None, threads=0):
+    """COMPLETE check of a witness map computed elsewhere (rs_identities.c): one limb, EVERY slot.
+    assignment [n_vars][S]; vectors: dict name -> [m][S] ([m+1][S] for H) -- arrays may be strided views of
+    [rows][L][N] host arrays sliced to one limb (row stride taken from the array, slots contiguous); points: <= 4 integers in [m, q); d1..d3 [S]; Z [m+1].
+    Returns (number of failing slots, bad [S] uint8 bit mask by IDENTITY_NAMES order)."""
+    def rows(a):
+        assert a.dtype == np.uint64 and a.ndim == 2 and a.strides[1] == 8 and a.strides[0] % 8 == 0, (a.dtype, a.shape, a.strides)
+        return a.ctypes.data_as(u64p), a.strides[0] // 8
+
+    S = assignment.shape[1]
+    ap, astride = rows(assignment)
+    v = WMVectors()
+    for k, name in enumerate(IDENTITY_NAMES):
+        a = vectors.get(name)
+        if a is None:
+            continue
+        assert a.shape == (cs.m + (name == "H"), S), (name, a.shape)
+        ptr, v.stride[k] = rows(a)
+        setattr(v, name, ptr)
+    if Z is not None:
+        Z = np.ascontiguousarray(Z, dtype=np.uint64)
+        assert Z.shape == (cs.m + 1,)
+        v.Z = p64(Z)
+    ds = [None if d is None else np.ascontiguousarray(d, dtype=np.uint64) for d in (d1, d2, d3)]
+    pts = np.ascontiguousarray([int(p) for p in points], dtype=np.uint64)
+    bad = np.zeros(S, dtype=np.uint8)
+    n = lib().rso_witness_identities(q, S, cs.ref(), limb, ap, astride, p64(ds[0]), p64(ds[1]), p64(ds[2]), C.byref(v),
+                                     p64(pts), len(pts), bad.ctypes.data_as(u8p), threads)
+    n = int(n)
+    if n == 2**64 - 1:
+        raise ValueError("witness_identities: bad arguments (a point below m, or more than 4 points)")
+    if n == 2**64 - 2:
+        raise AssertionError("witness_identities: Z is not prod (x - i)")
+    return n, bad
 
 
 def _kinds_arg(kinds, n):

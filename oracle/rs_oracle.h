@@ -182,6 +182,23 @@ void rso_witness_map_mt(uint64_t q, size_t S, const rso_r1cs *cs, int limb, cons
                         uint64_t *B_io, uint64_t *C_io, uint64_t *A_mid, uint64_t *B_mid,
                         uint64_t *C_mid, uint64_t *Z, uint64_t *H, int threads);
 
+/* ---- rs_identities.c: COMPLETE check of a witness map computed elsewhere (the device), one limb, S slots, by the
+ * polynomial identities that define its outputs (r1cs_to_qrp.tcc:149-259) at n_points <= 4 points r >= m shared by all
+ * slots: X_io(r) = sum_j evaluate_X(primary || 0)_j L_j(r), X_mid(r) = sum_j evaluate_X(0 || aux)_j L_j(r),
+ * H(r) Z(r) = A(r) B(r) - C(r) + Z(r) (d2 A(r) + d1 B(r) - d3 + d1 d2 Z(r)) -- O(m + nnz) per slot and point.
+ * assignment: row v at assignment + v * asg_stride, S slots each; vectors: row k at ptr + k * stride[.] (NULL = not
+ * checked); H has m + 1 rows; Z [m + 1] scalars (NULL = not checked); d1, d2, d3 [S] (NULL = 0).
+ * bad[S] (may be NULL): bit k set = identity k failed (0..2 A/B/C_io, 3..5 A/B/C_mid, 6 H).
+ * Returns the number of failing slots; (size_t)-1 on bad arguments (a point below m), (size_t)-2 if Z is wrong. */
+typedef struct rso_wm_vectors {
+  const uint64_t *A_io, *B_io, *C_io, *A_mid, *B_mid, *C_mid, *H;
+  size_t stride[7]; /* words between rows, per vector in the order above */
+  const uint64_t *Z;
+} rso_wm_vectors;
+size_t rso_witness_identities(uint64_t q, size_t S, const rso_r1cs *cs, int limb, const uint64_t *assignment,
+                              size_t asg_stride, const uint64_t *d1, const uint64_t *d2, const uint64_t *d3,
+                              const rso_wm_vectors *v, const uint64_t *points, int n_points, uint8_t *bad, int threads);
+
 /* ---- provers (zk_proof_systems/groth16/groth16.tcc:70-115, rinocchio/rinocchio.tcc:75-190).
  * All vectors in ring layout [count][L][N] / encoding layout [count][L][2][K][N_enc].
  * empty[k]=1 marks a proof element the reference leaves EMPTY. */

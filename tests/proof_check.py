@@ -100,6 +100,45 @@ def check_columns(prm, cs, asg, w, cols, rng, ds=(None, None, None)):
     return None
 
 
+def check_all_columns(prm, cs, asg, w, ds=(None, None, None), limbs=None, slot0=0, nslots=None, seed=77, points=2, Z=None):
+    """EVERY (limb, slot) column of a device witness map through the identities that define its outputs
+    (oracle/rs_identities.c: C + OpenMP, O(m + nnz) per column and point; points shared by the slots of a limb).
+    asg: device assignment [n_vars][L][N]; w: dict of device vectors [rows][L][S] (S = N, or a slot range
+    [slot0, slot0 + nslots) of every limb: the compact outputs of rs_witness_map_slots); ds: device ring elements [L][N].
+    limbs: the limb indices of `prm` to check (default all).  Returns (error string or None, info dict)."""
+    from oracle import oracle as O
+    from ringsnark_amd.device import to_host
+    from tests import helpers as H
+
+    t0 = time.perf_counter()
+    ocs = H.oracle_cs(cs)
+    nslots = prm.N - slot0 if nslots is None else nslots
+    rng = np.random.RandomState(seed)
+    names = [k for k in O.IDENTITY_NAMES if w.get(k) is not None]
+    checked = 0
+    t_copy = 0.0
+    for limb in (range(prm.L) if limbs is None else limbs):
+        q = int(prm.q[limb])
+        pts = [cs.m + (int(rng.randint(1, 2**31)) * 65537 + 12345) % (q - cs.m) for _ in range(points)]
+        tc = time.perf_counter()
+        a = to_host(asg[:, limb, slot0:slot0 + nslots].contiguous())
+        vec = {k: to_host(w[k][:, limb, :].contiguous()) for k in names}
+        dv = [None if d is None else to_host(d[limb, slot0:slot0 + nslots].contiguous()) for d in ds]
+        t_copy += time.perf_counter() - tc
+        for k in names:
+            assert vec[k].shape[1] == nslots, (k, vec[k].shape, nslots)
+        n_bad, bad = O.witness_identities(q, ocs.at_slots(slot0), limb, a, vec, pts, *dv, Z=None if Z is None else Z[limb], threads=0)
+        if n_bad:
+            s = int(np.flatnonzero(bad)[0])
+            failed = [O.IDENTITY_NAMES[b] for b in range(7) if bad[s] >> b & 1]
+            return ("%d of %d columns of limb %d fail; first: slot %d, identities %s" % (n_bad, nslots, limb, slot0 + s, failed),
+                    {"columns_failed": n_bad})
+        checked += nslots
+        del a, vec
+    return None, {"columns": checked, "points_per_column": points, "vectors": names,
+                  "seconds": round(time.perf_counter() - t0, 1), "copy_seconds": round(t_copy, 1)}
+
+
 def slab_inner_product(octx, acc, key_slab, vec, limb, j, T, kinds=None, step=4096):
     """acc += the (limb, ., j) slab of <key, vec[:T]> by the CPU oracle; key_slab [W][N_enc] (W < T: tiled key)."""
     from ringsnark_amd.device import to_host
@@ -114,11 +153,13 @@ def key_slab(t, l, c, j, n_enc):
     return to_host(t[..., l, c, j, :].contiguous()).reshape(-1, n_enc)
 
 
-def groth16_check(dev, prm, cs, dcs, asg, pk, proof, m, W=None, seed=5, n_cols=4):
+def groth16_check(dev, prm, cs, dcs, asg, pk, proof, m, W=None, seed=5, n_cols=None, n_slabs=3):
     """ringGroth16 proof (groth16.tcc:70-115) computed by the device for (cs, asg, pk): (1) witness-map identities
-    on n_cols random columns + the two corner columns; (2) two full (limb, component, prime) slabs -- one of A, one
-    of C -- against the CPU oracle.  pk: dict of device tensors; its entries are RELEASED (the caller must hold no
-    other reference when memory is tight).  Returns (ok, info)."""
+    on EVERY column (n_cols = None; round 4 sampled n_cols random columns + the two corners, kept for callers that ask
+    for it); (2) n_slabs full (limb, component, prime) slabs -- A, C, B, then A, C, B again on other coordinates, ... --
+    recomputed by the CPU oracle from the (now fully checked) coefficient vectors and the key.  pk: dict of device
+    tensors; its entries are RELEASED (the caller must hold no other reference when memory is tight).
+    Returns (ok, info)."""
     import torch
 
     from ringsnark_amd.device import to_host
@@ -130,6 +171,11 @@ def groth16_check(dev, prm, cs, dcs, asg, pk, proof, m, W=None, seed=5, n_cols=4
     slabs = [("A", int(rng.randint(prm.L)), int(rng.randint(2)), int(rng.randint(prm.K))),
              ("C", int(rng.randint(prm.L)), int(rng.randint(2)), int(rng.randint(prm.K)))]
     slabs.append(("B", int(rng.randint(prm.L)), int(rng.randint(2)), int(rng.randint(prm.K))))  # drawn last: A and C keep their round-3 slabs
+    while len(slabs) < n_slabs:  # further slabs walk the limbs, components and primes
+        k = len(slabs)
+        cand = ("ACB"[k % 3], (slabs[k - 3][1] + 1) % prm.L, (slabs[k - 3][2] + 1) % 2, (slabs[k - 3][3] + 1 + k // 6) % prm.K)
+        slabs.append(cand)
+    slabs = slabs[:n_slabs]
     key = {}
     for elem, l, c, j in slabs:
         for nme in {"A": ("s_pows", "alpha"), "B": ("s_pows", "beta"), "C": ("delta_ts", "delta_mid")}[elem]:
@@ -141,8 +187,13 @@ def groth16_check(dev, prm, cs, dcs, asg, pk, proof, m, W=None, seed=5, n_cols=4
     # the prover's own witness map, re-run through the same chunking (deterministic: identical vectors)
     w = dev.witness_map(dcs, asg, want=("A_io", "A_mid", "B_io", "B_mid", "H"))
     torch.cuda.synchronize()
-    cols = [(int(rng.randint(prm.L)), int(rng.randint(prm.N))) for _ in range(n_cols)] + [(0, 0), (prm.L - 1, prm.N - 1)]
-    err = check_columns(prm, cs, asg, {k: w[k] for k in ("A_io", "A_mid", "B_io", "B_mid", "H")}, cols, rng)
+    wv = {k: w[k] for k in ("A_io", "A_mid", "B_io", "B_mid", "H")}
+    if n_cols is None:
+        err, col_info = check_all_columns(prm, cs, asg, wv, seed=seed + 1)
+        n_checked = prm.L * prm.N
+    else:
+        cols = [(int(rng.randint(prm.L)), int(rng.randint(prm.N))) for _ in range(n_cols)] + [(0, 0), (prm.L - 1, prm.N - 1)]
+        err, col_info, n_checked = check_columns(prm, cs, asg, wv, cols, rng), {}, len(cols)
     if err:
         return False, {"error": err}
     t_cols = time.perf_counter() - t_start
@@ -157,18 +208,22 @@ def groth16_check(dev, prm, cs, dcs, asg, pk, proof, m, W=None, seed=5, n_cols=4
             slab_inner_product(octx, acc, key[("delta_mid", l, c, j)], asg[cs.n_inputs:], l, j, cs.n_aux)
         if not (acc == proof_h[(elem, l, c, j)]).all():
             return False, {"error": "proof element %s slab (limb %d, component %d, prime %d) differs from the CPU oracle" % (elem, l, c, j)}
-    return True, {"kind": "SAMPLED check (not every column, not every slab)",
-                  "sample": "%d of %d witness-map columns x 2 random points; %d of %d (element, limb, component, prime) slabs of the proof" % (
-                      len(cols), prm.L * prm.N, len(slabs), 3 * prm.L * 2 * prm.K),
-                  "columns": len(cols), "points_per_column": 2,
+    all_cols = n_checked == prm.L * prm.N
+    return True, {"kind": ("every witness-map column (identities at 2 random points per limb, C + OpenMP); " if all_cols else
+                           "SAMPLED columns; ") + "%d of %d proof slabs recomputed by the CPU oracle from the checked vectors" % (
+                               len(slabs), 3 * prm.L * 2 * prm.K),
+                  "sample": "%s of %d witness-map columns x 2 random points; %d of %d (element, limb, component, prime) slabs of the proof" % (
+                      "all" if all_cols else n_checked, prm.L * prm.N, len(slabs), 3 * prm.L * 2 * prm.K),
+                  "columns": "all" if all_cols else n_checked, "columns_checked": n_checked, "points_per_column": 2,
+                  "columns_detail": col_info,
                   "slabs": ["%s[limb %d][comp %d][prime %d]" % s for s in slabs],
                   "seconds": round(time.perf_counter() - t_start, 1), "columns_seconds": round(t_cols, 1)}
 
 
-def rinocchio_check(dev, prm, cs, dcs, asg, pk, proof, m, ds=(None, None, None), seed=6, n_cols=3):
-    """Rinocchio proof {A,A',B,B',C,C',D,D',F} (rinocchio.tcc:75-190): witness-map identities on sampled columns
-    (with the ZK patch when ds are given) and, without ZK shifts on them, the slabs D' = <alpha_s_pows, H> and
-    F = <beta_prods, aux> (non-ZK) or B = <s_pows, B_mid> against the CPU oracle."""
+def rinocchio_check(dev, prm, cs, dcs, asg, pk, proof, m, ds=(None, None, None), seed=6, n_cols=None):
+    """Rinocchio proof {A,A',B,B',C,C',D,D',F} (rinocchio.tcc:75-190): witness-map identities on EVERY column
+    (n_cols = None; an integer samples that many, as round 4 did), with the ZK patch when ds are given, Z included; and,
+    without ZK shifts on them, the slabs D' = <alpha_s_pows, H> and F = <beta_prods, aux> (non-ZK) against the CPU oracle."""
     import torch
 
     from ringsnark_amd.device import to_host
@@ -179,8 +234,13 @@ def rinocchio_check(dev, prm, cs, dcs, asg, pk, proof, m, ds=(None, None, None),
     zk = ds[0] is not None
     w = dev.witness_map(dcs, asg, *ds, want=("A_mid", "B_mid", "C_mid", "H"))
     torch.cuda.synchronize()
-    cols = [(int(rng.randint(prm.L)), int(rng.randint(prm.N))) for _ in range(n_cols)] + [(prm.L - 1, prm.N - 1)]
-    err = check_columns(prm, cs, asg, {k: w[k] for k in ("A_mid", "B_mid", "C_mid", "H")}, cols, rng, ds)
+    wv = {k: w[k] for k in ("A_mid", "B_mid", "C_mid", "H")}
+    if n_cols is None:
+        err, col_info = check_all_columns(prm, cs, asg, wv, ds, seed=seed + 1, Z=w["Z"])
+        n_checked = prm.L * prm.N
+    else:
+        cols = [(int(rng.randint(prm.L)), int(rng.randint(prm.N))) for _ in range(n_cols)] + [(prm.L - 1, prm.N - 1)]
+        err, col_info, n_checked = check_columns(prm, cs, asg, wv, cols, rng, ds), {}, len(cols)
     if err:
         return False, {"error": err}
     # D' (index 7) carries no ZK shift (rinocchio.tcc:167-174 shifts A..C' only); F (index 8) only without ZK
@@ -196,7 +256,8 @@ def rinocchio_check(dev, prm, cs, dcs, asg, pk, proof, m, ds=(None, None, None),
         if not (acc == to_host(proof[idx, l, c, j].contiguous())).all():
             return False, {"error": "proof element %d slab (limb %d, component %d, prime %d) differs from the CPU oracle" % (idx, l, c, j)}
         done.append("elem%d[limb %d][comp %d][prime %d]" % (idx, l, c, j))
-    return True, {"kind": "SAMPLED check (not every column, not every slab)",
-                  "sample": "%d of %d witness-map columns; %d of %d (element, limb, component, prime) slabs of the proof" % (
-                      len(cols), prm.L * prm.N, len(done), 9 * prm.L * 2 * prm.K),
-                  "columns": len(cols), "slabs": done}
+    all_cols = n_checked == prm.L * prm.N
+    return True, {"kind": ("every witness-map column; " if all_cols else "SAMPLED columns; ") + "sampled proof slabs",
+                  "sample": "%s of %d witness-map columns; %d of %d (element, limb, component, prime) slabs of the proof" % (
+                      "all" if all_cols else n_checked, prm.L * prm.N, len(done), 9 * prm.L * 2 * prm.K),
+                  "columns": "all" if all_cols else n_checked, "columns_detail": col_info, "slabs": done}

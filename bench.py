@@ -147,6 +147,25 @@ PRIME_CLASS = {
 }
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): this process starts the N ranks -- one process per
+    GPU under torch.distributed.run, rendezvous on 127.0.0.1 -- as CHILDREN, before anything here has touched the GPU
+    (importing torch does not initialise HIP; nothing above calls into it), passes their output through (rank 0 prints the
+    one JSON line) and returns their exit code.  No exec, no retry: a failed rank means a non-zero exit."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def single_gpu_leg(preset, m, logw, steps, warmup, check):
     """The same headline statement on another preset (one GPU): time, phases, top kernels and the post-run oracle check."""
     from ringsnark_amd.device import Device
@@ -330,10 +349,14 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short Rinocchio legs at the shapes of BASELINE configs[3] / configs[4]")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))  # plain `python bench.py --gpus N`: start the N ranks, relay their line and exit code
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N ranks with torch.distributed.run --nproc-per-node N, "
+                 "or run plain `python bench.py --gpus N`, which launches them itself)" % (args.gpus, world))
     import torch.distributed as dist
 
     from ringsnark_amd import dist as RD
@@ -565,6 +588,17 @@ def main():
                        "key_window": (min(W, m + 1) if tiled else None),
                        "parallelism": "limbs%d x shards%d" % (plan.limb_groups, plan.term_shards)},
         }
+        if world > 1:
+            out["config"]["parallelism_detail"] = (
+                "%d limb group(s) x %d rank(s) per group; witness map split: %s%s; inner products by terms inside a group, one "
+                "all-reduce(SUM) of the partial encoding sums per group, one all-gather assembles the proof" % (
+                    plan.limb_groups, plan.term_shards,
+                    "none (each rank owns whole limbs and runs the fused prover)" if plan.term_shards == 1 else RD.WITNESS_SPLIT,
+                    "" if plan.term_shards == 1 or RD.WITNESS_SPLIT != "slots" else
+                    (", slot->term exchange relayed through the other groups" if RD.RELAY else ", slot->term exchange on the group's direct links")))
+            out["transport"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                                "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
+                                "devices_visible": torch.cuda.device_count(), "rehearsal_all_ranks_on_one_gpu": rehearsal}
         out["setup"] = setup
         if MEASURED:
             out["measured_peaks"] = {"hbm_copy_gbs": round(MEASURED["hbm_copy_gbs"], 1), "hbm_read_gbs": round(MEASURED["hbm_read_gbs"], 1),

@@ -44,6 +44,13 @@ static uint64_t powm(uint64_t a, uint64_t e, uint64_t q) {
   return r;
 }
 
+/* x mod q; most values met here are small (absent constant terms, sums of a few products of 44-bit residues) */
+static inline uint64_t red128(u128 x, uint64_t q) {
+  const uint64_t hi = (uint64_t)(x >> 64), lo = (uint64_t)x;
+  if (!hi) return lo < q ? lo : lo % q;
+  return (uint64_t)(x % q);
+}
+
 /* how many products of two residues < q a 128-bit accumulator (holding one reduced value) takes before a reduction */
 static size_t burst_of(uint64_t q) {
   int bits = 64 - __builtin_clzll(q);
@@ -147,8 +154,7 @@ size_t rso_witness_identities(uint64_t q, size_t S, const rso_r1cs *cs, int limb
             }
           }
           for (size_t s = 0; s < w; s++) {
-            const uint64_t e_cst = (uint64_t)(ev[2][s] % q), e_io = addm((uint64_t)(ev[0][s] % q), e_cst, q),
-                           e_aux = (uint64_t)(ev[1][s] % q);
+            const uint64_t e_cst = red128(ev[2][s], q), e_io = addm(red128(ev[0][s], q), e_cst, q), e_aux = red128(ev[1][s], q);
             for (int p = 0; p < n_points; p++) {
               lag[p][which][0][s] += (u128)e_io * Lw[p][i];
               lag[p][which][1][s] += (u128)e_aux * Lw[p][i];

@@ -10,11 +10,13 @@ Sharding:
       - the INNER PRODUCTS by terms (constraints): each rank multiplies its term range of the key,
         and the partial encoding sums are combined by ONE all-reduce(SUM) (residues < 2^50, so integer
         sums of <= 2^13 partials cannot overflow int64) followed by a reduction mod Q_j;
-      - the WITNESS MAP not at all by default (every rank of the group runs it whole and keeps the rows of its
-        term range: WITNESS_SPLIT = "replicate"), or by NTT slots (it is column parallel: rank s takes slots
-        [s N/G_t, (s+1) N/G_t) of every limb it owns, rs_witness_map_slots) followed by ONE pairwise exchange
-        (point-to-point sends over xGMI, issued as one batch) that turns the slot-sharded coefficient vectors
-        into term-sharded ones -- see WITNESS_SPLIT below for the trade.
+      - the WITNESS MAP by NTT slots by default (WITNESS_SPLIT = "slots": it is column parallel, rank s takes slots
+        [s N/G_t, (s+1) N/G_t) of every limb it owns, rs_witness_map_slots, in sub-ranges) followed per sub-range by
+        an exchange INSIDE the limb group (point-to-point sends over xGMI, one batch on the group's communicator) that
+        turns the slot-sharded coefficient vectors into term-sharded ones; or not at all (WITNESS_SPLIT = "replicate":
+        every rank of the group runs it whole and keeps the rows of its term range, no exchange).  The exchange can
+        also be RELAYED through the ranks outside the group (RINGSNARK_RELAY=1, two batches on the world group, every
+        rank of the node in lock-step): opt-in until it has run on a real multi-GPU RCCL node -- see RELAY below.
   * The proof is assembled by an all-gather over the limb axis.
 
 `backend` abstracts the arithmetic (DeviceBackend in production; the CPU tests drive the same code over
@@ -145,9 +147,12 @@ def rinocchio_key_ranges(plan: ShardPlan, m, n_aux):
 # (configs[3]): d = 0.6 P.  Two phases (first hop + first half of the direct part, then second hop + second half), each one
 # batch of point-to-point operations on the WORLD group; every rank derives the same global list of transfers from the
 # plan alone, so matching sends and receives are issued in the same order on both ends of every link.
-# UNMEASURED on hardware (no multi-GPU node): correctness is covered by the 8-rank gloo tests.
+# UNMEASURED on hardware (no multi-GPU node): correctness is covered by the 8-rank gloo tests.  For that reason the relays
+# are OPT-IN (RINGSNARK_RELAY=1): the default exchange uses the direct links of the limb group only, as ONE batch on the
+# group's own communicator -- ranks of other limb groups take no part in it, so a late or failed rank elsewhere cannot
+# hold a proof up (round-4 advisor finding).
 # ---------------------------------------------------------------------------------------------------
-RELAY = os.environ.get("RINGSNARK_RELAY", "1") != "0"
+RELAY = os.environ.get("RINGSNARK_RELAY", "0") == "1"
 
 
 def _split_parts(numel, g, n_rel):
@@ -159,12 +164,42 @@ def _split_parts(numel, g, n_rel):
     return direct // 2, direct - direct // 2, r
 
 
+class _BufferPool:
+    """Receive / relay buffers of the re-shard, allocated once per (role, size) and reused by every sub-range of every
+    proof (a configs[3] rank peaks at 236-260 of 288 GiB: fresh torch.empty calls per phase and sub-range would leave
+    the caching allocator to find multi-GiB holes there).  Two sub-ranges are in flight at a time, so keys carry the
+    sub-range parity.  Reuse is ordered by the streams: a buffer of step i is consumed (copied into the output rows on the
+    caller's stream, after it waited for the side stream) before step i + 2 is started (whose side stream first waits
+    for the caller's stream)."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, key, numel, dtype, device):
+        k = (key, str(dtype), str(device))
+        t = self.bufs.get(k)
+        if t is None or t.numel() < numel:
+            t = torch.empty(numel, dtype=dtype, device=device)
+            self.bufs[k] = t
+        return t[:numel]
+
+    def clear(self):
+        self.bufs.clear()
+
+
+_POOL = _BufferPool()
+
+
 class _Exchange:
     """One re-shard step.  msgs[x] = [(dst, numel), ...] for EVERY rank x of the world (derived from the plan; the same on
     every rank), send[i] / recv-buffers for this rank's own entries.  start() issues phase 1; finish() completes."""
 
-    def __init__(self, world, rank, groups, msgs, send_tensors, recv_tensors, like):
+    def __init__(self, world, rank, groups, msgs, send_tensors, recv_tensors, like, group=None, parity=0):
+        """group: the limb group's process group -- the communicator of the direct (un-relayed) exchange; parity: which
+        of the two in-flight sub-ranges this is (buffer reuse)."""
         self.world, self.rank, self.msgs = world, rank, msgs
+        self.pg = None if RELAY else group  # relays cross the groups: world communicator
+        self.parity = parity
         self.group_of = {}
         for g in groups:
             for x in g:
@@ -226,7 +261,7 @@ class _Exchange:
             if rcv == self.rank:
                 if kind == "hop1":
                     dev = "cpu" if self.stage else self.like.device
-                    buf = torch.empty(ln, dtype=self.like.dtype, device=dev)
+                    buf = _POOL.get(("relay", self.parity, src, idx, j), ln, self.like.dtype, dev)
                     self.relay_buf[(src, idx, j)] = buf
                 else:
                     buf = self.recv[(src, idx)][off:off + ln]
@@ -238,7 +273,9 @@ class _Exchange:
             recv_h = [(t if not t.is_cuda else torch.empty(t.shape, dtype=t.dtype), p_) for t, p_ in recvs]
         else:
             send_h, recv_h = sends, recvs
-        ops = [dist.P2POp(dist.isend, t, p_) for t, p_ in send_h] + [dist.P2POp(dist.irecv, t, p_) for t, p_ in recv_h]
+        # peers are GLOBAL ranks in both cases; with the group given the batch runs on the limb group's communicator
+        ops = ([dist.P2POp(dist.isend, t, p_, group=self.pg) for t, p_ in send_h] +
+               [dist.P2POp(dist.irecv, t, p_, group=self.pg) for t, p_ in recv_h])
         works = dist.batch_isend_irecv(ops)
 
         def wait():
@@ -273,7 +310,7 @@ class _Exchange:
 
 # How the ranks of one limb group (N > L: two ranks per limb at N = 8) share the witness map:
 #   "slots" (default)      each maps its share of the NTT slots (rs_witness_map_slots), in SUB-RANGES of slots: the compact
-#                          vectors of one sub-range are re-sharded from slots to terms (the relayed exchange above) while the
+#                          vectors of one sub-range are re-sharded from slots to terms (the exchange above; relays opt-in) while the
 #                          next sub-range is computed, and only one sub-range of compact vectors is alive at a time (the
 #                          four vectors of a configs[3] rank are 96 GiB: they would not fit beside their re-sharded form).
 #                          Headline, N = 8: 67 ms of witness map per rank + 24 ms of inner products, the 5.4 GiB exchange
@@ -306,6 +343,10 @@ def sharded_witness(backend, plan: ShardPlan, group, cs_local, assignment_local,
     With one rank per limb group this is the plain witness map; otherwise see WITNESS_SPLIT.
     defer=True: returns (out, finish); the vectors are complete only after finish() -- work that does not read them
     (the inner product over the auxiliary inputs) goes in between and overlaps the tail of the exchange."""
+    if plan.term_shards > 1 and group is not None and dist.is_initialized():
+        mine = sorted(dist.get_process_group_ranks(group))
+        if mine != sorted(plan.group_ranks()):
+            raise ValueError("sharded_witness: `group` holds ranks %s, the plan's limb group is %s" % (mine, sorted(plan.group_ranks())))
     if plan.term_shards == 1 or WITNESS_SPLIT == "replicate":
         # every rank of the limb group runs the whole witness map of its limbs and keeps the rows of its term range
         # (only those rows are written: five full-length vectors of a three-limb configs[3] rank would be 480 GiB)
@@ -369,10 +410,10 @@ def sharded_witness(backend, plan: ShardPlan, group, cs_local, assignment_local,
             for k in want:
                 lo, hi = rows_of[k][me]
                 if hi > lo and pn > 0:
-                    buf = torch.empty((hi - lo, L_local, pn), dtype=like.dtype, device=like.device)
+                    buf = _POOL.get(("recv", i & 1, x, k), (hi - lo) * L_local * pn, like.dtype, like.device).view(hi - lo, L_local, pn)
                     recv_t.append(buf)
                     pending.append((out[k], pa, pn, buf))
-        ex = _Exchange(plan.world, plan.rank, groups, msgs, send_t, recv_t, like).start()
+        ex = _Exchange(plan.world, plan.rank, groups, msgs, send_t, recv_t, like, group=group, parity=i & 1).start()
         if steps:  # the previous sub-range's exchange completes behind this sub-range's witness map
             _finish_step(steps.pop())
         steps.append((ex, pending, wc))

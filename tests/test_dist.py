@@ -220,7 +220,17 @@ def test_sharded_provers_pass_scalar_one_wires_through(tmp_path, prover, q_overr
 
 
 def test_relay_parts_cover_every_message():
-    """the split of a message into direct halves and relayed parts: sizes add up, the balance is the one DESIGN.md derives"""
+    """the split of a message into direct halves and relayed parts: sizes add up, the balance is the one DESIGN.md derives
+    (relays are opt-in, RINGSNARK_RELAY=1: switched on here for the arithmetic)"""
+    assert RD.RELAY is False and RD._split_parts(800, 2, 6) == (800, 0, 0)  # the default: direct links of the limb group only
+    RD.RELAY = True
+    try:
+        _relay_parts()
+    finally:
+        RD.RELAY = False
+
+
+def _relay_parts():
     for numel in (1, 7, 1000, 12345678):
         for g, n_rel in ((2, 6), (4, 4), (2, 0), (3, 5)):
             d1, d2, r = RD._split_parts(numel, g, n_rel)
@@ -251,13 +261,25 @@ def test_shard_plans():
         assert (cover == 1).all()
 
 
-def _gpu_worker(rank, world, port, m, q_override, tmp, prover="groth16", zk=False, split="slots"):
-    """Both ranks drive the REAL device backend on cuda:0 (gloo transports the collectives)."""
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+def _gpu_worker(rank, world, port, m, q_override, tmp, prover="groth16", zk=False, split="slots", transport="gloo", relay=False,
+                preset="toy"):
+    """Every rank drives the REAL device backend.  transport "gloo": all ranks on cuda:0, gloo moves the collectives
+    (one-GPU boxes); "nccl": rank r on cuda:r, RCCL over xGMI -- the production transport (needs >= world devices)."""
+    if transport == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world,
+                                device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dev_index = rank if transport == "nccl" else 0
     RD.WITNESS_SPLIT = split
+    RD.RELAY = relay
     try:
         from ringsnark_amd.device import Device, to_host
-        prm = P.preset("toy")
+        if preset == "toy4":  # four ring limbs (the headline's limb count) at toy scale
+            prm = P.make_params(32, [30, 30, 30, 30], 64, [40, 40, 41], ring_factor=1 << 12, name="toy4")
+        else:
+            prm = P.preset(preset)
         if q_override:
             prm = P.RingParams(prm.N, prm.q[:q_override], prm.N_enc, prm.Q)
         ctx_full = H.oracle_ctx(prm)
@@ -272,7 +294,7 @@ def _gpu_worker(rank, world, port, m, q_override, tmp, prover="groth16", zk=Fals
         plan = RD.make_plan(world, rank, prm.L)
         tg = RD.groups_for(plan)
         prm_local = P.RingParams(prm.N, [prm.q[i] for i in plan.limbs], prm.N_enc, prm.Q)
-        dev = Device(prm_local, 0)
+        dev = Device(prm_local, dev_index)
         dcs = dev.r1cs(R.wide_r1cs(m, prm_local.q))
         pk_local = {}
         ranges = (RD.groth16_key_ranges if prover == "groth16" else RD.rinocchio_key_ranges)(plan, m, cs_full.n_aux)
@@ -314,6 +336,36 @@ def test_sharded_rinocchio_on_device_backend(tmp_path, q_override, m, zk, split)
     both ranks on the real device backend, against the single-process oracle."""
     out = str(tmp_path / "result.txt")
     mp.spawn(_gpu_worker, args=(2, _free_port(), m, q_override, out, "rinocchio", zk, split), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def _rccl_world(want):
+    n = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if n < want:
+        pytest.skip("RCCL transport test: needs %d visible devices, this box has %d" % (want, n))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,preset,q_override,prover,zk,split,relay,desc", [
+    (2, "toy", None, "groth16", False, "slots", False, "limb split (N <= L): fused prover per rank, all-gather over RCCL"),
+    (2, "toy", 1, "groth16", False, "slots", False, "one limb on two ranks: slot split, direct exchange on the group communicator, all-reduce"),
+    (2, "toy", 1, "rinocchio", True, "slots", False, "Rinocchio, one limb on two ranks, ZK shifts on the reduced sums"),
+    (2, "toy", 1, "groth16", False, "replicate", False, "one limb on two ranks, no exchange"),
+    (4, "toy", None, "groth16", False, "slots", False, "2 limb groups x 2: direct exchanges of two groups at the same time"),
+    (4, "toy", None, "groth16", False, "slots", True, "2 limb groups x 2 with RELAYS through the other group (two batches on the world group)"),
+    (8, "toy4", None, "groth16", False, "slots", False, "the headline's N = 8 plan: 4 limb groups x 2"),
+    (8, "toy4", None, "groth16", False, "slots", True, "the headline's N = 8 plan with relays"),
+    (8, "toy", None, "rinocchio", True, "slots", True, "configs[3]'s plan shape: 2 limb groups x 4, relays through the other group"),
+])
+def test_sharded_provers_over_rccl(tmp_path, world, preset, q_override, prover, zk, split, relay, desc):
+    """The production transport: one process per GPU, torch.distributed backend "nccl" (= RCCL over xGMI).  Skipped on
+    boxes with fewer devices than ranks; on a multi-GPU lease these are the first things that meet RCCL: all-gather,
+    all-reduce on a limb group, batch_isend_irecv on the group communicator and -- opt-in -- the relayed exchange on the
+    world group.  Every sharded proof must equal the one-process oracle proof bit for bit."""
+    _rccl_world(world)
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_gpu_worker, args=(world, _free_port(), 9 if world <= 2 else 12, q_override, out, prover, zk, split, "nccl", relay, preset),
+             nprocs=world, join=True)
     assert open(out).read() == "ok"
 
 

@@ -201,7 +201,7 @@ def single_gpu_leg(preset, m, logw, steps, warmup, check):
            "phase_ms": {"witness_map": round(timings["witness_ms"], 3), "msm": round(timings["msm_ms"], 3)},
            "kernels": [{"name": k["name"], "ms": round(k["total_ms"], 2), "launches": k["launches"]} for k in stats[:6]]}
     if check:
-        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk, proof, m, window or None, n_slabs=6)
+        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk, proof, m, window or None, n_slabs=3)
         out["check"] = dict(info, ok=ok)
     del proof, asg, pk, dcs, dev
     torch.cuda.empty_cache()
@@ -383,7 +383,11 @@ def main():
     dev = Device(prm_local, local_rank)
     setup["context_ms"] = round((time.perf_counter() - t_s) * 1e3, 1)  # rs_ctx_create: transform tables of every prime, index map
     if world == 1:
-        MEASURED.update(dev.measure_peaks())
+        try:
+            MEASURED.update(dev.measure_peaks())
+        except Exception as e:  # e.g. the two 2 GiB buffers do not fit: the line then carries no measured denominators
+            setup["measured_peaks_error"] = str(e)
+            torch.cuda.empty_cache()
     cs = R.chain_r1cs(m, prm_local.q)
     t_s = time.perf_counter()
     dcs = dev.r1cs(cs)
@@ -550,7 +554,7 @@ def main():
     check = None
     if world == 1 and not args.no_check:
         pk.clear()  # the check releases the key (pk1 holds the last references) before it re-runs the witness map
-        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk1, proof[0], m, window1 or pk1["s_pows"].shape[0], n_slabs=6)
+        ok, info = post_run_check(dev, prm, cs, dcs, asg, pk1, proof[0], m, window1 or pk1["s_pows"].shape[0], n_slabs=3)
         check = dict(info, ok=ok)
 
     # ---- the same statement on the ring primes the reference's own recipe yields (preset C3R), one GPU

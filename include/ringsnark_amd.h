@@ -38,6 +38,7 @@ extern "C" {
 #define RS_ERR_HIP 2            /* a HIP runtime call failed */
 #define RS_ERR_UNSUPPORTED 3    /* valid in the reference, not built here (message says what) */
 #define RS_ERR_NOT_INVERTIBLE 4 /* "element is not invertible in ring" (seal_ring.tcc:93,98) */
+#define RS_ERR_NOISE 5          /* decoding_error: "ciphertext #i has remaining noise budget 0 <= 0" (seal_ring.tcc:446-454) */
 
 #define RS_MAX_L 8
 #define RS_MAX_K 12
@@ -100,9 +101,17 @@ int rs_enc_add(rs_ctx *ctx, uint64_t *d_dst, const uint64_t *d_a, const uint64_t
 /* EncodingElem::decode (ringsnark/seal/seal_ring.tcc:435-477; called by the verifiers at
  * groth16.tcc:118-121, rinocchio.tcc:203-214): BGV decryption (c0 + c1*s, coefficient form, centred
  * composition mod Q, reduction mod t = q_i) + BatchEncoder::decode.  d_sk: secret key [K][N_enc] in NTT
- * form; d_enc [count][L][2][K][N_enc]; d_rings [count][L][N].  The noise-budget check of the
- * reference (seal_ring.tcc:443-451) is a debugging aid and is not reproduced.  Synchronises. */
+ * form; d_enc [count][L][2][K][N_enc]; d_rings [count][L][N].
+ * The reference's guard (seal_ring.tcc:446-454) is reproduced: a ciphertext whose invariant noise budget is <= 0 -- the
+ * encoding parameters were too small, or the prover spent more budget than they allow -- makes the call return
+ * RS_ERR_NOISE with the reference's message ("ciphertext #i has remaining noise budget 0 <= 0"; i = the ring limb, as
+ * there; the adapters throw decoding_error).  Every decoding is still written (they are garbage for the ciphertexts
+ * that failed), so a caller that wants them regardless can ignore that one status.  Synchronises. */
 int rs_enc_decode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size_t count, uint64_t *d_rings, rs_stream stream);
+/* Decryptor::invariant_noise_budget (SEAL 4.x, scheme bgv; the quantity the guard above tests, seal_ring.tcc:446) of
+ * every ciphertext: h_budget[count][L] = max(0, bit_count(Q) - significant_bits(|| c0 + c1 s mod Q ||_inf, centred) - 1).
+ * Computed inside the decryption (the centred CRT composition already holds the value).  Synchronises. */
+int rs_enc_noise_budget(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size_t count, int *h_budget, rs_stream stream);
 /* EncodingElem::encode (ringsnark/seal/seal_ring.tcc:324-359; called by the generators at
  * groth16.tcc:57-62, rinocchio.tcc:48-61): BatchEncoder::encode + symmetric BGV encryption
  * c1 = a, c0 = -(a*s + t*e) + m.  Element k draws its randomness from the stream `seed + k`
@@ -142,6 +151,8 @@ int rs_inner_product(rs_ctx *ctx, const uint64_t *d_encs, const uint64_t *d_ring
  * one pass.  Vectors of one group are summed AFTER the centred lift, which is bit-identical to
  * adding their separate inner products (the ciphertext ring is distributive; DESIGN.md "MSM").
  *   d_out[c][g] = sum_{v in group g} sum_{t < vec[v].T} d_crs[c][t] * vec[v].d_coeff[t]      */
+/* ZERO-INITIALISE the struct (`rs_msm_vec v = {0}`): slot_const was added (rs_version() >= 101) where callers of version
+ * 100 had tail padding; values other than 0 and 1 are rejected with RS_ERR_INVALID. */
 typedef struct rs_msm_vec {
   const uint64_t *d_coeff; /* [T][L][N]; slot_const: [T][L] */
   const uint8_t *h_kinds;  /* host [T] or NULL */
@@ -217,7 +228,13 @@ int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, ui
  * scalars (coefficients_for_Z).  d1,d2,d3: ring elements [L][N] or all NULL (zero).  Any output
  * pointer may be NULL to skip it.  Exact quasi-linear algorithm: cyclic transforms of length 2*next_pow2(m) when
  * every q_i has the 2-adicity for them (q_i = 1 mod 4*next_pow2(m)), otherwise block convolutions over the largest
- * transform the primes support (same results). */
+ * transform the primes support (same results).
+ * PRECONDITION when C_mid / C_io is requested at multi-pass sizes (M > 2^14, full-length transforms): the assignment
+ * SATISFIES the constraint system.  H is then recovered from values on a coset, H = (A B - C) / Z point by point, which
+ * equals the reference's quotient (util/polynomials.tcc:76-81 drops the remainder) only when Z divides A B - C; for an
+ * unsatisfied assignment that form returns a different polynomial than the long division (which the other shapes, and
+ * every call that does not ask for C, still compute: quo(A B - C, Z) = quo(A B, Z) for any assignment).  The reference
+ * asserts satisfaction before proving (r1cs_to_qrp.tcc:156); rs_rinocchio_prove inherits the precondition. */
 int rs_witness_map(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_assignment, const uint64_t *d_d1,
                    const uint64_t *d_d2, const uint64_t *d_d3, uint64_t *d_A_io, uint64_t *d_B_io,
                    uint64_t *d_C_io, uint64_t *d_A_mid, uint64_t *d_B_mid, uint64_t *d_C_mid, uint64_t *d_H,

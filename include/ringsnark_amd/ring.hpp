@@ -43,9 +43,17 @@ struct Params {
   std::vector<uint64_t> q, Q;
 };
 
+// EncodingElem::decoding_error (seal/seal_ring.hpp:233-238): thrown by decode when a ciphertext's noise budget is spent
+class decoding_error : public std::invalid_argument {
+ public:
+  explicit decoding_error() : std::invalid_argument("decoding error") {}
+  explicit decoding_error(const std::string &msg) : std::invalid_argument("decoding error: " + msg) {}
+};
+
 inline void check(int status) {
   if (status == RS_OK) return;
   if (status == RS_ERR_NOT_INVERTIBLE) throw std::invalid_argument("element is not invertible in ring");
+  if (status == RS_ERR_NOISE) throw decoding_error(rs_last_error());
   throw std::runtime_error(std::string("librs_hip: ") + rs_last_error());
 }
 
@@ -489,6 +497,7 @@ class EncodingElem {
   // SecretKey here is the [K][N_enc] NTT-form key words; `seed` replaces SEAL's process-global PRNG.
   using SecretKey = std::vector<uint64_t>;
   using PublicKey = std::nullptr_t;  // seal_ring.hpp:230-231: affine combinations need no public key material
+  using decoding_error = ::ringsnark::amd::decoding_error;  // seal_ring.hpp:233-238 (a member class there too)
   // seal_ring.hpp:254-264: one secret key per encoding context.  All L contexts here share N_enc and the data
   // primes Q_j, so ONE ternary secret in NTT form [K][N_enc] serves them all (as rs_enc_encode / rs_enc_decode
   // expect); the ternary coefficients come from Context::prng(), the transform runs on the device.

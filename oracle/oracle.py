@@ -45,7 +45,7 @@ class R1CS(C.Structure):
 
 
 class WMVectors(C.Structure):
-    _fields_ = [(k, u64p) for k in ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")] + [("stride", C.c_size_t * 7), ("Z", u64p)]
+    _fields_ = [(k, u64p) for k in ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")] + [("stride", C.c_size_t * 7), ("Z", u64p), ("blocked", C.c_int)]
 
 
 class Groth16PK(C.Structure):
@@ -108,6 +108,8 @@ def lib():
         L.rso_decrypt.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p]
         L.rso_enc_encode.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, u64p]
         L.rso_enc_decode.argtypes = [C.c_void_p, u64p, u64p, u64p]
+        L.rso_noise_budget.argtypes = [C.c_void_p, C.c_int, u64p, u64p]
+        L.rso_enc_decode_checked.argtypes = [C.c_void_p, u64p, u64p, u64p]
         L.rso_interpolate.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, u64p, u64p]
         L.rso_interpolate_nodes.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, u64p, u64p, u64p]
         L.rso_eval.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, u64p, C.c_uint64, u64p]
@@ -349,6 +351,18 @@ class Ctx:
         lib().rso_enc_decode(self.h, p64(sk), p64(np.ascontiguousarray(enc)), p64(out))
         return out
 
+    def noise_budget(self, sk, enc):
+        """Decryptor::invariant_noise_budget of the L ciphertexts of one encoding element (bits; 0 = spent)."""
+        enc = np.ascontiguousarray(enc).reshape(self.L, self.ct_words)
+        return [int(lib().rso_noise_budget(self.h, i, p64(sk), p64(enc[i]))) for i in range(self.L)]
+
+    def enc_decode_checked(self, sk, enc):
+        """decode with the reference's guard (seal_ring.tcc:443-454): (ring, -1) or (None, i) for the first ciphertext
+        #i whose noise budget is spent (the reference throws decoding_error there)."""
+        out = np.empty(self.ring_shape(), dtype=np.uint64)
+        i = int(lib().rso_enc_decode_checked(self.h, p64(sk), p64(np.ascontiguousarray(enc)), p64(out)))
+        return (out, -1) if i < 0 else (None, i)
+
     def __del__(self):
         if getattr(self, "h", None):
             lib().rso_ctx_destroy(self.h)
@@ -487,7 +501,7 @@ def witness_map(q, cs, limb, assignment, d1=None, d2=None, d3=None, threads=1):
 IDENTITY_NAMES = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
 
 
-def witness_identities(q, cs, limb, assignment, vectors, points, d1=None, d2=None, d3=None, Z=None, threads=0):
+def witness_identities(q, cs, limb, assignment, vectors, points, d1=None, d2=None, d3=None, Z=None, threads=0, blocked=False):
     """COMPLETE check of a witness map computed elsewhere (rs_identities.c): one limb, EVERY slot.
     assignment [n_vars][S]; vectors: dict name -> [m][S] ([m+1][S] for H) -- arrays may be strided views of
     [rows][L][N] host arrays sliced to one limb (row stride taken from the array, slots contiguous); points: <= 4 integers in [m, q); d1..d3 [S]; Z [m+1].
@@ -496,15 +510,25 @@ def witness_identities(q, cs, limb, assignment, vectors, points, d1=None, d2=Non
         assert a.dtype == np.uint64 and a.ndim == 2 and a.strides[1] == 8 and a.strides[0] % 8 == 0, (a.dtype, a.shape, a.strides)
         return a.ctypes.data_as(u64p), a.strides[0] // 8
 
-    S = assignment.shape[1]
-    ap, astride = rows(assignment)
     v = WMVectors()
+    if blocked:  # blocked=True: every array is C-contiguous [S/32][rows][32] (32 slots of a block together, row after row)
+        S = assignment.shape[0] * 32
+        assert assignment.dtype == np.uint64 and assignment.flags["C_CONTIGUOUS"] and assignment.shape[1:] == (cs.n_vars, 32), assignment.shape
+        ap, astride = assignment.ctypes.data_as(u64p), 0
+        v.blocked = 1
+    else:
+        S = assignment.shape[1]
+        ap, astride = rows(assignment)
     for k, name in enumerate(IDENTITY_NAMES):
         a = vectors.get(name)
         if a is None:
             continue
-        assert a.shape == (cs.m + (name == "H"), S), (name, a.shape)
-        ptr, v.stride[k] = rows(a)
+        if blocked:
+            assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"] and a.shape == (S // 32, cs.m + (name == "H"), 32), (name, a.shape)
+            ptr = a.ctypes.data_as(u64p)
+        else:
+            assert a.shape == (cs.m + (name == "H"), S), (name, a.shape)
+            ptr, v.stride[k] = rows(a)
         setattr(v, name, ptr)
     if Z is not None:
         Z = np.ascontiguousarray(Z, dtype=np.uint64)

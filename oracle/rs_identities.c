@@ -94,6 +94,7 @@ size_t rso_witness_identities(uint64_t q, size_t S, const rso_r1cs *cs, int limb
                               const rso_wm_vectors *v, const uint64_t *points, int n_points, uint8_t *bad, int threads) {
   const size_t m = cs->m, ni = cs->n_inputs;
   if (n_points < 1 || n_points > RSI_MAXP || m < 1) return (size_t)-1;
+  if (v->blocked && S % RSI_BLOCK) return (size_t)-1;
   if (m >= q) return (size_t)-1; /* the nodes 0..m-1 must be distinct residues */
   const size_t burst = burst_of(q);
   uint64_t *Lw[RSI_MAXP], *rp[RSI_MAXP], Zr[RSI_MAXP];
@@ -117,6 +118,10 @@ size_t rso_witness_identities(uint64_t q, size_t S, const rso_r1cs *cs, int limb
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nt) reduction(+ : n_bad)
   for (long long blk = 0; blk < n_blocks; blk++) {
     const size_t lo = (size_t)blk * RSI_BLOCK, w = (S - lo < RSI_BLOCK) ? S - lo : RSI_BLOCK;
+    /* blocked layout: the 32 slots of a block are contiguous row after row -- [S/32][rows][32] -- so a block streams
+     * through memory instead of touching one page per row */
+    const uint64_t *a_base = v->blocked ? assignment + (size_t)blk * cs->n_vars * RSI_BLOCK : assignment + lo;
+    const size_t a_stride = v->blocked ? RSI_BLOCK : asg_stride;
     /* Lagrange sums of the three kinds of evaluation of a, b, c -- io: constant + primary terms, aux: auxiliary
      * terms, cst: constant terms (the reference's io AND mid passes both see index-0 terms, :175-201) */
     u128 lag[RSI_MAXP][3][3][RSI_BLOCK];
@@ -136,7 +141,7 @@ size_t rso_witness_identities(uint64_t q, size_t S, const rso_r1cs *cs, int limb
           for (uint32_t e = rowp[i]; e < rowp[i + 1]; e++) {
             const uint32_t c = col[e];
             const int kind = c == 0 ? 2 : ((size_t)(c - 1) < ni ? 0 : 1);
-            const uint64_t *a = c ? assignment + (size_t)(c - 1) * asg_stride + lo : NULL;
+            const uint64_t *a = c ? a_base + (size_t)(c - 1) * a_stride : NULL;
             if (pidx && pidx[e] >= 0) { /* coefficient = a general ring element (rs_oracle.h, rso_r1cs) */
               const uint64_t *pc = cs->ptab + ((size_t)pidx[e] * cs->ptab_L + (size_t)limb) * cs->ptab_N + cs->ptab_slot0 + lo;
               for (size_t s = 0; s < w; s++) ev[kind][s] += a ? (u128)a[s] * (pc[s] % q) : (u128)(pc[s] % q);
@@ -165,7 +170,7 @@ size_t rso_witness_identities(uint64_t q, size_t S, const rso_r1cs *cs, int limb
       }
       for (int k = 0; k < 7; k++) {
         if (!vec[k] || (i == m && k != 6)) continue; /* H has m + 1 rows (:225-253), the others m */
-        const uint64_t *row = vec[k] + i * v->stride[k] + lo;
+        const uint64_t *row = v->blocked ? vec[k] + ((size_t)blk * (m + (k == 6)) + i) * RSI_BLOCK : vec[k] + i * v->stride[k] + lo;
         for (int p = 0; p < n_points; p++) {
           const uint64_t rk = rp[p][i];
           for (size_t s = 0; s < w; s++) hor[p][k][s] += (u128)row[s] * rk;

@@ -656,6 +656,92 @@ void rso_decrypt(const rso_ctx *c, int limb, const uint64_t *sk, const uint64_t 
   }
   free(v);
 }
+/* SEAL 4.x Decryptor::invariant_noise_budget for scheme_type::bgv (un-vendored dependency; its published algorithm --
+ * PARITY UNPINNED like the rest of rows a4-a9): noise polynomial = c0 + c1 s mod Q in coefficient form (for BGV that is
+ * m + t e; the multiplication by the plain modulus is the BFV branch), CRT-composed, infinity norm over the centred
+ * representatives, budget = max(0, bit_count(Q) - significant_bits(norm) - 1).  The composition here is an explicit
+ * multi-word integer (K <= 12 words), not the digit comparison the device library uses. */
+#define RSO_BIGW (RSO_MAXK + 2)
+static void big_muladd(uint64_t *w, uint64_t m, uint64_t a) {
+  u128 carry = a;
+  for (int i = 0; i < RSO_BIGW; i++) {
+    u128 cur = (u128)w[i] * m + carry;
+    w[i] = (uint64_t)cur;
+    carry = cur >> 64;
+  }
+}
+static int big_cmp(const uint64_t *a, const uint64_t *b) {
+  for (int i = RSO_BIGW - 1; i >= 0; i--)
+    if (a[i] != b[i]) return a[i] > b[i] ? 1 : -1;
+  return 0;
+}
+static void big_sub(uint64_t *d, const uint64_t *a, const uint64_t *b) { /* d = a - b, a >= b */
+  uint64_t borrow = 0;
+  for (int i = 0; i < RSO_BIGW; i++) {
+    u128 cur = (u128)a[i] - b[i] - borrow;
+    d[i] = (uint64_t)cur;
+    borrow = (uint64_t)(cur >> 64) & 1;
+  }
+}
+static int big_bits(const uint64_t *w) {
+  for (int i = RSO_BIGW - 1; i >= 0; i--)
+    if (w[i]) return 64 * i + 64 - __builtin_clzll(w[i]);
+  return 0;
+}
+int rso_noise_budget(const rso_ctx *c, int limb, const uint64_t *sk, const uint64_t *ct) {
+  (void)limb; /* the budget does not depend on the plain modulus for BGV */
+  size_t n = c->N_enc;
+  int K = c->K;
+  uint64_t *v = (uint64_t *)malloc(sizeof(uint64_t) * K * n);
+  for (int j = 0; j < K; j++) {
+    uint64_t Q = c->Q[j];
+    for (size_t x = 0; x < n; x++)
+      v[(size_t)j * n + x] = addmod(ct[(size_t)j * n + x], rso_mulmod(ct[((size_t)K + j) * n + x], sk[(size_t)j * n + x], Q), Q);
+    rso_ntt_inv(c->coeff[j], v + (size_t)j * n);
+  }
+  uint64_t Qbig[RSO_BIGW] = {1}, half[RSO_BIGW], norm[RSO_BIGW] = {0};
+  for (int k = 0; k < K; k++) big_muladd(Qbig, c->Q[k], 0);
+  { /* half = floor(Q / 2) */
+    uint64_t carry = 0;
+    for (int i = RSO_BIGW - 1; i >= 0; i--) {
+      half[i] = (Qbig[i] >> 1) | (carry << 63);
+      carry = Qbig[i] & 1;
+    }
+  }
+  uint64_t prod_inv[RSO_MAXK];
+  for (int k = 1; k < K; k++) {
+    uint64_t prod = 1;
+    for (int i = 0; i < k; i++) prod = rso_mulmod(prod, c->Q[i] % c->Q[k], c->Q[k]);
+    prod_inv[k] = rso_invmod(prod, c->Q[k]);
+  }
+  for (size_t x = 0; x < n; x++) {
+    uint64_t d[RSO_MAXK];
+    d[0] = v[x];
+    for (int k = 1; k < K; k++) { /* Garner digits, as rso_decrypt */
+      uint64_t Qk = c->Q[k], acc = 0;
+      for (int i = k - 1; i >= 0; i--) acc = addmod(rso_mulmod(acc, c->Q[i] % Qk, Qk), d[i] % Qk, Qk);
+      d[k] = rso_mulmod(submod(v[(size_t)k * n + x], acc, Qk), prod_inv[k], Qk);
+    }
+    uint64_t val[RSO_BIGW] = {0}, mag[RSO_BIGW];
+    for (int k = K - 1; k >= 0; k--) big_muladd(val, c->Q[k], d[k]); /* val = d0 + Q0 (d1 + Q1 (...)) */
+    if (big_cmp(val, half) > 0)
+      big_sub(mag, Qbig, val);
+    else
+      memcpy(mag, val, sizeof(mag));
+    if (big_cmp(mag, norm) > 0) memcpy(norm, mag, sizeof(norm));
+  }
+  free(v);
+  int diff = big_bits(Qbig) - big_bits(norm) - 1;
+  return diff > 0 ? diff : 0;
+}
+/* EncodingElem::decode WITH the guard of seal_ring.tcc:443-454: returns -1 when every ciphertext has budget left (ring
+ * = the decoding), else the index i of the first "ciphertext #i has remaining noise budget 0 <= 0" (decoding_error). */
+int rso_enc_decode_checked(const rso_ctx *c, const uint64_t *sk, const uint64_t *enc, uint64_t *ring) {
+  for (int i = 0; i < c->L; i++)
+    if (rso_noise_budget(c, i, sk, enc + (size_t)i * rso_ct_words(c)) <= 0) return i;
+  rso_enc_decode(c, sk, enc, ring);
+  return -1;
+}
 /* EncodingElem::encode for one element, seal_ring.tcc:349-356. */
 void rso_enc_encode(const rso_ctx *c, const uint64_t *sk, const uint64_t *ring, uint64_t seed,
                     uint64_t *enc) {
@@ -667,7 +753,7 @@ void rso_enc_encode(const rso_ctx *c, const uint64_t *sk, const uint64_t *ring, 
   }
   free(plain);
 }
-/* EncodingElem::decode, seal_ring.tcc:435-477 (noise-budget check omitted). */
+/* EncodingElem::decode, seal_ring.tcc:435-477, without the guard (rso_enc_decode_checked has it). */
 void rso_enc_decode(const rso_ctx *c, const uint64_t *sk, const uint64_t *enc, uint64_t *ring) {
   uint64_t *plain = (uint64_t *)malloc(sizeof(uint64_t) * c->N_enc);
   for (int i = 0; i < c->L; i++) {

@@ -125,6 +125,10 @@ void rso_decrypt(const rso_ctx *c, int limb, const uint64_t *sk, const uint64_t 
 void rso_enc_encode(const rso_ctx *c, const uint64_t *sk, const uint64_t *ring, uint64_t seed,
                     uint64_t *enc);
 void rso_enc_decode(const rso_ctx *c, const uint64_t *sk, const uint64_t *enc, uint64_t *ring);
+/* Decryptor::invariant_noise_budget (SEAL 4.x, bgv) of one ciphertext, and decode with the reference's guard
+ * (seal_ring.tcc:443-454): -1 = decoded, i >= 0 = "ciphertext #i has remaining noise budget 0 <= 0". */
+int rso_noise_budget(const rso_ctx *c, int limb, const uint64_t *sk, const uint64_t *ct);
+int rso_enc_decode_checked(const rso_ctx *c, const uint64_t *sk, const uint64_t *enc, uint64_t *ring);
 
 /* ---- generic ring algebra over one prime q, S independent slots, arrays [n][S] ---- */
 /* util/polynomials.tcc:10-43 with x_j = j (util/evaluation_domain.tcc:8-13). */
@@ -194,6 +198,8 @@ typedef struct rso_wm_vectors {
   const uint64_t *A_io, *B_io, *C_io, *A_mid, *B_mid, *C_mid, *H;
   size_t stride[7]; /* words between rows, per vector in the order above */
   const uint64_t *Z;
+  int blocked; /* 1: assignment and vectors are laid out [S/32][rows][32] (S a multiple of 32; strides unused): a block of
+                  32 slots streams through memory row after row */
 } rso_wm_vectors;
 size_t rso_witness_identities(uint64_t q, size_t S, const rso_r1cs *cs, int limb, const uint64_t *assignment,
                               size_t asg_stride, const uint64_t *d1, const uint64_t *d2, const uint64_t *d3,

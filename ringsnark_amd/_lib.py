@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librs_hip.so")
 LIB_PATH = os.environ.get("RINGSNARK_AMD_LIB", LIB_PATH)  # developer override: A/B builds of the same ABI
 
-RS_OK, RS_ERR_INVALID, RS_ERR_HIP, RS_ERR_UNSUPPORTED, RS_ERR_NOT_INVERTIBLE = 0, 1, 2, 3, 4
+RS_OK, RS_ERR_INVALID, RS_ERR_HIP, RS_ERR_UNSUPPORTED, RS_ERR_NOT_INVERTIBLE, RS_ERR_NOISE = 0, 1, 2, 3, 4, 5
 RS_MOD_PLAIN, RS_MOD_COEFF = 0, 1
 RS_KIND_POLY, RS_KIND_ONE = 0, 2
 RS_EVAL_FULL, RS_EVAL_IO, RS_EVAL_MID = 0, 1, 2
@@ -85,6 +85,7 @@ SIGNATURES = {
     "rs_enc_deserialize": (C.c_int, [vp, vp, C.c_size_t, vp, u8p, C.c_size_t, C.POINTER(C.c_size_t), vp]),
     "rs_instance_map_eval": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "rs_enc_decode": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp]),
+    "rs_enc_noise_budget": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(C.c_int), vp]),
     "rs_enc_encode": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint64, vp, vp]),
     "rs_inner_product": (C.c_int, [vp, vp, vp, u8p, C.c_size_t, vp, C.POINTER(C.c_size_t), vp]),
     "rs_msm": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_size_t, C.c_size_t, C.POINTER(MsmVec), C.c_int, C.c_int, vp,

@@ -56,14 +56,46 @@ struct CrtLimb {
   double Q_mod_t;
 };
 
+// ---- the noise guard of EncodingElem::decode (seal_ring.tcc:443-454) ----------------------------------------------
+// SEAL 4.x Decryptor::invariant_noise_budget, scheme bgv (un-vendored dependency; its published algorithm): the noise
+// polynomial is c0 + c1 s mod Q in coefficient form -- for BGV that IS m + t e, no scaling by the plain modulus (the
+// multiplication by t is the BFV branch) -- CRT-composed, its infinity norm taken on the centred representatives, and
+//     budget = max(0, bit_count(Q) - significant_bits(norm) - 1).
+// The composition already runs here in mixed radix (digits d_k, value = d_0 + Q_0 (d_1 + Q_1 (...))), so the bit length
+// of a centred magnitude is found WITHOUT big integers: thr[b][.] holds the digits of 2^b - 1 for b < bit_count(Q)
+// (host, exact), |v| >= 2^b is a lexicographic digit comparison, and significant_bits(|v|) = #{b : |v| >= 2^b} by
+// binary search (the predicate is monotone).  For v > floor(Q/2) the magnitude is Q - v = (Q - 1 - v) + 1 and
+// Q - 1 - v has digits Q_k - 1 - d_k.
+template <class T>
+__device__ __forceinline__ int magnitude_bits(const T *d, bool upper, const T *Qk, const T *__restrict__ thr, int tb, int K) {
+  T w[RS_MAX_K];
+  for (int k = 0; k < K; k++) w[k] = upper ? Qk[k] - (T)1 - d[k] : d[k];
+  int lo = 0, hi = tb;  // lo = number of b with |v| >= 2^b
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const T *t = thr + (size_t)mid * RS_MAX_K;
+    int cmp = 0;
+    for (int k = K - 1; k >= 0 && cmp == 0; k--) cmp = w[k] > t[k] ? 1 : (w[k] < t[k] ? -1 : 0);
+    // lower half: |v| = w >= 2^b  <=>  w > 2^b - 1;   upper half: |v| = w + 1 >= 2^b  <=>  w >= 2^b - 1
+    if (upper ? cmp >= 0 : cmp > 0) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 // centred CRT composition mod t, forward NTT mod t, slot gather.  grid (count * L)
 __global__ void __launch_bounds__(1024)
 crt_decode_kernel(const double *__restrict__ V, uint64_t *__restrict__ rings, int N, int L, int logn, CrtConsts cc,
                   const CrtLimb *__restrict__ limbs, const uint32_t *__restrict__ index_map,
-                  const NttTable *__restrict__ plain_tabs) {
+                  const NttTable *__restrict__ plain_tabs, const double *__restrict__ thr, int tb, int *__restrict__ noise_bits) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_bits;
   double *s = reinterpret_cast<double *>(smem);
   const int n = 1 << logn, K = cc.K;
+  if (threadIdx.x == 0) s_bits = 0;
+  __syncthreads();
+  int my_bits = 0;
+  double Qk[RS_MAX_K];
+  for (int k = 0; k < K; k++) Qk[k] = cc.Qmod[k].p;
   const size_t el = blockIdx.x;
   const int limb = (int)(el % (size_t)L);
   const CrtLimb cl = limbs[limb];
@@ -85,12 +117,16 @@ crt_decode_kernel(const double *__restrict__ V, uint64_t *__restrict__ rings, in
         upper = d[k] > cc.half[k];
         break;
       }
+    my_bits = max(my_bits, magnitude_bits<double>(d, upper, Qk, thr, tb, K));
     double r = 0.0;
     for (int k = K - 1; k >= 0; k--) r = reduce(mulmod(r, cl.Qk_mod_t[k], tmod) + reduce(d[k], tmod), tmod);
     if (upper) r -= cl.Q_mod_t;
     s[pidx(x)] = reduce(r, tmod);
   }
+  atomicMax(&s_bits, my_bits);
   __syncthreads();
+  if (threadIdx.x == 0) noise_bits[el] = s_bits;  // significant bits of the infinity norm of this ciphertext's noise polynomial
+  if (!rings) return;                              // rs_enc_noise_budget: the budget only
   lds_ntt_fwd(s, logn, tab.d_tw, 1, tmod, tab.fwd_red_mask);  // BatchEncoder::decode
   uint64_t *dst = rings + el * (size_t)N;
   for (int i = threadIdx.x; i < N; i += blockDim.x) dst[i] = to_u64(canon(s[pidx((int)index_map[i])], tmod));
@@ -199,10 +235,16 @@ struct CrtLimbI {
 __global__ void __launch_bounds__(1024)
 crt_decode_kernel_int(const uint64_t *__restrict__ V, uint64_t *__restrict__ rings, int N, int L, int logn, CrtConstsI cc,
                       const CrtLimbI *__restrict__ limbs, const uint32_t *__restrict__ index_map,
-                      const NttTableI *__restrict__ plain_tabs) {
+                      const NttTableI *__restrict__ plain_tabs, const uint64_t *__restrict__ thr, int tb, int *__restrict__ noise_bits) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_bits;
   uint64_t *s = reinterpret_cast<uint64_t *>(smem);
   const int n = 1 << logn, K = cc.K;
+  if (threadIdx.x == 0) s_bits = 0;
+  __syncthreads();
+  int my_bits = 0;
+  uint64_t Qk[RS_MAX_K];
+  for (int k = 0; k < K; k++) Qk[k] = cc.Qmod[k].p;
   const size_t el = blockIdx.x;
   const int limb = (int)(el % (size_t)L);
   const CrtLimbI cl = limbs[limb];
@@ -224,12 +266,16 @@ crt_decode_kernel_int(const uint64_t *__restrict__ V, uint64_t *__restrict__ rin
         upper = d[k] > cc.half[k];
         break;
       }
+    my_bits = max(my_bits, magnitude_bits<uint64_t>(d, upper, Qk, thr, tb, K));
     uint64_t r = 0;
     for (int k = K - 1; k >= 0; k--) r = addm(mulmod(r, cl.Qk_mod_t[k], tmod), d[k] % tmod.p, tmod);
     if (upper) r = subm(r, cl.Q_mod_t, tmod);
     s[pidx(x)] = r;
   }
+  atomicMax(&s_bits, my_bits);
   __syncthreads();
+  if (threadIdx.x == 0) noise_bits[el] = s_bits;
+  if (!rings) return;
   lds_ntt_fwd(s, logn, tab.d_tw, 1, tmod, 0u);  // BatchEncoder::decode
   uint64_t *dst = rings + el * (size_t)N;
   for (int i = threadIdx.x; i < N; i += blockDim.x) dst[i] = s[pidx((int)index_map[i])];
@@ -328,17 +374,109 @@ struct TabCopies {
   }
 };
 
+// Host side of the noise guard: bit_count(Q) and the mixed-radix digits (radices Q_0, Q_1, ...) of 2^b - 1 for every
+// b < bit_count(Q), by exact multi-word arithmetic (K <= 12 words of 62 bits).
+struct BigU {
+  uint64_t w[RS_MAX_K + 2];
+  BigU() { memset(w, 0, sizeof(w)); }
+  void mul_add(uint64_t m, uint64_t a) {  // this = this * m + a
+    unsigned __int128 carry = a;
+    for (int i = 0; i < RS_MAX_K + 2; i++) {
+      const unsigned __int128 cur = (unsigned __int128)w[i] * m + carry;
+      w[i] = (uint64_t)cur;
+      carry = cur >> 64;
+    }
+  }
+  uint64_t divmod(uint64_t dv) {  // this /= dv, returns the remainder
+    unsigned __int128 rem = 0;
+    for (int i = RS_MAX_K + 1; i >= 0; i--) {
+      const unsigned __int128 cur = (rem << 64) | w[i];
+      w[i] = (uint64_t)(cur / dv);
+      rem = cur % dv;
+    }
+    return (uint64_t)rem;
+  }
+  int bits() const {
+    for (int i = RS_MAX_K + 1; i >= 0; i--)
+      if (w[i]) return 64 * i + 64 - __builtin_clzll(w[i]);
+    return 0;
+  }
+};
+
+// thr[b * RS_MAX_K + k] = digit k of 2^b - 1; returns bit_count(Q)
+static int noise_thresholds(const rs_ctx *ctx, std::vector<uint64_t> &thr) {
+  BigU Q;
+  Q.w[0] = 1;
+  for (int k = 0; k < ctx->K; k++) Q.mul_add(ctx->Q[k], 0);
+  const int tb = Q.bits();
+  thr.assign((size_t)tb * RS_MAX_K, 0);
+  for (int b = 0; b < tb; b++) {
+    BigU v;  // 2^b - 1
+    for (int i = 0; i < b / 64; i++) v.w[i] = ~0ull;
+    if (b % 64) v.w[b / 64] = (1ull << (b % 64)) - 1;
+    for (int k = 0; k < ctx->K; k++) thr[(size_t)b * RS_MAX_K + k] = v.divmod(ctx->Q[k]);
+  }
+  return tb;
+}
+
 }  // namespace rs
 
 using namespace rs;
+
+// EncodingElem::decode and Decryptor::invariant_noise_budget share everything up to the centred composition.
+// d_rings == nullptr: budgets only.  h_budget [count * L] (may be null).  Returns RS_ERR_NOISE -- after writing every
+// decoding -- when d_rings is given and a ciphertext has no budget left (seal_ring.tcc:446-454).
+static int decode_impl(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size_t count, uint64_t *d_rings, int *h_budget,
+                       rs_stream stream);
 
 extern "C" {
 
 int rs_enc_decode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size_t count, uint64_t *d_rings, rs_stream stream) {
   RS_API_BEGIN_CTX(ctx)
   RS_REQUIRE(ctx && d_sk && d_enc && d_rings, "null argument");
+  return decode_impl(ctx, d_sk, d_enc, count, d_rings, nullptr, stream);
+  RS_API_END
+}
+
+int rs_enc_noise_budget(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size_t count, int *h_budget, rs_stream stream) {
+  RS_API_BEGIN_CTX(ctx)
+  RS_REQUIRE(ctx && d_sk && d_enc && h_budget, "null argument");
+  return decode_impl(ctx, d_sk, d_enc, count, nullptr, h_budget, stream);
+  RS_API_END
+}
+
+}  // extern "C"
+
+// the guard's verdict on the significant-bit counts the kernels found
+static int noise_verdict(rs_ctx *ctx, const int *d_bits, size_t count, int tb, bool guard, int *h_budget) {
+  std::vector<int> bits(count * (size_t)ctx->L);
+  RS_HIP(hipMemcpy(bits.data(), d_bits, bits.size() * sizeof(int), hipMemcpyDeviceToHost));
+  long long bad = -1;
+  for (size_t e = 0; e < bits.size(); e++) {
+    const int budget = std::max(0, tb - bits[e] - 1);  // "The -1 accounts for scaling the invariant noise by 2" (SEAL)
+    if (h_budget) h_budget[e] = budget;
+    if (budget <= 0 && bad < 0) bad = (long long)e;
+  }
+  if (guard && bad >= 0) {
+    // the reference's message (seal_ring.tcc:450-453); the budget it prints is max(0, .), i.e. 0
+    throw rs::Error(RS_ERR_NOISE, "ciphertext #" + std::to_string((int)(bad % ctx->L)) + " has remaining noise budget 0 <= 0 (element " +
+                                      std::to_string((size_t)(bad / ctx->L)) + ")");
+  }
+  return RS_OK;
+}
+
+static int decode_impl(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size_t count, uint64_t *d_rings, int *h_budget,
+                       rs_stream stream) {
   if (count == 0) return RS_OK;
   WsScope ws_scope(ctx, S(stream));
+  std::vector<uint64_t> thr_h;
+  const int tb = noise_thresholds(ctx, thr_h);
+  int *d_bits = nullptr;
+  RS_HIP(hipMalloc(&d_bits, sizeof(int) * count * (size_t)ctx->L));
+  struct BitsGuard { int *p; ~BitsGuard() { (void)hipFree(p); } } bits_guard{d_bits};
+  void *d_thr = nullptr;
+  RS_HIP(hipMalloc(&d_thr, thr_h.size() * 8));
+  struct ThrGuard { void *p; ~ThrGuard() { (void)hipFree(p); } } thr_guard{d_thr};
   const int L = ctx->L, K = ctx->K, n = ctx->N_enc;
   hipStream_t st = S(stream);
   if (ctx->use_int) {  // the same composition on the integer arithmetic
@@ -385,12 +523,13 @@ int rs_enc_decode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size
     RS_HIP(hipFuncSetAttribute((const void *)crt_decode_kernel_int, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(decrypt_dot_kernel_int, dim3((unsigned)(count * L), K), dim3(thr), lds, st, d_enc, d_sk, V, K, ctx->logN_enc,
                        tabs.d_coeff);
+    RS_HIP(hipMemcpyAsync(d_thr, thr_h.data(), thr_h.size() * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(crt_decode_kernel_int, dim3((unsigned)(count * L)), dim3(thr), lds, st, V, d_rings, ctx->N, L, ctx->logN_enc,
-                       cc, d_limbs, ctx->d_index_map, tabs.d_plain);
+                       cc, d_limbs, ctx->d_index_map, tabs.d_plain, (const uint64_t *)d_thr, tb, d_bits);
     RS_HIP(hipGetLastError());
     RS_HIP(hipStreamSynchronize(st));
     (void)hipFree(d_limbs);
-    return RS_OK;
+    return noise_verdict(ctx, d_bits, count, tb, d_rings != nullptr, h_budget);
   }
   // host constants of the CRT composition
   CrtConsts cc;
@@ -435,13 +574,18 @@ int rs_enc_decode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size
   RS_HIP(hipFuncSetAttribute((const void *)crt_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(decrypt_dot_kernel, dim3((unsigned)(count * L), K), dim3(thr), lds, st, d_enc, d_sk, V, K, ctx->logN_enc,
                      tabs.d_coeff);
+  std::vector<double> thr_d(thr_h.size());
+  for (size_t i = 0; i < thr_h.size(); i++) thr_d[i] = (double)thr_h[i];  // digits < Q_k < 2^50: exact
+  RS_HIP(hipMemcpyAsync(d_thr, thr_d.data(), thr_d.size() * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(crt_decode_kernel, dim3((unsigned)(count * L)), dim3(thr), lds, st, V, d_rings, ctx->N, L, ctx->logN_enc,
-                     cc, d_limbs, ctx->d_index_map, tabs.d_plain);
+                     cc, d_limbs, ctx->d_index_map, tabs.d_plain, (const double *)d_thr, tb, d_bits);
   RS_HIP(hipGetLastError());
   RS_HIP(hipStreamSynchronize(st));  // the table copies die with this call
   (void)hipFree(d_limbs);
-  RS_API_END
+  return noise_verdict(ctx, d_bits, count, tb, d_rings != nullptr, h_budget);
 }
+
+extern "C" {
 
 int rs_enc_encode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_rings, size_t count, uint64_t seed, uint64_t *d_enc,
                   rs_stream stream) {

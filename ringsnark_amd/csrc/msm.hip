@@ -251,6 +251,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     RS_REQUIRE(vecs[v].group >= 0 && vecs[v].group < n_groups, "group index out of range");
     RS_REQUIRE(vecs[v].T <= crs_len, "coefficient vector longer than the CRS vector");
     RS_REQUIRE(vecs[v].d_coeff || vecs[v].T == 0, "null coefficient vector");
+    RS_REQUIRE(vecs[v].slot_const == 0 || vecs[v].slot_const == 1, "rs_msm_vec::slot_const must be 0 or 1 (zero-initialise the struct)");
     Tmax = std::max(Tmax, vecs[v].T);
     group_T[vecs[v].group] = std::max(group_T[vecs[v].group], vecs[v].T);
     if (h_used) nz_total += vecs[v].T;
@@ -276,6 +277,9 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     hipLaunchKernelGGL(fill_value_kernel, dim3((unsigned)((rw + 255) / 256)), dim3(256), 0, st, ones, rw, 1ull);
     RS_HIP(hipMalloc(&sc.d_ones_plain, (size_t)L * n * sizeof(uint64_t)));
     batch_encode_run(ctx, ones, sc.d_ones_plain, 1, st);  // sc is the context's entry itself (scratch_for returns a reference)
+    // the table is cached for the life of the context and read by later calls on ANY stream: it must be complete
+    // before its pointer is visible to them (once per context)
+    RS_HIP(hipStreamSynchronize(st));
   }
   if (any_sc && !sc_native) {
     size_t rows = 0;

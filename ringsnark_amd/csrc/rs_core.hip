@@ -727,7 +727,7 @@ using namespace rs;
 extern "C" {
 
 const char *rs_last_error(void) { return g_last_error.c_str(); }
-int rs_version(void) { return 100; }
+int rs_version(void) { return 101; }  // 101: rs_msm_vec::slot_const (struct must be zero-initialised), rs_enc_noise_budget, RS_ERR_NOISE
 
 int rs_ctx_create(int device, int N, int L, const uint64_t *q, int N_enc, int K, const uint64_t *Q, rs_ctx **out) {
   RS_API_BEGIN
@@ -1159,9 +1159,22 @@ int rs_measure_peaks(rs_ctx *ctx, rs_peaks *out, rs_stream stream) {
   RS_REQUIRE(ctx && out, "null argument");
   hipStream_t st = S(stream);
   memset(out, 0, sizeof(*out));
-  hipEvent_t e0, e1;
-  RS_HIP(hipEventCreate(&e0));
-  RS_HIP(hipEventCreate(&e1));
+  struct Events {  // released on every path (a failed allocation below throws)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
+  } ev;
+  struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+      if (p) (void)hipFree(p);
+    }
+  };
+  RS_HIP(hipEventCreate(&ev.e0));
+  RS_HIP(hipEventCreate(&ev.e1));
+  hipEvent_t &e0 = ev.e0, &e1 = ev.e1;
   auto timed = [&](auto &&launch, int reps) {
     launch();  // warm-up
     RS_HIP(hipEventRecord(e0, st));
@@ -1175,9 +1188,10 @@ int rs_measure_peaks(rs_ctx *ctx, rs_peaks *out, rs_stream stream) {
   // device-to-device copy of 1 GiB (16-byte accesses): read + written bytes per second
   {
     const size_t bytes = (size_t)2 << 30;
-    void *a = nullptr, *b = nullptr;
-    RS_HIP(hipMalloc(&a, bytes));
-    RS_HIP(hipMalloc(&b, bytes));
+    DevBuf buf_a, buf_b;
+    RS_HIP(hipMalloc(&buf_a.p, bytes));
+    RS_HIP(hipMalloc(&buf_b.p, bytes));
+    void *a = buf_a.p, *b = buf_b.p;
     RS_HIP(hipMemsetAsync(a, 1, bytes, st));
     double best = 0;
     for (unsigned blocks : {256u * 2, 256u * 4, 256u * 8, 256u * 16}) {  // the best of four grid sizes x two access kinds (2 GiB read + 2 GiB written each)
@@ -1206,24 +1220,20 @@ int rs_measure_peaks(rs_ctx *ctx, rs_peaks *out, rs_stream stream) {
     }
     out->hbm_read_gbs = best_r;
     out->hbm_inplace_gbs = best_i;
-    (void)hipFree(a);
-    (void)hipFree(b);
   }
   {
     const unsigned blocks = 256 * 8;
-    uint64_t *d = nullptr;
-    RS_HIP(hipMalloc(&d, (size_t)blocks * 256 * sizeof(uint64_t)));
+    DevBuf buf_d;
+    RS_HIP(hipMalloc(&buf_d.p, (size_t)blocks * 256 * sizeof(uint64_t)));
+    uint64_t *d = (uint64_t *)buf_d.p;
     const Mod mf = HostArith<Mod>::make(ctx->Q[0] < (1ull << 50) ? ctx->Q[0] : 1125899906826241ull);
     const ModI mi = HostArith<ModI>::make(1152921504606830593ull);  // a 60-bit prime (microbench.cpp:35-36 sizes)
     const double lanes = (double)blocks * 256.0 * PEAK_ITERS * 8.0;  // lane-operations of the inner statement per launch
     out->fp64_fma_T = lanes / timed([&] { hipLaunchKernelGGL(peak_rate_kernel<0>, dim3(blocks), dim3(256), 0, st, d, 1.5, 1.0000001, mf, mi); }, 3) / 1e12;
     out->fp64_mulmod_G = lanes / timed([&] { hipLaunchKernelGGL(peak_rate_kernel<1>, dim3(blocks), dim3(256), 0, st, d, 1.5, 12345.0, mf, mi); }, 3) / 1e9;
     out->int_montmul_G = lanes / timed([&] { hipLaunchKernelGGL(peak_rate_kernel<2>, dim3(blocks), dim3(256), 0, st, d, 1.5, 12345.0, mf, mi); }, 3) / 1e9;
-    (void)hipFree(d);
   }
   RS_HIP(hipGetLastError());
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   RS_API_END
 }
 

@@ -258,11 +258,20 @@ class Device:
 
     # ---- 8(f) f2 / f3
     def enc_decode(self, sk, enc):
-        """EncodingElem::decode (seal_ring.tcc:435-477): sk [K][N_enc] NTT form -> ring elements."""
+        """EncodingElem::decode (seal_ring.tcc:435-477): sk [K][N_enc] NTT form -> ring elements.  Raises
+        RsError(RS_ERR_NOISE, "ciphertext #i has remaining noise budget 0 <= 0") like the reference's decoding_error
+        (seal_ring.tcc:446-454) when a ciphertext's invariant noise budget is spent."""
         count = self._count(enc, self.enc_words)
         out = self.ring_empty(count) if enc.dim() > 4 else self.ring_empty()
         _lib.check(self.lib.rs_enc_decode(self.h, _ptr(sk), _ptr(enc), count, _ptr(out), self.stream()))
         return out
+
+    def enc_noise_budget(self, sk, enc):
+        """Decryptor::invariant_noise_budget of every ciphertext (bits; 0 = spent): int array [count][L]."""
+        count = self._count(enc, self.enc_words)
+        out = (C.c_int * (count * self.L))()
+        _lib.check(self.lib.rs_enc_noise_budget(self.h, _ptr(sk), _ptr(enc), count, out, self.stream()))
+        return np.array(out, dtype=np.int64).reshape(count, self.L)
 
     def enc_encode(self, sk, rings, seed):
         """EncodingElem::encode (seal_ring.tcc:324-359); element k uses the oracle's stream seed*65537 + k."""

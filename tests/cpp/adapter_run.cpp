@@ -139,6 +139,17 @@ int main(int argc, char **argv) {
     const std::vector<EncodingElem> e2 = EncodingElem::encode(sk2, {u, nz});
     EXPECT(EncodingElem::decode(sk2, e2[0]) == u && EncodingElem::decode(sk2, e2[1]) == nz);
     EXPECT(EncodingElem::decode(sk2, e2[0] * nz + e2[1]) == u * nz + nz);
+    {  // the verifier's guard (seal_ring.tcc:443-454): an encoding multiplied past its noise budget is refused
+      EncodingElem spent = e2[0];
+      for (int k = 0; k < 8; k++) spent *= nz;
+      try {
+        (void)EncodingElem::decode(sk2, spent);
+        EXPECT(false);
+      } catch (const EncodingElem::decoding_error &e) {
+        const std::string w = e.what();  // "decoding error: ciphertext #0 has remaining noise budget 0 <= 0 ..."
+        EXPECT(w.rfind("decoding error: ciphertext #", 0) == 0 && w.find("has remaining noise budget 0 <= 0") != std::string::npos);
+      }
+    }
     // util/polynomials.hpp helpers: divide(multiply(q, x), x) == q (util/division_test.cpp:28-49, n = 12)
     std::vector<RingElem> xs, qs;
     for (uint64_t i = 0; i < 12; i++) {

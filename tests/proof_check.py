@@ -121,13 +121,19 @@ def check_all_columns(prm, cs, asg, w, ds=(None, None, None), limbs=None, slot0=
         q = int(prm.q[limb])
         pts = [cs.m + (int(rng.randint(1, 2**31)) * 65537 + 12345) % (q - cs.m) for _ in range(points)]
         tc = time.perf_counter()
-        a = to_host(asg[:, limb, slot0:slot0 + nslots].contiguous())
-        vec = {k: to_host(w[k][:, limb, :].contiguous()) for k in names}
+        blocked = nslots % 32 == 0
+        if blocked:  # [rows][slots] -> [slots/32][rows][32] on the device: a block of 32 columns then streams through host memory
+            blk = lambda t: to_host(t.reshape(t.shape[0], nslots // 32, 32).permute(1, 0, 2).contiguous())
+        else:
+            blk = lambda t: to_host(t.contiguous())
+        a = blk(asg[:, limb, slot0:slot0 + nslots])
+        for k in names:
+            assert w[k].shape[2] == nslots, (k, w[k].shape, nslots)
+        vec = {k: blk(w[k][:, limb, :]) for k in names}
         dv = [None if d is None else to_host(d[limb, slot0:slot0 + nslots].contiguous()) for d in ds]
         t_copy += time.perf_counter() - tc
-        for k in names:
-            assert vec[k].shape[1] == nslots, (k, vec[k].shape, nslots)
-        n_bad, bad = O.witness_identities(q, ocs.at_slots(slot0), limb, a, vec, pts, *dv, Z=None if Z is None else Z[limb], threads=0)
+        n_bad, bad = O.witness_identities(q, ocs.at_slots(slot0), limb, a, vec, pts, *dv, Z=None if Z is None else Z[limb], threads=0,
+                                          blocked=blocked)
         if n_bad:
             s = int(np.flatnonzero(bad)[0])
             failed = [O.IDENTITY_NAMES[b] for b in range(7) if bad[s] >> b & 1]

@@ -104,3 +104,25 @@ def test_subsets_of_vectors_and_slot_ranges():
     sub["B_mid"][4, 20] ^= 2
     n_bad, bad = O.witness_identities(q, ocs.at_slots(lo), 0, a[:, lo:hi], sub, pts)
     assert n_bad == 1 and bad[20] == 1 << 4
+
+
+def test_blocked_layout_gives_the_same_verdicts():
+    """[S/32][rows][32]: the layout the configuration-scale callers hand over (a block of 32 columns streams through
+    memory); same answers as the row-major form, corruption found in the same slot."""
+    prm, ctx, cs, asg, ds = _case("toy", 11, True)
+    ocs = H.oracle_cs(cs)
+    q = int(prm.q[1])
+    assert prm.N % 32 == 0
+    d = [np.ascontiguousarray(x[1]) for x in ds]
+    a = np.ascontiguousarray(asg[:, 1, :])
+    w = O.witness_map(q, ocs, 1, a, *d)
+    blk = lambda t: np.ascontiguousarray(t.reshape(t.shape[0], -1, 32).transpose(1, 0, 2))
+    pts = _points(q, cs.m, 21)
+    v = {k: blk(w[k]) for k in O.IDENTITY_NAMES}
+    n_bad, bad = O.witness_identities(q, ocs, 1, blk(a), v, pts, *d, Z=w["Z"], blocked=True)
+    assert n_bad == 0
+    wrong = w["C_mid"].copy()
+    wrong[5, prm.N - 1] ^= 4
+    v["C_mid"] = blk(wrong)
+    n_bad, bad = O.witness_identities(q, ocs, 1, blk(a), v, pts, *d, blocked=True)
+    assert n_bad == 1 and bad[prm.N - 1] == 1 << 5

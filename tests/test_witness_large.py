@@ -71,10 +71,8 @@ def test_witness_map_at_2_17_and_2_18(m, zk, force):
     else:
         assert not any(n.startswith("bc") for n in names), names
         assert any(n.startswith("cross_kernel") for n in names), names
-    rng = np.random.RandomState(m % 1000 + force)
-    cols = [(0, 0), (prm.L - 1, prm.N - 1), (int(rng.randint(prm.L)), int(rng.randint(prm.N)))]
-    err = proof_check.check_columns(prm, cs, asg, {k: w[k] for k in KEYS}, cols, rng, tuple(ds))
-    assert err is None, err
+    err, info = proof_check.check_all_columns(prm, cs, asg, {k: w[k] for k in KEYS}, tuple(ds), seed=m % 1000 + force, Z=w["Z"])
+    assert err is None and info["columns"] == prm.L * prm.N, err  # every column of the ring (round 4 sampled three)
     # rows beyond the degree bound: H has m + 1 rows, row m is d1 d2 (the top of the ZK patch) or zero
     from ringsnark_amd.device import to_host
     if not zk:
@@ -88,9 +86,8 @@ def test_two_level_transform_across_blocks_at_2_19_and_2_20(m, force):
     prm = P.preset("toy44")
     dev, cs, asg, ds, w, names = _run(prm, m, False, force, want=("A_mid", "B_mid", "H"))
     assert "bc2_yfwd_big_kernel" in names and "bc2_yinv_a_kernel" in names and "bc2_yinv_b_kernel" in names, names
-    rng = np.random.RandomState(3)
-    err = proof_check.check_columns(prm, cs, asg, {k: w[k] for k in ("A_mid", "B_mid", "H")}, [(1, 17)], rng, tuple(ds))
-    assert err is None, err
+    err, info = proof_check.check_all_columns(prm, cs, asg, {k: w[k] for k in ("A_mid", "B_mid", "H")}, tuple(ds), seed=3, Z=w["Z"])
+    assert err is None and info["columns"] == prm.L * prm.N, err
 
 
 @pytest.mark.parametrize("m", [131072, 262144])
@@ -173,9 +170,8 @@ def test_h_on_a_coset_equals_the_long_division_form(m, zk, int_arith):
             _set_tuning(b"witness_h_coset", 1)
         assert any("<4" in n and n.startswith("sub_ntt") for n in names) == (coset == 1), names
         if coset:
-            rng = np.random.RandomState(m % 1000)
-            err = proof_check.check_columns(prm, cs, asg, {k: w[k] for k in KEYS}, [(0, 1), (prm.L - 1, prm.N - 2)], rng, tuple(ds))
-            assert err is None, err
+            err, info = proof_check.check_all_columns(prm, cs, asg, {k: w[k] for k in KEYS}, tuple(ds), seed=m % 1000, Z=w["Z"])
+            assert err is None and info["columns"] == prm.L * prm.N, err
         runs[coset] = {k: to_host(w[k]) for k in KEYS}
         del dev, asg, w
     for k in KEYS:
@@ -193,3 +189,51 @@ def test_integer_arithmetic_at_2_17():
     b = _run(prm, m, True, 0, int_arith=True, want=want)
     for k in want:
         assert (to_host(a[4][k]) == to_host(b[4][k])).all(), k
+
+
+def test_unsatisfied_assignment_long_division_and_coset_forms():
+    """The reference asserts satisfaction before it maps (r1cs_to_qrp.tcc:156) and then long-divides, dropping the remainder
+    (util/polynomials.tcc:76-81).  Pinned here (round-4 advisor finding): for an UNSATISFIED column the long-division
+    form -- every call that does not ask for C, every one-tile size, witness_h_coset = 0 -- still returns the quotient
+    quo(A B - C, Z) = quo(A B, Z); the coset form (C requested, multi-pass size: Rinocchio) returns another polynomial in
+    that column and the same one in every satisfied column.  include/ringsnark_amd.h states the precondition."""
+    from oracle import oracle as O
+    from ringsnark_amd.device import Device, to_host
+    # one tile: the device equals the oracle's literal long division on an unsatisfied assignment
+    prm = P.preset("toy")
+    dev, ctx = Device(prm), H.oracle_ctx(prm)
+    cs = R.wide_r1cs(12, prm.q)
+    asg = H.make_assignment(ctx, cs)
+    asg[cs.n_inputs + 3, 0, 5] = (int(asg[cs.n_inputs + 3, 0, 5]) + 1) % prm.q[0]
+    w = dev.witness_map(dev.r1cs(cs), dev.put(asg))
+    for limb in range(prm.L):
+        ow = O.witness_map(prm.q[limb], H.oracle_cs(cs), limb, np.ascontiguousarray(asg[:, limb, :]))
+        for k in KEYS:
+            assert (to_host(w[k])[:, limb, :] == ow[k]).all(), k
+    del dev, w
+    # multi-pass size
+    prm = P.preset("toy44")
+    m = 20000
+    runs = {}
+    for tag, coset, want in (("long", 0, KEYS), ("coset", 1, KEYS), ("no_c", 1, ("A_mid", "B_mid", "H"))):
+        _set_tuning(b"witness_h_coset", coset)
+        try:
+            dev = Device(prm)
+            cs = R.chain_r1cs(m, prm.q)
+            asg = dev.ring_empty(m + 2)
+            dev.fill_uniform(asg[:2], 0, 9)
+            dev.chain_assignment(asg, m)
+            asg[777, 0, 3] += 1  # one wire of one column no longer satisfies its constraints
+            w = dev.witness_map(dev.r1cs(cs), asg, want=want)
+            runs[tag] = {k: to_host(w[k]) for k in want}
+        finally:
+            _set_tuning(b"witness_h_coset", 1)
+        del dev, asg, w
+    for k in ("A_mid", "B_mid"):
+        assert (runs["long"][k] == runs["coset"][k]).all() and (runs["long"][k] == runs["no_c"][k]).all()
+    assert (runs["long"]["H"] == runs["no_c"]["H"]).all()  # without C: the quotient, for any assignment
+    same = runs["long"]["H"] == runs["coset"]["H"]
+    bad = np.zeros(same.shape[1:], dtype=bool)
+    bad[0, 3] = True
+    assert same[:, ~bad].all()           # satisfied columns: the two forms are the same polynomial
+    assert not same[:, 0, 3].all()       # the unsatisfied one: documented difference

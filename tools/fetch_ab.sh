@@ -1,9 +1,13 @@
 #!/bin/bash
 # FETCH_SIZE of the multiply-accumulate kernels at the configs[3] shape (and the headline) for a tuning-knob value:
-#   gpurun -- 'bash tools/fetch_ab.sh <tag> <knob> <value> [groth16|rinocchio|both]'
+#   gpurun -- 'bash tools/fetch_ab.sh <tag> <knob> <value> [groth16|rinocchio]'
 # one rocprofv3 --pmc pass (kernel-trace only); prints GiB fetched per proof per kernel (x2: the gfx950 correction)
 set -u
 TAG=$1; KNOB=$2; VAL=$3; WHICH=${4:-rinocchio}
+# per-proof figures divide by the proofs ONE prover ran for ONE knob value: both provers emit kernels of the same names
+# (mac_kernel_*, plain_*), and every further value runs five more proofs
+case "$WHICH" in groth16|rinocchio) ;; *) echo "fetch_ab.sh: which must be groth16 or rinocchio (not '$WHICH': per-proof figures would mix two shapes)"; exit 2;; esac
+case "$VAL" in *,*) echo "fetch_ab.sh: one knob value per run (got '$VAL')"; exit 2;; esac
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG

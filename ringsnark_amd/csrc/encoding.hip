@@ -519,8 +519,8 @@ static int decode_impl(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc,
     uint64_t *V = (uint64_t *)ws_get(ctx, 14, count * (size_t)L * K * n * sizeof(uint64_t));
     const size_t lds = padded_len((size_t)n) * sizeof(uint64_t);
     const int thr = enc_threads(ctx->logN_enc);
-    RS_HIP(hipFuncSetAttribute((const void *)decrypt_dot_kernel_int, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    RS_HIP(hipFuncSetAttribute((const void *)crt_decode_kernel_int, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)decrypt_dot_kernel_int, (int)lds);
+    set_max_dyn_lds((const void *)crt_decode_kernel_int, (int)lds);
     hipLaunchKernelGGL(decrypt_dot_kernel_int, dim3((unsigned)(count * L), K), dim3(thr), lds, st, d_enc, d_sk, V, K, ctx->logN_enc,
                        tabs.d_coeff);
     RS_HIP(hipMemcpyAsync(d_thr, thr_h.data(), thr_h.size() * 8, hipMemcpyHostToDevice, st));
@@ -570,8 +570,8 @@ static int decode_impl(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc,
   double *V = (double *)ws_get(ctx, 14, count * (size_t)L * K * n * sizeof(double));
   const size_t lds = padded_len((size_t)n) * sizeof(double);
   const int thr = enc_threads(ctx->logN_enc);
-  RS_HIP(hipFuncSetAttribute((const void *)decrypt_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  RS_HIP(hipFuncSetAttribute((const void *)crt_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  set_max_dyn_lds((const void *)decrypt_dot_kernel, (int)lds);
+  set_max_dyn_lds((const void *)crt_decode_kernel, (int)lds);
   hipLaunchKernelGGL(decrypt_dot_kernel, dim3((unsigned)(count * L), K), dim3(thr), lds, st, d_enc, d_sk, V, K, ctx->logN_enc,
                      tabs.d_coeff);
   std::vector<double> thr_d(thr_h.size());
@@ -599,7 +599,7 @@ int rs_enc_encode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_rings, si
     TabCopiesI tabs(ctx);
     const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(uint64_t);
     const int thr = std::max(enc_threads(ctx->logN_enc), ctx->N_enc / 16);
-    RS_HIP(hipFuncSetAttribute((const void *)encode_kernel_int, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)encode_kernel_int, (int)lds);
     hipLaunchKernelGGL(encode_kernel_int, dim3((unsigned)(count * ctx->L), ctx->K), dim3(thr), lds, st, d_rings, d_sk, d_enc, seed,
                        ctx->N, ctx->L, ctx->K, ctx->logN_enc, ctx->d_index_map, tabs.d_plain, tabs.d_coeff);
     RS_HIP(hipGetLastError());
@@ -609,7 +609,7 @@ int rs_enc_encode(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_rings, si
   TabCopies tabs(ctx);
   const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(double);
   const int thr = std::max(enc_threads(ctx->logN_enc), ctx->N_enc / 16);
-  RS_HIP(hipFuncSetAttribute((const void *)encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  set_max_dyn_lds((const void *)encode_kernel, (int)lds);
   hipLaunchKernelGGL(encode_kernel, dim3((unsigned)(count * ctx->L), ctx->K), dim3(thr), lds, st, d_rings, d_sk, d_enc, seed,
                      ctx->N, ctx->L, ctx->K, ctx->logN_enc, ctx->d_index_map, tabs.d_plain, tabs.d_coeff, tabs.d_q, tabs.d_Q);
   RS_HIP(hipGetLastError());

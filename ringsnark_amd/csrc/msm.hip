@@ -107,7 +107,7 @@ static void launch_mac(rs_ctx *ctx, const MacArgs &a, const MsmScratch &sc, hipS
   const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(double);
   const int rows = a.n_chunks * ctx->L;
   const unsigned blocks = (unsigned)(((rows + 7) / 8) * 8 * ctx->K);
-  RS_HIP(hipFuncSetAttribute((const void *)mac_kernel<NG, NC, PAIRS, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  set_max_dyn_lds((const void *)mac_kernel<NG, NC, PAIRS, M>, (int)lds);
   hipLaunchKernelGGL((mac_kernel<NG, NC, PAIRS, M>), dim3(blocks), dim3(tile_threads(ctx->logN_enc)), lds, st, a, ctx->L,
                      ctx->K, ctx->logN_enc, sc.template coeff<M>());
   RS_HIP(hipGetLastError());
@@ -119,7 +119,7 @@ static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, 
   const int rows = a.n_chunks * ctx->L;
   const unsigned blocks = (unsigned)(((rows + 7) / 8) * 8 * ctx->K);
   if (g_mac_variant == 3 && ctx->logN_enc == 13) {  // 16 waves of 128 VGPRs (4 waves per SIMD), plaintext row not prefetched
-    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<1024, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)mac_kernel_v2<1024, 13>, (int)lds);
     hipLaunchKernelGGL((mac_kernel_v2<1024, 13>), dim3(blocks), dim3(1024), lds, st, a, ctx->L, ctx->K, ctx->logN_enc, sc.coeff<Mod>());
     RS_HIP(hipGetLastError());
     return;
@@ -127,8 +127,8 @@ static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, 
   if (ctx->logN_enc == 13 && g_mac_variant != 4) {
 #define RS_MAC_LAUNCH(AB)                                                                                             \
   do {                                                                                                                \
-    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<512, 13, AB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                               (int)lds));                                                                           \
+    set_max_dyn_lds((const void *)mac_kernel_v2<512, 13, AB>, \
+                               (int)lds);                                                                           \
     hipLaunchKernelGGL((mac_kernel_v2<512, 13, AB>), dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K,             \
                        ctx->logN_enc, sc.coeff<Mod>());                                                               \
   } while (0)
@@ -146,7 +146,7 @@ static void launch_mac_v2(rs_ctx *ctx, const MacArgs2 &a, const MsmScratch &sc, 
     RS_HIP(hipGetLastError());
     return;
   }
-  RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  set_max_dyn_lds((const void *)mac_kernel_v2<512>, (int)lds);
   hipLaunchKernelGGL(mac_kernel_v2<512>, dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K, ctx->logN_enc, sc.coeff<Mod>());
   RS_HIP(hipGetLastError());
 }
@@ -175,13 +175,13 @@ static void launch_mac_v3(rs_ctx *ctx, const MacArgs3 &a, const MsmScratch &sc, 
   const unsigned parts = (unsigned)ctx->N_enc / 4096u;  // workgroups per (limb, prime): halves at 8192 points, quarters at 16384
   const unsigned blocks = ((rows + 7) / 8) * 8 * parts * (unsigned)ctx->K * (unsigned)a.n_groups;
   if (ctx->N_enc == 16384) {
-    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v3<false, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)mac_kernel_v3<false, 14>, (int)lds);
     hipLaunchKernelGGL((mac_kernel_v3<false, 14>), dim3(blocks), dim3(256), lds, st, a, ctx->L, ctx->K, tabs);
   } else if (a.paired) {
-    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)mac_kernel_v3<true>, (int)lds);
     hipLaunchKernelGGL(mac_kernel_v3<true>, dim3(blocks), dim3(256), lds, st, a, ctx->L, ctx->K, tabs);
   } else {
-    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)mac_kernel_v3<false>, (int)lds);
     hipLaunchKernelGGL(mac_kernel_v3<false>, dim3(blocks), dim3(256), lds, st, a, ctx->L, ctx->K, tabs);
   }
   RS_HIP(hipGetLastError());
@@ -195,7 +195,7 @@ static void launch_mac_v4(rs_ctx *ctx, const MacArgs4 &a, bool paired, const Msm
   const unsigned blocks = ((rows + 7) / 8) * 8 * parts * (unsigned)ctx->K * (unsigned)a.n_groups;
 #define RS_MAC4_LAUNCH(LOGN_, PAIRED_)                                                                                          \
   do {                                                                                                                         \
-    RS_HIP(hipFuncSetAttribute((const void *)mac_kernel_v4<LOGN_, PAIRED_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    set_max_dyn_lds((const void *)mac_kernel_v4<LOGN_, PAIRED_>, (int)lds); \
     hipLaunchKernelGGL((mac_kernel_v4<LOGN_, PAIRED_>), dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K, tabs);             \
   } while (0)
   if (ctx->N_enc == 16384) RS_MAC4_LAUNCH(14, false);
@@ -431,9 +431,9 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
   bool multi = false;
   for (int g = 0; g < n_groups; g++) multi = multi || pa.g[g].n > 1;
   if (plain16)
-    RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<16, 0, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)plain_center_kernel<16, 0, M>, (int)lds);
   else
-    RS_HIP(hipFuncSetAttribute((const void *)plain_center_kernel<8, 0, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)plain_center_kernel<8, 0, M>, (int)lds);
 
   // rooflines: per (term, limb) a plaintext row costs one inverse transform of
   // length n, the batching scatter and the centred lift; per (term, limb, prime) the MAC reads two
@@ -466,8 +466,8 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
         for (int i = 0; i < L; i++) twp.itw[i] = ctx->plain[i].d_itw;
 #define RS_PLAIN_WIDE_NE(MULTI_, PAIRED_, NE_, LIN_)                                                                          \
   do {                                                                                                                        \
-    RS_HIP(hipFuncSetAttribute((const void *)plain_center_wide_kernel<MULTI_, PAIRED_, NE_, LIN_>,                            \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, wl));                                              \
+    set_max_dyn_lds((const void *)plain_center_wide_kernel<MULTI_, PAIRED_, NE_, LIN_>, \
+                               wl);                                              \
     hipLaunchKernelGGL((plain_center_wide_kernel<MULTI_, PAIRED_, NE_, LIN_>), grid, dim3(256), wl, st, pa,                   \
                        reinterpret_cast<double *>(d_C), (unsigned long long)t0, (unsigned long long)tile_terms,               \
                        (unsigned long long)tt, n_groups, ctx->N, L, ctx->d_index_map, sc.plain<Mod>(), twp);                  \
@@ -705,11 +705,11 @@ void batch_encode_run(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, s
   MsmScratch &sc = scratch_for(ctx);
   const size_t lds = padded_len((size_t)ctx->N_enc) * sizeof(double);
   if (ctx->use_int) {
-    RS_HIP(hipFuncSetAttribute((const void *)batch_encode_kernel<ModI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)batch_encode_kernel<ModI>, (int)lds);
     hipLaunchKernelGGL(batch_encode_kernel<ModI>, dim3((unsigned)count, ctx->L), dim3(tile_threads(ctx->logN_enc)), lds, st, d_rings, d_plain,
                        ctx->N, ctx->L, ctx->logN_enc, ctx->d_index_map, sc.plain<ModI>());
   } else {
-    RS_HIP(hipFuncSetAttribute((const void *)batch_encode_kernel<Mod>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)batch_encode_kernel<Mod>, (int)lds);
     hipLaunchKernelGGL(batch_encode_kernel<Mod>, dim3((unsigned)count, ctx->L), dim3(tile_threads(ctx->logN_enc)), lds, st, d_rings, d_plain,
                        ctx->N, ctx->L, ctx->logN_enc, ctx->d_index_map, sc.plain<Mod>());
   }

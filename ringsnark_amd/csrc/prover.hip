@@ -13,6 +13,7 @@ bool msm_supports_lin(const rs_ctx *ctx);
 void batch_encode_run(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, size_t count, hipStream_t st);
 bool witness_io_shortcut(const rs_r1cs *cs);
 void enc_add_run(rs_ctx *ctx, uint64_t *dst, const uint64_t *x, const uint64_t *y, size_t count, hipStream_t st);
+const uint64_t *witness_Z_rows(rs_ctx *ctx, size_t m);
 void witness_run(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_asg, const uint64_t *d1, const uint64_t *d2,
                  const uint64_t *d3, uint64_t *const outs[7], uint64_t *h_Z, hipStream_t st, int slot0 = 0, int nslots = -1,
                  bool compact = false, const size_t (*rows)[2] = nullptr);
@@ -201,18 +202,11 @@ int rs_rinocchio_prove_kinds(rs_ctx *ctx, const rs_r1cs *cs, const rs_rinocchio_
   uint64_t *wbuf = (uint64_t *)ws_get(ctx, 8, (4 * m + 1) * rw * sizeof(uint64_t));
   uint64_t *A_mid = wbuf, *B_mid = wbuf + m * rw, *C_mid = wbuf + 2 * m * rw, *H = wbuf + 3 * m * rw;
   uint64_t *outs[7] = {nullptr, nullptr, nullptr, A_mid, B_mid, C_mid, H};
-  std::vector<uint64_t> hZ((size_t)ctx->L * (m + 1));
-  witness_run(ctx, cs, d_assignment, d_d1, d_d2, d_d3, outs, hZ.data(), st);
+  witness_run(ctx, cs, d_assignment, d_d1, d_d2, d_d3, outs, nullptr, st);
   // coefficients_for_Z are slot constant: they go to the inner products as the compact [m+1][L] array of their values
-  // (rs_msm_vec::slot_const) -- round 3 materialised m + 1 ring elements for them (a fifth of the prover's vectors)
-  uint64_t *dZ = (uint64_t *)ws_get(ctx, 9, hZ.size() * sizeof(uint64_t));
-  {
-    std::vector<uint64_t> hZt(hZ.size());
-    for (int i = 0; i < ctx->L; i++)
-      for (size_t t = 0; t <= m; t++) hZt[t * ctx->L + i] = hZ[(size_t)i * (m + 1) + t];
-    RS_HIP(hipMemcpyAsync(dZ, hZt.data(), hZt.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    RS_HIP(hipStreamSynchronize(st));  // hZt is a host temporary
-  }
+  // (rs_msm_vec::slot_const) -- round 3 materialised m + 1 ring elements for them (a fifth of the prover's vectors).
+  // A constant of the (context, m) plan: cached on the device, no host transpose and no synchronisation inside the proof.
+  const uint64_t *dZ = witness_Z_rows(ctx, m);
   pt.mark(1);
   // the ten inner products of rinocchio.tcc:106-163 in one grouped pass over both CRS vectors
   uint64_t *mo = (uint64_t *)ws_get(ctx, 10, 11 * ew * sizeof(uint64_t));  // [2][5] + tmp

@@ -303,7 +303,7 @@ static void launch_ntt_wp(const NttTable &t, uint64_t *d_data, size_t batch, hip
   int logw = 0;
   while ((64 << logw) < THREADS) logw++;
   auto kern = ntt_kernel_wp<INV, MAXR, THREADS, MINW>;
-  RS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  set_max_dyn_lds((const void *)kern, (int)lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(THREADS), lds, st, d_data, t.logn, logw, INV ? t.d_itw : t.d_tw,
                      t.mod, t.ninv, INV ? t.inv_red_mask : t.fwd_red_mask, g_ntt_repeat);
   RS_HIP(hipGetLastError());
@@ -467,10 +467,10 @@ void launch_ntt_int(rs_ctx *ctx, const NttTableI &t, uint64_t *d_data, size_t ba
     const size_t lds = padded_len((size_t)1 << t.logn) * sizeof(uint64_t);
     const int thr = std::max(64, std::min(1024, (1 << t.logn) >> 4));
     if (inverse) {
-      RS_HIP(hipFuncSetAttribute((const void *)ntt_io_kernel<true, uint64_t, ModI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set_max_dyn_lds((const void *)ntt_io_kernel<true, uint64_t, ModI>, (int)lds);
       hipLaunchKernelGGL((ntt_io_kernel<true, uint64_t, ModI>), dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, t.d_itw, t.mod, t.ninv);
     } else {
-      RS_HIP(hipFuncSetAttribute((const void *)ntt_io_kernel<false, uint64_t, ModI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set_max_dyn_lds((const void *)ntt_io_kernel<false, uint64_t, ModI>, (int)lds);
       hipLaunchKernelGGL((ntt_io_kernel<false, uint64_t, ModI>), dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, t.d_tw, t.mod, t.ninv);
     }
     RS_HIP(hipGetLastError());
@@ -479,10 +479,10 @@ void launch_ntt_int(rs_ctx *ctx, const NttTableI &t, uint64_t *d_data, size_t ba
   const size_t lds = padded_len((size_t)1 << t.logn) * sizeof(uint64_t);
   const int thr = std::max(64, std::min(1024, (1 << t.logn) >> 3));
   if (inverse) {
-    RS_HIP(hipFuncSetAttribute((const void *)ntt_generic_kernel<true, uint64_t, ModI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)ntt_generic_kernel<true, uint64_t, ModI>, (int)lds);
     hipLaunchKernelGGL((ntt_generic_kernel<true, uint64_t, ModI>), dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, t.d_itw, t.mod, t.ninv);
   } else {
-    RS_HIP(hipFuncSetAttribute((const void *)ntt_generic_kernel<false, uint64_t, ModI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)ntt_generic_kernel<false, uint64_t, ModI>, (int)lds);
     hipLaunchKernelGGL((ntt_generic_kernel<false, uint64_t, ModI>), dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, t.d_tw, t.mod, t.ninv);
   }
   RS_HIP(hipGetLastError());
@@ -497,7 +497,7 @@ static void launch_ntt_variant(const NttTable &t, uint64_t *d_data, size_t batch
   const int n = 1 << t.logn;
   const int thr = std::max(64, std::min(THREADS, n >> MAXR));
   auto kern = ntt_kernel<INV, MAXR, DIN, DOUT, THREADS>;
-  RS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  set_max_dyn_lds((const void *)kern, (int)lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(thr), lds, st, d_data, t.logn, INV ? t.d_itw : t.d_tw, t.mod,
                      t.ninv, INV ? t.inv_red_mask : t.fwd_red_mask);
   RS_HIP(hipGetLastError());
@@ -513,12 +513,12 @@ static void launch_ntt_wide_shape(const NttTable &t, uint64_t *d_data, size_t ba
   const unsigned grid = (unsigned)std::min<size_t>(batch, (size_t)g_ntt_wide_grid * per_cu);
   if (inverse) {
     auto kern = ntt_inv_wide_kernel<LOGN, RED>;
-    RS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    set_max_dyn_lds((const void *)kern, lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(S::T), lds, st, d_data, (unsigned long long)batch, t.d_itw, t.mod, t.ninv,
                        t.inv_red_mask);
   } else {
     auto kern = ntt_fwd_wide_kernel<LOGN, RED>;
-    RS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    set_max_dyn_lds((const void *)kern, lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(S::T), lds, st, d_data, (unsigned long long)batch, t.d_tw, t.mod, t.fwd_red_mask);
   }
   RS_HIP(hipGetLastError());
@@ -551,11 +551,11 @@ void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, 
     const size_t lds = (padded_len((size_t)1 << t.logn) + ((size_t)1 << t.logn)) * sizeof(double);
     const unsigned grid = (unsigned)std::min<size_t>(batch, 256);
     if (t.logn == 13) {
-      RS_HIP(hipFuncSetAttribute((const void *)ntt_fwd_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set_max_dyn_lds((const void *)ntt_fwd_stream_kernel<2>, (int)lds);
       hipLaunchKernelGGL(ntt_fwd_stream_kernel<2>, dim3(grid), dim3(1024), lds, st, d_data, (unsigned long long)batch, t.logn,
                          t.d_tw, t.mod, t.fwd_red_mask);
     } else {
-      RS_HIP(hipFuncSetAttribute((const void *)ntt_fwd_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set_max_dyn_lds((const void *)ntt_fwd_stream_kernel<1>, (int)lds);
       hipLaunchKernelGGL(ntt_fwd_stream_kernel<1>, dim3(grid), dim3(1024), lds, st, d_data, (unsigned long long)batch, t.logn,
                          t.d_tw, t.mod, t.fwd_red_mask);
     }

@@ -84,6 +84,9 @@ struct WitnessPlan {
   // "two-dimensional block convolutions" below): blocks of B = 2^13 coefficients, bcLog = 14.
   bool bc2 = false;
   std::vector<LimbPlan> limb;
+  // coefficients_for_Z of every limb as the compact [m + 1][L] device array the inner products take a slot-constant
+  // vector in (rs_msm_vec::slot_const): a per-(context, m) constant, uploaded once (witness_Z_rows)
+  uint64_t *d_Zt = nullptr;
 };
 
 // ---- host-side helpers (integer arithmetic; builds the tables above) -------------------------
@@ -524,6 +527,7 @@ static void free_plan_tables(WitnessPlan *P) {
 }
 static void free_plan(WitnessPlan *P) {
   free_plan_tables(P);
+  if (P->d_Zt) (void)hipFree(P->d_Zt);
   delete P;
 }
 
@@ -536,6 +540,21 @@ WitnessPlan *get_plan(rs_ctx *ctx, size_t m) {
 }
 
 
+
+// Z as the provers hand it to the inner products: [m + 1][L] values on the device, built at first use (one blocking
+// upload per plan; every later proof reads the cached array -- no host transpose, no synchronisation inside a proof)
+const uint64_t *witness_Z_rows(rs_ctx *ctx, size_t m) {
+  WitnessPlan *P = get_plan(ctx, m);
+  if (!P->d_Zt) {
+    const int L = ctx->L;
+    std::vector<uint64_t> zt((size_t)L * (m + 1));
+    for (int i = 0; i < L; i++)
+      for (size_t t = 0; t <= m; t++) zt[t * L + i] = P->limb[i].Z[t];
+    RS_HIP(hipMalloc(&P->d_Zt, zt.size() * sizeof(uint64_t)));
+    RS_HIP(hipMemcpy(P->d_Zt, zt.data(), zt.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
+  return P->d_Zt;
+}
 
 // Column plans of limbs limb0, limb0+1, ...: entry k serves the k-th limb of a chunk
 template <class M>
@@ -620,7 +639,7 @@ static void launch_tree_tiles(rs_ctx *ctx, double *cols, size_t ncols, size_t co
   RS_REQUIRE(!newton || logT == logM, "fused Newton conversion needs single-tile columns");
 #define RS_TREE_LAUNCH_K(KERN)                                                                                   \
   do {                                                                                                           \
-    RS_HIP(hipFuncSetAttribute((const void *)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));     \
+    set_max_dyn_lds((const void *)KERN, (int)lds1);     \
     hipLaunchKernelGGL(KERN, dim3(grid), dim3(thr), lds1, st, cols, logM, logT, col0, (unsigned)S,               \
                        (unsigned)slots_per_limb, cp);                                                            \
   } while (0)
@@ -634,10 +653,10 @@ static void launch_tree_tiles(rs_ctx *ctx, double *cols, size_t ncols, size_t co
   if (wide) {
     const int wl = (int)((T + T / 32) * sizeof(double));
     if (logT == 14) {
-      RS_HIP(hipFuncSetAttribute((const void *)tree_wide_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+      set_max_dyn_lds((const void *)tree_wide_kernel<14>, wl);
       hipLaunchKernelGGL(tree_wide_kernel<14>, dim3(grid), dim3(512), wl, st, cols, logM, col0, (unsigned)S, (unsigned)slots_per_limb, cp);
     } else {
-      RS_HIP(hipFuncSetAttribute((const void *)tree_wide_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+      set_max_dyn_lds((const void *)tree_wide_kernel<13>, wl);
       hipLaunchKernelGGL(tree_wide_kernel<13>, dim3(grid), dim3(256), wl, st, cols, logM, col0, (unsigned)S, (unsigned)slots_per_limb, cp);
     }
   } else if (thr == 512 && logT == 13 && g_witness_tree_ct) {
@@ -681,7 +700,7 @@ static void launch_tree_tiles_generic(rs_ctx *ctx, typename ArithOf<M>::T *cols,
   const size_t lds = padded_len(tree_scratch_offset((int)T) + T) * sizeof(uint64_t);
   ProfScope prof(ctx, st, "tree_tiles_generic_kernel", (double)(ncols << (logM - logT)) * (double)T * 16.0,
                  (double)(ncols << (logM - logT)) * tree_fp64((double)T, logT));
-  RS_HIP(hipFuncSetAttribute((const void *)tree_tiles_generic_kernel<ColPlansT<M>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  set_max_dyn_lds((const void *)tree_tiles_generic_kernel<ColPlansT<M>>, (int)lds);
   hipLaunchKernelGGL(tree_tiles_generic_kernel<ColPlansT<M>>, dim3((unsigned)(ncols << (logM - logT))), dim3(col_threads(2 * T)), lds, st,
                      cols, logM, logT, col0, (unsigned)S, (unsigned)slots_per_limb, cp);
   RS_HIP(hipGetLastError());
@@ -806,7 +825,7 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
     if (logB == 13 && MODE != 1 && MODE != 4 && g_witness_sub_ct == 3) {
       const int wl = (int)(WideShape<13>::TILE * sizeof(double));
       const unsigned long long nb = (unsigned long long)(ncols * bpc);
-      RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_wide16_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+      set_max_dyn_lds((const void *)sub_ntt_wide16_kernel<MODE>, wl);
       hipLaunchKernelGGL((sub_ntt_wide16_kernel<MODE>), dim3((unsigned)std::min<unsigned long long>(nb, 512)), dim3(512), wl, st, X,
                          logsub - logB, tp, (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp, nb);
       RS_HIP(hipGetLastError());
@@ -816,7 +835,7 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
     if (logB == 13 && MODE != 1 && g_witness_sub_ct == 2) {
       const int wl = (int)(WideShape<13>::TILE * sizeof(double));
       const unsigned long long nb = (unsigned long long)(ncols * bpc);
-      RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_wide_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+      set_max_dyn_lds((const void *)sub_ntt_wide_kernel<MODE>, wl);
       hipLaunchKernelGGL((sub_ntt_wide_kernel<MODE>), dim3((unsigned)std::min<unsigned long long>(nb, 512)), dim3(256), wl, st, X,
                          logsub - logB, tp, (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp, nb,
                          (const double *)nullptr);
@@ -825,7 +844,7 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
     }
 #ifdef RS_EXPERIMENTS
     if (logB == 13 && MODE != 1 && MODE != 4 && g_witness_sub_ct) {
-      RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_ct_kernel<MODE, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set_max_dyn_lds((const void *)sub_ntt_ct_kernel<MODE, 13>, (int)lds);
       hipLaunchKernelGGL((sub_ntt_ct_kernel<MODE, 13>), dim3((unsigned)(ncols * bpc)), dim3(512), lds, st, X, logsub - logB, tp,
                          (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp);
       RS_HIP(hipGetLastError());
@@ -833,7 +852,7 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
     }
 #endif
   }
-  RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_kernel<MODE, ColPlansT<M>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  set_max_dyn_lds((const void *)sub_ntt_kernel<MODE, ColPlansT<M>>, (int)lds);
   const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, ((size_t)1 << logB) / 16));
   hipLaunchKernelGGL((sub_ntt_kernel<MODE, ColPlansT<M>>), dim3((unsigned)(ncols * bpc)), dim3(thr), lds, st, X, logB, logsub - logB, tp,
                      (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp);
@@ -878,7 +897,7 @@ static void bc2_conv(rs_ctx *ctx, Bc2Args a, int logY, size_t ncols, const TabPt
     if (MODE == 3) tp.t[0] = other;
     {
       const int wl = (int)(WideShape<13>::TILE * sizeof(double));
-      RS_HIP(hipFuncSetAttribute((const void *)sub_ntt_wide_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, wl));
+      set_max_dyn_lds((const void *)sub_ntt_wide_kernel<MODE>, wl);
       hipLaunchKernelGGL((sub_ntt_wide_kernel<MODE>), dim3((unsigned)std::min<unsigned long long>(nb, 512)), dim3(256), wl, st, a.Ws, 1, tp,
                          (unsigned)((size_t)a.units * Y * 2), (unsigned)((size_t)a.units * Y * 2), a.col0, a.S, a.slots_per_limb, cp, nb,
                          (const double *)a.Wy);
@@ -1085,13 +1104,13 @@ static void bc_conv(rs_ctx *ctx, BcArgs a, size_t ncols, size_t per_unit, const 
   for (int k = 0; k < a.nk; k++) pairs += std::min(k, a.nxb - 1) - std::max(0, k - a.nyb + 1) + 1;
   {
     ProfScope prof(ctx, st, "bc_fwd_kernel", nfwd * (double)B2 * 12.0, nfwd * ntt_fp64((double)B2, a.bcLog));
-    RS_HIP(hipFuncSetAttribute((const void *)bc_fwd_kernel<SRC, CPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)bc_fwd_kernel<SRC, CPS>, (int)lds);
     hipLaunchKernelGGL((bc_fwd_kernel<SRC, CPS>), dim3((unsigned)(ncols * a.units * a.nxb)), dim3(thr), lds, st, a, cp);
   }
   {
     ProfScope prof(ctx, st, "bc_mac_kernel", nmac * (double)B2 * 8.0 + (double)ncols * a.units * pairs * (double)B2 * 8.0,
                    nmac * ntt_fp64((double)B2, a.bcLog) + (double)ncols * a.units * pairs * (double)B2 * 7.0);
-    RS_HIP(hipFuncSetAttribute((const void *)bc_mac_kernel<YK, CPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)bc_mac_kernel<YK, CPS>, (int)lds);
     hipLaunchKernelGGL((bc_mac_kernel<YK, CPS>), dim3((unsigned)(ncols * a.units * a.nk)), dim3(thr), lds, st, a, cp);
   }
   {
@@ -1183,7 +1202,7 @@ static void bc_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, cons
     b.Xhat = Yhat;
     const size_t lds = padded_len(B2) * sizeof(uint64_t);
     ProfScope prof(ctx, st, "bc_fwd_kernel", (double)ncols * nb * (double)B2 * 12.0, (double)ncols * nb * ntt_fp64((double)B2, bc));
-    RS_HIP(hipFuncSetAttribute((const void *)bc_fwd_kernel<BS_CENTER, CPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)bc_fwd_kernel<BS_CENTER, CPS>, (int)lds);
     hipLaunchKernelGGL((bc_fwd_kernel<BS_CENTER, CPS>), dim3((unsigned)(ncols * nb)), dim3(col_threads(B2)), lds, st, b, cp);
   }
   // P = A * B, 2M coefficients
@@ -1313,7 +1332,7 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> 
   if (P->logM <= g_witness_lds_logM) {
     // the 2M convolution tile, or the product tree's tile + scratch when M is below the LDS block size
     const size_t lds = std::max(padded_len(2 * P->M), padded_len(tree_scratch_offset((int)P->M) + P->M)) * sizeof(double);
-    RS_HIP(hipFuncSetAttribute((const void *)interp_columns_kernel<ColPlansT<M>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)interp_columns_kernel<ColPlansT<M>>, (int)lds);
     ProfScope prof(ctx, st, "interp_columns_kernel", (double)ncols * (double)P->M * 16.0,
                    (double)ncols * (2.0 * ntt_fp64(2.0 * (double)P->M, P->logM + 1) + 21.0 * (double)P->M + tree_fp64((double)P->M, P->logM)));
     hipLaunchKernelGGL(interp_columns_kernel<ColPlansT<M>>, dim3((unsigned)ncols), dim3(col_threads(2 * P->M)), lds, st, cols, P->logM,
@@ -1360,7 +1379,7 @@ static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, 
                      (double)S * (10.0 * ntt_fp64((double)Mlen, P->logM) + (d1 ? 52.0 : 28.0) * (double)Mlen));
 #define RS_H_LAUNCH(KERN)                                                                                            \
   do {                                                                                                               \
-    RS_HIP(hipFuncSetAttribute((const void *)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));         \
+    set_max_dyn_lds((const void *)KERN, (int)lds1);         \
     hipLaunchKernelGGL(KERN, dim3((unsigned)S), dim3(thr), lds1, st, A, B, H, P->logM, (int)P->m, (unsigned)spl, cp, \
                        d1, d2, d3, cm);                                                                              \
   } while (0)
@@ -1377,7 +1396,7 @@ static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, 
   }
   if (P->logM <= g_witness_lds_logM) {
     const size_t lds = padded_len(2 * Mlen) * sizeof(double);
-    RS_HIP(hipFuncSetAttribute((const void *)h_columns_kernel<ColPlansT<M>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    set_max_dyn_lds((const void *)h_columns_kernel<ColPlansT<M>>, (int)lds);
     ProfScope prof(ctx, st, "h_columns_kernel", (double)S * (double)Mlen * 24.0,
                    (double)S * (5.0 * ntt_fp64(2.0 * (double)Mlen, P->logM + 1) + (d1 ? 52.0 : 28.0) * (double)Mlen));
     hipLaunchKernelGGL(h_columns_kernel<ColPlansT<M>>, dim3((unsigned)S), dim3(col_threads(2 * Mlen)), lds, st, A, B, H, P->logM, (int)P->m,

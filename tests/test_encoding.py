@@ -54,9 +54,11 @@ def _budget_ladder(ctx, sk, seed=3):
     r = ctx.random_ring(seed, 2)
     cur = ctx.enc_encode(sk, r[:1], 5)[0]
     out = [cur]
-    for _ in range(4):
+    for _ in range(16):  # as long as it takes (C5: eight 48-bit data primes under a 54-bit plain modulus), one step beyond
         cur = ctx.enc_mul_ring(cur, r[1])
         out.append(cur)
+        if len(out) >= 5 and max(ctx.noise_budget(sk, out[-2])) == 0:
+            break
     return np.stack(out), r
 
 

@@ -2,9 +2,10 @@
 the HBM-bound passes with the FP64-bound tile kernels can only pay if a streaming pass keeps most of its bandwidth on a
 small share of the CUs while the tile kernels lose only that share.)
 
-One headline proof (C3, 2^16 constraints, tiled key) per CU mask -- hipExtStreamCreateWithCUMask, every k-th CU kept so
-that the share is spread evenly over the XCDs whatever the numbering -- with the library's per-kernel profile; printed
-per kernel class.  Then the arithmetic: best spatial split  min_f max(T_valu(1 - f), T_hbm(f))  against the serial sum.
+One headline proof (C3, 2^16 constraints, tiled key) per CU mask -- hipExtStreamCreateWithCUMask, the LOW k/8 of the 256
+mask bits (an interleaved pattern, "every other bit", changes nothing on this driver: tools/cumask_probe.py, and the first
+run of this probe, profiles/r05_cu_share_probe_interleaved.txt) -- with the library's per-kernel profile; printed per
+kernel class.  Then the arithmetic: best spatial split  min_f max(T_valu(1 - f), T_hbm(f))  against the serial sum.
 usage: gpurun -- python tools/cu_share_probe.py [logm=16]"""
 import ctypes as C
 import json
@@ -24,7 +25,7 @@ hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, 
 
 
 def masked_stream(keep_of_8):
-    bits = sum(1 << i for i in range(256) if (i % 8) < keep_of_8)
+    bits = (1 << (32 * keep_of_8)) - 1
     words = (C.c_uint32 * 8)(*[(bits >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
     s = C.c_void_p()
     rc = hip.hipExtStreamCreateWithCUMask(C.byref(s), 8, words)
@@ -81,4 +82,5 @@ for keep in (7, 6, 4):  # tile kernels on keep/8, streaming passes on the rest
     rest = 8 - keep
     a, b = t_valu["%d/8 of the CUs" % keep], t_hbm.get("%d/8 of the CUs" % rest)
     if b is not None:
+        a, b = a, t_hbm["%d/8 of the CUs" % rest]
         print("spatial split %d/8 + %d/8: max(%.1f, %.1f) = %.1f ms against %.1f ms serial (%.3f)" % (keep, rest, a, b, max(a, b), serial, max(a, b) / serial))

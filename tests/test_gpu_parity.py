@@ -1012,7 +1012,7 @@ def test_multipass_tuned_sub_transform_kernel_equals_generic(m, zk):
     ds = [dev.put(ctx.random_ring(60 + k)) for k in range(3)] if zk else [None] * 3
     dcs = dev.r1cs(cs)
     keys = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
-    from ringsnark_amd.witness_knobs import SUB_CT_DEFAULT
+    from tests.witness_knobs import SUB_CT_DEFAULT
     runs = {}
     from ringsnark_amd import _lib
     try:
@@ -1030,7 +1030,7 @@ def test_multipass_tuned_sub_transform_kernel_equals_generic(m, zk):
         for k in keys:
             assert (runs[variant][k] == runs[0][k]).all(), (variant, k)
     # the product-tree kernels of the 2^13 tiles: level loop not unrolled (0), wave-private radix-8 (1), wide (2)
-    from ringsnark_amd.witness_knobs import TREE_CT_DEFAULT
+    from tests.witness_knobs import TREE_CT_DEFAULT
     try:
         for variant, tile in ((0, 13), (1, 13), (2, 13), (2, 14)):  # the wide kernel on 2^13 and on 2^14 tiles
             _set_tuning(b"witness_tree_ct", variant)

@@ -243,3 +243,21 @@ def test_reference_gadgetlib_drives_the_device_provers(tmp_path, poly):
     assert (to_host(got) == cppr).all()
     expr, _ = O.rinocchio_prove(ctx, H.oracle_cs(cs), rpk, asg, *ds)
     assert (cppr == expr).all()
+
+
+def test_bench_launches_its_own_ranks_and_reports_their_failure():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) must start the two ranks itself
+    (round-4 verdict: the driver's command form died on an assert) and, when they fail -- here: no GPU -- exit non-zero
+    without hanging or retrying.  On the GPU box the same command is rehearsed with RINGSNARK_BENCH_REHEARSAL=1
+    (profiles/r05_bench_rehearsal_gpus2.json)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check of the launcher's failure path")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "No HIP GPUs are available" in (r.stdout + r.stderr) or "HIP device" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-2000:]
+    assert '"metric"' not in r.stdout

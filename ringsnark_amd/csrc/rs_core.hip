@@ -1033,7 +1033,12 @@ int rs_set_tuning(const char *key, int value) {
   }
   else if (std::string(key) == "witness_tree_ct")
     g_witness_tree_ct = value;
-  else if (std::string(key) == "witness_col_budget_mib") {
+  else if (std::string(key) == "witness_tree_once")
+    g_witness_tree_once = value ? 1 : 0;
+  else if (std::string(key) == "witness_big_ws_mib") {
+    RS_REQUIRE(value >= 64, "witness_big_ws_mib must be at least 64");
+    g_witness_big_ws_mib = value;
+  } else if (std::string(key) == "witness_col_budget_mib") {
     RS_REQUIRE(value >= 1, "witness_col_budget_mib must be positive");
     g_witness_col_budget_mib = value;
   } else if (std::string(key) == "witness_lds_logM") {

@@ -298,6 +298,8 @@ extern int g_prover_lin_io;               // prover.hip: io vectors as linear fo
 extern int g_witness_tree_log;            // witness.hip: tile of the wide product-tree kernel (13 or 14)
 extern int g_witness_sub_ct;              // witness.hip: compile-time-length sub-transform kernel
 extern int g_witness_tree_ct;             // witness.hip: level-unrolled product-tree kernel
+extern int g_witness_tree_once;            // witness.hip: product-tree tiles in one launch per chunk
+extern int g_witness_big_ws_mib;           // witness.hip: workspaces of one multi-pass sub-chunk of columns
 extern int g_witness_col_budget_mib;       // witness.hip: column workspace of one chunk of the witness map
 extern int g_witness_lds_logM;           // witness.hip: largest column (log2) handled inside one LDS tile
 void launch_ntt(rs_ctx *ctx, const NttTable &t, uint64_t *d_data, size_t batch, bool inverse, hipStream_t st);

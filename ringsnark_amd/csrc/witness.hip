@@ -931,10 +931,12 @@ static void bc2_conv(rs_ctx *ctx, Bc2Args a, int logY, size_t ncols, const TabPt
   RS_HIP(hipGetLastError());
 }
 
-// multi-pass interpolation of `ncols` columns X[ncols][M] in place; W: workspace [ncols][2M]
+// multi-pass interpolation of `ncols` columns X[ncols][M] in place; W: workspace [ncols][2M].
+// phases: 1 = values -> Newton coefficients, 2 = the product tree's tiles (in place on X: no workspace, so the caller may run
+// it ONCE over all the columns of a chunk instead of per workspace-sized sub-chunk), 4 = the levels above the tiles.
 template <class M>
 static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, typename ArithOf<M>::T *X, typename ArithOf<M>::T *W,
-                       size_t ncols, size_t col0, size_t S, size_t spl, int limb0, hipStream_t st) {
+                       size_t ncols, size_t col0, size_t S, size_t spl, int limb0, hipStream_t st, int phases = 7) {
   using T = typename ArithOf<M>::T;
   constexpr bool FP = std::is_same<M, Mod>::value;
   const int logM = P->logM, logT = std::min(g_witness_lds_logM, logM);
@@ -951,20 +953,23 @@ static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp
   a.slots_per_limb = (unsigned)spl;
   a.col0 = col0;
   TabPtrs tp{};
-  // values -> Newton coefficients: one cyclic convolution of length 2M
-  a.logtot = a.logsub = logM + 1;
-  launch_cross<false, CS_SCALE_PAD, M>(ctx, a, ncols, logB, cp, st);
-  for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_ehat;
-  launch_sub<2, M>(ctx, W, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * Mlen) >> logB, S, spl, cp, st);
-  launch_cross<true, CD_TAKE_LOW, M>(ctx, a, ncols, logB, cp, st);
+  if (phases & 1) {
+    // values -> Newton coefficients: one cyclic convolution of length 2M
+    a.logtot = a.logsub = logM + 1;
+    launch_cross<false, CS_SCALE_PAD, M>(ctx, a, ncols, logB, cp, st);
+    for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_ehat;
+    launch_sub<2, M>(ctx, W, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * Mlen) >> logB, S, spl, cp, st);
+    launch_cross<true, CD_TAKE_LOW, M>(ctx, a, ncols, logB, cp, st);
+  }
   // product tree: levels <= logTree inside LDS tiles (the wide kernel takes 2^14 tiles: one multi-pass level less)
   int logTree = logT;
   if constexpr (FP) {
     if (logT == 13 && logM >= 15 && g_witness_tree_ct == 2 && g_witness_tree_log >= 14) logTree = 14;
-    launch_tree_tiles(ctx, X, ncols, col0, logM, logTree, S, spl, cp, st);
+    if (phases & 2) launch_tree_tiles(ctx, X, ncols, col0, logM, logTree, S, spl, cp, st);
   } else {
-    launch_tree_tiles_generic<M>(ctx, X, ncols, col0, logM, logT, S, spl, cp, st);
+    if (phases & 2) launch_tree_tiles_generic<M>(ctx, X, ncols, col0, logM, logT, S, spl, cp, st);
   }
+  if (!(phases & 4)) return;
   // levels above: F_node = F_left + D_left * F_right with multi-pass transforms of length 2^l
   a.logtot = logM;
   for (int l = logTree + 1; l <= logM; l++) {
@@ -1079,10 +1084,12 @@ static void big_h_coset(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &c
   RS_HIP(hipGetLastError());
 }
 
+int g_witness_tree_once = 1;  // tuning knob "witness_tree_once": the product tree's tiles in one launch per chunk of columns
+int g_witness_big_ws_mib = 6 * 1024;  // tuning knob "witness_big_ws_mib": the two [cols][2M] workspaces of a multi-pass sub-chunk
 static size_t big_chunk_cols(const WitnessPlan *P) {
   // two [cols][2M] workspaces within ~6 GiB
   const size_t per_col = 4 * P->M * sizeof(double);
-  return std::max<size_t>(1, ((size_t)6 << 30) / per_col);
+  return std::max<size_t>(1, ((size_t)g_witness_big_ws_mib << 20) / per_col);
 }
 
 // Columns handled by the M-tile kernels (fused Newton + tree, h_tile): 2^10 .. 2^13 at two workgroups
@@ -1124,7 +1131,7 @@ static void bc_conv(rs_ctx *ctx, BcArgs a, size_t ncols, size_t per_unit, const 
 
 // columns per chunk such that the block workspaces (spectra + pair products, up to ~8M words per column) stay within ~6 GiB
 static size_t bc_chunk_cols(const WitnessPlan *P) {
-  return std::max<size_t>(1, ((size_t)6 << 30) / ((P->bc2 ? 12 : 10) * P->M * sizeof(double)));
+  return std::max<size_t>(1, ((size_t)g_witness_big_ws_mib << 20) / ((P->bc2 ? 12 : 10) * P->M * sizeof(double)));
 }
 
 template <class M>
@@ -1229,26 +1236,32 @@ static void bc_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, cons
 // workspaces: Wy [ncols][2M] and Ws [ncols][4M] words per convolution in flight (+ the same again and a [ncols][2M]
 // product buffer for H); bc_chunk_cols keeps a chunk of columns within ~6 GiB
 static void bc2_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, double *X, size_t ncols, size_t col0, size_t S, size_t spl,
-                       int limb0, hipStream_t st) {
+                       int limb0, hipStream_t st, int phases = 7) {  // phases: as big_interp
   const int logM = P->logM;
   const size_t Mlen = P->M;
   Bc2Args a{};
   a.src = X;
   a.dst = X;
-  a.Wy = (double *)ws_get(ctx, 12, ncols * 2 * Mlen * sizeof(double));
-  a.Ws = (double *)ws_get(ctx, 13, ncols * 4 * Mlen * sizeof(double));
+  if (phases & 5) {  // the tree tiles work in place: no workspace (and `ncols` may then be a whole chunk)
+    a.Wy = (double *)ws_get(ctx, 12, ncols * 2 * Mlen * sizeof(double));
+    a.Ws = (double *)ws_get(ctx, 13, ncols * 4 * Mlen * sizeof(double));
+  }
   a.logM = logM;
   a.m = (int)P->m;
   a.col0 = col0;
   a.S = (unsigned)S;
   a.slots_per_limb = (unsigned)spl;
   TabPtrs tp{};
-  // values -> Newton coefficients: low M terms of (y_k / k!) * ((-1)^k / k!)
-  a.units = 1;
-  for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_b2_e;
-  bc2_conv<BS_SCALE, BD_NEWTON, 2>(ctx, a, logM + 1 - BC2_LOGB, ncols, &tp, nullptr, cp, st);
+  if (phases & 1) {
+    // values -> Newton coefficients: low M terms of (y_k / k!) * ((-1)^k / k!)
+    a.units = 1;
+    for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_b2_e;
+    bc2_conv<BS_SCALE, BD_NEWTON, 2>(ctx, a, logM + 1 - BC2_LOGB, ncols, &tp, nullptr, cp, st);
+  }
   // product tree: levels <= 14 inside LDS tiles, the levels above as block convolutions F_node = F_left + (x^h + d) * F_right
-  launch_tree_tiles(ctx, X, ncols, col0, logM, (g_witness_tree_ct == 2 && g_witness_tree_log >= 14) ? 14 : 13, S, spl, cp, st);
+  if (phases & 2)
+    launch_tree_tiles(ctx, X, ncols, col0, logM, (g_witness_tree_ct == 2 && g_witness_tree_log >= 14) ? 14 : 13, S, spl, cp, st);
+  if (!(phases & 4)) return;
   const int first = (g_witness_tree_ct == 2 && g_witness_tree_log >= 14) ? 15 : 14;
   for (int l = first; l <= logM; l++) {
     a.l = l;
@@ -1310,6 +1323,16 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> 
   constexpr bool FP = std::is_same<M, Mod>::value;
   if (P->bcLog) {  // a ring prime without a 2M-th root of unity: block convolutions
     const size_t chunk = std::min(ncols, bc_chunk_cols(P));
+    if constexpr (FP) {
+      if (P->bc2 && chunk < ncols && g_witness_tree_once) {  // the product tree's tiles in one launch (see the full-length path below)
+        for (size_t c0 = 0; c0 < ncols; c0 += chunk)
+          bc2_interp(ctx, P, cp, cols + c0 * P->M, std::min(chunk, ncols - c0), c0, S, slots_per_limb, limb0, st, 1);
+        bc2_interp(ctx, P, cp, cols, ncols, 0, S, slots_per_limb, limb0, st, 2);
+        for (size_t c0 = 0; c0 < ncols; c0 += chunk)
+          bc2_interp(ctx, P, cp, cols + c0 * P->M, std::min(chunk, ncols - c0), c0, S, slots_per_limb, limb0, st, 4);
+        return;
+      }
+    }
     for (size_t c0 = 0; c0 < ncols; c0 += chunk) {
       if constexpr (FP) {
         if (P->bc2) {
@@ -1342,6 +1365,17 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> 
   }
   const size_t chunk = std::min(ncols, big_chunk_cols(P));
   T *W = (T *)ws_get(ctx, 12, chunk * 2 * P->M * sizeof(double));
+  if (chunk < ncols && g_witness_tree_once) {
+    // the tiles of the product tree work in place on the columns: ONE launch over all of them between the sub-chunked
+    // phases (tile kernels like long launches: 183.5 -> 176 ms per headline proof when every launch covers a whole chunk,
+    // profiles/r05_knob_ab_big_ws.txt; the workspace-bound phases keep their 6 GiB sub-chunks, which they prefer)
+    for (size_t c0 = 0; c0 < ncols; c0 += chunk)
+      big_interp<M>(ctx, P, cp, cols + c0 * P->M, W, std::min(chunk, ncols - c0), c0, S, slots_per_limb, limb0, st, 1);
+    big_interp<M>(ctx, P, cp, cols, W, ncols, 0, S, slots_per_limb, limb0, st, 2);
+    for (size_t c0 = 0; c0 < ncols; c0 += chunk)
+      big_interp<M>(ctx, P, cp, cols + c0 * P->M, W, std::min(chunk, ncols - c0), c0, S, slots_per_limb, limb0, st, 4);
+    return;
+  }
   for (size_t c0 = 0; c0 < ncols; c0 += chunk) {
     const size_t nc = std::min(chunk, ncols - c0);
     big_interp<M>(ctx, P, cp, cols + c0 * P->M, W, nc, c0, S, slots_per_limb, limb0, st);

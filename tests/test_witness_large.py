@@ -237,3 +237,31 @@ def test_unsatisfied_assignment_long_division_and_coset_forms():
     bad[0, 3] = True
     assert same[:, ~bad].all()           # satisfied columns: the two forms are the same polynomial
     assert not same[:, 0, 3].all()       # the unsatisfied one: documented difference
+
+
+@pytest.mark.parametrize("force", [0, 14])
+def test_product_tree_tiles_in_one_launch_per_chunk(force):
+    """force = 14: the same on the two-dimensional block convolutions of the recipe primes.  witness_tree_once (default on): when the columns of a chunk are worked through in workspace-sized sub-chunks, the
+    product tree's tiles -- in place on the columns, no workspace -- run as ONE launch between the sub-chunked phases.
+    Forced at test scale by a 64 MiB workspace (16 columns per sub-chunk at M = 2^17): bit-equal to the per-sub-chunk order
+    and to the unchunked default, every column through the identities."""
+    from ringsnark_amd.device import to_host
+    prm = P.preset("toy44")
+    m = 100000
+    runs = {}
+    for tag, ws, once in (("default", 6144, 1), ("sub-chunks, one tree launch", 64, 1), ("sub-chunks, tree per sub-chunk", 64, 0)):
+        _set_tuning(b"witness_big_ws_mib", ws)
+        _set_tuning(b"witness_tree_once", once)
+        try:
+            dev, cs, asg, ds, w, names = _run(prm, m, True, force)
+        finally:
+            _set_tuning(b"witness_big_ws_mib", 6144)
+            _set_tuning(b"witness_tree_once", 1)
+        if ws == 64 and once:
+            err, info = proof_check.check_all_columns(prm, cs, asg, {k: w[k] for k in KEYS}, tuple(ds), seed=4, Z=w["Z"])
+            assert err is None and info["columns"] == prm.L * prm.N, err
+        runs[tag] = {k: to_host(w[k]) for k in KEYS}
+        del dev, asg, w
+    for tag in runs:
+        for k in KEYS:
+            assert (runs[tag][k] == runs["default"][k]).all(), (tag, k)

@@ -219,6 +219,7 @@ void batch_encode_run(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, s
 int g_mac_ablate = 0;
 int g_mac_share_keys = 1;  // tuning knob "mac_share_keys": two key vectors share the plaintext spectrum (mac_kernel_v4; 8192 and 16384 points)
 int g_msm_host_tile = 1024;  // tuning knob "msm_host_tile": terms per staging buffer of a host-resident key
+int g_msm_c_mib = 2048;       // tuning knob "msm_c_mib": workspace of the centred plaintext rows of one term tile
 int g_mac_chunk_units = 768;  // tuning knob "mac_chunk_units": (limb, prime, chunk) units per MAC launch (term chunks = units / (L K))
 int g_plain_variant = 1;  // 1: plain_center_wide_kernel at N_enc = 8192; 0: plain_center_kernel
 int g_mac_variant = 5;  // 5: half-spectrum wide kernel at N_enc = 8192 (else as 3); 3: streaming kernel, 1024-thread shape at N_enc = 8192 (else as 2); 2: 512-thread streaming kernel; 1: generic kernel
@@ -330,9 +331,9 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
         group_T[g] = std::max<size_t>(group_T[g], (size_t)lin[g].T);
       }
   const int n_sets = n_crs * n_groups;
-  // tiling: C workspace <= ~2 GiB
+  // tiling: C workspace <= ~2 GiB (knob msm_c_mib)
   const size_t c_bytes_per_term = (size_t)n_groups * L * n * sizeof(double);
-  size_t tile_terms = std::max<size_t>(1, std::min<size_t>(Tmax, ((size_t)2 << 30) / c_bytes_per_term));
+  size_t tile_terms = std::max<size_t>(1, std::min<size_t>(Tmax, ((size_t)g_msm_c_mib << 20) / c_bytes_per_term));
   if (crs_window) {
     size_t p2 = 1;
     while (p2 * 2 <= tile_terms) p2 *= 2;

@@ -994,7 +994,10 @@ int rs_set_tuning(const char *key, int value) {
     g_prover_lin_io = value;
   else if (std::string(key) == "msm_host_tile")
     g_msm_host_tile = std::max(1, value);
-  else if (std::string(key) == "mac_chunk_units")
+  else if (std::string(key) == "msm_c_mib") {
+    RS_REQUIRE(value >= 1, "msm_c_mib must be positive");
+    g_msm_c_mib = value;
+  } else if (std::string(key) == "mac_chunk_units")
     g_mac_chunk_units = std::max(1, value);
   else if (std::string(key) == "mac_share_keys")
     g_mac_share_keys = value != 0;

@@ -286,7 +286,7 @@ inline hipStream_t S(rs_stream s) { return (hipStream_t)s; }
 
 // launch helpers implemented in the .hip files
 void msm_scratch_release(rs_ctx *ctx);  // msm.hip
-extern int g_mac_variant, g_mac_ablate, g_plain_variant, g_mac_chunk_units, g_msm_host_tile, g_mac_share_keys;  // msm.hip tuning knobs
+extern int g_mac_variant, g_mac_ablate, g_plain_variant, g_mac_chunk_units, g_msm_host_tile, g_mac_share_keys, g_msm_c_mib;  // msm.hip tuning knobs
 extern int g_witness_h_coset;               // witness.hip: coset form of H when C is interpolated
 extern int g_witness_sub12_cross;           // witness.hip: most cross stages of a transform run on 2^12 blocks
 extern int g_witness_sub_log;              // witness.hip: block (log2) of the rooted sub-transforms, 13 or 12

@@ -1195,3 +1195,45 @@ def test_groth16_prover_on_recipe_primes_matches_oracle():
     exp, exp_empty = O.groth16_prove(ctx, H.oracle_cs(cs), pk, asg)
     got, empty = dev.groth16_prove(dev.r1cs(cs), {k: dev.put(v) for k, v in pk.items()}, dev.put(asg))
     assert empty == exp_empty and (host(got) == exp).all()
+
+
+@pytest.mark.gpu
+def test_steady_state_proofs_allocate_nothing_and_repeat_bit_for_bit():
+    """A prover process proves again and again: after the first proof of a (context, m) -- plan tables, the cached Z rows
+    of Rinocchio (witness_Z_rows), first-call workspaces -- further proofs must not take device memory, and must return
+    the same bytes (the witness map and the inner products are deterministic).  Both provers, ZK on."""
+    import torch
+
+    from ringsnark_amd.device import Device, to_host
+    prm = P.preset("C2")
+    dev = Device(prm)
+    m = 1 << 10
+    cs = R.chain_r1cs(m, prm.q)
+    dcs = dev.r1cs(cs)
+    asg = dev.ring_empty(m + 2)
+    dev.fill_uniform(asg[:2], 0, 7)
+    dev.chain_assignment(asg, m)
+    W = 1 << 8
+    gk = {k: dev.fill_uniform(dev.enc_empty(W), 1, 13 + i) for i, k in enumerate(("s_pows", "delta_ts", "delta_mid"))}
+    gk["alpha"], gk["beta"] = dev.fill_uniform(dev.enc_empty(), 1, 16), dev.fill_uniform(dev.enc_empty(), 1, 17)
+    rk = {k: dev.fill_uniform(dev.enc_empty(W), 1, 22 + i) for i, k in enumerate(("s_pows", "alpha_s_pows", "beta_prods"))}
+    for i, k in enumerate(("beta_rv_ts", "beta_rw_ts", "beta_ry_ts")):
+        rk[k] = dev.fill_uniform(dev.enc_empty(), 1, 25 + i)
+    ds = [dev.fill_uniform(dev.ring_empty(), 0, 30 + k) for k in range(3)]
+
+    def both():
+        a = dev.groth16_prove(dcs, gk, asg, want_empty=False, window=W)[0]
+        b = dev.rinocchio_prove(dcs, rk, asg, *ds, window=W)[0]
+        torch.cuda.synchronize()
+        return to_host(a), to_host(b)
+
+    first = both()
+    both()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        got = both()
+        assert (got[0] == first[0]).all() and (got[1] == first[1]).all()
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 <= (8 << 20), "device memory taken by steady-state proofs: %d bytes" % (free0 - free1)

@@ -242,13 +242,18 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
   P->M = (size_t)1 << P->logM;
   const size_t M = P->M;
   const int logM = P->logM;
-  if (logM > 20)
-    throw Error(RS_ERR_UNSUPPORTED, "witness map beyond 2^20 constraints is not supported");
+  if (logM > 22)
+    throw Error(RS_ERR_UNSUPPORTED, "witness map beyond 2^22 constraints is not supported");
   P->limb.resize(ctx->L);
   int vmin = 64;
   for (int li = 0; li < ctx->L; li++) vmin = std::min(vmin, host::two_adicity(ctx->q[li]));
   if (g_witness_force_bc > 0) vmin = std::min(vmin, g_witness_force_bc);  // tests: the block path on well-endowed primes
   const bool blocked = vmin < logM + 1;
+  // full-length transforms serve 2^21 and 2^22 constraints as they serve 2^20 (one more cross pass); the block
+  // convolutions stop at 2^20 (the two-level transform across blocks is built for Y <= 256 blocks of 2^13)
+  if (blocked && logM > 20)
+    throw Error(RS_ERR_UNSUPPORTED, "witness map beyond 2^20 constraints needs ring primes = 1 mod 2^(log2 M + 1) (full-length transforms); "
+                                    "the block convolutions of other primes stop at 2^20");
   P->bc2 = blocked && g_witness_bc2 && !ctx->use_int && vmin >= 14 && logM >= 15;
   P->bcLog = blocked ? (P->bc2 ? 14 : std::min(vmin, 13)) : 0;
   // every context prime is 1 mod 2*N_enc with N_enc >= 16, so the 2-adicity is at least 5

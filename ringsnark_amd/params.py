@@ -176,6 +176,8 @@ def preset(name: str) -> RingParams:
                            notes="C4 with the ring primes default_double_batching_modulus-style recipe yields (seal_util.hpp:20-32)")
     if name == "toy":  # CPU-test scale
         return make_params(32, [30, 30], 64, [40, 40, 41], ring_factor=1 << 12, name="toy")
+    if name == "toy44x":  # the same with primes = 1 mod 2^23: full-length transforms to 2^22 constraints
+        return make_params(32, [43, 44], 64, [43, 44, 44], ring_factor=1 << 23, name="toy44x")
     if name == "toy44":  # small ring, headline-size primes (= 1 mod 2^20): large-m witness-map tests
         return make_params(32, [43, 44], 64, [43, 44, 44], ring_factor=1 << 20, name="toy44")
     if name == "toy49":  # stresses the 50-bit bound of the FP64 modmul path

@@ -354,3 +354,10 @@ def test_new_entry_points_reject_bad_arguments():
     assert lib.rs_instance_map_eval(dev.h, None, None, None, None, None, None, None, None) == _lib.RS_ERR_INVALID
     # count == 0 is a no-op
     assert lib.rs_enc_decode(dev.h, _ptr(enc), _ptr(enc), 0, _ptr(dev.ring_empty()), None) == _lib.RS_OK
+    # the noise budget: null arguments, a null context, count == 0
+    out = (C.c_int * 4)()
+    assert lib.rs_enc_noise_budget(dev.h, None, _ptr(enc), 2, out, None) == _lib.RS_ERR_INVALID
+    assert lib.rs_enc_noise_budget(dev.h, _ptr(enc), _ptr(enc), 2, None, None) == _lib.RS_ERR_INVALID
+    assert lib.rs_enc_noise_budget(None, _ptr(enc), _ptr(enc), 2, out, None) == _lib.RS_ERR_INVALID
+    assert lib.rs_enc_noise_budget(dev.h, _ptr(enc), _ptr(enc), 0, out, None) == _lib.RS_OK
+    assert lib.rs_version() >= 101

@@ -936,6 +936,42 @@ static void bc2_conv(rs_ctx *ctx, Bc2Args a, int logY, size_t ncols, const TabPt
   RS_HIP(hipGetLastError());
 }
 
+int g_witness_h_turn = 1;  // tuning knob "witness_h_turn": fuse the last inverse cross pass of A B with the first forward pass of rev(A B)
+// The turn of H as one pass (cross_turn_kernel): reads a.W (the product's workspace, sub-transformed), writes a.dst (the
+// workspace of T = rev(P) mod x^(m-1), cross stages done).  Returns false when the two transforms need more than one cross
+// pass each (the caller then runs the two passes).
+template <class M>
+static bool launch_cross_turn(rs_ctx *ctx, CrossArgs a, size_t ncols, int logB, const ColPlansT<M> &cp, hipStream_t st) {
+  using CPS = ColPlansT<M>;
+  constexpr bool FP = std::is_same<M, Mod>::value;
+  const int R = a.logtot - logB;
+  const int maxr = FP ? std::max(1, std::min(6, g_witness_cross_maxr)) : 4;
+  if (!g_witness_h_turn || R < 1 || R > maxr || a.logsub != a.logtot || logB < 8) return false;
+  if ((((uintptr_t)a.W | (uintptr_t)a.dst) & 15) != 0) return false;
+  const size_t B = (size_t)1 << logB;
+  const bool pair = R <= 5;
+  const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>((B / (pair ? 2 : 1)) / 256, 1024));
+  const dim3 grid(gx, (unsigned)ncols);
+  const double n = (double)((size_t)1 << a.logtot);
+  static const char *const names[7] = {"", "cross_turn_kernel<1", "cross_turn_kernel<2", "cross_turn_kernel<3", "cross_turn_kernel<4", "cross_turn_kernel<5",
+                                       "cross_turn_kernel<6"};
+  ProfScope prof(ctx, st, names[R], (double)ncols * 8.0 * 2.0 * n, (double)ncols * (ntt_fp64(n, R) + ntt_fp64(n, R - 1)));
+  switch (R) {
+    case 1: hipLaunchKernelGGL((cross_turn_kernel<1, CPS, 2>), grid, dim3(256), 0, st, a, cp); break;
+    case 2: hipLaunchKernelGGL((cross_turn_kernel<2, CPS, 2>), grid, dim3(256), 0, st, a, cp); break;
+    case 3: hipLaunchKernelGGL((cross_turn_kernel<3, CPS, 2>), grid, dim3(256), 0, st, a, cp); break;
+    case 4: hipLaunchKernelGGL((cross_turn_kernel<4, CPS, 2>), grid, dim3(256), 0, st, a, cp); break;
+    case 5:
+      if constexpr (FP) hipLaunchKernelGGL((cross_turn_kernel<5, CPS, 2>), grid, dim3(256), 0, st, a, cp);
+      break;
+    default:
+      if constexpr (FP) hipLaunchKernelGGL((cross_turn_kernel<6, CPS, 1>), grid, dim3(256), 0, st, a, cp);
+      break;
+  }
+  RS_HIP(hipGetLastError());
+  return true;
+}
+
 // multi-pass interpolation of `ncols` columns X[ncols][M] in place; W: workspace [ncols][2M].
 // phases: 1 = values -> Newton coefficients, 2 = the product tree's tiles (in place on X: no workspace, so the caller may run
 // it ONCE over all the columns of a chunk instead of per workspace-sized sub-chunk), 4 = the levels above the tiles.
@@ -1018,11 +1054,14 @@ static void big_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, con
   launch_cross<false, CS_PAD_CENTER, M>(ctx, a, ncols, logB, cp, st);
   tp.t[0] = W1;
   launch_sub<3, M>(ctx, W2, ncols, col0, logM + 1, logM + 1, logB, &tp, 1, S, spl, cp, st);
-  launch_cross<true, CD_PLAIN, M>(ctx, a, ncols, logB, cp, st);
-  // U = rev(P) * rev(Z)^-1 mod x^(m-1)
+  // U = rev(P) * rev(Z)^-1 mod x^(m-1): the product's last inverse cross pass and the first forward pass of its reversal are
+  // one pass over memory when each transform has a single cross pass (cross_turn_kernel); otherwise the two passes
+  a.dst = W1;
+  const bool turned = launch_cross_turn<M>(ctx, a, ncols, logB, cp, st);  // a.W = W2 -> W1
+  if (!turned) launch_cross<true, CD_PLAIN, M>(ctx, a, ncols, logB, cp, st);
   a.W = W1;
   a.src = W2;
-  launch_cross<false, CS_REV_TRUNC, M>(ctx, a, ncols, logB, cp, st);
+  if (!turned) launch_cross<false, CS_REV_TRUNC, M>(ctx, a, ncols, logB, cp, st);
   for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_shat;
   launch_sub<2, M>(ctx, W1, ncols, col0, logM + 1, logM + 1, logB, &tp, (2 * Mlen) >> logB, S, spl, cp, st);
   a.dst = H;

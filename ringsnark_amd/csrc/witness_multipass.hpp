@@ -337,6 +337,141 @@ __global__ void __launch_bounds__(256) cross_kernel(CrossArgs a, CPS plans) {
   }
 }
 
+// ---- the turn of H (round 5): the LAST inverse cross pass of P = A B and the FIRST forward cross pass of T = rev(P) mod
+// x^(m-1), as ONE pass over memory.  big_h (witness.hip) runs "inverse cross stages of the product, in place" and then
+// "forward cross stages of the reversed, truncated product, from W2 into W1": two HBM-bound passes, 7 n words of traffic per
+// column (n = 2M), of which the second re-reads what the first has just written.  Both passes hold a RESIDUE CLASS mod
+// B = n / 2^R in a thread -- the inverse one positions rho + e B, the forward one positions j + e' B -- and
+//     T_k = P_{2m-2-k}  (k < m - 1, zero otherwise),      k = j + e' B   <->   i = 2m - 2 - k = rho + (E0 - e') B,
+//     rho = (2m - 2 - j) mod B,  E0 = (2m - 2 - j) div B,
+// so the thread that finishes the inverse stages of class rho holds every input of the forward group of class j: the
+// register tile is reversed (compile time) and shifted by E - 1 - E0 (a per-lane amount: a barrel of R select rounds), the
+// truncation is a select, and the forward stages follow -- 4 n words per column instead of 7 n.  Same stages, reduction
+// masks, twiddles and reduce-on-load as cross_kernel<true, R, CD_PLAIN> followed by cross_kernel<false, R, CS_REV_TRUNC>: the
+// stored words are identical (knob witness_h_turn = 0 restores the two passes; tests compare).
+// V = 2: forward pair (j, j + 1), j even, stored with 16-byte accesses; its inverse classes rho, rho - 1 are odd aligned
+// (2m - 2 is even) and are loaded as 8-byte words.  V = 1 (R = 6: 64 words per group): one class per thread.
+// Needs ONE pass each way: logtot - logB = R <= 6 (FP64) / 4 (integers).  grid (x, columns).
+template <int R, class CPS, int V>
+__global__ void __launch_bounds__(256) cross_turn_kernel(CrossArgs a, CPS plans) {
+  using T = typename CPS::T;
+  using Mt = typename CPS::M;
+  constexpr int E = 1 << R;
+  const size_t col = blockIdx.y;
+  const ColPlanT<Mt> &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const Mt mod = P.mod;
+  const T *__restrict__ win = static_cast<const T *>(a.W) + (col << a.logtot);
+  T *__restrict__ wout = static_cast<T *>(a.dst) + (col << a.logtot);
+  const T *__restrict__ tw = P.tw;
+  const T *__restrict__ itw = P.itw;
+  const int logB = a.logtot - R, B = 1 << logB;
+  const int q = 2 * a.m - 2;
+  const uint32_t imask = P.imask[a.logtot] >> logB, fmask = P.fmask[a.logtot];
+  const int ngroups = B / V;
+  for (int g = (int)(blockIdx.x * blockDim.x + threadIdx.x); g < ngroups; g += (int)(gridDim.x * blockDim.x)) {
+    const int j = V * g;
+    T v[V][E];
+    int E0[V];
+#pragma unroll
+    for (int c = 0; c < V; c++) {
+      const int i0 = q - j - c;  // >= 0: q >= M >= B > j + c
+      const int rho = i0 & (B - 1);
+      E0[c] = i0 >> logB;
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+#if RS_WORKSPACE_NT
+        v[c][e] = __builtin_nontemporal_load(win + rho + e * B);
+#else
+        v[c][e] = win[rho + e * B];
+#endif
+      }
+    }
+    // inverse stages logB .. logB + R - 1 of the length-2^logtot transform (inv_round2 with u0 = logB, hi = 0)
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      if ((imask >> k) & 1u) {
+#pragma unroll
+        for (int c = 0; c < V; c++)
+#pragma unroll
+          for (int e = 0; e < E; e++) v[c][e] = reduce(v[c][e], mod);
+      }
+      const int twbase = 1 << (R - 1 - k);
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        if (e & (1 << k)) continue;
+        const T w = itw[twbase + (e >> (k + 1))];
+#pragma unroll
+        for (int c = 0; c < V; c++) {
+          const T x = v[c][e], y = v[c][e + (1 << k)];
+          v[c][e] = addm(x, y, mod);
+          v[c][e + (1 << k)] = mulmod(subm(x, y, mod), w, mod);
+        }
+      }
+    }
+    // T_{j + c + e' B} = P_{rho_c + (E0_c - e') B}: reverse, shift by E - 1 - E0_c, truncate at m - 1, reduce (CS_REV_TRUNC)
+    T x[V][E];
+#pragma unroll
+    for (int c = 0; c < V; c++) {
+      T u[E];
+#pragma unroll
+      for (int e = 0; e < E; e++) u[e] = v[c][E - 1 - e];
+      const int sh = E - 1 - E0[c];  // 0 <= sh < E; entries shifted in from beyond the tile belong to k > 2m - 2: truncated below
+#pragma unroll
+      for (int b = 0; b < R; b++) {
+        const bool on = (sh >> b) & 1;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const T far = (e + (1 << b) < E) ? u[e + (1 << b)] : T(0);
+          u[e] = on ? far : u[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < E / 2; e++) x[c][e] = (j + c + e * B < a.m - 1) ? reduce(u[e], mod) : T(0);
+    }
+    // forward stages 0 .. R - 1 on a zero-padded input (fwd_round2 with s0 = 0, hi = 0; stage 0 is a copy)
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      if ((fmask >> k) & 1u) {
+#pragma unroll
+        for (int c = 0; c < V; c++)
+#pragma unroll
+          for (int e = 0; e < (k == 0 ? E / 2 : E); e++) x[c][e] = reduce(x[c][e], mod);
+      }
+      if (k == 0) {
+#pragma unroll
+        for (int c = 0; c < V; c++)
+#pragma unroll
+          for (int e = 0; e < E / 2; e++) x[c][e + E / 2] = x[c][e];
+        continue;
+      }
+      const int half = E >> (k + 1);
+#pragma unroll
+      for (int blk = 0; blk < (1 << k); blk++) {
+        const T w = tw[(1 << k) + blk];
+#pragma unroll
+        for (int e0 = 0; e0 < half; e0++) {
+          const int ia = blk * 2 * half + e0, ib = ia + half;
+#pragma unroll
+          for (int c = 0; c < V; c++) {
+            const T t = mulmod(x[c][ib], w, mod);
+            const T z = x[c][ia];
+            x[c][ia] = addm(z, t, mod);
+            x[c][ib] = subm(z, t, mod);
+          }
+        }
+      }
+    }
+    const GlobalIOT<T> out{wout};
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      if (V == 2)
+        out.store2(j + e * B, x[0][e], x[V - 1][e]);
+      else
+        out.store(j + e * B, 0, 0, 0, x[0][e]);
+    }
+  }
+}
+
 // Sub-transforms on blocks of Bn = 2^logB doubles.  MODE 0: forward, 1: inverse, 2: forward,
 // multiply by tab[(blk % tab_period) * Bn + j], inverse (fused); 3: like 2 with a per-column table
 // (another workspace of the same shape, lazily reduced): tab[blk * Bn + j].  Block blk belongs to column

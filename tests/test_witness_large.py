@@ -286,3 +286,29 @@ def test_block_convolutions_refuse_more_than_2_20_constraints():
     with pytest.raises(_lib.RsError) as ei:
         _run(prm, 1500000, False, 0, want=("A_mid",))
     assert ei.value.code == _lib.RS_ERR_UNSUPPORTED and "2^20" in str(ei.value)
+
+
+@pytest.mark.parametrize("m,zk,int_arith", [(20000, True, False), (32768, False, False), (50000, True, False), (65536, True, False),
+                                             (100000, False, False), (262144, True, False), (30000, True, True)])
+def test_the_turn_of_h_as_one_pass(m, zk, int_arith):
+    """witness_h_turn (default on): the last inverse cross pass of the product A B and the first forward cross pass of its
+    reversal rev(A B) mod x^(m-1) as ONE pass over memory (cross_turn_kernel: R = 3, 4, 5 cross stages with paired 16-byte
+    stores, R = 6 one class per thread; m = M and m < M; both arithmetics) -- bit-equal H to the two separate passes, and
+    every column through H Z = A B - C (+ ZK patch)."""
+    from ringsnark_amd.device import to_host
+    prm = P.preset("toy44")
+    runs = {}
+    for turn in (0, 1):
+        _set_tuning(b"witness_h_turn", turn)
+        try:
+            dev, cs, asg, ds, w, names = _run(prm, m, zk, 0, int_arith=int_arith, want=("A_mid", "B_mid", "H"))
+        finally:
+            _set_tuning(b"witness_h_turn", 1)
+        assert any(n.startswith("cross_turn_kernel") for n in names) == (turn == 1), names
+        if turn:
+            err, info = proof_check.check_all_columns(prm, cs, asg, {k: w[k] for k in ("A_mid", "B_mid", "H")}, tuple(ds), seed=m % 991, Z=w["Z"])
+            assert err is None and info["columns"] == prm.L * prm.N, err
+        runs[turn] = {k: to_host(w[k]) for k in ("A_mid", "B_mid", "H")}
+        del dev, asg, w
+    for k in ("A_mid", "B_mid", "H"):
+        assert (runs[0][k] == runs[1][k]).all(), k

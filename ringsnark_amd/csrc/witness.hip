@@ -972,6 +972,41 @@ static bool launch_cross_turn(rs_ctx *ctx, CrossArgs a, size_t ncols, int logB, 
   return true;
 }
 
+int g_witness_level_turn = 1;  // tuning knob "witness_level_turn": fuse the last inverse cross pass of tree level l with the first forward pass of level l + 1
+// The turn between tree levels l = a.l and l + 1 as one pass (cross_level_turn_kernel) on the workspace a.W and the columns
+// a.dst; false when the two levels differ in block size or need more than one cross pass each.
+template <class M>
+static bool launch_level_turn(rs_ctx *ctx, CrossArgs a, size_t ncols, int logB, int logB_next, const ColPlansT<M> &cp, hipStream_t st) {
+  using CPS = ColPlansT<M>;
+  constexpr bool FP = std::is_same<M, Mod>::value;
+  const int RL = a.l - logB;
+  const int maxr = FP ? std::max(1, std::min(6, g_witness_cross_maxr)) : 4;
+  if (!g_witness_level_turn || logB != logB_next || RL < 1 || RL + 1 > maxr || logB < 8 || a.l + 1 > a.logtot) return false;
+  if ((((uintptr_t)a.W | (uintptr_t)a.dst) & 15) != 0) return false;
+  const bool pair = RL <= 3;
+  const size_t groups = (((size_t)1 << a.logtot) >> (a.l + 1)) * (((size_t)1 << logB) / (pair ? 2 : 1));
+  const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>(groups / 256, 1024));
+  const dim3 grid(gx, (unsigned)ncols);
+  const double n = (double)((size_t)1 << a.logtot);
+  static const char *const names[6] = {"", "cross_level_turn_kernel<1", "cross_level_turn_kernel<2", "cross_level_turn_kernel<3", "cross_level_turn_kernel<4",
+                                       "cross_level_turn_kernel<5"};
+  // words per coefficient position of the column: workspace read + written, the children's lower halves read, the left child written
+  ProfScope prof(ctx, st, names[RL], (double)ncols * 8.0 * 3.0 * n, (double)ncols * (ntt_fp64(n, RL) + ntt_fp64(n / 2.0, RL)));
+  switch (RL) {
+    case 1: hipLaunchKernelGGL((cross_level_turn_kernel<1, CPS, 2>), grid, dim3(256), 0, st, a, cp); break;
+    case 2: hipLaunchKernelGGL((cross_level_turn_kernel<2, CPS, 2>), grid, dim3(256), 0, st, a, cp); break;
+    case 3: hipLaunchKernelGGL((cross_level_turn_kernel<3, CPS, 2>), grid, dim3(256), 0, st, a, cp); break;
+    case 4:
+      if constexpr (FP) hipLaunchKernelGGL((cross_level_turn_kernel<4, CPS, 1>), grid, dim3(256), 0, st, a, cp);
+      break;
+    default:
+      if constexpr (FP) hipLaunchKernelGGL((cross_level_turn_kernel<5, CPS, 1>), grid, dim3(256), 0, st, a, cp);
+      break;
+  }
+  RS_HIP(hipGetLastError());
+  return true;
+}
+
 // multi-pass interpolation of `ncols` columns X[ncols][M] in place; W: workspace [ncols][2M].
 // phases: 1 = values -> Newton coefficients, 2 = the product tree's tiles (in place on X: no workspace, so the caller may run
 // it ONCE over all the columns of a chunk instead of per workspace-sized sub-chunk), 4 = the levels above the tiles.
@@ -1013,17 +1048,23 @@ static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp
   if (!(phases & 4)) return;
   // levels above: F_node = F_left + D_left * F_right with multi-pass transforms of length 2^l
   a.logtot = logM;
+  bool fwd_done = false;  // the forward cross pass of this level was run by the previous level's turn
   for (int l = logTree + 1; l <= logM; l++) {
     a.l = l;
     a.logsub = l;
     logB = sub_block_log<M>(logT, l);
-    launch_cross<false, CS_FILL_RIGHT, M>(ctx, a, ncols, logB, cp, st);
+    if (!fwd_done) launch_cross<false, CS_FILL_RIGHT, M>(ctx, a, ncols, logB, cp, st);
+    fwd_done = false;
     for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = static_cast<const T *>(P->limb[i].d_dhat) + (size_t)l * Mlen;
     launch_sub<2, M>(ctx, W, ncols, col0, logM, l, logB, &tp, Mlen >> logB, S, spl, cp, st);
-    if (l == logM)
+    if (l == logM) {
       launch_cross<true, CD_COMBINE_CANON, M>(ctx, a, ncols, logB, cp, st);
-    else
-      launch_cross<true, CD_COMBINE, M>(ctx, a, ncols, logB, cp, st);
+    } else {
+      // this level's last inverse cross pass and the next level's first forward pass as one pass over memory, when the
+      // two levels share their block size (cross_level_turn_kernel); else the inverse pass alone
+      fwd_done = launch_level_turn<M>(ctx, a, ncols, logB, sub_block_log<M>(logT, l + 1), cp, st);
+      if (!fwd_done) launch_cross<true, CD_COMBINE, M>(ctx, a, ncols, logB, cp, st);
+    }
   }
 }
 

@@ -472,6 +472,147 @@ __global__ void __launch_bounds__(256) cross_turn_kernel(CrossArgs a, CPS plans)
   }
 }
 
+// ---- the turn between two tree levels (round 5): the last inverse cross pass of level l (sink CD_COMBINE: F_node = (F_left, 0)
+// + D_left F_right) and the first forward cross pass of level l + 1 (source CS_FILL_RIGHT: the parent's input is its RIGHT
+// child, zero padded), as one pass.  A thread owns a residue class j mod B of a PARENT node: the classes of both children
+// (2^RL words each) are the class of the parent (2^(RL+1) words).  It finishes both children, writes the left child's
+// coefficients (level l + 1 adds them back as F_left), keeps the right child's in registers -- nothing reads them from the
+// columns again: level l + 1 overwrites the whole parent -- and runs the parent's forward stages on them, writing the
+// parent's class of the workspace it has just read.  3 words of traffic per coefficient instead of 4.  Same stages, masks,
+// twiddles and reductions as cross_kernel<true, RL, CD_COMBINE> + cross_kernel<false, RL + 1, CS_FILL_RIGHT> (knob
+// witness_level_turn = 0 restores them).  Needs the same block size at both levels and one cross pass each.
+template <int RL, class CPS, int V>
+__global__ void __launch_bounds__(256) cross_level_turn_kernel(CrossArgs a, CPS plans) {
+  using T = typename CPS::T;
+  using Mt = typename CPS::M;
+  constexpr int EL = 1 << RL, E = 2 * EL, R = RL + 1;
+  const size_t col = blockIdx.y;
+  const ColPlanT<Mt> &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const Mt mod = P.mod;
+  const GlobalIOT<T> w{static_cast<T *>(a.W) + (col << a.logtot)};
+  T *__restrict__ xcol = static_cast<T *>(a.dst) + (col << a.logM);
+  const T *__restrict__ tw = P.tw;
+  const T *__restrict__ itw = P.itw;
+  const int l = a.l;  // the CHILD level: nodes of 2^l coefficients; parents of 2^(l+1)
+  const int logB = l - RL, B = 1 << logB;
+  const uint32_t imask = P.imask[l] >> logB, fmask = P.fmask[l + 1];
+  const int per_parent = B / V, ngroups = ((1 << a.logtot) >> (l + 1)) * per_parent;
+  for (int g = (int)(blockIdx.x * blockDim.x + threadIdx.x); g < ngroups; g += (int)(gridDim.x * blockDim.x)) {
+    const int pn = __builtin_amdgcn_readfirstlane(g / per_parent);  // B / V >= 128: a wave stays inside one parent
+    const int j = V * (g - pn * per_parent);
+    const int base = (pn << (l + 1)) + j;
+    T v[2][V][EL];  // [child][word of the pair][e]
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+      for (int e = 0; e < EL; e++) {
+        const int k = base + (ch << l) + e * B;
+        if (V == 2) {
+          const Pair<T> x = w.load2(k);
+          v[ch][0][e] = x.x;
+          v[ch][V - 1][e] = x.y;
+        } else {
+          v[ch][0][e] = w.load(k, 0, 0, 0);
+        }
+      }
+    // inverse stages logB .. l - 1 of both children's length-2^l transforms
+#pragma unroll
+    for (int k = 0; k < RL; k++) {
+      if ((imask >> k) & 1u) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+          for (int c = 0; c < V; c++)
+#pragma unroll
+            for (int e = 0; e < EL; e++) v[ch][c][e] = reduce(v[ch][c][e], mod);
+      }
+      const int twbase = 1 << (RL - 1 - k);
+#pragma unroll
+      for (int e = 0; e < EL; e++) {
+        if (e & (1 << k)) continue;
+        const T wt = itw[twbase + (e >> (k + 1))];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+          for (int c = 0; c < V; c++) {
+            const T x = v[ch][c][e], y = v[ch][c][e + (1 << k)];
+            v[ch][c][e] = addm(x, y, mod);
+            v[ch][c][e + (1 << k)] = mulmod(subm(x, y, mod), wt, mod);
+          }
+      }
+    }
+    // CD_COMBINE: + F_left on the lower half of each child (e < EL / 2), reduce; the left child goes back to the columns
+    T x[V][E];
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+      for (int e = 0; e < EL; e++) {
+        const int k = base + (ch << l) + e * B;
+        T a0 = T(0), a1 = T(0);  // (F_left, 0): the lower half of the child
+        if (e < EL / 2) {
+          if (V == 2) {
+            const Pair<T> fl = ld_pair(xcol + k);
+            a0 = fl.x;
+            a1 = fl.y;
+          } else {
+            a0 = xcol[k];
+          }
+        }
+        T f0 = reduce(addm(v[ch][0][e], a0, mod), mod), f1 = T(0);
+        if (V == 2) f1 = reduce(addm(v[ch][V - 1][e], a1, mod), mod);
+        if (ch == 0) {
+          if (V == 2)
+            st_pair(xcol + k, f0, f1);
+          else
+            xcol[k] = f0;
+        } else {
+          x[0][e] = f0;
+          if (V == 2) x[V - 1][e] = f1;
+        }
+      }
+    // forward stages 0 .. RL of the parent's length-2^(l+1) transform on (F_right, 0): stage 0 is a copy
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      if ((fmask >> k) & 1u) {
+#pragma unroll
+        for (int c = 0; c < V; c++)
+#pragma unroll
+          for (int e = 0; e < (k == 0 ? E / 2 : E); e++) x[c][e] = reduce(x[c][e], mod);
+      }
+      if (k == 0) {
+#pragma unroll
+        for (int c = 0; c < V; c++)
+#pragma unroll
+          for (int e = 0; e < E / 2; e++) x[c][e + E / 2] = x[c][e];
+        continue;
+      }
+      const int half = E >> (k + 1);
+#pragma unroll
+      for (int blk = 0; blk < (1 << k); blk++) {
+        const T wt = tw[(1 << k) + blk];
+#pragma unroll
+        for (int e0 = 0; e0 < half; e0++) {
+          const int ia = blk * 2 * half + e0, ib = ia + half;
+#pragma unroll
+          for (int c = 0; c < V; c++) {
+            const T t = mulmod(x[c][ib], wt, mod);
+            const T z = x[c][ia];
+            x[c][ia] = addm(z, t, mod);
+            x[c][ib] = subm(z, t, mod);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      if (V == 2)
+        w.store2(base + e * B, x[0][e], x[V - 1][e]);
+      else
+        w.store(base + e * B, 0, 0, 0, x[0][e]);
+    }
+  }
+}
+
 // Sub-transforms on blocks of Bn = 2^logB doubles.  MODE 0: forward, 1: inverse, 2: forward,
 // multiply by tab[(blk % tab_period) * Bn + j], inverse (fused); 3: like 2 with a per-column table
 // (another workspace of the same shape, lazily reduced): tab[blk * Bn + j].  Block blk belongs to column

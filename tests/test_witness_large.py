@@ -312,3 +312,30 @@ def test_the_turn_of_h_as_one_pass(m, zk, int_arith):
         del dev, asg, w
     for k in ("A_mid", "B_mid", "H"):
         assert (runs[0][k] == runs[1][k]).all(), k
+
+
+@pytest.mark.parametrize("m,zk,int_arith", [(50000, True, False), (65536, False, False), (100000, True, False), (262144, False, False),
+                                             (400000, True, False), (60000, False, True)])
+def test_the_turn_between_tree_levels_as_one_pass(m, zk, int_arith):
+    """witness_level_turn (default on): the last inverse cross pass of tree level l (+ F_left, reduce) and the first forward
+    cross pass of level l + 1 on the right child, as one pass (cross_level_turn_kernel: levels 15 -> 16 on 2^12 blocks with
+    paired accesses, 17 -> 18 and 18 -> 19 on 2^13 blocks with one class per thread; integers at 2^16) -- every output
+    vector bit-equal to the separate passes, every column through the identities."""
+    from ringsnark_amd.device import to_host
+    prm = P.preset("toy44")
+    runs = {}
+    for turn in (0, 1):
+        _set_tuning(b"witness_level_turn", turn)
+        try:
+            dev, cs, asg, ds, w, names = _run(prm, m, zk, 0, int_arith=int_arith, want=("A_mid", "B_mid", "C_mid", "H"))
+        finally:
+            _set_tuning(b"witness_level_turn", 1)
+        assert any(n.startswith("cross_level_turn_kernel") for n in names) == (turn == 1), names
+        if turn:
+            err, info = proof_check.check_all_columns(prm, cs, asg, {k: w[k] for k in ("A_mid", "B_mid", "C_mid", "H")}, tuple(ds),
+                                                      seed=m % 983, Z=w["Z"])
+            assert err is None and info["columns"] == prm.L * prm.N, err
+        runs[turn] = {k: to_host(w[k]) for k in ("A_mid", "B_mid", "C_mid", "H")}
+        del dev, asg, w
+    for k in runs[0]:
+        assert (runs[0][k] == runs[1][k]).all(), k

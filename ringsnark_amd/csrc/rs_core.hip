@@ -1036,6 +1036,8 @@ int rs_set_tuning(const char *key, int value) {
   }
   else if (std::string(key) == "witness_tree_ct")
     g_witness_tree_ct = value;
+  else if (std::string(key) == "witness_tree_fwd")
+    g_witness_tree_fwd = value ? 1 : 0;
   else if (std::string(key) == "witness_level_turn")
     g_witness_level_turn = value ? 1 : 0;
   else if (std::string(key) == "witness_h_turn")

@@ -298,6 +298,7 @@ extern int g_prover_lin_io;               // prover.hip: io vectors as linear fo
 extern int g_witness_tree_log;            // witness.hip: tile of the wide product-tree kernel (13 or 14)
 extern int g_witness_sub_ct;              // witness.hip: compile-time-length sub-transform kernel
 extern int g_witness_tree_ct;             // witness.hip: level-unrolled product-tree kernel
+extern int g_witness_tree_fwd;             // witness.hip: forward cross stages of level 15 inside the tile kernel
 extern int g_witness_level_turn;           // witness.hip: the turn between two tree levels as one pass (cross_level_turn_kernel)
 extern int g_witness_h_turn;               // witness.hip: the turn of H as one pass (cross_turn_kernel)
 extern int g_witness_tree_once;            // witness.hip: product-tree tiles in one launch per chunk

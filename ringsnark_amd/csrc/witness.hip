@@ -621,8 +621,11 @@ static double tree_fp64(double T, int logT, bool pw_reduce = true) {
   for (int l = SCHOOL_LEVELS + 1; l <= logT; l++) f += 2.0 * ntt_fp64(T, l) + (pw_reduce ? 10.0 : 7.0) * T;
   return f;
 }
+// Wout / rf (2^14 tiles of the wide kernel only): the right tiles also run the rf forward cross stages of level 15 and write
+// that level's workspace [ncols][2^logM] (tree_wide_kernel<14, RF>); the caller then skips the level's source pass.
+static bool wide_ok_for_fwd(int logT, int rf) { return g_witness_tree_ct == 2 && logT == 14 && (rf == 2 || rf == 3); }
 static void launch_tree_tiles(rs_ctx *ctx, double *cols, size_t ncols, size_t col0, int logM, int logT, size_t S,
-                              size_t slots_per_limb, const ColPlans &cp, hipStream_t st, bool newton = false) {
+                              size_t slots_per_limb, const ColPlans &cp, hipStream_t st, bool newton = false, double *Wout = nullptr, int rf = 0) {
   const size_t T = (size_t)1 << logT;
   const double tiles = (double)(ncols << (logM - logT));
   // Newton conversion (single-tile columns): two passes of forward + inverse M-point transforms and two pointwise products
@@ -630,13 +633,16 @@ static void launch_tree_tiles(rs_ctx *ctx, double *cols, size_t ncols, size_t co
   // names as rocprofv3 prints them (a prefix of "rs::<name>") so that profiles/ and the live record can be joined
   const bool ct13 = logT == 13 && g_witness_tree_ct;
   const bool wide = !newton && g_witness_tree_ct == 2 && (logT == 13 || logT == 14);
-  const char *pname = wide ? (logT == 14 ? "tree_wide_kernel<14>" : "tree_wide_kernel<13>")
+  RS_REQUIRE(!Wout || (wide_ok_for_fwd(logT, rf) && !newton), "tree tiles: forward stages of the next level need the wide 2^14 tile");
+  const char *pname = wide ? (logT == 14 ? (Wout ? (rf == 3 ? "tree_wide_kernel<14, 3>" : "tree_wide_kernel<14, 2>") : "tree_wide_kernel<14, 0>") : "tree_wide_kernel<13, 0>")
                       : ct13 ? (newton ? "tree_columns_kernel<512, 13, true>" : "tree_columns_kernel<512, 13, false>")
                            : (newton ? "tree_columns_kernel<NEWTON>" : "tree_columns_kernel");
   bool pw = !wide;  // the model count follows what the wide kernel executes: the pre-product reduction per level only where asked for
   if (wide)
     for (int i = 0; i < RS_MAX_L; i++) pw = pw || ((cp.l[i].pwmask >> logT) & 1u);
-  ProfScope prof(ctx, st, pname, tiles * (double)T * 16.0, tiles * (tree_fp64((double)T, logT, pw) + newton_fp64));
+  // with Wout: half of the tiles also write a 2^(logT+1)-word node of the next level's workspace, rf - 1 stages each
+  ProfScope prof(ctx, st, pname, tiles * (double)T * (Wout ? 24.0 : 16.0),
+                 tiles * (tree_fp64((double)T, logT, pw) + newton_fp64) + (Wout ? tiles / 2.0 * ntt_fp64(2.0 * (double)T, rf - 1) : 0.0));
   const size_t lds1 = padded_len(T) * sizeof(double);
   const unsigned grid = (unsigned)(ncols << (logM - logT));
   const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, T / 16));  // 1024 only for a 2^14 tile (one workgroup per CU)
@@ -657,12 +663,20 @@ static void launch_tree_tiles(rs_ctx *ctx, double *cols, size_t ncols, size_t co
   } while (0)
   if (wide) {
     const int wl = (int)((T + T / 32) * sizeof(double));
-    if (logT == 14) {
-      set_max_dyn_lds((const void *)tree_wide_kernel<14>, wl);
-      hipLaunchKernelGGL(tree_wide_kernel<14>, dim3(grid), dim3(512), wl, st, cols, logM, col0, (unsigned)S, (unsigned)slots_per_limb, cp);
+    if (logT == 14 && Wout && rf == 3) {
+      set_max_dyn_lds((const void *)tree_wide_kernel<14, 3>, wl);
+      hipLaunchKernelGGL((tree_wide_kernel<14, 3>), dim3(grid), dim3(512), wl, st, cols, logM, col0, (unsigned)S, (unsigned)slots_per_limb, cp, Wout);
+    } else if (logT == 14 && Wout) {
+      set_max_dyn_lds((const void *)tree_wide_kernel<14, 2>, wl);
+      hipLaunchKernelGGL((tree_wide_kernel<14, 2>), dim3(grid), dim3(512), wl, st, cols, logM, col0, (unsigned)S, (unsigned)slots_per_limb, cp, Wout);
+    } else if (logT == 14) {
+      set_max_dyn_lds((const void *)tree_wide_kernel<14, 0>, wl);
+      hipLaunchKernelGGL((tree_wide_kernel<14, 0>), dim3(grid), dim3(512), wl, st, cols, logM, col0, (unsigned)S, (unsigned)slots_per_limb, cp,
+                         (double *)nullptr);
     } else {
-      set_max_dyn_lds((const void *)tree_wide_kernel<13>, wl);
-      hipLaunchKernelGGL(tree_wide_kernel<13>, dim3(grid), dim3(256), wl, st, cols, logM, col0, (unsigned)S, (unsigned)slots_per_limb, cp);
+      set_max_dyn_lds((const void *)tree_wide_kernel<13, 0>, wl);
+      hipLaunchKernelGGL((tree_wide_kernel<13, 0>), dim3(grid), dim3(256), wl, st, cols, logM, col0, (unsigned)S, (unsigned)slots_per_limb, cp,
+                         (double *)nullptr);
     }
   } else if (thr == 512 && logT == 13 && g_witness_tree_ct) {
     if (newton)
@@ -1007,12 +1021,28 @@ static bool launch_level_turn(rs_ctx *ctx, CrossArgs a, size_t ncols, int logB, 
   return true;
 }
 
+// tuning knob "witness_tree_fwd": the tile kernel runs the forward cross stages of the first level above the tiles.  OFF by
+// default -- measured (profiles/r05_knob_ab_tree_once.txt): it removes a 9.8 ms pass and costs the tile kernel 16 ms (176 ->
+// 192 ms per headline proof): one workgroup per CU has nothing to hide its epilogue's LDS reads and stores behind.
+int g_witness_tree_fwd = 0;
+// Can the wide 2^14 tile kernel run the forward cross stages of level 15 (2 or 3 of them: blocks of 2^13 / 2^12)?
+template <class M>
+static bool tree_fwd_stages(const WitnessPlan *P) {
+  if constexpr (!std::is_same<M, Mod>::value) return false;
+  const int logM = P->logM, logT = std::min(g_witness_lds_logM, logM);
+  if (!g_witness_tree_fwd || !(logT == 13 && logM >= 15 && g_witness_tree_ct == 2 && g_witness_tree_log >= 14)) return false;
+  const int rf = 15 - sub_block_log<M>(logT, 15);
+  return rf == 2 || rf == 3;
+}
+
 // multi-pass interpolation of `ncols` columns X[ncols][M] in place; W: workspace [ncols][2M].
 // phases: 1 = values -> Newton coefficients, 2 = the product tree's tiles (in place on X: no workspace, so the caller may run
 // it ONCE over all the columns of a chunk instead of per workspace-sized sub-chunk), 4 = the levels above the tiles.
 template <class M>
+// tree_fwd (phases 2 and 4 must agree): the tile kernel of the right children also runs the forward cross stages of the first
+// level above the tiles, into W as [ncols][M] (tree_fwd_stages() says whether it can) -- that level's source pass is skipped.
 static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, typename ArithOf<M>::T *X, typename ArithOf<M>::T *W,
-                       size_t ncols, size_t col0, size_t S, size_t spl, int limb0, hipStream_t st, int phases = 7) {
+                       size_t ncols, size_t col0, size_t S, size_t spl, int limb0, hipStream_t st, int phases = 7, bool tree_fwd = false) {
   using T = typename ArithOf<M>::T;
   constexpr bool FP = std::is_same<M, Mod>::value;
   const int logM = P->logM, logT = std::min(g_witness_lds_logM, logM);
@@ -1041,14 +1071,15 @@ static void big_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp
   int logTree = logT;
   if constexpr (FP) {
     if (logT == 13 && logM >= 15 && g_witness_tree_ct == 2 && g_witness_tree_log >= 14) logTree = 14;
-    if (phases & 2) launch_tree_tiles(ctx, X, ncols, col0, logM, logTree, S, spl, cp, st);
+    const int rf = tree_fwd ? logTree + 1 - sub_block_log<M>(logT, logTree + 1) : 0;
+    if (phases & 2) launch_tree_tiles(ctx, X, ncols, col0, logM, logTree, S, spl, cp, st, false, tree_fwd ? W : nullptr, rf);
   } else {
     if (phases & 2) launch_tree_tiles_generic<M>(ctx, X, ncols, col0, logM, logT, S, spl, cp, st);
   }
   if (!(phases & 4)) return;
   // levels above: F_node = F_left + D_left * F_right with multi-pass transforms of length 2^l
   a.logtot = logM;
-  bool fwd_done = false;  // the forward cross pass of this level was run by the previous level's turn
+  bool fwd_done = tree_fwd;  // the forward cross pass of this level was run by the previous level's turn (or by the tile kernel)
   for (int l = logTree + 1; l <= logM; l++) {
     a.l = l;
     a.logsub = l;
@@ -1449,21 +1480,24 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> 
     return;
   }
   const size_t chunk = std::min(ncols, big_chunk_cols(P));
-  T *W = (T *)ws_get(ctx, 12, chunk * 2 * P->M * sizeof(double));
+  // the tile kernel also writes level 15's workspace for the right children ([ncols][M], for ALL the columns it covers)
+  // when that fits beside everything else (24 GiB; a configs[3] rank is tight)
+  const bool tfwd = tree_fwd_stages<M>(P) && ncols * P->M * sizeof(double) <= ((size_t)24 << 30);
+  T *W = (T *)ws_get(ctx, 12, std::max(chunk * 2 * P->M, (tfwd && chunk < ncols && g_witness_tree_once) ? ncols * P->M : 0) * sizeof(double));
   if (chunk < ncols && g_witness_tree_once) {
     // the tiles of the product tree work in place on the columns: ONE launch over all of them between the sub-chunked
     // phases (tile kernels like long launches: 183.5 -> 176 ms per headline proof when every launch covers a whole chunk,
     // profiles/r05_knob_ab_big_ws.txt; the workspace-bound phases keep their 6 GiB sub-chunks, which they prefer)
     for (size_t c0 = 0; c0 < ncols; c0 += chunk)
       big_interp<M>(ctx, P, cp, cols + c0 * P->M, W, std::min(chunk, ncols - c0), c0, S, slots_per_limb, limb0, st, 1);
-    big_interp<M>(ctx, P, cp, cols, W, ncols, 0, S, slots_per_limb, limb0, st, 2);
-    for (size_t c0 = 0; c0 < ncols; c0 += chunk)
-      big_interp<M>(ctx, P, cp, cols + c0 * P->M, W, std::min(chunk, ncols - c0), c0, S, slots_per_limb, limb0, st, 4);
+    big_interp<M>(ctx, P, cp, cols, W, ncols, 0, S, slots_per_limb, limb0, st, 2, tfwd);
+    for (size_t c0 = 0; c0 < ncols; c0 += chunk)  // a sub-chunk's levels above the tiles work on its slice of the [ncols][M] workspace
+      big_interp<M>(ctx, P, cp, cols + c0 * P->M, W + (tfwd ? c0 * P->M : 0), std::min(chunk, ncols - c0), c0, S, slots_per_limb, limb0, st, 4, tfwd);
     return;
   }
   for (size_t c0 = 0; c0 < ncols; c0 += chunk) {
     const size_t nc = std::min(chunk, ncols - c0);
-    big_interp<M>(ctx, P, cp, cols + c0 * P->M, W, nc, c0, S, slots_per_limb, limb0, st);
+    big_interp<M>(ctx, P, cp, cols + c0 * P->M, W, nc, c0, S, slots_per_limb, limb0, st, 7, tfwd);
   }
 }
 

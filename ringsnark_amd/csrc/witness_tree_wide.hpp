@@ -306,9 +306,16 @@ __device__ __forceinline__ void tree_school16(double (&v)[16], int gpos, int log
 // LOGT = 13: 256 threads, two workgroups per CU; LOGT = 14: 512 threads, one workgroup per CU (the same 8 waves per CU)
 // and one more level inside the tile -- one level less through the multi-pass transforms (two cross passes and a
 // sub-transform pass over the whole column workspace).
-template <int LOGT>
+// RF > 0 (round 5): the workgroup of a RIGHT tile -- the right child of a level-(LOGT+1) node, i.e. that level's whole
+// transform input (F_right, 0) -- also runs the RF forward cross stages of that level (blocks of 2^(LOGT+1-RF) words; stage 0
+// is a copy) on the finished tile and writes the node's 2^(LOGT+1) workspace words to Wout [ncols][2^logM]: the separate
+// source pass cross_kernel<false, RF, CS_FILL_RIGHT> (a read of half the columns and a write of the workspace, 10 ms per
+// headline proof) disappears into a kernel that leaves HBM idle.  Same values: the pass would read these canonical
+// coefficients back and run the same stages.
+template <int LOGT, int RF = 0>
 __global__ void __launch_bounds__(1 << (LOGT - 5), 2)
-tree_wide_kernel(double *__restrict__ cols, int logM, size_t col0, unsigned S, unsigned slots_per_limb, ColPlans plans) {
+tree_wide_kernel(double *__restrict__ cols, int logM, size_t col0, unsigned S, unsigned slots_per_limb, ColPlans plans,
+                 double *__restrict__ Wout = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   const int t = threadIdx.x;
@@ -378,6 +385,64 @@ tree_wide_kernel(double *__restrict__ cols, int logM, size_t col0, unsigned S, u
     for (int i = 0; i < 16; i++) {
       const int pa = tw_addr(2048 * wave + 128 * i + 2 * lane);
       dst[64 * i] = make_double2(canon(s[pa], mod), canon(s[pa + 1], mod));
+    }
+  }
+  if (RF > 0) {
+    const unsigned ti = blockIdx.x % nb;
+    if (ti & 1u) {  // a right child: the forward cross stages of the parent's transform (fwd_round2, s0 = 0, zero-padded input)
+      constexpr int RR = RF > 0 ? RF : 1, E = 1 << RR, LOGB = LOGT + 1 - RR, B = 1 << LOGB;
+      double *__restrict__ wnode = Wout + col * M + ((size_t)(ti >> 1) << (LOGT + 1));
+      const double *__restrict__ tw = P.tw;
+      const uint32_t fmask = P.fmask[LOGT + 1];
+      for (int j = 2 * t; j < B; j += 2 << (LOGT - 5)) {
+        double x[2][E];
+#pragma unroll
+        for (int e = 0; e < E / 2; e++) {
+          const int pa = tw_addr(j + B * e);
+          x[0][e] = canon(s[pa], mod);
+          x[1][e] = canon(s[pa + 1], mod);  // j is even and below the tile's 32-word run boundary: the neighbour word
+        }
+#pragma unroll
+        for (int k = 0; k < RR; k++) {
+          if ((fmask >> k) & 1u) {
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+              for (int e = 0; e < (k == 0 ? E / 2 : E); e++) x[cc][e] = reduce(x[cc][e], mod);
+          }
+          if (k == 0) {
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+              for (int e = 0; e < E / 2; e++) x[cc][e + E / 2] = x[cc][e];
+            continue;
+          }
+          const int half = E >> (k + 1);
+#pragma unroll
+          for (int blk = 0; blk < (1 << k); blk++) {
+            const double wt = tw[(1 << k) + blk];
+#pragma unroll
+            for (int e0 = 0; e0 < half; e0++) {
+              const int ia = blk * 2 * half + e0, ib = ia + half;
+#pragma unroll
+              for (int cc = 0; cc < 2; cc++) {
+                const double tt = mulmod(x[cc][ib], wt, mod);
+                const double z = x[cc][ia];
+                x[cc][ia] = z + tt;
+                x[cc][ib] = z - tt;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          typedef double V2 __attribute__((ext_vector_type(2)));
+          V2 o;
+          o.x = x[0][e];
+          o.y = x[1][e];
+          __builtin_nontemporal_store(o, reinterpret_cast<V2 *>(wnode + j + B * e));
+        }
+      }
     }
   }
 }

@@ -339,3 +339,37 @@ def test_the_turn_between_tree_levels_as_one_pass(m, zk, int_arith):
         del dev, asg, w
     for k in runs[0]:
         assert (runs[0][k] == runs[1][k]).all(), k
+
+
+@pytest.mark.parametrize("m,zk,sub_log,ws", [(30000, True, 12, 6144), (65536, False, 12, 6144), (100000, True, 12, 6144), (50000, True, 13, 6144),
+                                             (100000, False, 12, 64), (262144, True, 12, 64)])
+def test_level_15_forward_stages_inside_the_tile_kernel(m, zk, sub_log, ws):
+    """witness_tree_fwd (OFF by default: it removes a 9.8 ms pass of the headline proof and costs the tile kernel 16 ms; kept as a
+    measured negative): the workgroup of a right 2^14 tile also runs the forward cross stages of level 15
+    (three on 2^12 blocks, two on 2^13 blocks: witness_sub_log = 13) and writes that level's workspace, so the level's source
+    pass is not launched.  M = 2^15 (level 15 is the last), 2^16, 2^17, 2^18; with workspace-sized sub-chunks (the tiles of
+    all columns in one launch, the levels above per sub-chunk on slices of the workspace).  Bit-equal to the separate pass;
+    every column through the identities."""
+    from ringsnark_amd.device import to_host
+    prm = P.preset("toy44")
+    runs = {}
+    want = ("A_mid", "B_mid", "C_mid", "H")
+    for fwd in (0, 1):
+        _set_tuning(b"witness_tree_fwd", fwd)
+        _set_tuning(b"witness_sub_log", sub_log)
+        _set_tuning(b"witness_big_ws_mib", ws)
+        try:
+            dev, cs, asg, ds, w, names = _run(prm, m, zk, 0, want=want)
+        finally:
+            _set_tuning(b"witness_tree_fwd", 0)
+            _set_tuning(b"witness_sub_log", SUB_LOG_DEFAULT)
+            _set_tuning(b"witness_big_ws_mib", 6144)
+        rf = 3 if sub_log == 12 else 2
+        assert (("tree_wide_kernel<14, %d>" % rf) in names) == (fwd == 1), names
+        if fwd:
+            err, info = proof_check.check_all_columns(prm, cs, asg, {k: w[k] for k in want}, tuple(ds), seed=m % 977, Z=w["Z"])
+            assert err is None and info["columns"] == prm.L * prm.N, err
+        runs[fwd] = {k: to_host(w[k]) for k in want}
+        del dev, asg, w
+    for k in want:
+        assert (runs[0][k] == runs[1][k]).all(), k

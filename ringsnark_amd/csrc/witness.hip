@@ -882,15 +882,16 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
 // one two-dimensional block convolution of `ncols * units` operands of Y/2 blocks each.  MODE 2: against the table
 // `tab` ([units][Y][2B] per limb, limbs from limb0 on); MODE 3: against the data spectra `other` ([ncols*units][Y][2][B], same
 // layout as Ws); MODE 0: forward only (Ws receives the spectra; no sink).
+// skip_fwd / skip_inv: the transform across blocks at that end is run by a turn kernel (bc2_level_turn_kernel, bc2_h_turn_kernel)
 template <int SRC, int DST, int MODE>
 static void bc2_conv(rs_ctx *ctx, Bc2Args a, int logY, size_t ncols, const TabPtrs *tab, const double *other, const ColPlans &cp,
-                     hipStream_t st) {
+                     hipStream_t st, bool skip_fwd = false, bool skip_inv = false) {
   const size_t Y = (size_t)1 << logY, cu = ncols * (size_t)a.units;
   const dim3 grid((unsigned)(BC2_B / 2 / 256), (unsigned)cu);
   // Y <= 32: the transform across blocks in one thread's registers; Y = 64 .. 256 (M >= 2^18): in two levels
   RS_REQUIRE(cu <= 65535 && logY >= 2 && logY <= 8, "two-dimensional block convolution out of range");
   const dim3 grid_parts(grid.x << std::max(0, logY - 5), grid.y);  // one workgroup per (position range, part of 32 blocks)
-  {
+  if (!skip_fwd) {
     // words: the Y/2 source blocks (read once per part in the two-level form) + Y blocks written
     const double reads = logY > 5 ? (double)(Y / 2) * (double)(1 << (logY - 5)) : (double)(Y / 2);
     ProfScope prof(ctx, st, logY > 5 ? "bc2_yfwd_big_kernel" : "bc2_yfwd_kernel", (double)cu * ((double)Y + reads) * BC2_B * 8.0,
@@ -921,6 +922,10 @@ static void bc2_conv(rs_ctx *ctx, Bc2Args a, int logY, size_t ncols, const TabPt
                          (unsigned)((size_t)a.units * Y * 2), (unsigned)((size_t)a.units * Y * 2), a.col0, a.S, a.slots_per_limb, cp, nb,
                          (const double *)a.Wy);
     }
+  }
+  if (skip_inv) {
+    RS_HIP(hipGetLastError());
+    return;
   }
   if (MODE != 0 && logY <= 5) {
     ProfScope prof(ctx, st, "bc2_yinv_kernel", (double)cu * (double)Y * BC2_B * 24.0, (double)cu * 2.0 * BC2_B * ntt_fp64((double)Y, logY));
@@ -1379,15 +1384,36 @@ static void bc2_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, do
     launch_tree_tiles(ctx, X, ncols, col0, logM, (g_witness_tree_ct == 2 && g_witness_tree_log >= 14) ? 14 : 13, S, spl, cp, st);
   if (!(phases & 4)) return;
   const int first = (g_witness_tree_ct == 2 && g_witness_tree_log >= 14) ? 15 : 14;
+  bool fwd_done = false;  // this level's transform across blocks was run by the previous level's turn
   for (int l = first; l <= logM; l++) {
     a.l = l;
     a.units = (int)(Mlen >> l);
     for (int i = limb0; i < ctx->L; i++)
       tp.t[i - limb0] = static_cast<const double *>(P->limb[i].d_b2_d) + (size_t)(l - P->bcLog - 1) * 2 * Mlen;
-    if (l == logM)
-      bc2_conv<BS_RIGHT, BD_COMBINE_CANON, 2>(ctx, a, l - BC2_LOGB, ncols, &tp, nullptr, cp, st);
-    else
-      bc2_conv<BS_RIGHT, BD_COMBINE, 2>(ctx, a, l - BC2_LOGB, ncols, &tp, nullptr, cp, st);
+    if (l == logM) {
+      bc2_conv<BS_RIGHT, BD_COMBINE_CANON, 2>(ctx, a, l - BC2_LOGB, ncols, &tp, nullptr, cp, st, fwd_done);
+      fwd_done = false;
+      continue;
+    }
+    // level l's inverse transform across blocks + sink and level l + 1's source + forward transform as one pass
+    // (bc2_level_turn_kernel; one-level transforms: the parent has at most 32 blocks)
+    const int logYc = l - BC2_LOGB;
+    const bool turn = g_witness_level_turn && logYc >= 2 && logYc <= 4 && (size_t)ncols * (size_t)(a.units / 2) <= 65535;
+    bc2_conv<BS_RIGHT, BD_COMBINE, 2>(ctx, a, logYc, ncols, &tp, nullptr, cp, st, fwd_done, turn);
+    fwd_done = turn;
+    if (turn) {
+      const size_t cpn = ncols * (size_t)(a.units / 2), Yp = (size_t)2 << logYc;
+      const dim3 grid((unsigned)(BC2_B / 2 / 256), (unsigned)cpn);
+      // words per parent and position: both children's spectra read (2 Yc x 2), their lower halves... the children read, the left written, Wy written
+      ProfScope prof(ctx, st, "bc2_level_turn_kernel", (double)cpn * BC2_B * 8.0 * (2.0 * Yp + 1.5 * Yp + Yp),
+                     (double)cpn * BC2_B * (2.0 * ntt_fp64((double)(Yp / 2), logYc) * 2.0 + ntt_fp64((double)Yp, logYc + 1)));
+      switch (logYc) {
+        case 2: hipLaunchKernelGGL((bc2_level_turn_kernel<2>), grid, dim3(256), 0, st, a, cp); break;
+        case 3: hipLaunchKernelGGL((bc2_level_turn_kernel<3>), grid, dim3(256), 0, st, a, cp); break;
+        default: hipLaunchKernelGGL((bc2_level_turn_kernel<4>), grid, dim3(256), 0, st, a, cp); break;
+      }
+      RS_HIP(hipGetLastError());
+    }
   }
 }
 
@@ -1416,13 +1442,27 @@ static void bc2_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const d
   a.src = Bc;
   a.Ws = Ws;
   a.dst = Pbuf;
-  bc2_conv<BS_CENTER, BD_PLAIN_SCALED, 3>(ctx, a, logY, ncols, nullptr, WsA, cp, st);
+  // the turn of H (bc2_h_turn_kernel): the product's inverse transform across blocks and the forward one of its reversal as
+  // one pass, the 2M-word product buffer neither written nor read (one-level transforms of at most 16 blocks: M <= 2^16)
+  const bool turn = g_witness_h_turn && logY >= 2 && logY <= 4;
+  bc2_conv<BS_CENTER, BD_PLAIN_SCALED, 3>(ctx, a, logY, ncols, nullptr, WsA, cp, st, false, turn);
+  if (turn) {
+    const size_t Y = (size_t)1 << logY;
+    const dim3 grid((unsigned)(BC2_B / 2 / 256), (unsigned)ncols);
+    ProfScope prof(ctx, st, "bc2_h_turn_kernel", (double)ncols * BC2_B * 8.0 * (2.0 * Y + Y), (double)ncols * BC2_B * 3.0 * ntt_fp64((double)Y, logY));
+    switch (logY) {
+      case 2: hipLaunchKernelGGL((bc2_h_turn_kernel<2>), grid, dim3(256), 0, st, a, cp); break;
+      case 3: hipLaunchKernelGGL((bc2_h_turn_kernel<3>), grid, dim3(256), 0, st, a, cp); break;
+      default: hipLaunchKernelGGL((bc2_h_turn_kernel<4>), grid, dim3(256), 0, st, a, cp); break;
+    }
+    RS_HIP(hipGetLastError());
+  }
   // U = rev(P) * rev(Z)^-1 mod x^(m-1);  H_j = U_{m-2-j}
   TabPtrs tp{};
   for (int i = limb0; i < ctx->L; i++) tp.t[i - limb0] = P->limb[i].d_b2_s;
   a.src = Pbuf;
   a.dst = H;
-  bc2_conv<BS_REVTRUNC, BD_HFIN, 2>(ctx, a, logY, ncols, &tp, nullptr, cp, st);
+  bc2_conv<BS_REVTRUNC, BD_HFIN, 2>(ctx, a, logY, ncols, &tp, nullptr, cp, st, turn);
   const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((ncols * Mlen + 255) / 256, 256 * 16));
   ProfScope prof(ctx, st, "h_patch_kernel", (double)ncols * (double)Mlen * (d1 ? 32.0 : 16.0), d1 ? 24.0 * (double)ncols * (double)Mlen : 0.0);
   hipLaunchKernelGGL(h_patch_kernel<ColPlans>, dim3(blocks), dim3(256), 0, st, H, A, Bc, logM, (int)P->m, ncols, col0, (unsigned)S, (unsigned)spl, cp,

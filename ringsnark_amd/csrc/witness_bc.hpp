@@ -262,6 +262,126 @@ __global__ void __launch_bounds__(256) bc2_yinv_kernel(Bc2Args a, ColPlans plans
   }
 }
 
+// ---- the two turns of the multi-pass path (witness_multipass.hpp: cross_turn_kernel, cross_level_turn_kernel) on the
+// two-dimensional convolutions: a thread of the across-block passes owns a POSITION r inside the blocks (all Y blocks of
+// it), and where the sink of one convolution is the source of the next at the same positions, the two HBM-bound passes
+// are one.  Same arithmetic as bc2_yinv_kernel followed by bc2_yfwd_kernel; one-level transforms only (Y <= 32).
+//
+// Tree levels l -> l + 1: both children of a parent node at position r -- the last stage of the 2B-point transforms, the
+// inverse transform across blocks, the overlap-add, the recombination (BD_COMBINE) -- both back to the columns, and the
+// right one (the parent's whole input, BS_RIGHT) through the parent's forward transform across blocks into Wy without
+// being read again.
+template <int LOGYC>
+__global__ void __launch_bounds__(256) bc2_level_turn_kernel(Bc2Args a, ColPlans plans) {
+  constexpr int YC = 1 << LOGYC, YP = 2 * YC, B = BC2_B;
+  const int r = 2 * (int)(blockIdx.x * 256 + threadIdx.x);
+  const size_t parents = (size_t)a.units / 2, cpn = blockIdx.y, parent = cpn % parents, col = cpn / parents, M = (size_t)1 << a.logM;
+  const ColPlan &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const Mod mod = P.mod;
+  const double *__restrict__ itw = P.itw;
+  const double *__restrict__ tw = P.tw;
+  double v0[YP], v1[YP];
+#pragma unroll
+  for (int ch = 0; ch < 2; ch++) {
+    const size_t unit = 2 * parent + ch, cu = col * (size_t)a.units + unit;
+    double lo[2][YC], hi[2][YC];
+    const double *in = a.Ws + cu * (size_t)YC * 2 * B + r;
+#pragma unroll
+    for (int y = 0; y < YC; y++) {
+      const double2 u = *reinterpret_cast<const double2 *>(in + (size_t)(2 * y) * B), w = *reinterpret_cast<const double2 *>(in + (size_t)(2 * y + 1) * B);
+      lo[0][y] = reduce(u.x + w.x, mod);
+      hi[0][y] = reduce(u.x - w.x, mod);
+      lo[1][y] = reduce(u.y + w.y, mod);
+      hi[1][y] = reduce(u.y - w.y, mod);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      reg_inv_stages<LOGYC, true>(lo[c], mod, P.imask[LOGYC], [&](int k, int i) { return itw[(YC >> (k + 1)) + i]; });
+      reg_inv_stages<LOGYC, true>(hi[c], mod, P.imask[LOGYC], [&](int k, int i) { return itw[(YC >> (k + 1)) + i]; });
+    }
+#pragma unroll
+    for (int k = 0; k < YC; k++) {
+      const size_t t = (size_t)k * B + r;
+      double o0 = lo[0][k], o1 = lo[1][k];
+      if (k >= 1) {
+        o0 += hi[0][k - 1];
+        o1 += hi[1][k - 1];
+      }
+      double2 *p = reinterpret_cast<double2 *>(a.dst + col * M + unit * ((size_t)1 << a.l) + t);
+      const double2 d = *p;
+      const double f0 = reduce(o0 + d.x, mod), f1 = reduce(o1 + d.y, mod);
+      // both children go back to the columns: the parent's recombination reads F_left AND x^h F_right at their positions
+      // (D_left = x^h + d: only d F_right is a convolution here, bc2_yinv_kernel BD_COMBINE)
+      *p = make_double2(f0, f1);
+      if (ch == 1) {  // the right child is also the parent's transform input, (F_right, 0): not read back
+        v0[k] = f0;
+        v1[k] = f1;
+      }
+    }
+  }
+  reg_fwd_stages_zu<LOGYC + 1>(v0, mod, P.fmask[LOGYC + 1], [&](int st, int blk) { return tw[(1 << st) + blk]; });
+  reg_fwd_stages_zu<LOGYC + 1>(v1, mod, P.fmask[LOGYC + 1], [&](int st, int blk) { return tw[(1 << st) + blk]; });
+  double *out = a.Wy + cpn * (size_t)YP * B + r;
+#pragma unroll
+  for (int y = 0; y < YP; y++) *reinterpret_cast<double2 *>(out + (size_t)y * B) = make_double2(reduce(v0[y], mod), reduce(v1[y], mod));
+}
+
+// The turn of H: P = A B (sink BD_PLAIN_SCALED) straight into T = rev(P) mod x^(m-1) (source BS_REVTRUNC).  T_k = P_{2m-2-k}:
+// the forward positions r, r + 1 (r even) take their inputs from the product's positions rho = (2m - 2 - r) mod B and
+// rho - 1 -- odd aligned: 8-byte loads -- block K0 - i for block i, K0 = (2m - 2 - r - c) div B: the register tile is
+// reversed and shifted by Y - 1 - K0 (a barrel of LOGY select rounds) and truncated at m - 1.  The 2M-word product buffer
+// is neither written nor read.
+template <int LOGY>
+__global__ void __launch_bounds__(256) bc2_h_turn_kernel(Bc2Args a, ColPlans plans) {
+  constexpr int Y = 1 << LOGY, B = BC2_B;
+  const int r = 2 * (int)(blockIdx.x * 256 + threadIdx.x);
+  const size_t cu = blockIdx.y, col = cu;  // units = 1
+  const ColPlan &P = plans.l[((a.col0 + col) % a.S) / a.slots_per_limb];
+  const Mod mod = P.mod;
+  const double *__restrict__ itw = P.itw;
+  const double *__restrict__ tw = P.tw;
+  const int q = 2 * a.m - 2;
+  double x[2][Y];
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const int i0 = q - r - c, rho = i0 & (B - 1), K0 = i0 >> BC2_LOGB;
+    double lo[Y], hi[Y];
+    const double *in = a.Ws + cu * (size_t)Y * 2 * B + rho;
+#pragma unroll
+    for (int y = 0; y < Y; y++) {
+      const double u = in[(size_t)(2 * y) * B], w = in[(size_t)(2 * y + 1) * B];
+      lo[y] = reduce(u + w, mod);
+      hi[y] = reduce(u - w, mod);
+    }
+    reg_inv_stages<LOGY, true>(lo, mod, P.imask[LOGY], [&](int k, int i) { return itw[(Y >> (k + 1)) + i]; });
+    reg_inv_stages<LOGY, true>(hi, mod, P.imask[LOGY], [&](int k, int i) { return itw[(Y >> (k + 1)) + i]; });
+    double u_[Y];  // u_[e] = P at block Y - 1 - e of class rho
+#pragma unroll
+    for (int k = 0; k < Y; k++) {
+      double o = lo[k];
+      if (k >= 1) o += hi[k - 1];
+      u_[Y - 1 - k] = mulmod(reduce(o, mod), P.b2_inv, mod);
+    }
+    const int sh = Y - 1 - K0;
+#pragma unroll
+    for (int b = 0; b < LOGY; b++) {
+      const bool on = (sh >> b) & 1;
+#pragma unroll
+      for (int e = 0; e < Y; e++) {
+        const double far = (e + (1 << b) < Y) ? u_[e + (1 << b)] : 0.0;
+        u_[e] = on ? far : u_[e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < Y / 2; i++) x[c][i] = ((long long)i * B + r + c < (long long)a.m - 1) ? reduce(u_[i], mod) : 0.0;
+  }
+  reg_fwd_stages_zu<LOGY>(x[0], mod, P.fmask[LOGY], [&](int st, int blk) { return tw[(1 << st) + blk]; });
+  reg_fwd_stages_zu<LOGY>(x[1], mod, P.fmask[LOGY], [&](int st, int blk) { return tw[(1 << st) + blk]; });
+  double *out = a.Wy + cu * (size_t)Y * B + r;
+#pragma unroll
+  for (int y = 0; y < Y; y++) *reinterpret_cast<double2 *>(out + (size_t)y * B) = make_double2(reduce(x[0][y], mod), reduce(x[1][y], mod));
+}
+
 // ---- Y > 32 blocks (M >= 2^18 at B = 2^13): the transform across blocks in two levels -----------------------------
 // A thread cannot hold Y = 64 .. 256 values of two positions.  Y = R x 32, R = 2^S1:
 //   forward   the first S1 stages mix elements 32 apart, the last five are R independent 32-point sub-transforms rooted

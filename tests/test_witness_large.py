@@ -373,3 +373,33 @@ def test_level_15_forward_stages_inside_the_tile_kernel(m, zk, sub_log, ws):
         del dev, asg, w
     for k in want:
         assert (runs[0][k] == runs[1][k]).all(), k
+
+
+@pytest.mark.parametrize("m,zk", [(30000, True), (50000, False), (65536, True), (100000, True), (262144, False)])
+def test_the_turns_on_the_two_dimensional_block_convolutions(m, zk):
+    """The same two fusions on the recipe primes' path (forced: witness_force_bc = 14): bc2_h_turn_kernel (the product's
+    inverse transform across blocks + the forward one of its reversal, M <= 2^16) and bc2_level_turn_kernel (tree level l's
+    sink + level l + 1's source, parents of at most 32 blocks) -- bit-equal to the separate passes and to nothing less than
+    every column's identities."""
+    from ringsnark_amd.device import to_host
+    prm = P.preset("toy44")
+    want = ("A_mid", "B_mid", "C_mid", "H")
+    runs = {}
+    for turn in (0, 1):
+        _set_tuning(b"witness_h_turn", turn)
+        _set_tuning(b"witness_level_turn", turn)
+        try:
+            dev, cs, asg, ds, w, names = _run(prm, m, zk, 14, want=want)
+        finally:
+            _set_tuning(b"witness_h_turn", 1)
+            _set_tuning(b"witness_level_turn", 1)
+        logM = (m - 1).bit_length()
+        assert ("bc2_h_turn_kernel" in names) == (turn == 1 and logM <= 16), names
+        assert ("bc2_level_turn_kernel" in names) == (turn == 1 and logM >= 16), names
+        if turn:
+            err, info = proof_check.check_all_columns(prm, cs, asg, {k: w[k] for k in want}, tuple(ds), seed=m % 971, Z=w["Z"])
+            assert err is None and info["columns"] == prm.L * prm.N, err
+        runs[turn] = {k: to_host(w[k]) for k in want}
+        del dev, asg, w
+    for k in want:
+        assert (runs[0][k] == runs[1][k]).all(), k

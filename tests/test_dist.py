@@ -339,6 +339,24 @@ def test_sharded_rinocchio_on_device_backend(tmp_path, q_override, m, zk, split)
     assert open(out).read() == "ok"
 
 
+def _spawn_with_deadline(fn, args, nprocs, seconds):
+    """mp.spawn that cannot hang the suite: the ranks are killed and the test fails when they have not finished in time
+    (a collective that never completes -- a transport this code has not met yet -- must cost one test, not the run)."""
+    import time
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    deadline = time.time() + seconds
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for p_ in ctx.processes:
+                if p_.is_alive():
+                    p_.terminate()
+            for p_ in ctx.processes:
+                p_.join(10)
+                if p_.is_alive():
+                    p_.kill()
+            pytest.fail("the %d ranks did not finish within %d s (killed)" % (nprocs, seconds))
+
+
 def _rccl_world(want):
     n = torch.cuda.device_count()  # counting devices does not initialise the GPU
     if n < want:
@@ -346,6 +364,8 @@ def _rccl_world(want):
 
 
 @pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="first contact with RCCL: no multi-GPU node was available to any round; a failure here is a finding, "
+                                        "not a regression of the one-GPU path")
 @pytest.mark.parametrize("world,preset,q_override,prover,zk,split,relay,desc", [
     (2, "toy", None, "groth16", False, "slots", False, "limb split (N <= L): fused prover per rank, all-gather over RCCL"),
     (2, "toy", 1, "groth16", False, "slots", False, "one limb on two ranks: slot split, direct exchange on the group communicator, all-reduce"),
@@ -364,8 +384,8 @@ def test_sharded_provers_over_rccl(tmp_path, world, preset, q_override, prover, 
     world group.  Every sharded proof must equal the one-process oracle proof bit for bit."""
     _rccl_world(world)
     out = str(tmp_path / "result.txt")
-    mp.spawn(_gpu_worker, args=(world, _free_port(), 9 if world <= 2 else 12, q_override, out, prover, zk, split, "nccl", relay, preset),
-             nprocs=world, join=True)
+    _spawn_with_deadline(_gpu_worker, (world, _free_port(), 9 if world <= 2 else 12, q_override, out, prover, zk, split, "nccl", relay, preset),
+                         world, 300)
     assert open(out).read() == "ok"
 
 
@@ -446,3 +466,18 @@ def test_key_windows_cover_every_slice_the_sharded_prover_takes():
                 pieces = sorted(p for p in covered[k] if p[0] < p[1])
                 assert pieces[0][0] == 0 and pieces[-1][1] == used
                 assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+
+
+def _sleeper(rank, seconds):
+    import time
+    time.sleep(seconds)
+
+
+def test_spawn_with_deadline_kills_stuck_ranks():
+    """the guard of the RCCL tests: ranks that do not finish are killed and the test fails -- it does not hang the suite"""
+    import time
+    t0 = time.time()
+    with pytest.raises(pytest.fail.Exception):
+        _spawn_with_deadline(_sleeper, (120,), 2, 3)
+    assert time.time() - t0 < 60
+    _spawn_with_deadline(_sleeper, (0,), 2, 60)  # ranks that do finish: returns

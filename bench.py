@@ -372,7 +372,10 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            import datetime
+            # a collective that never completes (a transport this code has not met on hardware) must end the run with an
+            # error after five minutes -- the NCCL watchdog aborts the ranks -- not hold the node
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
 
     prm = P.preset(args.preset)
     m = 1 << args.logm

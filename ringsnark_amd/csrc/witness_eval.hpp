@@ -77,12 +77,41 @@ io_mid_out_kernel(const typename ArithOf<M>::T *__restrict__ cols, IoDesc io,
   const size_t pair = cm.in_index(limb, slot) >> 1, Si = cm.in_stride();
   const size_t opair = cm.out_index(limb, slot) >> 1, So = cm.out_stride();
   const M mod = qmod[limb];
+  // the primary inputs of this lane's two slots do not depend on the row: the first XC terms keep them in registers (round 5:
+  // they were re-read from L2 for every row -- two 16-byte loads per lane and row beside 8 bytes of column data)
+  constexpr int XC = 4;
+  T xa[XC], xb[XC];
+#pragma unroll
+  for (int e = 0; e < XC; e++) {
+    xa[e] = xb[e] = T(0);
+    if (e < io.count && io.k[e] != 0) {
+      const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(asg + (size_t)(io.k[e] - 1) * Si)[pair];
+      xa[e] = from_res<T>(v.x);
+      xb[e] = from_res<T>(v.y);
+    }
+  }
   for (int k = ty; k < 32; k += 8) {
     const size_t r = r0 + k;
     if (r >= m || r < cm.row0 || r >= cm.row1) continue;
     const size_t ro = r - cm.row0;  // output row
     T a0 = T(0), a1 = T(0);
-    for (int e = 0; e < io.count; e++) {
+#pragma unroll
+    for (int e = 0; e < XC; e++) {
+      if (e >= io.count) break;
+      const T lv = center(Lcols[((size_t)io.column[e] * cm.L + limb) * Mlen + r], mod);
+      if (io.k[e] == 0) {
+        a0 = addm(a0, lv, mod);
+        a1 = addm(a1, lv, mod);
+      } else {
+        a0 = addm(a0, mulmod_dd(xa[e], lv, mod), mod);
+        a1 = addm(a1, mulmod_dd(xb[e], lv, mod), mod);
+      }
+      if ((e & 3) == 3) {
+        a0 = reduce(a0, mod);
+        a1 = reduce(a1, mod);
+      }
+    }
+    for (int e = XC; e < io.count; e++) {
       const T lv = center(Lcols[((size_t)io.column[e] * cm.L + limb) * Mlen + r], mod);
       const int kk = io.k[e];
       if (kk == 0) {

@@ -69,11 +69,12 @@ __device__ __forceinline__ int wide_group(int t, int j) {
 }
 
 // R forward stages on a register tile of 2^R values; tw(k, blk) = twiddle of block blk of local stage k.
-template <int R, bool RED, class TwFn>
+// NST < R: only the first NST of them (incomplete transforms, witness_inc.hpp).
+template <int R, bool RED, int NST = R, class TwFn>
 __device__ __forceinline__ void reg_fwd_stages(double (&v)[1 << R], const Mod mod, uint32_t red_mask, TwFn tw) {
   constexpr int E = 1 << R;
 #pragma unroll
-  for (int k = 0; k < R; k++) {
+  for (int k = 0; k < NST; k++) {
     if (RED && ((red_mask >> k) & 1u)) {
 #pragma unroll
       for (int e = 0; e < E; e++) v[e] = reduce(v[e], mod);
@@ -93,13 +94,13 @@ __device__ __forceinline__ void reg_fwd_stages(double (&v)[1 << R], const Mod mo
     }
   }
 }
-// Inverse stages 0..NST-1 of a register tile of 2^R values (local gap 2^k at local stage k);
-// tw(k, i) = twiddle of butterfly block i = e >> (k+1).
-template <int R, bool RED, int NST = R, class TwFn>
+// Inverse stages K0..NST-1 of a register tile of 2^R values (local gap 2^k at local stage k);
+// tw(k, i) = twiddle of butterfly block i = e >> (k+1).  K0 > 0: incomplete transforms (witness_inc.hpp).
+template <int R, bool RED, int NST = R, int K0 = 0, class TwFn>
 __device__ __forceinline__ void reg_inv_stages(double (&v)[1 << R], const Mod mod, uint32_t red_mask, TwFn tw) {
   constexpr int E = 1 << R;
 #pragma unroll
-  for (int k = 0; k < NST; k++) {
+  for (int k = K0; k < NST; k++) {
     if (RED && ((red_mask >> k) & 1u)) {
 #pragma unroll
       for (int e = 0; e < E; e++) v[e] = reduce(v[e], mod);

@@ -104,11 +104,12 @@ bool fwd_end_needs_reduce(uint64_t p, int logn) {
   }
   return B > lim;
 }
-uint32_t inv_reduce_mask(uint64_t p, int logn) {
+// u0 > 0: the inverse of an incomplete transform (witness_inc.hpp) starts at stage u0, on values |v| <= p
+uint32_t inv_reduce_mask(uint64_t p, int logn, int u0) {
   const double lim = 1125899906842624.0 / (double)p;
   double B = 1.0;
   uint32_t mask = 0;
-  for (int u = 0; u < logn; u++) {
+  for (int u = u0; u < logn; u++) {
     if (2.0 * B > lim) {
       mask |= 1u << u;
       B = 0.51;
@@ -1023,6 +1024,8 @@ int rs_set_tuning(const char *key, int value) {
     g_witness_force_bc = value;  // takes effect for plans built afterwards (plans are cached per context and size)
   } else if (std::string(key) == "witness_bc2") {
     g_witness_bc2 = value ? 1 : 0;  // takes effect for plans built afterwards, like witness_force_bc
+  } else if (std::string(key) == "witness_inc") {
+    g_witness_inc = value ? 1 : 0;  // incomplete transforms instead of block convolutions; plans built afterwards
   } else if (std::string(key) == "witness_tree_log") {
     RS_REQUIRE(value == 13 || value == 14, "witness_tree_log must be 13 or 14");
     g_witness_tree_log = value;

@@ -280,7 +280,7 @@ void free_table(NttTableT<T, M> &t) {
   t.d_tw = t.d_itw = nullptr;
 }
 uint32_t fwd_reduce_mask(uint64_t p, int logn);
-uint32_t inv_reduce_mask(uint64_t p, int logn);
+uint32_t inv_reduce_mask(uint64_t p, int logn, int u0 = 0);
 bool fwd_end_needs_reduce(uint64_t p, int logn);
 inline hipStream_t S(rs_stream s) { return (hipStream_t)s; }
 
@@ -294,6 +294,7 @@ extern int g_witness_cross_pair;           // witness.hip: paired groups / 16-by
 extern int g_witness_cross_maxr;           // witness.hip: stages per cross pass of the multi-pass transforms
 extern int g_witness_force_bc;             // witness.hip: cap on the transform length (block-convolution path)
 extern int g_witness_bc2;                  // witness.hip: two-dimensional block convolutions where they apply
+extern int g_witness_inc;                  // witness.hip: incomplete transforms (witness_inc.hpp) where they apply, instead of block convolutions
 extern int g_prover_lin_io;               // prover.hip: io vectors as linear forms in groth16::prover
 extern int g_witness_tree_log;            // witness.hip: tile of the wide product-tree kernel (13 or 14)
 extern int g_witness_sub_ct;              // witness.hip: compile-time-length sub-transform kernel

@@ -68,6 +68,8 @@ struct LimbPlan {
   void *d_b2_e = nullptr, *d_b2_s = nullptr;  // [Y][2B], Y = 2M/B
   void *d_b2_d = nullptr;                     // [logM - bcLog][2M]: per level l, [node][Y_l][2B], Y_l = 2^l / B
   uint32_t fwd_mask2 = 0, inv_mask2 = 0;     // reduce masks for length 2M
+  int adic = 64;                             // incomplete transforms (WitnessPlan::incomplete): d_tw / d_itw hold 2^adic entries and
+                                             // every spectrum table of a longer transform is in the incomplete form (witness_inc.hpp)
   std::vector<uint64_t> Z;                   // m+1 coefficients of the vanishing polynomial
 };
 
@@ -83,6 +85,10 @@ struct WitnessPlan {
   // Block convolutions as TWO-DIMENSIONAL transforms (FP64 arithmetic, primes with 2-adicity >= 14, M >= 2^15; see
   // "two-dimensional block convolutions" below): blocks of B = 2^13 coefficients, bcLog = 14.
   bool bc2 = false;
+  // Some ring prime lacks a 2M-th root of unity and the columns take the multi-pass path with INCOMPLETE transforms
+  // (witness_inc.hpp; LimbPlan::adic per prime) instead of block convolutions: bcLog = 0, the full-length launch sequences run.
+  bool incomplete = false;
+  uint64_t knob_sig = 0;  // plan_knob_sig() when the plan was built: get_plan rebuilds when a knob it depends on has changed
   std::vector<LimbPlan> limb;
   // coefficients_for_Z of every limb as the compact [m + 1][L] device array the inner products take a slot-constant
   // vector in (rs_msm_vec::slot_const): a per-(context, m) constant, uploaded once (witness_Z_rows)
@@ -124,10 +130,12 @@ static CycTab make_cyc(uint64_t p, int logn_max) {
   }
   return t;
 }
-static void ntt_fwd(std::vector<uint64_t> &a, int logn, const CycTab &t) {
+// nst >= 0: the first nst stages only (incomplete transforms, witness_inc.hpp: leaves of 2^(logn - nst) consecutive words)
+static void ntt_fwd(std::vector<uint64_t> &a, int logn, const CycTab &t, int nst = -1) {
   const size_t n = (size_t)1 << logn;
   const uint64_t p = t.p;
-  for (size_t m = 1, gap = n >> 1; m < n; m <<= 1, gap >>= 1)
+  const size_t mend = nst < 0 ? n : (size_t)1 << nst;
+  for (size_t m = 1, gap = n >> 1; m < mend; m <<= 1, gap >>= 1)
     for (size_t i = 0; i < m; i++) {
       const uint64_t W = t.tw[m + i];
       for (size_t j = 2 * i * gap; j < 2 * i * gap + gap; j++) {
@@ -232,6 +240,17 @@ int g_witness_cross_maxr = 6;  // tuning knob "witness_cross_maxr": most stages 
 int g_witness_force_bc = 0;  // tuning knob "witness_force_bc": pretend the ring primes have only this 2-adicity (tests)
 int g_witness_bc2 = 1;       // tuning knob "witness_bc2": two-dimensional block convolutions where they apply (0: the pairwise form)
 
+// tuning knob "witness_inc": ring primes without a 2M-th root of unity run the multi-pass path on INCOMPLETE transforms
+// (witness_inc.hpp) where the conditions of build_plan hold; 0: the block convolutions (round 3's path for those primes)
+int g_witness_inc = 1;
+extern int g_witness_lds_logM, g_witness_tree_log, g_witness_tree_ct;
+static bool single_tile_ok(int logM);
+// largest tile of the product tree in the multi-pass path: full transforms of that length run inside the tile kernels
+static int tree_tile_log(bool fp, int logM) {
+  const int logT = std::min(g_witness_lds_logM, logM);
+  return (fp && logT == 13 && logM >= 15 && g_witness_tree_ct == 2 && g_witness_tree_log >= 14) ? 14 : logT;
+}
+
 static void free_plan_tables(WitnessPlan *P);
 static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
   using namespace hostw;
@@ -249,17 +268,26 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
   for (int li = 0; li < ctx->L; li++) vmin = std::min(vmin, host::two_adicity(ctx->q[li]));
   if (g_witness_force_bc > 0) vmin = std::min(vmin, g_witness_force_bc);  // tests: the block path on well-endowed primes
   const bool blocked = vmin < logM + 1;
-  // full-length transforms serve 2^21 and 2^22 constraints as they serve 2^20 (one more cross pass); the block
-  // convolutions stop at 2^20 (the two-level transform across blocks is built for Y <= 256 blocks of 2^13)
-  if (blocked && logM > 20)
-    throw Error(RS_ERR_UNSUPPORTED, "witness map beyond 2^20 constraints needs ring primes = 1 mod 2^(log2 M + 1) (full-length transforms); "
-                                    "the block convolutions of other primes stop at 2^20");
-  P->bc2 = blocked && g_witness_bc2 && !ctx->use_int && vmin >= 14 && logM >= 15;
-  P->bcLog = blocked ? (P->bc2 ? 14 : std::min(vmin, 13)) : 0;
+  // Incomplete transforms (witness_inc.hpp): the multi-pass path as it is, every transform longer than 2^(a prime's
+  // 2-adicity) stopped that many stages early.  Needs: columns that take the multi-pass path; full transforms inside the
+  // product tree's tiles; at most RS_INC_MAX stages missing, all of them inside the LAST round of a sub-transform block.
+  {
+    const int logT = std::min(g_witness_lds_logM, logM);
+    const bool multi = logM > g_witness_lds_logM && !(!ctx->use_int && single_tile_ok(logM));
+    P->incomplete = blocked && g_witness_inc && multi && vmin >= tree_tile_log(!ctx->use_int, logM) && logM + 1 - vmin <= RS_INC_MAX &&
+                    std::min(logT, 12) > RS_INC_MAX;
+  }
+  const bool bcpath = blocked && !P->incomplete;
+  // full-length transforms serve 2^21 and 2^22 constraints as they serve 2^20 (one more cross pass), complete or not; the
+  // block convolutions stop at 2^20 (the two-level transform across blocks is built for Y <= 256 blocks of 2^13)
+  if (bcpath && logM > 20)
+    throw Error(RS_ERR_UNSUPPORTED, "witness map beyond 2^20 constraints needs ring primes = 1 mod 2^(log2 M - 3) (full-length transforms, "
+                                    "at most four stages short); the block convolutions of other primes stop at 2^20");
+  P->bc2 = bcpath && g_witness_bc2 && !ctx->use_int && vmin >= 14 && logM >= 15;
+  P->bcLog = bcpath ? (P->bc2 ? 14 : std::min(vmin, 13)) : 0;
   // every context prime is 1 mod 2*N_enc with N_enc >= 16, so the 2-adicity is at least 5
-  RS_REQUIRE(!blocked || P->bcLog > SCHOOL_LEVELS, "ring prime with too little 2-adicity for the witness map");
-  const int tabLog = blocked ? P->bcLog : logM + 1;  // longest transform the device tables serve
-  const size_t Bc = blocked ? (size_t)1 << (P->bcLog - 1) : 0, nblk = blocked ? std::max<size_t>(1, M / Bc) : 0;
+  RS_REQUIRE(!bcpath || P->bcLog > SCHOOL_LEVELS, "ring prime with too little 2-adicity for the witness map");
+  const size_t Bc = bcpath ? (size_t)1 << (P->bcLog - 1) : 0, nblk = bcpath ? std::max<size_t>(1, M / Bc) : 0;
   // one host thread per ring limb: the tables of different primes are independent (product tree, Newton iteration for
   // rev(Z)^-1 -- 0.6 s per limb at the headline, the bulk of a process's first proof)
   auto build_limb = [&](int li) {
@@ -267,6 +295,16 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
     const uint64_t p = ctx->q[li];
     RS_REQUIRE(p > 2 * M, "ring prime too small for the evaluation domain");
     lp.p = p;
+    // longest transform the device tables serve: the block length (block convolutions), this prime's 2-adicity
+    // (incomplete transforms: longer ones stop there), else 2M
+    lp.adic = 64;
+    if (P->incomplete) {
+      int a = host::two_adicity(p);
+      if (g_witness_force_bc > 0) a = std::min(a, g_witness_force_bc);
+      if (a < logM + 1) lp.adic = a;
+    }
+    const int tabLog = bcpath ? P->bcLog : std::min(logM + 1, lp.adic);
+    auto inc_of = [&](int logn) { return logn > lp.adic ? logn - lp.adic : 0; };
     const CycTab T = make_cyc(p, tabLog);
     auto bal = [&](uint64_t v) { return konst_word(ctx, v, p); };
     {
@@ -316,7 +354,7 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
       lp.d_invfact = up(v);
       std::vector<uint64_t> e(2 * M, 0);
       for (size_t k = 0; k < m; k++) e[k] = (k & 1) ? (p - ifact[k]) % p : ifact[k];
-      if (blocked) {
+      if (bcpath) {
         e.resize(M);
         lp.d_bc_e = up(block_spectra(e, nblk));
         if (P->bc2) {
@@ -325,8 +363,9 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
           lp.d_b2_e = up(t2);
         }
       } else {
-        ntt_fwd(e, logM + 1, T);
-        const uint64_t s2 = invmod((uint64_t)(2 * M) % p, p);
+        const int nst = logM + 1 - inc_of(logM + 1);  // the inverse undoes nst stages: scale 2^-nst
+        ntt_fwd(e, logM + 1, T, nst);
+        const uint64_t s2 = invmod(((uint64_t)1 << nst) % p, p);
         std::vector<uint64_t> eh(2 * M);
         for (size_t k = 0; k < 2 * M; k++) eh[k] = bal(mulmod(e[k], s2, p));
         lp.d_ehat = up(eh);
@@ -351,7 +390,7 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
     // D_left spectra (levels > SCHOOL_LEVELS) and low coefficients (levels <= SCHOOL_LEVELS)
     {
       std::vector<uint64_t> dhat((size_t)(logM + 1) * M, 0), dlow((size_t)(SCHOOL_LEVELS + 1) * (M / 2 + 1), 0);
-      std::vector<uint64_t> bcd(blocked && logM > P->bcLog ? (size_t)(logM - P->bcLog) * M : 0, 0);
+      std::vector<uint64_t> bcd(bcpath && logM > P->bcLog ? (size_t)(logM - P->bcLog) * M : 0, 0);
       std::vector<uint64_t> b2d(P->bc2 && logM > P->bcLog ? (size_t)(logM - P->bcLog) * 2 * M : 0, 0);
       for (int l = 1; l <= logM; l++) {
         const size_t n = (size_t)1 << l, h = n >> 1;
@@ -359,7 +398,7 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
           const auto &dl = prod[l - 1][2 * i];  // h low coefficients, monic of degree h
           if (l <= SCHOOL_LEVELS) {
             for (size_t k = 0; k < h; k++) dlow[(size_t)l * (M / 2 + 1) + i * h + k] = bal(dl[k]);
-          } else if (blocked && l > P->bcLog) {
+          } else if (bcpath && l > P->bcLog) {
             // node i of level l: the h / Bc blocks of D_left's low part (the monic x^h term is added by the sink)
             const std::vector<uint64_t> sp = block_spectra(dl, h / Bc);
             std::copy(sp.begin(), sp.end(), bcd.begin() + (size_t)(l - P->bcLog - 1) * M + i * n);
@@ -368,8 +407,9 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
             std::vector<uint64_t> f(n, 0);
             for (size_t k = 0; k < h; k++) f[k] = dl[k];
             f[h] = 1;
-            ntt_fwd(f, l, T);
-            const uint64_t sc = invmod((uint64_t)n % p, p);
+            const int nst = l - inc_of(l);
+            ntt_fwd(f, l, T, nst);
+            const uint64_t sc = invmod(((uint64_t)1 << nst) % p, p);
             for (size_t k = 0; k < n; k++) dhat[(size_t)l * M + i * n + k] = bal(mulmod(f[k], sc, p));
           }
         }
@@ -473,13 +513,14 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
           g = ng;
         }
         for (size_t i2 = 0; i2 < g.size(); i2++) shat[i2] = g[i2];
-        if (!blocked) {
-          ntt_fwd(shat, logM + 1, T);
-          const uint64_t s2 = invmod((uint64_t)(2 * M) % p, p), s4 = mulmod(s2, s2, p);
+        if (!bcpath) {
+          const int nst = logM + 1 - inc_of(logM + 1);
+          ntt_fwd(shat, logM + 1, T, nst);
+          const uint64_t s2 = invmod(((uint64_t)1 << nst) % p, p), s4 = mulmod(s2, s2, p);
           for (auto &x : shat) x = mulmod(x, s4, p);
         }
       }
-      if (blocked) {
+      if (bcpath) {
         shat.resize(M);  // S itself, m - 1 <= M coefficients
         lp.d_bc_s = up(block_spectra(shat, nblk));
         if (P->bc2) {
@@ -536,10 +577,25 @@ static void free_plan(WitnessPlan *P) {
   delete P;
 }
 
+// the knobs build_plan's choice of path (full length / incomplete / block convolutions) and table forms depend on
+static uint64_t plan_knob_sig() {
+  uint64_t h = 1469598103934665603ull;
+  for (int v : {g_witness_lds_logM, g_witness_tree_log, g_witness_tree_ct, g_witness_inc, g_witness_bc2, g_witness_force_bc})
+    h = (h ^ (uint64_t)(uint32_t)v) * 1099511628211ull;
+  return h;
+}
 WitnessPlan *get_plan(rs_ctx *ctx, size_t m) {
+  const uint64_t sig = plan_knob_sig();
   auto it = ctx->plans.find(m);
-  if (it != ctx->plans.end()) return it->second;
+  if (it != ctx->plans.end()) {
+    if (it->second->knob_sig == sig) return it->second;
+    // a tuning knob changed since the plan was built (tests, A/B tools): its tables may be in another form -- rebuild
+    RS_HIP(hipDeviceSynchronize());
+    free_plan(it->second);
+    ctx->plans.erase(it);
+  }
   WitnessPlan *P = build_plan(ctx, m);
+  P->knob_sig = sig;
   ctx->plans[m] = P;
   return P;
 }
@@ -593,9 +649,11 @@ static ColPlansT<M> make_colplans(rs_ctx *ctx, const WitnessPlan *P, int limb0 =
     c.fwd_mask2 = lp.fwd_mask2;
     c.inv_mask2 = lp.inv_mask2;
     c.pwmask = 0;
+    c.adic = lp.adic;
     for (int l = 0; l < 24; l++) {
       c.fmask[l] = fwd_reduce_mask(lp.p, l);
-      c.imask[l] = inv_reduce_mask(lp.p, l);
+      // an incomplete transform's inverse starts at stage inc(l) on reduced values (inc_polymul)
+      c.imask[l] = inv_reduce_mask(lp.p, l, c.inc(l));
       if (fwd_end_needs_reduce(lp.p, l)) c.pwmask |= 1u << l;
     }
   }
@@ -809,41 +867,70 @@ static int sub_block_log(int logT, int logsub) {
   return (std::is_same<M, Mod>::value && g_witness_sub_log == 12 && logT == 13 && logsub - 12 <= g_witness_sub12_cross) ? 12 : logT;
 }
 
+// FP64 instructions per coefficient of the pointwise step of a fused sub-transform: one modular product, or (incomplete
+// transforms, witness_inc.hpp) 2^inc of them, their sums and reductions, and the product with eta
+static double pointwise_fp64(int inc) { return inc ? 7.0 * (double)(1 << inc) + 13.0 : 7.0; }
+
+// `inc`: stages every transform of this launch stops short (the same for every column: launch_sub splits otherwise)
 template <int MODE, class M>
-static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, size_t col0, int logtot, int logsub, int logB,
-                       const TabPtrs *tabs, size_t tab_period, size_t S, size_t spl, const ColPlansT<M> &cp, hipStream_t st) {
+static void launch_sub_inc(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, size_t col0, int logtot, int logsub, int logB,
+                           const TabPtrs *tabs, size_t tab_period, size_t S, size_t spl, const ColPlansT<M> &cp, hipStream_t st, int inc) {
   constexpr bool FP = std::is_same<M, Mod>::value;
   const size_t lds = padded_len((size_t)1 << logB) * sizeof(double);
   const size_t bpc = (size_t)1 << (logtot - logB);
   static const char *const names[5] = {"sub_ntt_kernel<0", "sub_ntt_kernel<1", "sub_ntt_kernel<2", "sub_ntt_kernel<3", "sub_ntt_kernel<4"};
   static const char *const names_ct[5] = {"sub_ntt_ct_kernel<0, 13>", "sub_ntt_ct_kernel<1, 13>", "sub_ntt_ct_kernel<2, 13>", "sub_ntt_ct_kernel<3, 13>", "sub_ntt_ct_kernel<4, 13>"};
-  static const char *const names_wide[5] = {"sub_ntt_wide_kernel<0>", "sub_ntt_wide_kernel<1>", "sub_ntt_wide_kernel<2>", "sub_ntt_wide_kernel<3>", "sub_ntt_wide_kernel<4>"};
+  // names as rocprofv3 prints them: "sub_ntt_wide_kernel<MODE, INC>"
+  static const char *const names_wide[5][5] = {
+      {"sub_ntt_wide_kernel<0, 0>", "sub_ntt_wide_kernel<0, 1>", "sub_ntt_wide_kernel<0, 2>", "sub_ntt_wide_kernel<0, 3>", "sub_ntt_wide_kernel<0, 4>"},
+      {"sub_ntt_wide_kernel<1, 0>", "", "", "", ""},
+      {"sub_ntt_wide_kernel<2, 0>", "sub_ntt_wide_kernel<2, 1>", "sub_ntt_wide_kernel<2, 2>", "sub_ntt_wide_kernel<2, 3>", "sub_ntt_wide_kernel<2, 4>"},
+      {"sub_ntt_wide_kernel<3, 0>", "sub_ntt_wide_kernel<3, 1>", "sub_ntt_wide_kernel<3, 2>", "sub_ntt_wide_kernel<3, 3>", "sub_ntt_wide_kernel<3, 4>"},
+      {"sub_ntt_wide_kernel<4, 0>", "", "", "", ""}};
+  static const char *const names_w12[5][5] = {
+      {"sub_ntt_w12_kernel<0, 0>", "sub_ntt_w12_kernel<0, 1>", "sub_ntt_w12_kernel<0, 2>", "sub_ntt_w12_kernel<0, 3>", "sub_ntt_w12_kernel<0, 4>"},
+      {"sub_ntt_w12_kernel<1, 0>", "", "", "", ""},
+      {"sub_ntt_w12_kernel<2, 0>", "sub_ntt_w12_kernel<2, 1>", "sub_ntt_w12_kernel<2, 2>", "sub_ntt_w12_kernel<2, 3>", "sub_ntt_w12_kernel<2, 4>"},
+      {"sub_ntt_w12_kernel<3, 0>", "sub_ntt_w12_kernel<3, 1>", "sub_ntt_w12_kernel<3, 2>", "sub_ntt_w12_kernel<3, 3>", "sub_ntt_w12_kernel<3, 4>"},
+      {"sub_ntt_w12_kernel<4, 0>", "", "", "", ""}};
+  RS_REQUIRE(inc >= 0 && inc <= RS_INC_MAX && (inc == 0 || (MODE != 1 && MODE != 4)) && logB > inc, "internal: sub-transform launch out of range");
 #ifdef RS_EXPERIMENTS
-  const bool ct = FP && logB == 13 && MODE != 1 && g_witness_sub_ct && (MODE != 4 || g_witness_sub_ct == 2);  // MODE 4: generic, wide and 2^12 kernels only
+  const bool ct = FP && logB == 13 && MODE != 1 && g_witness_sub_ct && (MODE != 4 || g_witness_sub_ct == 2) && (inc == 0 || g_witness_sub_ct == 2);  // MODE 4: generic, wide and 2^12 kernels only
 #else
   const bool ct = FP && logB == 13 && MODE != 1 && g_witness_sub_ct == 2;  // 0: the generic kernel; 1 and 3 exist in the experiments build only
 #endif
   const double Bn = (double)((size_t)1 << logB), blocks = (double)(ncols * bpc);
   static const char *const names_w16[5] = {"sub_ntt_wide16_kernel<0>", "sub_ntt_wide16_kernel<1>", "sub_ntt_wide16_kernel<2>", "sub_ntt_wide16_kernel<3>", "sub_ntt_wide16_kernel<4>"};
-  static const char *const names_w12[5] = {"sub_ntt_w12_kernel<0>", "sub_ntt_w12_kernel<1>", "sub_ntt_w12_kernel<2>", "sub_ntt_w12_kernel<3>", "sub_ntt_w12_kernel<4>"};
   const bool w12 = FP && logB == 12 && MODE != 1 && g_witness_sub_log == 12;
-  ProfScope prof(ctx, st, w12 ? names_w12[MODE] : ct ? (g_witness_sub_ct == 3 ? names_w16[MODE] : g_witness_sub_ct == 2 ? names_wide[MODE] : names_ct[MODE]) : names[MODE], blocks * Bn * (MODE == 4 ? 32.0 : MODE == 3 ? 24.0 : 16.0),
-                 blocks * ((MODE >= 2 ? 2.0 : 1.0) * ntt_fp64(Bn, logB) + (MODE == 4 ? 24.0 * Bn : MODE >= 2 ? 7.0 * Bn : 0.0)));
+  ProfScope prof(ctx, st, w12 ? names_w12[MODE][inc] : ct ? (g_witness_sub_ct == 3 ? names_w16[MODE] : g_witness_sub_ct == 2 ? names_wide[MODE][inc] : names_ct[MODE]) : names[MODE], blocks * Bn * (MODE == 4 ? 32.0 : MODE == 3 ? 24.0 : 16.0),
+                 blocks * ((MODE >= 2 ? 2.0 : 1.0) * ntt_fp64(Bn, logB - inc) + (MODE == 4 ? 24.0 * Bn : MODE >= 2 ? pointwise_fp64(inc) * Bn : 0.0)));
   static TabPtrs none{};
   const TabPtrs &tp = tabs ? *tabs : none;
   if constexpr (FP) {
+    const unsigned long long nb = (unsigned long long)(ncols * bpc);
     if (logB == 12 && MODE != 1 && g_witness_sub_log == 12) {
       const int wl = 4352 * (int)sizeof(double);
-      const unsigned long long nb = (unsigned long long)(ncols * bpc);
-      hipLaunchKernelGGL((sub_ntt_w12_kernel<MODE>), dim3((unsigned)std::min<unsigned long long>(nb, 1024)), dim3(256), wl, st, X,
-                         logsub - logB, tp, (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp, nb);
+#define RS_W12_LAUNCH(INC)                                                                                                              \
+  hipLaunchKernelGGL((sub_ntt_w12_kernel<MODE, INC>), dim3((unsigned)std::min<unsigned long long>(nb, 1024)), dim3(256), wl, st, X,     \
+                     logsub - logB, tp, (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp, nb)
+      if constexpr (MODE == 4) {
+        RS_W12_LAUNCH(0);
+      } else {
+        switch (inc) {
+          case 0: RS_W12_LAUNCH(0); break;
+          case 1: RS_W12_LAUNCH(1); break;
+          case 2: RS_W12_LAUNCH(2); break;
+          case 3: RS_W12_LAUNCH(3); break;
+          default: RS_W12_LAUNCH(4); break;
+        }
+      }
+#undef RS_W12_LAUNCH
       RS_HIP(hipGetLastError());
       return;
     }
 #ifdef RS_EXPERIMENTS
-    if (logB == 13 && MODE != 1 && MODE != 4 && g_witness_sub_ct == 3) {
+    if (logB == 13 && MODE != 1 && MODE != 4 && g_witness_sub_ct == 3 && inc == 0) {
       const int wl = (int)(WideShape<13>::TILE * sizeof(double));
-      const unsigned long long nb = (unsigned long long)(ncols * bpc);
       set_max_dyn_lds((const void *)sub_ntt_wide16_kernel<MODE>, wl);
       hipLaunchKernelGGL((sub_ntt_wide16_kernel<MODE>), dim3((unsigned)std::min<unsigned long long>(nb, 512)), dim3(512), wl, st, X,
                          logsub - logB, tp, (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp, nb);
@@ -853,16 +940,30 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
 #endif
     if (logB == 13 && MODE != 1 && g_witness_sub_ct == 2) {
       const int wl = (int)(WideShape<13>::TILE * sizeof(double));
-      const unsigned long long nb = (unsigned long long)(ncols * bpc);
-      set_max_dyn_lds((const void *)sub_ntt_wide_kernel<MODE>, wl);
-      hipLaunchKernelGGL((sub_ntt_wide_kernel<MODE>), dim3((unsigned)std::min<unsigned long long>(nb, 512)), dim3(256), wl, st, X,
-                         logsub - logB, tp, (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp, nb,
-                         (const double *)nullptr);
+#define RS_WIDE_LAUNCH(INC)                                                                                                             \
+  do {                                                                                                                                  \
+    set_max_dyn_lds((const void *)sub_ntt_wide_kernel<MODE, INC>, wl);                                                                  \
+    hipLaunchKernelGGL((sub_ntt_wide_kernel<MODE, INC>), dim3((unsigned)std::min<unsigned long long>(nb, 512)), dim3(256), wl, st, X,   \
+                       logsub - logB, tp, (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp, \
+                       nb, (const double *)nullptr);                                                                                    \
+  } while (0)
+      if constexpr (MODE == 4) {
+        RS_WIDE_LAUNCH(0);
+      } else {
+        switch (inc) {
+          case 0: RS_WIDE_LAUNCH(0); break;
+          case 1: RS_WIDE_LAUNCH(1); break;
+          case 2: RS_WIDE_LAUNCH(2); break;
+          case 3: RS_WIDE_LAUNCH(3); break;
+          default: RS_WIDE_LAUNCH(4); break;
+        }
+      }
+#undef RS_WIDE_LAUNCH
       RS_HIP(hipGetLastError());
       return;
     }
 #ifdef RS_EXPERIMENTS
-    if (logB == 13 && MODE != 1 && MODE != 4 && g_witness_sub_ct) {
+    if (logB == 13 && MODE != 1 && MODE != 4 && g_witness_sub_ct && inc == 0) {
       set_max_dyn_lds((const void *)sub_ntt_ct_kernel<MODE, 13>, (int)lds);
       hipLaunchKernelGGL((sub_ntt_ct_kernel<MODE, 13>), dim3((unsigned)(ncols * bpc)), dim3(512), lds, st, X, logsub - logB, tp,
                          (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp);
@@ -871,11 +972,36 @@ static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, siz
     }
 #endif
   }
+  // the generic kernel reads every column's inc from its plan
   set_max_dyn_lds((const void *)sub_ntt_kernel<MODE, ColPlansT<M>>, (int)lds);
   const int thr = (int)std::max<size_t>(64, std::min<size_t>(1024, ((size_t)1 << logB) / 16));
   hipLaunchKernelGGL((sub_ntt_kernel<MODE, ColPlansT<M>>), dim3((unsigned)(ncols * bpc)), dim3(thr), lds, st, X, logB, logsub - logB, tp,
                      (unsigned)std::max<size_t>(1, tab_period), (unsigned)bpc, col0, (unsigned)S, (unsigned)spl, cp);
   RS_HIP(hipGetLastError());
+}
+
+// Sub-transforms of the length-2^logsub transforms in X[ncols][2^logtot].  The tuned kernels take the number of stages an
+// incomplete transform stops short as a template parameter, so columns of primes with different 2-adicity (column c belongs
+// to limb ((col0 + c) % S) / spl) go in separate launches -- one launch whenever they agree (always at the headline, where a
+// chunk of columns is one limb).
+template <int MODE, class M>
+static void launch_sub(rs_ctx *ctx, typename ArithOf<M>::T *X, size_t ncols, size_t col0, int logtot, int logsub, int logB,
+                       const TabPtrs *tabs, size_t tab_period, size_t S, size_t spl, const ColPlansT<M> &cp, hipStream_t st) {
+  auto inc_at = [&](size_t c) { return cp.l[((col0 + c) % S) / spl].inc(logsub); };
+  bool same = true;
+  for (size_t c = 0; c < ncols && same; c += spl - (col0 + c) % spl) same = inc_at(c) == inc_at(0);
+  if (same) {
+    launch_sub_inc<MODE, M>(ctx, X, ncols, col0, logtot, logsub, logB, tabs, tab_period, S, spl, cp, st, ncols ? inc_at(0) : 0);
+    return;
+  }
+  for (size_t c = 0; c < ncols;) {
+    size_t e = std::min(ncols, c + spl - (col0 + c) % spl);
+    while (e < ncols && inc_at(e) == inc_at(c)) e = std::min(ncols, e + spl);  // neighbouring limbs that agree: one launch
+    TabPtrs tp = tabs ? *tabs : TabPtrs{};
+    if (MODE == 3 && tabs) tp.t[0] = static_cast<const typename ArithOf<M>::T *>(tabs->t[0]) + (c << logtot);  // the other workspace: same shape as X
+    launch_sub_inc<MODE, M>(ctx, X + (c << logtot), e - c, col0 + c, logtot, logsub, logB, tabs ? &tp : nullptr, tab_period, S, spl, cp, st, inc_at(c));
+    c = e;
+  }
 }
 
 
@@ -909,7 +1035,7 @@ static void bc2_conv(rs_ctx *ctx, Bc2Args a, int logY, size_t ncols, const TabPt
   {
     const unsigned long long nb = (unsigned long long)(cu * Y * 2);
     const double Bn = (double)BC2_B;
-    static const char *const names[4] = {"sub_ntt_wide_kernel<0>", "sub_ntt_wide_kernel<1>", "sub_ntt_wide_kernel<2>", "sub_ntt_wide_kernel<3>"};
+    static const char *const names[4] = {"sub_ntt_wide_kernel<0, 0>", "sub_ntt_wide_kernel<1, 0>", "sub_ntt_wide_kernel<2, 0>", "sub_ntt_wide_kernel<3, 0>"};
     ProfScope prof(ctx, st, names[MODE], (double)nb * Bn * (MODE == 3 ? 24.0 : 16.0),
                    (double)nb * ((MODE >= 2 ? 2.0 : 1.0) * ntt_fp64(Bn, BC2_LOGB) + (MODE >= 2 ? 7.0 * Bn : 0.0)));
     TabPtrs tp{};

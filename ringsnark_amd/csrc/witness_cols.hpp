@@ -24,6 +24,10 @@ struct ColPlanT {
   uint32_t fwd_mask2, inv_mask2;
   uint32_t fmask[24], imask[24];  // reduce masks for transforms of length 2^l (FP64 arithmetic)
   uint32_t pwmask;                // bit l: the spectrum of a length-2^l forward transform must be reduced before it meets a table entry
+  // incomplete transforms (witness_inc.hpp): the tables tw / itw hold 2^adic entries and a transform of length 2^logn > 2^adic
+  // runs its first adic stages only (inc(logn) = logn - adic stages short; spectra tables of that length are in the same form)
+  int adic;
+  __host__ __device__ __forceinline__ int inc(int logn) const { return logn > adic ? logn - adic : 0; }
 };
 template <class M_>
 struct ColPlansT {

@@ -1,6 +1,7 @@
 // witness_multipass.hpp -- multi-pass column transforms: cross passes over global memory and rooted LDS sub-transforms (witness.hip)
 #pragma once
 #include "witness_cols.hpp"
+#include "witness_inc.hpp"
 
 namespace rs {
 
@@ -637,6 +638,20 @@ sub_ntt_kernel(typename CPS::T *__restrict__ X, int logB, int log_n1, TabPtrs ta
   T *x = X + blk * (size_t)Bn;
   for (int i = threadIdx.x; i < Bn; i += blockDim.x) s[pidx(i)] = x[i];
   __syncthreads();
+  // incomplete transform (witness_inc.hpp): this prime has no root of unity of order 2^logn -- the forward transform stops
+  // `inc` stages early, the pointwise step is a product modulo x^(2^inc) - eta per leaf, the inverse starts at stage inc
+  const int inc = P.inc(logn);
+  if (inc > 0) {
+    if (MODE == 0 || MODE >= 2) lds_ntt_fwd_part<3>(s, logB, logB - inc, P.tw, root, mod, P.fmask[logn] >> log_n1);
+    if (MODE == 2 || MODE == 3) {
+      const T *tab = MODE == 2 ? static_cast<const T *>(tabs.t[limb]) + (size_t)(blk % tab_period) * Bn
+                               : static_cast<const T *>(tabs.t[0]) + blk * (size_t)Bn;
+      inc_pointwise_tile<MODE == 3>(s, logB, inc, tab, P.tw, root, mod);
+    }
+    if (MODE >= 1) lds_ntt_inv_part<3>(s, logB, inc, P.itw, root, mod, P.imask[logn]);
+    for (int i = threadIdx.x; i < Bn; i += blockDim.x) x[i] = s[pidx(i)];
+    return;
+  }
   int logw = 0;
   while ((64 << logw) < (int)blockDim.x) logw++;
   const bool wp = FP && logw >= 1 && logw <= 4 && logB - logw >= 8;
@@ -780,13 +795,17 @@ struct SubTw {  // twiddle fetch: 2^k consecutive table entries, 16-byte loads w
     }
   }
 };
-template <int MODE>
+// INC > 0: incomplete transforms (witness_inc.hpp) -- every column of the launch belongs to a prime whose transform of this
+// length stops INC stages early: forward round 3 runs 4 - INC stages, the table product is a product of polynomials of
+// 2^INC coefficients per leaf (the leaf's eta is +- the last twiddle its lane has just used), inverse round 1 starts at stage INC.
+template <int MODE, int INC = 0>
 __global__ void __launch_bounds__(256, 2)
 sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab_period, unsigned blocks_per_col, size_t col0,
                     unsigned S_, unsigned slots_per_limb, ColPlans plans, unsigned long long nblocks,
                     const double *__restrict__ Xsrc /* null: in place.  Else block b reads block b >> 1 of Xsrc: the two
                     sub-transforms (roots 2 and 3) of ONE zero-padded block of 2^13 coefficients (two-dimensional block convolutions) */) {
   using S = WideShape<13>;
+  static_assert(MODE != 4 || INC == 0, "the coset form of H needs full-length transforms");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *s = reinterpret_cast<double *>(smem);
   const int t = threadIdx.x;
@@ -858,14 +877,15 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
       const int g = t + 256 * j;
       const int pb = S::px(16 * g);
       double w[15];
-      SubTw::run<1>(tw + (root << 9) + g, w);
-      SubTw::run<2>(tw + (root << 10) + (g << 1), w + 1);
-      SubTw::run<4>(tw + (root << 11) + (g << 2), w + 3);
-      SubTw::run<8>(tw + (root << 12) + (g << 3), w + 7);
+      if (INC < 4) SubTw::run<1>(tw + (root << 9) + g, w);
+      if (INC < 3) SubTw::run<2>(tw + (root << 10) + (g << 1), w + 1);
+      if (INC < 2) SubTw::run<4>(tw + (root << 11) + (g << 2), w + 3);
+      if (INC < 1) SubTw::run<8>(tw + (root << 12) + (g << 3), w + 7);
+      if (INC == 4) w[0] = tw[((root << 9) + g) >> 1];  // the parent of leaf g: its twiddle is the square root of the leaf's eta
       double x[16];
 #pragma unroll
       for (int e = 0; e < 16; e++) x[e] = s[pb + e];
-      reg_fwd_stages<4, true>(x, mod, fmask >> 9, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
+      reg_fwd_stages<4, true, 4 - INC>(x, mod, fmask >> 9, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
       if (MODE == 0) {
 #pragma unroll
         for (int e = 0; e < 16; e++) s[pb + e] = x[e];
@@ -907,7 +927,23 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
         } else {
           stage((MODE == 2) ? static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * S::N
                             : static_cast<const double *>(tabs.t[0]) + blk * (size_t)S::N);
-          if (MODE == 2) {
+          if (INC > 0) {  // 16 >> INC leaves of 2^INC words: products modulo x^(2^INC) - eta (witness_inc.hpp)
+            constexpr int G = 1 << INC;
+#pragma unroll
+            for (int q = 0; q < 16 / G; q++) {
+              double xq[G], tq[G];
+#pragma unroll
+              for (int e = 0; e < G; e++) {
+                xq[e] = reduce(x[q * G + e], mod);
+                tq[e] = MODE == 2 ? s[pb + q * G + e] : reduce(s[pb + q * G + e], mod);
+              }
+              const double wq = INC == 4 ? w[0] : w[(1 << (3 - (INC & 3))) - 1 + (q >> 1)];
+              const bool neg = INC == 4 ? (g & 1) : (q & 1);
+              inc_polymul<INC, MODE != 2>(xq, tq, neg ? -wq : wq, mod);
+#pragma unroll
+              for (int e = 0; e < G; e++) x[q * G + e] = xq[e];
+            }
+          } else if (MODE == 2) {
             if ((P.pwmask >> logn) & 1u) {  // primes above ~2^46 only (a guarded pass, not a select)
 #pragma unroll
               for (int e = 0; e < 16; e++) x[e] = reduce(x[e], mod);
@@ -921,11 +957,11 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
         }
       }
       // inverse stage k of the block: twiddle itw[(n >> (k+1)) root + (position >> (k+1))]
-      SubTw::run<8>(itw + ((size_t)root << 12) + (g << 3), w);
-      SubTw::run<4>(itw + ((size_t)root << 11) + (g << 2), w + 8);
-      SubTw::run<2>(itw + ((size_t)root << 10) + (g << 1), w + 12);
-      SubTw::run<1>(itw + ((size_t)root << 9) + g, w + 14);
-      reg_inv_stages<4, true>(x, mod, imask, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
+      if (INC < 1) SubTw::run<8>(itw + ((size_t)root << 12) + (g << 3), w);
+      if (INC < 2) SubTw::run<4>(itw + ((size_t)root << 11) + (g << 2), w + 8);
+      if (INC < 3) SubTw::run<2>(itw + ((size_t)root << 10) + (g << 1), w + 12);
+      if (INC < 4) SubTw::run<1>(itw + ((size_t)root << 9) + g, w + 14);
+      reg_inv_stages<4, true, 4, INC>(x, mod, imask, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
 #pragma unroll
       for (int e = 0; e < 16; e++) s[pb + e] = x[e];
     }
@@ -988,7 +1024,7 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
 // element t + 256 e.  Out (MODE >= 2): v[e] = element t + 256 e after the 12 inverse stages; MODE 0: the spectrum is
 // written to fwd_out (the wave that finished a range streams it out) and v is dead.  `root`: tree node of the block in
 // the long transform; fmask / imask: reduction bits of its 12 stages; tab: the 4096 table entries of this block.
-template <int MODE>
+template <int MODE, int INC = 0>
 __device__ __forceinline__ void w12_block(double (&v)[16], double *s, const double *__restrict__ tw, const double *__restrict__ itw,
                                           const Mod mod, int root, uint32_t fmask, uint32_t imask, bool pw_reduce,
                                           const double *__restrict__ tab, double *__restrict__ fwd_out,
@@ -1021,14 +1057,16 @@ __device__ __forceinline__ void w12_block(double (&v)[16], double *s, const doub
   // ---- forward round 3 (stages 8..11) on the 16 consecutive points 16 t .., table product, inverse round 1 (stages 0..3)
   const int pb3 = 17 * t;
   {
+    static_assert(MODE != 4 || INC == 0, "the coset form of H needs full-length transforms");
     double w[15];
-    SubTw::run<1>(tw + (root << 8) + t, w);
-    SubTw::run<2>(tw + (root << 9) + (t << 1), w + 1);
-    SubTw::run<4>(tw + (root << 10) + (t << 2), w + 3);
-    SubTw::run<8>(tw + (root << 11) + (t << 3), w + 7);
+    if (INC < 4) SubTw::run<1>(tw + (root << 8) + t, w);
+    if (INC < 3) SubTw::run<2>(tw + (root << 9) + (t << 1), w + 1);
+    if (INC < 2) SubTw::run<4>(tw + (root << 10) + (t << 2), w + 3);
+    if (INC < 1) SubTw::run<8>(tw + (root << 11) + (t << 3), w + 7);
+    if (INC == 4) w[0] = tw[((root << 8) + t) >> 1];  // the parent of leaf t (witness_inc.hpp)
 #pragma unroll
     for (int e = 0; e < 16; e++) v[e] = s[pb3 + e];
-    reg_fwd_stages<4, true>(v, mod, fmask >> 8, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
+    reg_fwd_stages<4, true, 4 - INC>(v, mod, fmask >> 8, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
     const int r0 = wave * 1024;                              // the wave's 64 groups: 1024 consecutive points
     const int p0 = r0 + (r0 >> 4) + 2 * lane + (lane >> 3);  // px(r0 + 2 lane)
     if (MODE == 0) {  // forward only: the wave streams its own range out
@@ -1065,7 +1103,23 @@ __device__ __forceinline__ void w12_block(double (&v)[16], double *s, const doub
         for (int e = 0; e < 16; e++) v[e] = mulmod(v[e], s[pb3 + e], mod);
       } else {
         stage(tab);
-        if (MODE == 2) {
+        if (INC > 0) {  // 16 >> INC leaves of 2^INC words: products modulo x^(2^INC) - eta (witness_inc.hpp)
+          constexpr int G = 1 << INC;
+#pragma unroll
+          for (int q = 0; q < 16 / G; q++) {
+            double xq[G], tq[G];
+#pragma unroll
+            for (int e = 0; e < G; e++) {
+              xq[e] = reduce(v[q * G + e], mod);
+              tq[e] = MODE == 2 ? s[pb3 + q * G + e] : reduce(s[pb3 + q * G + e], mod);
+            }
+            const double wq = INC == 4 ? w[0] : w[(1 << (3 - (INC & 3))) - 1 + (q >> 1)];
+            const bool neg = INC == 4 ? (t & 1) : (q & 1);
+            inc_polymul<INC, MODE != 2>(xq, tq, neg ? -wq : wq, mod);
+#pragma unroll
+            for (int e = 0; e < G; e++) v[q * G + e] = xq[e];
+          }
+        } else if (MODE == 2) {
           if (pw_reduce) {  // primes above ~2^46 only (a guarded pass, not a select)
 #pragma unroll
             for (int e = 0; e < 16; e++) v[e] = reduce(v[e], mod);
@@ -1078,11 +1132,11 @@ __device__ __forceinline__ void w12_block(double (&v)[16], double *s, const doub
         }
       }
     }
-    SubTw::run<8>(itw + ((size_t)root << 11) + (t << 3), w);
-    SubTw::run<4>(itw + ((size_t)root << 10) + (t << 2), w + 8);
-    SubTw::run<2>(itw + ((size_t)root << 9) + (t << 1), w + 12);
-    SubTw::run<1>(itw + ((size_t)root << 8) + t, w + 14);
-    reg_inv_stages<4, true>(v, mod, imask, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
+    if (INC < 1) SubTw::run<8>(itw + ((size_t)root << 11) + (t << 3), w);
+    if (INC < 2) SubTw::run<4>(itw + ((size_t)root << 10) + (t << 2), w + 8);
+    if (INC < 3) SubTw::run<2>(itw + ((size_t)root << 9) + (t << 1), w + 12);
+    if (INC < 4) SubTw::run<1>(itw + ((size_t)root << 8) + t, w + 14);
+    reg_inv_stages<4, true, 4, INC>(v, mod, imask, [&](int k, int i) { return w[16 - (16 >> k) + i]; });
 #pragma unroll
     for (int e = 0; e < 16; e++) s[pb3 + e] = v[e];
   }
@@ -1113,7 +1167,7 @@ __device__ __forceinline__ void w12_block(double (&v)[16], double *s, const doub
 // (16 waves, four per SIMD) per CU instead of two of 2^13 at two waves per SIMD.  The transform one level up gets one more
 // cross stage (still one pass over the workspace).  Stage arithmetic, reduction points and table products per coefficient
 // are those of the 2^13 kernel: the stored values are identical.
-template <int MODE>
+template <int MODE, int INC = 0>
 __global__ void __launch_bounds__(256, 4)
 sub_ntt_w12_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned tab_period, unsigned blocks_per_col, size_t col0,
                    unsigned S_, unsigned slots_per_limb, ColPlans plans, unsigned long long nblocks) {
@@ -1134,7 +1188,7 @@ sub_ntt_w12_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned ta
     const double *tab = (MODE == 2 || MODE == 4) ? static_cast<const double *>(tabs.t[limb]) + (size_t)(blk % tab_period) * N
                         : MODE == 3              ? static_cast<const double *>(tabs.t[0]) + blk * (size_t)N
                                                  : nullptr;
-    w12_block<MODE>(v, s, P.tw, P.itw, P.mod, root, P.fmask[logn] >> log_n1, P.imask[logn], (P.pwmask >> logn) & 1u, tab, xb,
+    w12_block<MODE, INC>(v, s, P.tw, P.itw, P.mod, root, P.fmask[logn] >> log_n1, P.imask[logn], (P.pwmask >> logn) & 1u, tab, xb,
                     MODE == 4 ? static_cast<const double *>(tabs.w1) + blk * (size_t)N : nullptr,
                     MODE == 4 ? static_cast<const double *>(tabs.w3) + blk * (size_t)N : nullptr);
     if (MODE == 0) continue;

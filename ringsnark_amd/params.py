@@ -174,6 +174,10 @@ def preset(name: str) -> RingParams:
     if name == "C4R":  # configs[3]'s shape on recipe primes: q_i = 1 mod 2*N_enc = 2^15 only (2-adicity 15..), block-convolution witness map beyond 2^14 constraints
         return make_params(16384, [48, 48, 48, 49, 49, 49], 16384, BFV_DEFAULT_BITS[16384][:-1], name="C4R",
                            notes="C4 with the ring primes default_double_batching_modulus-style recipe yields (seal_util.hpp:20-32)")
+    if name == "toyC3R":  # C3R's moduli (the recipe primes of the headline: 2-adicity 15, 15, 14, 14) on a 32-slot ring: large-m witness maps
+        c3r = preset("C3R")
+        return RingParams(32, list(c3r.q), 64, list(c3r.Q[:3]), name="toyC3R",
+                          notes="default_double_batching_modulus(8192, 8192) primes on a small ring").validate()
     if name == "toy":  # CPU-test scale
         return make_params(32, [30, 30], 64, [40, 40, 41], ring_factor=1 << 12, name="toy")
     if name == "toy44x":  # the same with primes = 1 mod 2^23: full-length transforms to 2^22 constraints

@@ -140,10 +140,11 @@ from tests.proof_check import groth16_check as post_run_check  # noqa: E402
 
 
 PRIME_CLASS = {
-    "C3": "ring primes q_i = 1 mod 2^20 (a custom coeff_modulus, valid in the reference: the fields have roots of unity of order 2M "
-          "and the witness map runs full-length transforms)",
-    "C3R": "ring primes exactly as the reference's recipe yields them (default_double_batching_modulus, seal/seal_util.hpp:20-32: "
-           "q_i = 1 mod 2N = 2^14 only), i.e. what a SEAL-produced headline key has; the witness map runs two-dimensional block convolutions",
+    "C3": "ring primes exactly as the reference's recipe yields them (default_double_batching_modulus(8192, 8192), seal/seal_util.hpp:20-32, "
+          "examples/example_SEAL.cpp:15-22: q_i = 1 mod 2N = 2^14 only, 2-adicity 15, 15, 14, 14), i.e. what a SEAL-produced headline key has "
+          "(SURVEY.md 8(d) C3); the witness map's transforms longer than 2^14 / 2^15 are INCOMPLETE (csrc/witness_inc.hpp)",
+    "C3F": "'friendly' ring primes q_i = 1 mod 2^20 (a custom coeff_modulus, valid in the reference: the fields have roots of unity of order 2M "
+           "and every transform of the witness map is complete) -- the preset rounds 1-5 quoted the headline on; an extra leg since round 6",
 }
 
 
@@ -345,7 +346,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-ntt", action="store_true", help="skip the standalone NTT bandwidth leg (profiling passes)")
-    ap.add_argument("--no-recipe-primes", action="store_true", help="skip the second leg on preset C3R (the reference recipe's ring primes)")
+    ap.add_argument("--no-friendly-primes", "--no-recipe-primes", dest="no_friendly_primes", action="store_true",
+                    help="skip the second leg on preset C3F (ring primes = 1 mod 2^20: complete transforms)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short Rinocchio legs at the shapes of BASELINE configs[3] / configs[4]")
     args = ap.parse_args()
 
@@ -560,20 +562,20 @@ def main():
         ok, info = post_run_check(dev, prm, cs, dcs, asg, pk1, proof[0], m, window1 or pk1["s_pows"].shape[0], n_slabs=3)
         check = dict(info, ok=ok)
 
-    # ---- the same statement on the ring primes the reference's own recipe yields (preset C3R), one GPU
-    recipe = None
-    if world == 1 and prm.name == "C3" and not args.no_recipe_primes:
+    # ---- the same statement on "friendly" ring primes (preset C3F: = 1 mod 2^20, complete transforms; the headline of rounds 1-5), one GPU
+    friendly = None
+    if world == 1 and prm.name == "C3" and not args.no_friendly_primes:
         del proof[0]
         proof.append(None)
         pk.clear()
         pk1.clear()
         del asg, dcs, dev, backend
         torch.cuda.empty_cache()
-        recipe = single_gpu_leg("C3R", m, min(14, W.bit_length() - 1), max(1, min(args.steps, 5)), 1, not args.no_check)
+        friendly = single_gpu_leg("C3F", m, min(14, W.bit_length() - 1), max(1, min(args.steps, 5)), 1, not args.no_check)
 
     # ---- the other BASELINE configurations' shapes, a few seconds each (extra keys, not the metric)
     other = None
-    if world == 1 and prm.name == "C3" and recipe is not None and not args.no_other_configs:
+    if world == 1 and prm.name == "C3" and friendly is not None and not args.no_other_configs:
         other = {"configs[1] (ringGroth16, 2^10 constraints, N=4096 L=2, N_enc=8192 K=4; whole 3 GiB key)": single_gpu_leg("C2", 1 << 10, 11, 20, 3, not args.no_check),
                  "configs[3] shape (Rinocchio, N=16384, 6 ring primes, K=8; 2^12 constraints, key window 2^9)": rinocchio_leg("C4", logm=12, logw=9, check=not args.no_check),
                  "configs[4] (Rinocchio, the reference's logistic-regression circuit and parameters)": rinocchio_leg("C5", steps=10, logreg=True, check=not args.no_check)}
@@ -626,8 +628,8 @@ def main():
             out["ntt_roofline"] = ntt_roofline
         if check is not None:
             out["check"] = check
-        if recipe is not None:
-            out["recipe_primes"] = recipe
+        if friendly is not None:
+            out["friendly_primes"] = friendly
         if other is not None:
             out["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
@@ -635,7 +637,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    bad = (check is not None and not check["ok"]) or (recipe is not None and "check" in recipe and not recipe["check"]["ok"])
+    bad = (check is not None and not check["ok"]) or (friendly is not None and "check" in friendly and not friendly["check"]["ok"])
     for leg in (other or {}).values():
         bad = bad or (isinstance(leg.get("check"), dict) and not leg["check"]["ok"])
     if bad:

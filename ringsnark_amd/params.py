@@ -8,7 +8,7 @@ The reference builds its parameters from SEAL helpers:
                                                             (seal/seal_ring.hpp:266-306)
 SEAL is not available here, so the prime search is restated (SEAL util::get_primes /
 CoeffModulus::Create).  It reproduces the BFVDefault(4096) primes written down in the
-reference's docs/qrp.sage:3-5 (0xffffee001, 0xffffc4001, 0x1ffffe0001) -- tests/test_params.py.
+reference's docs/qrp.sage:3-5 (0xffffee001, 0xffffc4001, 0x1ffffe0001) -- tests/test_oracle.py:12-15.
 
 Constraints enforced here:
   q_i = 1 (mod 2*N_enc)  (batching for the encoding contexts, seal_ring.hpp:297)
@@ -118,9 +118,11 @@ class RingParams:
         return self.L * self.ct_words
 
     def max_constraints_fast(self) -> int:
-        """Largest m the quasi-linear witness map supports: needs a cyclic NTT of length
-        2*next_pow2(m) in every F_{q_i}."""
-        return 1 << (min(two_adicity(p) for p in self.q) - 1)
+        """Largest m whose witness map runs on full-length transforms: complete ones need a cyclic NTT of length
+        2*next_pow2(m) in every F_{q_i}; incomplete ones (csrc/witness_inc.hpp) may stop up to four stages short
+        (multi-pass sizes, m > 2^14); beyond that the block convolutions take over (to 2^20)."""
+        v = min(two_adicity(p) for p in self.q)
+        return min(1 << 22, 1 << (v - 1 + (4 if v >= 14 else 0)))
 
     def validate(self):
         for p in self.q + self.Q:
@@ -148,13 +150,24 @@ def preset(name: str) -> RingParams:
     if name == "C2":  # ringGroth16 m=2^10, N=4096 L=2, N_enc=8192 K=4
         return make_params(4096, BFV_DEFAULT_BITS[4096][:-1], 8192, BFV_DEFAULT_BITS[8192][:-1], name="C2",
                            notes="default_double_batching_modulus(4096, 8192) + BFVDefault(8192) data primes")
-    if name == "C3":  # headline: N=8192 L=4, N_enc=8192 K=4; ring primes = 1 mod 2^20
+    if name in ("C3", "C3R"):  # the headline: N=8192 L=4, N_enc=8192 K=4, ring primes by the reference's recipe
+        # default_double_batching_modulus(8192, 8192) = BFVDefault(8192) at first data level: q_i = 1 mod 2*N_enc = 2^14 only
+        # (2-adicity 15, 15, 14, 14) -- what every shipped ringSNARK binary and a SEAL-produced key have (seal_util.hpp:20-32,
+        # examples/example_SEAL.cpp:15-22).  The witness map's long transforms are incomplete on them (csrc/witness_inc.hpp).
+        # "C3R" (rounds 3-5, when the headline ran on the 2^20-adic primes of C3F) is the same preset.
+        return make_params(8192, BFV_DEFAULT_BITS[8192][:-1], 8192, BFV_DEFAULT_BITS[8192][:-1], name="C3",
+                           notes="default_double_batching_modulus(8192, 8192): what a SEAL-produced headline key has")
+    if name == "C3F":  # the headline shape on "friendly" ring primes = 1 mod 2^20 (a custom coeff_modulus, valid in the reference): complete transforms
         return make_params(8192, BFV_DEFAULT_BITS[8192][:-1], 8192, BFV_DEFAULT_BITS[8192][:-1],
-                           ring_factor=1 << 20, name="C3",
-                           notes="ring primes = 1 mod 2^20 so the quasi-linear witness map reaches m = 2^19/2")
-    if name == "C4":  # Rinocchio N=16384 L=6 (custom 6-prime chain), N_enc=16384 K=8
+                           ring_factor=1 << 20, name="C3F",
+                           notes="ring primes = 1 mod 2^20: every transform of the witness map up to 2^19 constraints is complete")
+    if name in ("C4", "C4R"):  # configs[3]: Rinocchio N=16384 L=6 (a 6-prime chain of BFVDefault(16384)'s bit sizes), N_enc=16384 K=8; recipe primes
+        # q_i = 1 mod 2*N_enc = 2^15 only (2-adicity 20, 17, 15, 15, 16, 15), as default_double_batching_modulus yields them
+        return make_params(16384, [48, 48, 48, 49, 49, 49], 16384, BFV_DEFAULT_BITS[16384][:-1], name="C4",
+                           notes="configs[3]'s shape with ring primes as the default_double_batching_modulus recipe yields them (seal_util.hpp:20-32)")
+    if name == "C4F":  # configs[3]'s shape on ring primes = 1 mod 2^20: complete transforms to 2^19 constraints
         return make_params(16384, [48, 48, 48, 49, 49, 49], 16384, BFV_DEFAULT_BITS[16384][:-1],
-                           ring_factor=1 << 20, name="C4")
+                           ring_factor=1 << 20, name="C4F")
     if name == "C5":  # logistic regression as in the reference file: N=2048 L=1, N_enc=16384 K=8
         return make_params(2048, BFV_DEFAULT_BITS[2048], 16384, BFV_DEFAULT_BITS[16384][:-1], name="C5")
     if name == "C5s":  # C5's shape with a 49-bit ring prime (runs on the FP64 arithmetic; C5 itself runs on the integer one)
@@ -168,15 +181,9 @@ def preset(name: str) -> RingParams:
         return make_params(16384, [59], 16384, [60, 60], name="micro60")
     if name == "toyR":  # the reference's recipe verbatim: ring primes only = 1 mod 2*N_enc (seal_util.hpp:20-32), no extra 2-adicity
         return make_params(32, [30, 30], 64, [40, 40, 41], name="toyR")
-    if name == "C3R":  # the headline shape with recipe primes (q_i = 1 mod 2*N_enc = 2^14 only): the witness map runs on block convolutions
-        return make_params(8192, BFV_DEFAULT_BITS[8192][:-1], 8192, BFV_DEFAULT_BITS[8192][:-1], name="C3R",
-                           notes="default_double_batching_modulus(8192, 8192): what a SEAL-produced headline key has")
-    if name == "C4R":  # configs[3]'s shape on recipe primes: q_i = 1 mod 2*N_enc = 2^15 only (2-adicity 15..), block-convolution witness map beyond 2^14 constraints
-        return make_params(16384, [48, 48, 48, 49, 49, 49], 16384, BFV_DEFAULT_BITS[16384][:-1], name="C4R",
-                           notes="C4 with the ring primes default_double_batching_modulus-style recipe yields (seal_util.hpp:20-32)")
-    if name == "toyC3R":  # C3R's moduli (the recipe primes of the headline: 2-adicity 15, 15, 14, 14) on a 32-slot ring: large-m witness maps
-        c3r = preset("C3R")
-        return RingParams(32, list(c3r.q), 64, list(c3r.Q[:3]), name="toyC3R",
+    if name == "toyC3":  # C3's moduli (the recipe primes of the headline: 2-adicity 15, 15, 14, 14) on a 32-slot ring: large-m witness maps
+        c3 = preset("C3")
+        return RingParams(32, list(c3.q), 64, list(c3.Q[:3]), name="toyC3",
                           notes="default_double_batching_modulus(8192, 8192) primes on a small ring").validate()
     if name == "toy":  # CPU-test scale
         return make_params(32, [30, 30], 64, [40, 40, 41], ring_factor=1 << 12, name="toy")

@@ -35,13 +35,18 @@ def test_ctx_create_fails_loudly_without_gpu():
 
 
 def test_presets_are_consistent():
-    for name in ("C1", "C2", "C3", "C4", "C5", "C5s", "toy", "toy49"):
+    for name in ("C1", "C2", "C3", "C3F", "C4", "C4F", "C5", "C5s", "toy", "toy49", "toyC3"):
         prm = P.preset(name).validate()
-        if name != "C5":  # BFVDefault(2048) is one 54-bit prime: needs the (unbuilt) integer path
+        if name != "C5":  # BFVDefault(2048) is one 54-bit prime: the integer (Montgomery) arithmetic
             assert all(p < (1 << 50) for p in prm.q + prm.Q)
     c3 = P.preset("C3")
     assert (c3.N, c3.L, c3.N_enc, c3.K) == (8192, 4, 8192, 4)
-    assert c3.max_constraints_fast() >= 1 << 18
+    # q_i = default_double_batching_modulus(8192, 8192) = CoeffModulus::Create(8192, {43, 43, 44, 44}) -- the
+    # largest primes of those sizes = 1 mod 2^14, the later-found first (seal_util.hpp:20-32); Q_j the next ones
+    assert c3.q == P.coeff_modulus_create(16384, [43, 43, 44, 44]) == [0x7FFFFFC8001, 0x7FFFFFD8001, 0xFFFFFF6C001, 0xFFFFFFFC001]
+    assert [P.two_adicity(q) for q in c3.q] == [15, 15, 14, 14] and not set(c3.q) & set(c3.Q)
+    assert P.preset("C3R").q == c3.q and P.preset("C3R").name == "C3"  # the name rounds 3-5 used for this preset
+    assert c3.max_constraints_fast() >= 1 << 16 and P.preset("C3F").max_constraints_fast() >= 1 << 18
     assert P.preset("C2").q == P.coeff_modulus_create(16384, [36, 36])
 
 

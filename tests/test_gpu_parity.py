@@ -1056,9 +1056,10 @@ def test_two_dimensional_block_convolutions_equal_the_other_paths(m, zk):
     cs = R.chain_r1cs(m, prm.q)
     keys = ("A_io", "B_io", "C_io", "A_mid", "B_mid", "C_mid", "H")
     runs = {}
-    for label, force, bc2 in (("full-length", 0, 1), ("two-dimensional", 14, 1), ("pairwise", 14, 0)):
+    for label, force, bc2, inc in (("full-length", 0, 1, 1), ("two-dimensional", 14, 1, 0), ("pairwise", 14, 0, 0), ("incomplete", 14, 1, 1)):
         _set_tuning(b"witness_force_bc", force)
         _set_tuning(b"witness_bc2", bc2)
+        _set_tuning(b"witness_inc", inc)  # 1 (the default since round 6): such primes run incomplete transforms, not block convolutions
         try:
             dev = Device(prm)  # fresh context: plans are cached per context
             asg = dev.ring_empty(m + 2)
@@ -1071,11 +1072,13 @@ def test_two_dimensional_block_convolutions_equal_the_other_paths(m, zk):
             dev.set_profiling(False)
             assert ("bc2_yfwd_kernel" in names) == (label == "two-dimensional"), (label, names)
             assert ("bc_mac_kernel" in names) == (label == "pairwise"), (label, names)
+            assert any(n.startswith("sub_ntt_w") and not n.endswith(", 0>") for n in names) == (label == "incomplete"), (label, names)
             del dev, asg
         finally:
             _set_tuning(b"witness_force_bc", 0)
             _set_tuning(b"witness_bc2", 1)
-    for label in ("two-dimensional", "pairwise"):
+            _set_tuning(b"witness_inc", 1)
+    for label in ("two-dimensional", "pairwise", "incomplete"):
         for k in keys:
             assert (runs[label][k] == runs["full-length"][k]).all(), (label, k)
 

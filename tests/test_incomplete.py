@@ -6,7 +6,7 @@ every transform stopped at the prime's 2-adicity; the pointwise step multiplies 
 
   * against the CPU oracle's literal O(m^2) map at sizes it can follow, small LDS tiles forcing the multi-pass path: one to
     four stages short, both arithmetics, primes whose 2-adicity differs per limb (generic kernel sub_ntt_kernel);
-  * at the headline's sizes and ON THE HEADLINE'S PRIMES (preset toyC3R: 2-adicity 15, 15, 14, 14 on a 32-slot ring) through the
+  * at the headline's sizes and ON THE HEADLINE'S PRIMES (preset toyC3: 2-adicity 15, 15, 14, 14 on a 32-slot ring) through the
     tuned kernels (sub_ntt_wide_kernel<., INC>, sub_ntt_w12_kernel<., INC>): every column through the identities that define
     the map's outputs (oracle/rs_identities.c), and bit-equal to the two-dimensional block convolutions it replaces and --
     forced on well-endowed primes -- to complete transforms."""
@@ -143,7 +143,7 @@ def _run_large(prm, m, zk, want=KEYS, **knobs):
 def test_headline_primes_through_the_tuned_kernels(m, zk):
     """The ring primes of the headline (2-adicity 15, 15, 14, 14: per-limb launches of the tuned sub-transform kernels), M = 2^15
     .. 2^17 (four stages short at most: 2^18 constraints on these primes take the block convolutions): every column through the identities, and every vector bit-equal to the two-dimensional block convolutions."""
-    prm = P.preset("toyC3R")
+    prm = P.preset("toyC3")
     dev, cs, asg, ds, w, names = _run_large(prm, m, zk)
     logM = (m - 1).bit_length()
     assert not any(n.startswith("bc") for n in names), names
@@ -180,7 +180,7 @@ def test_incomplete_transforms_equal_complete_ones(m, force, sub_log):
 
 
 def test_generic_and_tuned_sub_transform_kernels_agree_on_incomplete_transforms():
-    prm = P.preset("toyC3R")
+    prm = P.preset("toyC3")
     runs = {}
     for ct in (0, 2):
         dev, cs, asg, ds, w, names = _run_large(prm, 40000, True, witness_sub_ct=ct, witness_sub_log=13 if ct == 0 else 12)
@@ -189,3 +189,17 @@ def test_generic_and_tuned_sub_transform_kernels_agree_on_incomplete_transforms(
         del dev, asg, w
     for k in KEYS:
         assert (runs[0][k] == runs[2][k]).all(), k
+
+
+@pytest.mark.parametrize("m", [1048576, 2097152])
+def test_beyond_the_two_adicity_at_2_20_and_2_21(m):
+    """toy44's primes are = 1 mod 2^20: 2^20 constraints (transforms of 2^21 words, one stage short) took the two-level block
+    convolutions until round 6 and 2^21 constraints were refused; both now run the multi-pass path (every column through the identities)."""
+    prm = P.preset("toy44")
+    want = ("A_mid", "B_mid", "H")
+    dev, cs, asg, ds, w, names = _run_large(prm, m, False, want=want)
+    assert not any(n.startswith("bc") for n in names), names
+    inc = (m - 1).bit_length() + 1 - 20
+    assert any(n.endswith(", %d>" % inc) for n in names if n.startswith("sub_ntt_w")), names
+    err, info = proof_check.check_all_columns(prm, cs, asg, {k: w[k] for k in want}, tuple(ds), seed=5, Z=w["Z"])
+    assert err is None and info["columns"] == prm.L * prm.N, err

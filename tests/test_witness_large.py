@@ -28,14 +28,17 @@ def _set_tuning(key, value):
     _lib.check(_lib.load().rs_set_tuning(key, value))
 
 
-def _run(prm, m, zk, force, int_arith=False, want=KEYS):
-    """Fresh context (plans are cached per context and read the knobs when they are built)."""
+def _run(prm, m, zk, force, int_arith=False, want=KEYS, inc=None):
+    """Fresh context (plans are cached per context and read the knobs when they are built).  force: pretend the ring primes
+    have only this 2-adicity AND take the block convolutions (witness_inc = 0) -- since round 6 such primes run incomplete
+    transforms by default (tests/test_incomplete.py); these tests keep the block-convolution kernels exercised."""
     import torch
 
     from ringsnark_amd.device import Device
     octx = H.oracle_ctx(prm)
     cs = R.chain_r1cs(m, prm.q)
     _set_tuning(b"witness_force_bc", force)
+    _set_tuning(b"witness_inc", (0 if force else 1) if inc is None else inc)
     if int_arith:
         _set_tuning(b"force_int_arith", 1)
     try:
@@ -55,6 +58,7 @@ def _run(prm, m, zk, force, int_arith=False, want=KEYS):
         dev.set_profiling(False)
     finally:
         _set_tuning(b"witness_force_bc", 0)
+        _set_tuning(b"witness_inc", 1)
     return dev, cs, asg, ds, w, names
 
 
@@ -84,7 +88,7 @@ def test_two_level_transform_across_blocks_at_2_19_and_2_20(m, force):
     """Y = 128 and 256 blocks (bc2_yfwd_big_kernel<., 2 | 3>).  2^20 constraints is the limit the plan accepts
     (witness.hip build_plan); toy44's primes (= 1 mod 2^20) have no 2^21-th root, so that size takes the block path unforced."""
     prm = P.preset("toy44")
-    dev, cs, asg, ds, w, names = _run(prm, m, False, force, want=("A_mid", "B_mid", "H"))
+    dev, cs, asg, ds, w, names = _run(prm, m, False, force, want=("A_mid", "B_mid", "H"), inc=0)
     assert "bc2_yfwd_big_kernel" in names and "bc2_yinv_a_kernel" in names and "bc2_yinv_b_kernel" in names, names
     err, info = proof_check.check_all_columns(prm, cs, asg, {k: w[k] for k in ("A_mid", "B_mid", "H")}, tuple(ds), seed=3, Z=w["Z"])
     assert err is None and info["columns"] == prm.L * prm.N, err
@@ -282,9 +286,9 @@ def test_full_length_transforms_at_2_21_and_2_22(m):
 
 def test_block_convolutions_refuse_more_than_2_20_constraints():
     from ringsnark_amd import _lib
-    prm = P.preset("toy44")  # = 1 mod 2^20 only: 2^21 constraints would need the block path
+    prm = P.preset("toy44")  # = 1 mod 2^20 only: with incomplete transforms off, 2^21 constraints would need the block path
     with pytest.raises(_lib.RsError) as ei:
-        _run(prm, 1500000, False, 0, want=("A_mid",))
+        _run(prm, 1500000, False, 0, want=("A_mid",), inc=0)
     assert ei.value.code == _lib.RS_ERR_UNSUPPORTED and "2^20" in str(ei.value)
 
 

@@ -39,7 +39,7 @@ def run(tag, dev, prove, m):
 
 
 if which in ("groth16", "both"):
-    prm = P.preset(os.environ.get("KNOB_AB_PRESET", "C3"))  # C3R: the recipe primes (two-dimensional block convolutions)
+    prm = P.preset(os.environ.get("KNOB_AB_PRESET", "C3"))  # C3 = the recipe primes (the headline); C3F: ring primes = 1 mod 2^20
     dev = Device(prm)
     m, W = 1 << 16, 1 << 13
     dcs = dev.r1cs(R.chain_r1cs(m, prm.q))

@@ -213,8 +213,9 @@ def single_gpu_leg(preset, m, logw, steps, warmup, check):
 def rinocchio_leg(preset, steps=3, logm=None, logw=None, logreg=False, check=True):
     """Rinocchio prover (rinocchio.tcc:75-190) on another BASELINE configuration's shape, one GPU: configs[3]'s ring shape
     (preset C4: N = 16384, 6 ring primes, N_enc = 16384, K = 8) on a chain circuit of 2^logm constraints with a tiled key
-    -- the configuration's 2^18 constraints need a 9 TiB key -- or configs[4] exactly as the reference's
-    benchmarks/bench_logistic_regression_inference.cpp has it (preset C5, 1031 constraints, whole key).  ZK blinding on."""
+    -- the configuration's 2^18 constraints need a 9 TiB key -- or configs[4]: the circuit of the reference's
+    benchmarks/bench_logistic_regression_inference.cpp (1031 constraints, whole key) on its own parameters (preset C5) or on
+    the ring BASELINE.json names for it (preset C3: N = 8192, 4 primes).  ZK blinding on."""
     from ringsnark_amd.device import Device
     prm = P.preset(preset)
     dev = Device(prm, 0)
@@ -476,6 +477,43 @@ def main():
     setup["note"] = ("not in the timed region: context creation, R1CS upload, and what the first proof of a (context, m) pays once -- witness-map "
                      "plan and tables built on the host, the circuit's io-vector cache, workspace allocations" + (" (a warm-up step here)" if args.warmup else ""))
 
+    # ---- N > 1: one more (untimed) step with the collectives bracketed by HIP events on the streams they run on: what each
+    # transport phase moved and how long it took on this rank, and the device time of the rank's own kernels
+    transport_phases = None
+    if world > 1:
+        RD.STATS.reset(True)
+        dev.set_profiling(True)
+        dev.profile_read()
+        fence()
+        t_s = time.perf_counter()
+        step()
+        fence()
+        step_ms = (time.perf_counter() - t_s) * 1e3
+        transport_phases = RD.STATS.read()
+        RD.STATS.reset(False)
+        kstats = dev.profile_read()
+        dev.set_profiling(False)
+        transport_phases["rank0_step_ms"] = round(step_ms, 3)
+        transport_phases["rank0_kernel_ms"] = round(sum(k["total_ms"] for k in kstats), 3)
+        transport_phases["rank0_top_kernels"] = [{"name": k["name"], "ms": round(k["total_ms"], 2)} for k in kstats[:5]]
+        transport_phases["note"] = ("rank 0, one untimed step after the timed ones: bytes this rank sent + received per collective and the time between "
+                                    "HIP events around it on the stream it ran on (the slot -> term exchange runs on a side stream under the next "
+                                    "sub-range's witness map, so its ms overlap the kernels'); GB_per_s = bytes / ms")
+
+    # ---- N > 1: a small statement over the SAME process group and plan shape against the one-process CPU oracle, bit for bit
+    # (tests/dist_check.py): no multi-GPU run has been measured by any round, so a bench line from one must say that the
+    # transport it timed also carries a correct proof (the headline-size proof itself is checked at N = 1)
+    transport_check = None
+    if world > 1 and not args.no_check:
+        from tests.dist_check import sharded_proof_matches_oracle
+        t_s = time.perf_counter()
+        tc_preset, tc_m = ("toyC3" if prm.L == 4 else "toy"), 12
+        ok_t = sharded_proof_matches_oracle(rank, world, local_rank, tc_preset, tc_m, None, "groth16", False)
+        fence()
+        transport_check = {"ok": ok_t, "what": "groth16_prove_sharded on preset %s (the headline's ring primes on a 32-slot ring), %d constraints, the same "
+                                               "ranks / plan shape / witness split / relays as the timed proof, equal to the one-process oracle proof bit for bit"
+                                               % (tc_preset, tc_m), "seconds": round(time.perf_counter() - t_s, 1)}
+
     # ---- per-kernel device time of one more (untimed) step: HIP events on the launch stream inside the library
     roofline = mac_roofline = timings = kernels = None
     if world == 1:
@@ -578,7 +616,8 @@ def main():
     if world == 1 and prm.name == "C3" and friendly is not None and not args.no_other_configs:
         other = {"configs[1] (ringGroth16, 2^10 constraints, N=4096 L=2, N_enc=8192 K=4; whole 3 GiB key)": single_gpu_leg("C2", 1 << 10, 11, 20, 3, not args.no_check),
                  "configs[3] shape (Rinocchio, N=16384, 6 ring primes, K=8; 2^12 constraints, key window 2^9)": rinocchio_leg("C4", logm=12, logw=9, check=not args.no_check),
-                 "configs[4] (Rinocchio, the reference's logistic-regression circuit and parameters)": rinocchio_leg("C5", steps=10, logreg=True, check=not args.no_check)}
+                 "configs[4] (Rinocchio, the reference's logistic-regression circuit and parameters: N=2048, one 54-bit prime, N_enc=16384 K=8)": rinocchio_leg("C5", steps=10, logreg=True, check=not args.no_check),
+                 "configs[4] as BASELINE.json words it (the same circuit on N=8192, 4 primes: the headline's parameters)": rinocchio_leg("C3", steps=10, logreg=True, check=not args.no_check)}
 
     if rank == 0:
         key_gib = (3 * m + 2) * prm.enc_words * 8 / 2**30
@@ -607,7 +646,8 @@ def main():
                     (", slot->term exchange relayed through the other groups" if RD.RELAY else ", slot->term exchange on the group's direct links")))
             out["transport"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
                                 "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
-                                "devices_visible": torch.cuda.device_count(), "rehearsal_all_ranks_on_one_gpu": rehearsal}
+                                "devices_visible": torch.cuda.device_count(), "rehearsal_all_ranks_on_one_gpu": rehearsal,
+                                "phases": transport_phases, "check": transport_check}
         out["setup"] = setup
         if MEASURED:
             out["measured_peaks"] = {"hbm_copy_gbs": round(MEASURED["hbm_copy_gbs"], 1), "hbm_read_gbs": round(MEASURED["hbm_read_gbs"], 1),
@@ -635,11 +675,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prm, m, n_aux)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
     bad = (check is not None and not check["ok"]) or (friendly is not None and "check" in friendly and not friendly["check"]["ok"])
     for leg in (other or {}).values():
         bad = bad or (isinstance(leg.get("check"), dict) and not leg["check"]["ok"])
+    if world > 1 and transport_check is not None:  # rank 0's verdict decides for every rank
+        flag = torch.tensor([0 if (rank != 0 or transport_check["ok"]) else 1], dtype=torch.int64, device=dev.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        bad = bad or bool(flag.item())
+    if world > 1:
+        RD.release_buffers()  # the pooled receive / relay buffers of the re-shard live until released (dist.py)
+        dist.destroy_process_group()
     if bad:
         sys.exit(3)
 

@@ -2,8 +2,10 @@
 
 The same CPU restatement as oracle/oracle.py compiled with the arithmetic Microsoft SEAL publishes for this path
 (Harvey lazy NTT with Shoup quotients and Barrett dyadic products: rs_fastcpu.c; Barrett instead of a 128-bit `%` in
-every other modular product: rs_oracle.c -DRSO_FAST_MULMOD).  Never used as a checker; tests/test_oracle.py asserts
-that its results equal the checker's bit for bit."""
+every other modular product: rs_oracle.c -DRSO_FAST_MULMOD).  tests/test_oracle.py asserts that its results equal the
+`%`-based checker's bit for bit.  One use as a checker since round 6: the COMPLETE inner-product check of a headline proof
+(all 96 slabs, tests/proof_check.py groth16_check(all_slabs=True)) runs inner_product_limb here -- the `%` build would take
+eight minutes on 128 threads -- with slabs of the same proof recomputed by the `%` checker beside it."""
 import ctypes as C
 import os
 import subprocess
@@ -34,6 +36,8 @@ def lib():
         L.rsf_ntt_inv.argtypes = [C.c_void_p, C.c_int, C.c_int, O.u64p]
         L.rsf_inner_product_mt.restype = C.c_size_t
         L.rsf_inner_product_mt.argtypes = [C.c_void_p, O.u64p, C.c_size_t, O.u64p, O.u8p, C.c_size_t, O.u64p, C.c_int]
+        L.rsf_inner_product_limb.restype = None
+        L.rsf_inner_product_limb.argtypes = [C.c_void_p, C.c_int, O.u64p, C.c_size_t, C.c_size_t, C.c_size_t, O.u64p, C.c_size_t, O.u64p, C.c_int]
         L.rso_witness_map.argtypes = [C.c_uint64, C.c_size_t, C.POINTER(O.R1CS), C.c_int] + [O.u64p] * 12
         L.rso_witness_map_mt.argtypes = [C.c_uint64, C.c_size_t, C.POINTER(O.R1CS), C.c_int] + [O.u64p] * 12 + [C.c_int]
         L.rso_max_threads.restype = C.c_int
@@ -71,6 +75,18 @@ class FastCtx:
             kp = kinds.ctypes.data_as(O.u8p)
         used = lib().rsf_inner_product_mt(self.h, O.p64(encs), window, O.p64(rings), kp, T, O.p64(out), threads)
         return out, int(used)
+
+    def inner_product_limb(self, limb, key, rows, acc, t0=0, window=None, threads=0):
+        """acc [2][K][N_enc] += ring limb `limb` of <key, rows>: key [W][2][K][N_enc] (the limb's slice of a key vector, W stored
+        elements; term t0 + t reads element (t0 + t) mod window), rows [T][N].  All 2 K slabs of the limb in one pass, the
+        plaintext of a term transformed once (rs_fastcpu.c rsf_inner_product_limb)."""
+        assert key.dtype == np.uint64 and key.flags.c_contiguous and key.shape[1:] == (2, self.K, self.N_enc)
+        assert acc.dtype == np.uint64 and acc.flags.c_contiguous and acc.shape == (2, self.K, self.N_enc)
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        assert rows.ndim == 2 and rows.shape[1] == self.N
+        w = key.shape[0] if window is None else window
+        assert w <= key.shape[0] or window is None
+        lib().rsf_inner_product_limb(self.h, limb, O.p64(key), 2 * self.K * self.N_enc, w, t0, O.p64(rows), rows.shape[0], O.p64(acc), threads)
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -230,3 +230,69 @@ size_t rsf_inner_product_mt(const rsf_ctx *c, const uint64_t *encs, size_t windo
   free(used);
   return total;
 }
+
+/* ONE RING LIMB of EncodingElem::inner_product (seal_ring.tcc:361-433), every (component, prime) slab of it at once:
+ *     acc[comp][j][.] += sum_{t < T, rows[t] != 0}  ct[(t0 + t) % window][comp][j][.] * NTT_Qj(lift(iNTT_qi(scatter(rows[t]))))
+ * ct: the limb's slice of the key vector, `window` stored elements of [2][K][N_enc] words, ct_stride words apart (tiled
+ * key: pass window >= t0 + T for an ordinary one); rows [T][N]: the limb's N values of each coefficient; acc [2][K][N_enc]
+ * canonical residues.  The plaintext of a term is transformed ONCE for the limb's 2 K slabs (the per-slab form,
+ * rso_inner_product_slab, repeats it per slab): what makes a check of ALL 96 slabs of a headline proof affordable
+ * (tests/proof_check.py).  Terms over `threads` threads (<= 0: all cores).  Same arithmetic as rsf_inner_product_mt. */
+void rsf_inner_product_limb(const rsf_ctx *c, int limb, const uint64_t *ct, size_t ct_stride, size_t window, size_t t0,
+                            const uint64_t *rows, size_t T, uint64_t *acc, int threads) {
+  const rso_ctx *b = c->base;
+  const size_t n = (size_t)b->N_enc, sw = (size_t)2 * b->K * n;
+#ifdef _OPENMP
+  const int nt = threads > 0 ? threads : omp_get_max_threads();
+#else
+  const int nt = 1;
+  (void)threads;
+#endif
+  uint64_t *part = (uint64_t *)calloc((size_t)nt * sw, sizeof(uint64_t));
+#pragma omp parallel num_threads(nt)
+  {
+#ifdef _OPENMP
+    const int id = omp_get_thread_num();
+#else
+    const int id = 0;
+#endif
+    uint64_t *plain = (uint64_t *)malloc(sizeof(uint64_t) * 2 * n), *P = plain + n, *a = part + (size_t)id * sw;
+#pragma omp for schedule(static)
+    for (long long t = 0; t < (long long)T; t++) {
+      const uint64_t *row = rows + (size_t)t * b->N;
+      int nz = 0;
+      for (int x = 0; x < b->N && !nz; x++) nz = row[x] != 0;
+      if (!nz) continue; /* is_zero terms are skipped (seal_ring.tcc:391-396): they contribute nothing */
+      memset(plain, 0, sizeof(uint64_t) * n);
+      for (int x = 0; x < b->N; x++) plain[b->index_map[x]] = row[x];
+      ntt_inv_lazy(&c->plain[limb], plain);
+      const uint64_t *cw = ct + (((size_t)t0 + (size_t)t) % window) * ct_stride;
+      for (int j = 0; j < b->K; j++) {
+        const rsf_ntt *tab = &c->coeff[j];
+        const uint64_t Q = b->Q[j];
+        for (size_t x = 0; x < n; x++) P[x] = lift(plain[x], b->q[limb], Q);
+        ntt_fwd_lazy(tab, P);
+        for (int comp = 0; comp < 2; comp++) {
+          const uint64_t *p = cw + ((size_t)comp * b->K + j) * n;
+          uint64_t *o = a + ((size_t)comp * b->K + j) * n;
+          for (size_t x = 0; x < n; x++) {
+            const uint64_t s = o[x] + barrett128((u128)p[x] * P[x], tab);
+            o[x] = s >= Q ? s - Q : s;
+          }
+        }
+      }
+    }
+    free(plain);
+  }
+  for (int k = 0; k < nt; k++)
+    for (int cj = 0; cj < 2 * b->K; cj++) {
+      const uint64_t Q = b->Q[cj % b->K];
+      uint64_t *o = acc + (size_t)cj * n;
+      const uint64_t *p = part + (size_t)k * sw + (size_t)cj * n;
+      for (size_t x = 0; x < n; x++) {
+        const uint64_t s = o[x] + p[x];
+        o[x] = s >= Q ? s - Q : s;
+      }
+    }
+  free(part);
+}

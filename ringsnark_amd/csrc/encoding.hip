@@ -459,8 +459,9 @@ static int noise_verdict(rs_ctx *ctx, const int *d_bits, size_t count, int tb, b
   }
   if (guard && bad >= 0) {
     // the reference's message (seal_ring.tcc:450-453); the budget it prints is max(0, .), i.e. 0
-    throw rs::Error(RS_ERR_NOISE, "ciphertext #" + std::to_string((int)(bad % ctx->L)) + " has remaining noise budget 0 <= 0 (element " +
-                                      std::to_string((size_t)(bad / ctx->L)) + ")");
+    // exactly the reference's text for one element (its decode takes one EncodingElem); a batch call says which element it was
+    throw rs::Error(RS_ERR_NOISE, "ciphertext #" + std::to_string((int)(bad % ctx->L)) + " has remaining noise budget 0 <= 0" +
+                                      (count > 1 ? " (element " + std::to_string((size_t)(bad / ctx->L)) + " of the batch)" : std::string()));
   }
   return RS_OK;
 }
@@ -468,15 +469,28 @@ static int noise_verdict(rs_ctx *ctx, const int *d_bits, size_t count, int tb, b
 static int decode_impl(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc, size_t count, uint64_t *d_rings, int *h_budget,
                        rs_stream stream) {
   if (count == 0) return RS_OK;
-  WsScope ws_scope(ctx, S(stream));
-  std::vector<uint64_t> thr_h;
-  const int tb = noise_thresholds(ctx, thr_h);
-  int *d_bits = nullptr;
-  RS_HIP(hipMalloc(&d_bits, sizeof(int) * count * (size_t)ctx->L));
-  struct BitsGuard { int *p; ~BitsGuard() { (void)hipFree(p); } } bits_guard{d_bits};
-  void *d_thr = nullptr;
-  RS_HIP(hipMalloc(&d_thr, thr_h.size() * 8));
-  struct ThrGuard { void *p; ~ThrGuard() { (void)hipFree(p); } } thr_guard{d_thr};
+  WsScope ws_scope(ctx, S(stream));  // holds ctx->mu: the lazily built constants below are built once
+  // constants of the context, built at the first call and kept on the device (round-5 advice: no hipMalloc / hipFree, no
+  // pageable upload -- an implicit device-wide synchronisation each -- per verifier decode): the digits of 2^b - 1
+  if (!ctx->d_noise_thr) {
+    std::vector<uint64_t> thr_h;
+    ctx->noise_tb = noise_thresholds(ctx, thr_h);
+    if (!ctx->use_int)
+      for (auto &x : thr_h) {  // digits < Q_k < 2^50: exact doubles
+        const double d = (double)x;
+        memcpy(&x, &d, 8);
+      }
+    void *p = nullptr;
+    RS_HIP(hipMalloc(&p, thr_h.size() * 8));
+    if (hipMemcpy(p, thr_h.data(), thr_h.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(p);
+      throw rs::Error(RS_ERR_HIP, "upload of the noise-threshold table failed");
+    }
+    ctx->d_noise_thr = p;
+  }
+  const int tb = ctx->noise_tb;
+  void *d_thr = ctx->d_noise_thr;
+  int *d_bits = (int *)ws_get(ctx, 9, sizeof(int) * count * (size_t)ctx->L);
   const int L = ctx->L, K = ctx->K, n = ctx->N_enc;
   hipStream_t st = S(stream);
   if (ctx->use_int) {  // the same composition on the integer arithmetic
@@ -512,9 +526,16 @@ static int decode_impl(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc,
       }
       hl[i].Q_mod_t = Qm;
     }
-    CrtLimbI *d_limbs = nullptr;
-    RS_HIP(hipMalloc(&d_limbs, sizeof(CrtLimbI) * L));
-    RS_HIP(hipMemcpyAsync(d_limbs, hl.data(), sizeof(CrtLimbI) * L, hipMemcpyHostToDevice, st));
+    if (!ctx->d_crt_limbs) {
+      void *p = nullptr;
+      RS_HIP(hipMalloc(&p, sizeof(CrtLimbI) * L));
+      if (hipMemcpy(p, hl.data(), sizeof(CrtLimbI) * L, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(p);
+        throw rs::Error(RS_ERR_HIP, "upload of the CRT constants failed");
+      }
+      ctx->d_crt_limbs = p;
+    }
+    const CrtLimbI *d_limbs = static_cast<const CrtLimbI *>(ctx->d_crt_limbs);
     TabCopiesI tabs(ctx);
     uint64_t *V = (uint64_t *)ws_get(ctx, 14, count * (size_t)L * K * n * sizeof(uint64_t));
     const size_t lds = padded_len((size_t)n) * sizeof(uint64_t);
@@ -523,12 +544,10 @@ static int decode_impl(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc,
     set_max_dyn_lds((const void *)crt_decode_kernel_int, (int)lds);
     hipLaunchKernelGGL(decrypt_dot_kernel_int, dim3((unsigned)(count * L), K), dim3(thr), lds, st, d_enc, d_sk, V, K, ctx->logN_enc,
                        tabs.d_coeff);
-    RS_HIP(hipMemcpyAsync(d_thr, thr_h.data(), thr_h.size() * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(crt_decode_kernel_int, dim3((unsigned)(count * L)), dim3(thr), lds, st, V, d_rings, ctx->N, L, ctx->logN_enc,
                        cc, d_limbs, ctx->d_index_map, tabs.d_plain, (const uint64_t *)d_thr, tb, d_bits);
     RS_HIP(hipGetLastError());
     RS_HIP(hipStreamSynchronize(st));
-    (void)hipFree(d_limbs);
     return noise_verdict(ctx, d_bits, count, tb, d_rings != nullptr, h_budget);
   }
   // host constants of the CRT composition
@@ -563,9 +582,16 @@ static int decode_impl(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc,
     }
     hl[i].Q_mod_t = balanced(Qm, t);
   }
-  CrtLimb *d_limbs = nullptr;
-  RS_HIP(hipMalloc(&d_limbs, sizeof(CrtLimb) * L));
-  RS_HIP(hipMemcpyAsync(d_limbs, hl.data(), sizeof(CrtLimb) * L, hipMemcpyHostToDevice, st));
+  if (!ctx->d_crt_limbs) {
+    void *p = nullptr;
+    RS_HIP(hipMalloc(&p, sizeof(CrtLimb) * L));
+    if (hipMemcpy(p, hl.data(), sizeof(CrtLimb) * L, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(p);
+      throw rs::Error(RS_ERR_HIP, "upload of the CRT constants failed");
+    }
+    ctx->d_crt_limbs = p;
+  }
+  const CrtLimb *d_limbs = static_cast<const CrtLimb *>(ctx->d_crt_limbs);
   TabCopies tabs(ctx);
   double *V = (double *)ws_get(ctx, 14, count * (size_t)L * K * n * sizeof(double));
   const size_t lds = padded_len((size_t)n) * sizeof(double);
@@ -574,14 +600,10 @@ static int decode_impl(rs_ctx *ctx, const uint64_t *d_sk, const uint64_t *d_enc,
   set_max_dyn_lds((const void *)crt_decode_kernel, (int)lds);
   hipLaunchKernelGGL(decrypt_dot_kernel, dim3((unsigned)(count * L), K), dim3(thr), lds, st, d_enc, d_sk, V, K, ctx->logN_enc,
                      tabs.d_coeff);
-  std::vector<double> thr_d(thr_h.size());
-  for (size_t i = 0; i < thr_h.size(); i++) thr_d[i] = (double)thr_h[i];  // digits < Q_k < 2^50: exact
-  RS_HIP(hipMemcpyAsync(d_thr, thr_d.data(), thr_d.size() * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(crt_decode_kernel, dim3((unsigned)(count * L)), dim3(thr), lds, st, V, d_rings, ctx->N, L, ctx->logN_enc,
                      cc, d_limbs, ctx->d_index_map, tabs.d_plain, (const double *)d_thr, tb, d_bits);
   RS_HIP(hipGetLastError());
   RS_HIP(hipStreamSynchronize(st));  // the table copies die with this call
-  (void)hipFree(d_limbs);
   return noise_verdict(ctx, d_bits, count, tb, d_rings != nullptr, h_budget);
 }
 

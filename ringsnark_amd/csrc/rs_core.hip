@@ -835,6 +835,8 @@ void rs_ctx_destroy(rs_ctx *c) {
   if (c->d_qmod_i) (void)hipFree(c->d_qmod_i);
   if (c->d_Qmod_i) (void)hipFree(c->d_Qmod_i);
   if (c->d_index_map) (void)hipFree(c->d_index_map);
+  if (c->d_noise_thr) (void)hipFree(c->d_noise_thr);
+  if (c->d_crt_limbs) (void)hipFree(c->d_crt_limbs);
   for (auto &r : c->prof) {
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);

@@ -176,6 +176,11 @@ struct rs_ctx {
   // constant device arrays of per-limb / per-prime moduli for pointwise kernels
   rs::Mod *d_qmod = nullptr;  // [L]
   rs::Mod *d_Qmod = nullptr;  // [K]
+  // decode / noise guard (encoding.hip): constants of the (context) built at the first rs_enc_decode / rs_enc_noise_budget and
+  // kept -- the digit table of 2^b - 1 for every b < bit_count(Q) in the context's arithmetic, the per-limb CRT constants
+  void *d_noise_thr = nullptr;
+  int noise_tb = 0;
+  void *d_crt_limbs = nullptr;
   std::mutex mu;
   std::map<size_t, rs::WitnessPlan *> plans;  // keyed by padded domain size M
   // workspace cache (grown on demand, per context; calls that need workspace serialise on mu)

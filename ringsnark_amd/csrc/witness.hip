@@ -1093,6 +1093,9 @@ static bool launch_cross_turn(rs_ctx *ctx, CrossArgs a, size_t ncols, int logB, 
   const int maxr = FP ? std::max(1, std::min(6, g_witness_cross_maxr)) : 4;
   if (!g_witness_h_turn || R < 1 || R > maxr || a.logsub != a.logtot || logB < 8) return false;
   if ((((uintptr_t)a.W | (uintptr_t)a.dst) & 15) != 0) return false;
+  // cross_turn_kernel indexes the product at i0 = 2m - 2 - j - c >= 0 and shifts by E - 1 - (i0 >> logB) >= 0: holds for
+  // M = next_pow2(m) (2m - 2 >= M >= B, 2m - 2 < 2M = 2^logtot) -- enforced, not assumed (round-5 advice): else the two passes
+  if (2 * (long long)a.m - 2 < ((long long)1 << logB) || 2 * (long long)a.m - 2 >= ((long long)1 << a.logtot)) return false;
   const size_t B = (size_t)1 << logB;
   const bool pair = R <= 5;
   const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>((B / (pair ? 2 : 1)) / 256, 1024));
@@ -1570,7 +1573,9 @@ static void bc2_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlans &cp, const d
   a.dst = Pbuf;
   // the turn of H (bc2_h_turn_kernel): the product's inverse transform across blocks and the forward one of its reversal as
   // one pass, the 2M-word product buffer neither written nor read (one-level transforms of at most 16 blocks: M <= 2^16)
-  const bool turn = g_witness_h_turn && logY >= 2 && logY <= 4;
+  // (the turn kernel reverses around 2m - 2: needs B <= 2m - 2 < 2M, true for M = next_pow2(m) -- checked, as in launch_cross_turn)
+  const bool turn = g_witness_h_turn && logY >= 2 && logY <= 4 && 2 * (long long)P->m - 2 >= (long long)BC2_B &&
+                    2 * (long long)P->m - 2 < ((long long)2 << logM);
   bc2_conv<BS_CENTER, BD_PLAIN_SCALED, 3>(ctx, a, logY, ncols, nullptr, WsA, cp, st, false, turn);
   if (turn) {
     const size_t Y = (size_t)1 << logY;

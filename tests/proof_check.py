@@ -159,7 +159,50 @@ def key_slab(t, l, c, j, n_enc):
     return to_host(t[..., l, c, j, :].contiguous()).reshape(-1, n_enc)
 
 
-def groth16_check(dev, prm, cs, dcs, asg, pk, proof, m, W=None, seed=5, n_cols=None, n_slabs=3):
+def limb_inner_product(fctx, acc, key_limb, vec, limb, T, step=4096):
+    """acc [2][K][N_enc] += ring limb `limb` of <key, vec[:T]>, all its (component, prime) slabs at once, by the CPU oracle in
+    its SEAL-arithmetic build (oracle/fastcpu.py inner_product_limb); key_limb [W][2][K][N_enc] on the host (W < T: tiled key)."""
+    from ringsnark_amd.device import to_host
+    for t0 in range(0, T, step):
+        rows = to_host(vec[t0:min(T, t0 + step), limb, :].contiguous())
+        fctx.inner_product_limb(limb, key_limb, rows, acc, t0=t0, window=key_limb.shape[0], threads=0)
+
+
+def groth16_all_slabs(prm, cs, asg, pk_host, proof, w, m):
+    """EVERY (element, limb, component, prime) slab of a ringGroth16 proof (3 L 2 K of them: 96 at the headline) recomputed from
+    the coefficient vectors w (device) and the key (pk_host: name -> [W][L][2][K][N_enc] host array, or a callable limb -> the
+    limb's [W][2][K][N_enc] slice) -- groth16.tcc:89-112 term for term, one ring limb at a time so that the plaintext of a term
+    is transformed once for the limb's 2 K slabs.  Returns (error or None, seconds)."""
+    from oracle import fastcpu as F
+    from ringsnark_amd.device import to_host
+    t0 = time.perf_counter()
+    fctx = F.FastCtx(prm.N, prm.q, prm.N_enc, prm.Q)
+    Qv = np.array(prm.Q, dtype=np.uint64).reshape(1, prm.K, 1)
+
+    def limb_of(name, l):
+        v = pk_host[name]
+        return v(l) if callable(v) else np.ascontiguousarray(v[:, l] if v.ndim == 5 else v[l])
+    for l in range(prm.L):
+        ks = limb_of("s_pows", l)
+        for e, elem in enumerate(("A", "B")):  # groth16.tcc:89-95, 97-103
+            acc = np.zeros((2, prm.K, prm.N_enc), dtype=np.uint64)
+            limb_inner_product(fctx, acc, ks, w[elem + "_io"], l, m)
+            limb_inner_product(fctx, acc, ks, w[elem + "_mid"], l, m)
+            acc = (acc + limb_of("alpha" if elem == "A" else "beta", l)) % Qv
+            if not (acc == to_host(proof[e, l].contiguous())).all():
+                bad = np.argwhere((acc != to_host(proof[e, l].contiguous())).any(axis=2))[0]
+                return "proof element %s slab (limb %d, component %d, prime %d) differs from the CPU oracle" % (elem, l, bad[0], bad[1]), time.perf_counter() - t0
+        del ks
+        acc = np.zeros((2, prm.K, prm.N_enc), dtype=np.uint64)  # groth16.tcc:105-112
+        limb_inner_product(fctx, acc, limb_of("delta_ts", l), w["H"], l, m + 1)
+        limb_inner_product(fctx, acc, limb_of("delta_mid", l), asg[cs.n_inputs:], l, cs.n_aux)
+        if not (acc == to_host(proof[2, l].contiguous())).all():
+            bad = np.argwhere((acc != to_host(proof[2, l].contiguous())).any(axis=2))[0]
+            return "proof element C slab (limb %d, component %d, prime %d) differs from the CPU oracle" % (l, bad[0], bad[1]), time.perf_counter() - t0
+    return None, time.perf_counter() - t0
+
+
+def groth16_check(dev, prm, cs, dcs, asg, pk, proof, m, W=None, seed=5, n_cols=None, n_slabs=3, all_slabs=False):
     """ringGroth16 proof (groth16.tcc:70-115) computed by the device for (cs, asg, pk): (1) witness-map identities
     on EVERY column (n_cols = None; round 4 sampled n_cols random columns + the two corners, kept for callers that ask
     for it); (2) n_slabs full (limb, component, prime) slabs -- A, C, B, then A, C, B again on other coordinates, ... --
@@ -186,6 +229,8 @@ def groth16_check(dev, prm, cs, dcs, asg, pk, proof, m, W=None, seed=5, n_cols=N
     for elem, l, c, j in slabs:
         for nme in {"A": ("s_pows", "alpha"), "B": ("s_pows", "beta"), "C": ("delta_ts", "delta_mid")}[elem]:
             key[(nme, l, c, j)] = key_slab(pk[nme], l, c, j, prm.N_enc)
+    # all_slabs: the whole key on the host, one limb slice at a time when asked for ([W][2][K][N_enc]: W 2 K N_enc 8 bytes each)
+    pk_host = {k: to_host(v.contiguous()) for k, v in pk.items()} if all_slabs else None
     proof_h = {(e, l, c, j): to_host(proof[{"A": 0, "B": 1, "C": 2}[e], l, c, j].contiguous()) for e, l, c, j in slabs}
     for k in list(pk.keys()):
         del pk[k]
@@ -215,14 +260,24 @@ def groth16_check(dev, prm, cs, dcs, asg, pk, proof, m, W=None, seed=5, n_cols=N
         if not (acc == proof_h[(elem, l, c, j)]).all():
             return False, {"error": "proof element %s slab (limb %d, component %d, prime %d) differs from the CPU oracle" % (elem, l, c, j)}
     all_cols = n_checked == prm.L * prm.N
+    n_total = 3 * prm.L * 2 * prm.K
+    slabs_all = None
+    if all_slabs:  # the complete inner-product check: every slab, SEAL-arithmetic build of the oracle (bit-identical to the `%` checker: tests/test_oracle.py)
+        err, secs = groth16_all_slabs(prm, cs, asg, pk_host, proof, w, m)
+        if err:
+            return False, {"error": err}
+        slabs_all = {"slabs": "%d of %d" % (n_total, n_total), "seconds": round(secs, 1),
+                     "how": "oracle/rs_fastcpu.c rsf_inner_product_limb (Harvey / Barrett arithmetic), one ring limb at a time; the %d slabs above "
+                            "also by the %%-based checker" % len(slabs)}
     return True, {"kind": ("every witness-map column (identities at 2 random points per limb, C + OpenMP); " if all_cols else
                            "SAMPLED columns; ") + "%d of %d proof slabs recomputed by the CPU oracle from the checked vectors" % (
-                               len(slabs), 3 * prm.L * 2 * prm.K),
+                               n_total if all_slabs else len(slabs), n_total),
                   "sample": "%s of %d witness-map columns x 2 random points; %d of %d (element, limb, component, prime) slabs of the proof" % (
-                      "all" if all_cols else n_checked, prm.L * prm.N, len(slabs), 3 * prm.L * 2 * prm.K),
+                      "all" if all_cols else n_checked, prm.L * prm.N, n_total if all_slabs else len(slabs), n_total),
                   "columns": "all" if all_cols else n_checked, "columns_checked": n_checked, "points_per_column": 2,
                   "columns_detail": col_info,
                   "slabs": ["%s[limb %d][comp %d][prime %d]" % s for s in slabs],
+                  "slabs_checked": n_total if all_slabs else len(slabs), "slabs_total": n_total, "all_slabs": slabs_all,
                   "seconds": round(time.perf_counter() - t_start, 1), "columns_seconds": round(t_cols, 1)}
 
 

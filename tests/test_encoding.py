@@ -131,6 +131,7 @@ def test_noise_budget_and_decode_guard_match_oracle(name):
     with pytest.raises(_lib.RsError) as ei:
         dev.enc_decode(dsk, dl[-1])
     assert ei.value.code == _lib.RS_ERR_NOISE and "ciphertext #%d " % bad in str(ei.value)
+    assert str(ei.value).endswith("has remaining noise budget 0 <= 0")  # one element: exactly the reference's text (seal_ring.tcc:450-453)
     # uniformly random residues are no ciphertext of anything
     assert (dev.enc_noise_budget(dsk, dev.put(ctx.random_enc(4, 2))) == 0).all()
 

@@ -277,6 +277,22 @@ def test_seal_style_timing_library_equals_the_checker(name, T):
     exp, used = ctx.inner_product(encs[:2], rings, kinds, threads=0, window=2)
     got, u = f.inner_product(encs[:2], rings, kinds, threads=0, window=2)
     assert u == used and (got == exp).all()
+    # one ring limb, all its 2 K slabs in one pass (the complete MSM check of a headline proof, tests/proof_check.py): equal to the
+    # checker's whole inner product on that limb and to its per-slab form, in two term ranges over a tiled key
+    rows_all = ctx.random_ring(33, T)
+    rows_all[min(3, T - 1)] = 0
+    W = min(5, T)
+    exp, _ = ctx.inner_product(encs[:W], rows_all, None, threads=0, window=W)
+    for limb in range(prm.L):
+        key = np.ascontiguousarray(encs[:W, limb])
+        acc = np.zeros((2, prm.K, prm.N_enc), dtype=np.uint64)
+        cut = T // 2
+        f.inner_product_limb(limb, key, rows_all[:cut, limb], acc, t0=0, window=W, threads=2)
+        f.inner_product_limb(limb, key, rows_all[cut:, limb], acc, t0=cut, window=W, threads=0)
+        assert (acc == exp[limb]).all()
+        slab = np.zeros(prm.N_enc, dtype=np.uint64)
+        ctx.inner_product_slab(limb, prm.K - 1, np.ascontiguousarray(key[:, 1, prm.K - 1]), rows_all[:, limb], slab, window=W)
+        assert (slab == acc[1, prm.K - 1]).all()
     if prm.N <= 64:
         cs = R.wide_r1cs(25, prm.q)
         asg = H.make_assignment(ctx, cs)

@@ -266,6 +266,88 @@ def rinocchio_leg(preset, steps=3, logm=None, logw=None, logreg=False, check=Tru
     return out
 
 
+def dyadic_leg(dev, prm, reps=100, gib=1.0):
+    """SURVEY.md 8(d) rows a2 / a8 and the reference's own micro-timings (microbench.cpp:157-205: scalar x ring, ring + ring,
+    ring x ring, encode + encrypt, decrypt + decode; 100 repetitions, mean microseconds).  Two figures per dyadic op:
+    the HBM roofline of a LARGE batch (`gib` GiB per operand: algorithmic 16 or 24 bytes per residue against 8 TB/s and against
+    the best streaming rate rs_measure_peaks found in this run) and the time of ONE element per call as the reference measures it
+    (launch-latency bound on a GPU).  Encode / decode: microseconds per EncodingElem in a batch of 64 and alone."""
+    from ringsnark_amd import _lib
+    lib, h = dev.lib, dev.h
+    ptr = lambda t: t.data_ptr()
+
+    def timed(fn, n=reps):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()  # the library launches on torch's current stream (device.py passes it down)
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n  # microseconds per call
+
+    def roof(us, nbytes):
+        gbs = nbytes / us / 1e3
+        o = {"us_per_launch": round(us, 2), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        if measured_hbm():
+            o["frac_of_measured"] = round(gbs / measured_hbm(), 4)
+        return o
+
+    out = {"bound": "hbm", "preset": prm.name, "reps": reps,
+           "shape": "ring N=%d L=%d (%d-byte elements), encodings N_enc=%d K=%d" % (prm.N, prm.L, prm.ring_words * 8, prm.N_enc, prm.K),
+           "reference": "microbench.cpp:157-205 (NUM_REPEATS = 100, mean microseconds per call on one element)"}
+    T = max(1, int(gib * 2**30) // (prm.ring_words * 8))
+    a = dev.fill_uniform(dev.ring_empty(T), 0, 51)
+    b = dev.fill_uniform(dev.ring_empty(T), 0, 52)
+    o = torch.empty_like(a)
+    st = dev.stream()
+    words = T * prm.ring_words
+    ops = {"ring_mul_scalar (A x R)": (lambda n: _lib.check(lib.rs_ring_mul_scalar(h, ptr(o), ptr(a), 3, n, st)), 16),
+           "ring_add (R + R)": (lambda n: _lib.check(lib.rs_ring_add(h, ptr(o), ptr(a), ptr(b), n, st)), 24),
+           "ring_mul (R x R)": (lambda n: _lib.check(lib.rs_ring_mul(h, ptr(o), ptr(a), ptr(b), n, st)), 24)}
+    for name, (fn, bpr) in ops.items():
+        big = roof(timed(lambda: fn(T), 20), words * bpr)
+        big["elements_per_launch"] = T
+        big["algorithmic_bytes_per_residue"] = bpr
+        big["us_per_element_in_batch"] = round(big["us_per_launch"] / T, 4)
+        big["us_one_element_per_call"] = round(timed(lambda: fn(1)), 2)
+        out[name] = big
+    del a, b, o
+    Te = max(1, int(gib * 2**30) // (prm.enc_words * 8))
+    ea = dev.fill_uniform(dev.enc_empty(Te), 1, 53)
+    eb = dev.fill_uniform(dev.enc_empty(Te), 1, 54)
+    eo = torch.empty_like(ea)
+    fn = lambda n: _lib.check(lib.rs_enc_add(h, ptr(eo), ptr(ea), ptr(eb), n, st))
+    big = roof(timed(lambda: fn(Te), 20), Te * prm.enc_words * 24)
+    big.update(elements_per_launch=Te, algorithmic_bytes_per_residue=24, us_per_element_in_batch=round(big["us_per_launch"] / Te, 4),
+               us_one_element_per_call=round(timed(lambda: fn(1)), 2))
+    out["enc_add (EncodingElem += EncodingElem, seal_ring.tcc:479-506)"] = big
+    del ea, eb, eo
+    # encode / decode: a ternary secret key in NTT form (any key times the same; a real one keeps the noise guard of decode quiet)
+    rng = np.random.RandomState(7)
+    s_coef = rng.randint(-1, 2, prm.N_enc)
+    sk = torch.empty((prm.K, prm.N_enc), dtype=torch.int64, device=dev.device)
+    for j, Qj in enumerate(prm.Q):
+        sk[j] = torch.from_numpy(np.mod(s_coef, Qj).astype(np.int64)).to(dev.device)
+        dev.ntt(sk[j:j + 1], _lib.RS_MOD_COEFF, j)
+    rings = dev.fill_uniform(dev.ring_empty(64), 0, 55)
+    enc = dev.enc_encode(sk, rings, 9)
+    dec = dev.enc_decode(sk, enc)
+    ok = bool((dec == rings).all())
+    e_b = timed(lambda: dev.enc_encode(sk, rings, 9), 20)
+    d_b = timed(lambda: dev.enc_decode(sk, enc), 20)
+    e_1 = timed(lambda: dev.enc_encode(sk, rings[0], 9), 50)
+    d_1 = timed(lambda: dev.enc_decode(sk, enc[0]), 50)
+    out["encode / decode (EncodingElem::encode, ::decode: L ciphertexts per element; seal_ring.tcc:324-359, 435-477)"] = {
+        "encode_us_per_element_in_batch_of_64": round(e_b / 64, 2), "decode_us_per_element_in_batch_of_64": round(d_b / 64, 2),
+        "encode_us_one_element_per_call": round(e_1, 2), "decode_us_one_element_per_call": round(d_1, 2),
+        "round_trip_equal": ok, "note": "each call ends with a stream synchronisation (the entry points return host-visible status)"}
+    del rings, enc, dec, sk
+    torch.cuda.empty_cache()
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (a port of the reference's algorithm) on a bounded sample
 # ---------------------------------------------------------------------------------------------------
@@ -593,6 +675,19 @@ def main():
         ntt_roofline["micro60_integer_arithmetic"] = leg
         del d60
 
+    # ---- rows a2 / a8 of SURVEY 8(d) and the reference's micro-timings: dyadic ring ops, enc_add, encode / decode
+    dyadic = None
+    if world == 1 and not args.no_ntt:
+        try:
+            dyadic = dyadic_leg(dev, prm)
+            p60 = P.preset("micro60")  # microbench.cpp:13-14,33-36: N = 16384, {59, 60, 60}-bit primes -- the integer (Montgomery) arithmetic
+            d60 = Device(p60, local_rank)
+            dyadic["micro60_integer_arithmetic"] = dyadic_leg(d60, p60, gib=0.5)
+            del d60
+        except Exception as e:  # an extra leg must not cost the line
+            dyadic = {"error": repr(e)}
+        torch.cuda.empty_cache()
+
     # ---- untimed post-run check of the timed proof against the CPU oracle
     check = None
     if world == 1 and not args.no_check:
@@ -666,6 +761,8 @@ def main():
             out["mac_roofline"] = mac_roofline
         if ntt_roofline:
             out["ntt_roofline"] = ntt_roofline
+        if dyadic:
+            out["dyadic_roofline"] = dyadic
         if check is not None:
             out["check"] = check
         if friendly is not None:

@@ -145,10 +145,11 @@ static void ntt_fwd(std::vector<uint64_t> &a, int logn, const CycTab &t, int nst
       }
     }
 }
-static void ntt_inv(std::vector<uint64_t> &a, int logn, const CycTab &t) {
+// u0 > 0: the inverse of an incomplete transform -- stages u0 .. logn-1, scaled by 2^-(logn - u0)
+static void ntt_inv(std::vector<uint64_t> &a, int logn, const CycTab &t, int u0 = 0) {
   const size_t n = (size_t)1 << logn;
   const uint64_t p = t.p;
-  for (size_t m = n >> 1, gap = 1; m >= 1; m >>= 1, gap <<= 1)
+  for (size_t m = n >> (u0 + 1), gap = (size_t)1 << u0; m >= 1; m >>= 1, gap <<= 1)
     for (size_t i = 0; i < m; i++) {
       const uint64_t W = t.itw[m + i];
       for (size_t j = 2 * i * gap; j < 2 * i * gap + gap; j++) {
@@ -157,7 +158,7 @@ static void ntt_inv(std::vector<uint64_t> &a, int logn, const CycTab &t) {
         a[j + gap] = mulmod(submod(u, v, p), W, p);
       }
     }
-  const uint64_t ninv = invmod((uint64_t)n % p, p);
+  const uint64_t ninv = invmod((uint64_t)(n >> u0) % p, p);
   for (auto &x : a) x = mulmod(x, ninv, p);
 }
 static int clog2(size_t x) {
@@ -174,8 +175,35 @@ static std::vector<uint64_t> polymul(const std::vector<uint64_t> &a, const std::
     return o;
   }
   const int lg = clog2(need);
+  if (lg > t.logmax && lg - t.logmax <= 4) {
+    // the prime has no root of unity of that order: incomplete transforms (witness_inc.hpp) -- the first logmax stages, then
+    // the product of the residues modulo x^G - eta per leaf, G = 2^(lg - logmax)
+    const int inc = lg - t.logmax, nst = t.logmax;
+    const size_t G = (size_t)1 << inc, n = (size_t)1 << lg;
+    std::vector<uint64_t> fa(a), fb(b), out(n);
+    fa.resize(n, 0);
+    fb.resize(n, 0);
+    ntt_fwd(fa, lg, t, nst);
+    ntt_fwd(fb, lg, t, nst);
+    for (size_t g = 0; g < (n >> inc); g++) {
+      const uint64_t w = t.tw[(((size_t)1 << nst) + g) >> 1], eta = (g & 1) ? (t.p - w) % t.p : w;
+      const uint64_t *x = &fa[g * G], *y = &fb[g * G];
+      for (size_t k = 0; k < G; k++) {
+        uint64_t lo = 0, hi = 0;
+        for (size_t i = 0; i < G; i++) {
+          const uint64_t pr = mulmod(x[i], y[(k - i) & (G - 1)], t.p);
+          if (i <= k) lo = addmod(lo, pr, t.p);
+          else hi = addmod(hi, pr, t.p);
+        }
+        out[g * G + k] = addmod(lo, mulmod(hi, eta, t.p), t.p);
+      }
+    }
+    ntt_inv(out, lg, t, inc);
+    out.resize(need);
+    return out;
+  }
   if (lg > t.logmax) {
-    // the prime has no root of unity of that order: block convolution over blocks of Bh = 2^(logmax-1)
+    // ... more than four stages short: block convolution over blocks of Bh = 2^(logmax-1)
     // coefficients (each block product fits one transform of length 2 Bh), overlap-added
     const size_t Bh = (size_t)1 << (t.logmax - 1);
     const size_t nab = (a.size() + Bh - 1) / Bh, nbb = (b.size() + Bh - 1) / Bh;

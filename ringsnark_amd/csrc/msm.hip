@@ -721,8 +721,12 @@ void enc_add_run(rs_ctx *ctx, uint64_t *dst, const uint64_t *x, const uint64_t *
   const size_t words = count * ctx->enc_words();
   if (!words) return;
   MsmScratch &sc = scratch_for(ctx);
-  const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 256 * 16);
-  hipLaunchKernelGGL(enc_add_kernel, dim3(blocks), dim3(256), 0, st, dst, x, y, words, ctx->N_enc, ctx->K, sc.d_Qint);
+  const size_t pairs = words / 2;  // N_enc is even: whole 16-byte words
+  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((pairs + 2047) / 2048, 256 * 8));
+  if (pairs * 16 >= ((size_t)64 << 20))  // non-temporal accesses for operands beyond the caches
+    hipLaunchKernelGGL(enc_add_kernel<true>, dim3(blocks), dim3(256), 0, st, dst, x, y, pairs, ctx->logN_enc, ctx->K, sc.d_Qint);
+  else
+    hipLaunchKernelGGL(enc_add_kernel<false>, dim3(blocks), dim3(256), 0, st, dst, x, y, pairs, ctx->logN_enc, ctx->K, sc.d_Qint);
   RS_HIP(hipGetLastError());
 }
 

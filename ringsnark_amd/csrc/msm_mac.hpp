@@ -933,15 +933,48 @@ reduce_kernel(const uint64_t *__restrict__ partial, uint64_t *__restrict__ out, 
   }
 }
 
-// a8: EncodingElem::operator+= (dyadic add mod Q_j)
+// a8: EncodingElem::operator+= (dyadic add mod Q_j, seal_ring.tcc:479-506): an HBM-bound stream of 24 bytes per residue, in the
+// shape of ring_pointwise_kernel (rs_core.hip): contiguous 32 KiB pieces per workgroup, eight 16-byte loads per operand in
+// flight per lane.  `pairs` 16-byte words; the prime of word i is (i >> logn) % K, uniform over a piece for logn >= 12.
+template <bool NT>
 __global__ void __launch_bounds__(256)
 enc_add_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ x, const uint64_t *__restrict__ y,
-               size_t words, int n, int K, const uint64_t *__restrict__ Qint) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) {
-    const uint64_t Q = Qint[(i / (size_t)n) % (size_t)K];
-    uint64_t sm = x[i] + y[i];
-    dst[i] = sm >= Q ? sm - Q : sm;
+               size_t pairs, int logn, int K, const uint64_t *__restrict__ Qint) {
+  const u64x2 *x2 = reinterpret_cast<const u64x2 *>(x), *y2 = reinterpret_cast<const u64x2 *>(y);
+  u64x2 *d2 = reinterpret_cast<u64x2 *>(dst);
+  const size_t full = pairs & ~(size_t)2047;
+  const bool uniform = logn >= 12;
+  for (size_t base = (size_t)blockIdx.x * 2048; base < full; base += (size_t)gridDim.x * 2048) {
+    u64x2 va[8], vb[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const size_t i = base + threadIdx.x + 256 * k;
+      va[k] = NT ? __builtin_nontemporal_load(x2 + i) : x2[i];
+      vb[k] = NT ? __builtin_nontemporal_load(y2 + i) : y2[i];
+    }
+    const uint64_t Qu = Qint[((2 * base) >> logn) % (size_t)K];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const size_t i = base + threadIdx.x + 256 * k;
+      const uint64_t Q = uniform ? Qu : Qint[(unsigned)((2 * i) >> logn) % (unsigned)K];
+      u64x2 o;
+      o.x = va[k].x + vb[k].x;
+      o.y = va[k].y + vb[k].y;
+      o.x = o.x >= Q ? o.x - Q : o.x;
+      o.y = o.y >= Q ? o.y - Q : o.y;
+      if (NT) __builtin_nontemporal_store(o, d2 + i);
+      else d2[i] = o;
+    }
+  }
+  for (size_t i = full + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {  // the tail
+    const uint64_t Q = Qint[(unsigned)((2 * i) >> logn) % (unsigned)K];
+    const u64x2 p = x2[i], q = y2[i];
+    u64x2 o;
+    o.x = p.x + q.x;
+    o.y = p.y + q.y;
+    o.x = o.x >= Q ? o.x - Q : o.x;
+    o.y = o.y >= Q ? o.y - Q : o.y;
+    d2[i] = o;
   }
 }
 

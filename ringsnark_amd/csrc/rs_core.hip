@@ -631,21 +631,50 @@ __device__ __forceinline__ uint64_t ring_apply(uint64_t a, uint64_t b, typename 
   return to_res(canon(r, m));
 }
 
-template <int OP, class M>
+// Rows a1 / a2 (SealPoly dyadic ops, seal_ring.tcc:62-247): HBM-bound streams -- 16 or 24 algorithmic bytes per residue.
+// The shape that reaches the device's copy rate (rs_measure_peaks' peak_copy_kernel): a workgroup moves CONTIGUOUS 32 KiB
+// pieces of every operand, eight 16-byte loads per operand in flight per lane before the first use, pieces dealt round-robin
+// to the workgroups; NT: non-temporal accesses (large batches, touched once).  `pairs` 16-byte words; limb of word i =
+// (i >> logN) % L -- uniform over a piece when a limb row holds at least a piece (logN >= 12), else per access.
+template <int OP, class M, bool NT>
 __global__ void __launch_bounds__(256) ring_pointwise_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ a,
-                                                             const uint64_t *__restrict__ b, size_t pairs, int N, int L,
+                                                             const uint64_t *__restrict__ b, size_t pairs, int logN, int L,
                                                              const M *__restrict__ qmod, ScalarPerLimbT<typename ArithOf<M>::T> sc) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
-    const int limb = (int)(((2 * i) / (size_t)N) % (size_t)L);
+  constexpr bool BIN = OP == OP_ADD || OP == OP_SUB || OP == OP_MUL;
+  const u64x2 *a2 = reinterpret_cast<const u64x2 *>(a), *b2 = reinterpret_cast<const u64x2 *>(b);
+  u64x2 *d2 = reinterpret_cast<u64x2 *>(dst);
+  const size_t full = pairs & ~(size_t)2047;
+  const bool uniform = logN >= 12;
+  for (size_t base = (size_t)blockIdx.x * 2048; base < full; base += (size_t)gridDim.x * 2048) {
+    u64x2 va[8], vb[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const size_t i = base + threadIdx.x + 256 * k;
+      va[k] = NT ? __builtin_nontemporal_load(a2 + i) : a2[i];
+      vb[k] = va[k];
+      if (BIN) vb[k] = NT ? __builtin_nontemporal_load(b2 + i) : b2[i];
+    }
+    const int limb_u = (int)(((2 * base) >> logN) % (size_t)L);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const size_t i = base + threadIdx.x + 256 * k;
+      const int limb = uniform ? limb_u : (int)((unsigned)((2 * i) >> logN) % (unsigned)L);
+      const M m = qmod[limb];
+      u64x2 o;
+      o.x = ring_apply<OP, M>(va[k].x, vb[k].x, sc.v[limb], m);
+      o.y = ring_apply<OP, M>(va[k].y, vb[k].y, sc.v[limb], m);
+      if (NT) __builtin_nontemporal_store(o, d2 + i);
+      else d2[i] = o;
+    }
+  }
+  for (size_t i = full + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {  // the tail (< 32 KiB)
+    const int limb = (int)((unsigned)((2 * i) >> logN) % (unsigned)L);
     const M m = qmod[limb];
-    const ulonglong2 va = reinterpret_cast<const ulonglong2 *>(a)[i];
-    ulonglong2 vb = va;
-    if (OP == OP_ADD || OP == OP_SUB || OP == OP_MUL) vb = reinterpret_cast<const ulonglong2 *>(b)[i];
-    ulonglong2 o;
-    o.x = ring_apply<OP, M>(va.x, vb.x, sc.v[limb], m);
-    o.y = ring_apply<OP, M>(va.y, vb.y, sc.v[limb], m);
-    reinterpret_cast<ulonglong2 *>(dst)[i] = o;
+    const u64x2 x = a2[i], y = BIN ? b2[i] : x;
+    u64x2 o;
+    o.x = ring_apply<OP, M>(x.x, y.x, sc.v[limb], m);
+    o.y = ring_apply<OP, M>(x.y, y.y, sc.v[limb], m);
+    d2[i] = o;
   }
 }
 
@@ -657,9 +686,17 @@ static void launch_pointwise_arith(rs_ctx *ctx, uint64_t *dst, const uint64_t *a
   ScalarPerLimbT<typename ArithOf<M>::T> sc{};
   for (int i = 0; i < ctx->L; i++)
     sc.v[i] = OP == OP_MUL_SCALAR ? HostArith<M>::konst(scalar, ctx->q[i]) : HostArith<M>::plain(scalar, ctx->q[i]);
-  const unsigned blocks = (unsigned)std::min<size_t>((pairs + 255) / 256, 256 * 16);
-  hipLaunchKernelGGL((ring_pointwise_kernel<OP, M>), dim3(blocks), dim3(256), 0, st, dst, a, b, pairs, ctx->N, ctx->L,
-                     CtxArith<M>::qmod(ctx), sc);
+  int logN = 0;
+  while ((1 << logN) < ctx->N) logN++;
+  RS_REQUIRE((1 << logN) == ctx->N, "ring degree must be a power of two");
+  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((pairs + 2047) / 2048, 256 * 8));
+  // non-temporal accesses once the operands are larger than the caches they would otherwise sweep (256 MiB Infinity Cache)
+  if (pairs * 16 >= ((size_t)64 << 20))
+    hipLaunchKernelGGL((ring_pointwise_kernel<OP, M, true>), dim3(blocks), dim3(256), 0, st, dst, a, b, pairs, logN, ctx->L,
+                       CtxArith<M>::qmod(ctx), sc);
+  else
+    hipLaunchKernelGGL((ring_pointwise_kernel<OP, M, false>), dim3(blocks), dim3(256), 0, st, dst, a, b, pairs, logN, ctx->L,
+                       CtxArith<M>::qmod(ctx), sc);
   RS_HIP(hipGetLastError());
 }
 template <int OP>

@@ -226,9 +226,11 @@ int rs_instance_map_eval(rs_ctx *ctx, const rs_r1cs *cs, const uint64_t *d_s, ui
 /* ---- a10-a13: r1cs_to_qrp_witness_map (reductions/r1cs_to_qrp/r1cs_to_qrp.tcc:149-259) ----
  * Outputs in ring layout: A_io..C_mid [m][L][N], H [m+1][L][N]; h_Z [L][m+1] slot-constant
  * scalars (coefficients_for_Z).  d1,d2,d3: ring elements [L][N] or all NULL (zero).  Any output
- * pointer may be NULL to skip it.  Exact quasi-linear algorithm: cyclic transforms of length 2*next_pow2(m) when
- * every q_i has the 2-adicity for them (q_i = 1 mod 4*next_pow2(m)), otherwise block convolutions over the largest
- * transform the primes support (same results).
+ * pointer may be NULL to skip it.  Exact quasi-linear algorithm: cyclic transforms of length 2*next_pow2(m) -- complete when
+ * q_i has the 2-adicity for them (q_i = 1 mod 4*next_pow2(m)), INCOMPLETE otherwise at multi-pass sizes (m > 2^14: the
+ * transform stops at the prime's 2-adicity, up to four stages short, and the pointwise step multiplies residues modulo
+ * x^G - eta: csrc/witness_inc.hpp -- the case of the ring primes the reference's own recipe yields, seal_util.hpp:20-32);
+ * block convolutions over the largest transform the primes support elsewhere.  Same results on every path.
  * PRECONDITION when C_mid / C_io is requested at multi-pass sizes (M > 2^14, full-length transforms): the assignment
  * SATISFIES the constraint system.  H is then recovered from values on a coset, H = (A B - C) / Z point by point, which
  * equals the reference's quotient (util/polynomials.tcc:76-81 drops the remainder) only when Z divides A B - C; for an
@@ -349,7 +351,7 @@ int rs_profile_read(rs_ctx *ctx, rs_kernel_stat *out, int capacity, int *n_out);
 /* process-wide kernel-shape knobs; results are identical for every accepted value:
  *   "ntt_variant" (14: wide kernels of ntt_wide.hpp, default), "ntt_wide_grid", "mac_variant" (5: mac_kernel_v3),
  *   "plain_variant" (1: plain_center_wide_kernel), "witness_lds_logM", "witness_sub_ct" (2: sub_ntt_wide_kernel),
- *   "witness_tree_ct" (2: tree_wide_kernel), "witness_tree_log" (14), "mac_chunk_units", "mac_share_keys" (1: mac_kernel_v4, one plaintext spectrum for two key vectors), "prover_lin_io" (1), "witness_col_budget_mib", "witness_force_bc", "witness_bc2" (1), "msm_host_tile" (1024 terms per staging buffer), "force_int_arith",
+ *   "witness_tree_ct" (2: tree_wide_kernel), "witness_tree_log" (14), "mac_chunk_units", "mac_share_keys" (1: mac_kernel_v4, one plaintext spectrum for two key vectors), "prover_lin_io" (1), "witness_col_budget_mib", "witness_force_bc", "witness_inc" (1: ring primes without a 2M-th root of unity run INCOMPLETE transforms on the multi-pass path, csrc/witness_inc.hpp; 0: block convolutions), "witness_bc2" (1), "msm_host_tile" (1024 terms per staging buffer), "force_int_arith",
  *   "witness_cross_maxr" (6: most stages of one cross pass), "witness_cross_pair" (1: two groups per thread, 16-byte accesses), "witness_sub_log" (12: rooted sub-transforms on 2^12 blocks, sub_ntt_w12_kernel, where the cross pass stays within "witness_sub12_cross" = 4 stages; 13: never), "int_ntt_variant" (1: ntt_io_kernel), "witness_h_coset" (1: H as an inverse coset transform when the call interpolates C).
  * (Variants that alter results -- timing ablations -- exist only as compile-time macros / the separate experiments
  * build, `make -C ringsnark_amd/csrc experiments`; never in the release library.) */

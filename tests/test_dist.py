@@ -121,6 +121,7 @@ def _worker(rank, world, port, preset, m, q_override, tmp, prover="groth16", zk=
     RD.RELAY = relay
     if chunk_bytes:
         RD.SLOT_CHUNK_BYTES = chunk_bytes  # tiny sub-ranges of slots: several pipelined exchange steps at toy scale
+    RD.STATS.reset(True)  # transport statistics (what bench.py --gpus N prints): written beside the verdict
     try:
         if preset == "toy4":  # four ring limbs (the headline's limb count) at toy scale
             prm = P.make_params(32, [30, 30, 30, 30], 64, [40, 40, 41], ring_factor=1 << 12, name="toy4")
@@ -166,8 +167,29 @@ def _worker(rank, world, port, preset, m, q_override, tmp, prover="groth16", zk=
         if rank == 0:
             ok = bool((OracleBackend._np(got) == exp).all()) and got_empty == exp_empty
             open(tmp, "w").write("ok" if ok else "mismatch")
+            import json
+            pooled = len(RD._POOL.bufs)
+            RD.release_buffers()
+            open(tmp + ".stats", "w").write(json.dumps({"phases": RD.STATS.read(), "pooled_before_release": pooled, "pooled_after": len(RD._POOL.bufs)}))
     finally:
         dist.destroy_process_group()
+
+
+def test_transport_statistics_and_buffer_release(tmp_path):
+    """What `bench.py --gpus N` prints per collective (dist.STATS) and the lifetime of the pooled re-shard buffers (round-5
+    advice: release_buffers): one limb on two ranks -> one slot -> term exchange, one all-reduce, one all-gather."""
+    import json
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(2, _free_port(), "toy", 7, 1, out, "groth16", False, "slots"), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+    st = json.load(open(out + ".stats"))
+    ph = st["phases"]
+    assert set(ph) == {"slot_to_term_exchange", "all_reduce_partial_sums", "all_gather_proof"}, ph
+    assert all(v["calls"] >= 1 and v["bytes"] > 0 and v["ms"] >= 0 for v in ph.values()), ph
+    # a rank of a 2-rank group sends and receives half of its four compact vectors' rows; the proof is 3 encoding elements of one limb
+    prm = P.preset("toy")
+    assert ph["all_gather_proof"]["bytes"] == 3 * 2 * prm.K * prm.N_enc * 8 and ph["all_reduce_partial_sums"]["bytes"] == ph["all_gather_proof"]["bytes"]
+    assert st["pooled_before_release"] > 0 and st["pooled_after"] == 0
 
 
 @pytest.mark.parametrize("q_override,split,desc", [

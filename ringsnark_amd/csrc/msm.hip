@@ -187,6 +187,22 @@ static void launch_mac_v3(rs_ctx *ctx, const MacArgs3 &a, const MsmScratch &sc, 
   RS_HIP(hipGetLastError());
 }
 
+// mac_kernel_v4 with ONE key vector (mac_variant 6, N_enc = 8192): two 512-thread workgroups per CU at <= 128 VGPRs
+static void launch_mac_v4_one(rs_ctx *ctx, const MacArgs4 &a, bool paired, const MsmScratch &sc, hipStream_t st) {
+  const size_t lds = (size_t)2 * (4096 + 512) * sizeof(double);  // two tiles
+  const unsigned rows = (unsigned)ctx->L * (unsigned)a.n_chunks;
+  const NttTable *tabs = ctx->use_int ? static_cast<const NttTable *>(sc.d_coeff_tabs_f64) : sc.coeff<Mod>();
+  const unsigned blocks = ((rows + 7) / 8) * 8 * 2u * (unsigned)ctx->K * (unsigned)a.n_groups;
+  if (paired) {
+    set_max_dyn_lds((const void *)mac_kernel_v4<13, true, 1>, (int)lds);
+    hipLaunchKernelGGL((mac_kernel_v4<13, true, 1>), dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K, tabs);
+  } else {
+    set_max_dyn_lds((const void *)mac_kernel_v4<13, false, 1>, (int)lds);
+    hipLaunchKernelGGL((mac_kernel_v4<13, false, 1>), dim3(blocks), dim3(512), lds, st, a, ctx->L, ctx->K, tabs);
+  }
+  RS_HIP(hipGetLastError());
+}
+
 static void launch_mac_v4(rs_ctx *ctx, const MacArgs4 &a, bool paired, const MsmScratch &sc, hipStream_t st) {
   const size_t lds = (size_t)2 * (4096 + 512) * sizeof(double);  // two tiles
   const unsigned rows = (unsigned)ctx->L * (unsigned)a.n_chunks;
@@ -217,12 +233,13 @@ __global__ void __launch_bounds__(256) broadcast_rows_kernel(const uint64_t *__r
 void batch_encode_run(rs_ctx *ctx, const uint64_t *d_rings, uint64_t *d_plain, size_t count, hipStream_t st);
 
 int g_mac_ablate = 0;
+int g_mac_ct_temporal = 0;  // tuning knob "mac_ct_temporal": mac_kernel_v3 reads the ciphertext words with temporal loads (A/B: does the second group's read of a shared key vector find them in L2 more often?)
 int g_mac_share_keys = 1;  // tuning knob "mac_share_keys": two key vectors share the plaintext spectrum (mac_kernel_v4; 8192 and 16384 points)
 int g_msm_host_tile = 1024;  // tuning knob "msm_host_tile": terms per staging buffer of a host-resident key
 int g_msm_c_mib = 2048;       // tuning knob "msm_c_mib": workspace of the centred plaintext rows of one term tile
 int g_mac_chunk_units = 768;  // tuning knob "mac_chunk_units": (limb, prime, chunk) units per MAC launch (term chunks = units / (L K))
 int g_plain_variant = 1;  // 1: plain_center_wide_kernel at N_enc = 8192; 0: plain_center_kernel
-int g_mac_variant = 5;  // 5: half-spectrum wide kernel at N_enc = 8192 (else as 3); 3: streaming kernel, 1024-thread shape at N_enc = 8192 (else as 2); 2: 512-thread streaming kernel; 1: generic kernel
+int g_mac_variant = 5;  // 6: as 5, one-key launches at N_enc = 8192 in the 512-thread shape (mac_kernel_v4<13, ., 1>: four waves per SIMD); 5: half-spectrum wide kernel at N_enc = 8192 (else as 3); 3: streaming kernel, 1024-thread shape at N_enc = 8192 (else as 2); 2: 512-thread streaming kernel; 1: generic kernel
 
 // Core grouped MSM.  addends: optional per-output (n_crs * n_groups) device pointers to encoding
 // elements added to the result (pk.alpha / pk.beta of groth16.tcc:95,103).
@@ -393,7 +410,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
   };
   // mac_kernel_v4 (two key vectors) runs ONE workgroup per CU: half the workgroup slots, half the chunks (measured at the
   // configs[3] shape: 111 -> 106 ms)
-  const int chunk_units = (n_crs == 2 && g_mac_share_keys && g_mac_variant == 5 && (n == 8192 || n == 16384)) ? (g_mac_chunk_units + 1) / 2
+  const int chunk_units = (n_crs == 2 && g_mac_share_keys && g_mac_variant >= 5 && (n == 8192 || n == 16384)) ? (g_mac_chunk_units + 1) / 2
                                                                                                               : g_mac_chunk_units;
   int n_chunks = (int)std::min<size_t>(tile_terms, (size_t)std::max(1, (chunk_units + L * K - 1) / (L * K)));
   {  // the (chunk, limb) rows of a launch are dealt to the 8 XCDs: a row count that is not a multiple of 8 leaves slots idle
@@ -413,7 +430,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
   (void)plain13;
   bool v3 = false, plain_wide = false, hybrid = false;
   if constexpr (FP) {
-    v3 = g_mac_variant == 5 && (n == 8192 || n == 16384);
+    v3 = g_mac_variant >= 5 && (n == 8192 || n == 16384);  // 6: one-key launches in the 512-thread shape (mac_kernel_v4<13, ., 1>)
     plain_wide = g_plain_variant == 1 && n == 8192 && (ctx->N == 8192 || ctx->N == 4096);
   } else {
     // Hybrid context: ring primes beyond 2^50 (SEAL's 54-bit BFVDefault(2048) prime of the reference's logistic-regression
@@ -423,7 +440,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
     for (int i = 0; i < L; i++) maxq = std::max(maxq, ctx->q[i]);
     int max_vecs = 1;
     for (int g = 0; g < n_groups; g++) max_vecs = std::max(max_vecs, pa.g[g].n);
-    hybrid = ctx->hybrid && g_mac_variant == 5 && (n == 8192 || n == 16384) &&
+    hybrid = ctx->hybrid && g_mac_variant >= 5 && (n == 8192 || n == 16384) &&
              (double)max_vecs * (0.5 * (double)maxq + 1.0) < 9007199254740992.0;
     v3 = hybrid;
   }
@@ -582,6 +599,40 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
                            terms * L * K * (ntt_fp64(nd, logn_d) + 8.0 * nd / 2.0 + 2.0 * 15.0 * nd));
             launch_mac_v4(ctx, a4, paired, sc, st);
           }
+        } else if (g_mac_variant == 6 && n == 8192) {
+          // one key vector per launch in the 512-thread shape of mac_kernel_v4 (four waves per SIMD), two groups that read it
+          // as neighbouring workgroups of an XCD (A and B against s_pows, groth16.tcc:89-103)
+          for (int c = 0; c < n_crs; c++)
+            for (int g0 = 0; g0 < n_groups; g0 += 2) {
+              const int ng = std::min(2, n_groups - g0);
+              MacArgs4 a4;
+              memset(&a4, 0, sizeof(a4));
+              unsigned long long tmax = 0;
+              double terms = 0;
+              for (int gi = 0; gi < ng; gi++) {
+                a4.C[gi] = reinterpret_cast<const double *>(Cptr(g0 + gi));
+                a4.terms[gi] = group_terms(g0 + gi);
+                a4.partial[0][gi] = d_partial + (size_t)(c * n_groups + g0 + gi) * enc_words;
+                tmax = std::max(tmax, a4.terms[gi]);
+                terms += (double)a4.terms[gi];
+              }
+              a4.crs[0] = crs_at(c, t0);
+              a4.part_stride = (size_t)n_sets * enc_words;
+              a4.n_groups = ng;
+              a4.n_chunks = base.n_chunks;
+              a4.terms_per_chunk = base.terms_per_chunk;
+              a4.accumulate = base.accumulate;
+              a4.acc_period = base.acc_period;
+              for (int jj = 0; jj < K; jj++) {
+                double end = 0;
+                a4.red_mask[jj] = fwd_reduce_mask_from(ctx->Q[jj], ctx->logN_enc, b0, &end);
+                if (end > 562949953421312.0) a4.reduce_u = 1;
+              }
+              ProfScope prof(ctx, st, paired ? "mac_kernel_v4<13, true, 1>" : "mac_kernel_v4<13, false, 1>",
+                             (double)tmax * (double)enc_words * 8.0 + terms * (double)L * nd * 8.0 + ng * (double)enc_words * 8.0,
+                             terms * L * K * (ntt_fp64(nd, logn_d) + 8.0 * nd / 2.0 + 15.0 * nd));
+              launch_mac_v4_one(ctx, a4, paired, sc, st);
+            }
         } else
         // chunks: two workgroups per CU in one wave of workgroups (512), shared by the groups of a launch
         for (int c = 0; c < n_crs; c++)
@@ -600,6 +651,7 @@ static void msm_run_arith(rs_ctx *ctx, const uint64_t *const *d_crs, int n_crs, 
             a3.part_stride = (size_t)n_sets * enc_words;
             a3.n_groups = ng;
             a3.paired = paired;
+            a3.ct_temporal = g_mac_ct_temporal;
             a3.n_chunks = base.n_chunks;
             a3.terms_per_chunk = base.terms_per_chunk;
             a3.accumulate = base.accumulate;

@@ -324,6 +324,7 @@ struct MacArgs3 {
   size_t part_stride;
   int n_groups, terms_per_chunk, n_chunks, accumulate, acc_period, reduce_u;
   int paired;                // rows in plain_center_wide_kernel's paired layout
+  int ct_temporal;           // tuning knob "mac_ct_temporal": ciphertext words with ordinary (temporal) loads instead of non-temporal ones
   uint32_t red_mask[RS_MAX_K];  // bit s: reduce before stage s of the forward transform mod Q_j (start bound = max |C|)
 };
 // LOGN = 14 (N_enc = 16384: the shapes of BASELINE configs[3] / [4] and of the reference's microbench.cpp:13-14): a
@@ -447,6 +448,7 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
   // issued and BEFORE its transform, so the ciphertext loads of term t (issued before the transform of term t) have a
   // whole term to land and the row loads of term t + 1 fly during the multiply-accumulate.
   u64x2 ct[2][8];
+  const bool temporal = a.ct_temporal != 0;
   auto issue_ct = [&]() {
 #pragma unroll
     for (int c = 0; c < 2; c++)
@@ -455,7 +457,8 @@ mac_kernel_v3(MacArgs3 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
 #if RS_MAC3_ABLATE & 2  // experiment: no ciphertext traffic (wrong results)
         ct[c][i] = u64x2{12345ull + i, 6789ull + c};
 #else
-        ct[c][i] = stream_load(reinterpret_cast<const u64x2 *>(ctp + c * comp) + lane + 64 * i);
+        const u64x2 *cp = reinterpret_cast<const u64x2 *>(ctp + c * comp) + lane + 64 * i;
+        ct[c][i] = temporal ? *cp : stream_load(cp);
 #endif
       }
     ctp += enc_words;
@@ -656,8 +659,13 @@ struct MacArgs4 {
 };
 // LOGN = 13 (N_enc = 8192): the workgroup owns HALF of the spectrum and folds one stage while the row is loaded (PAIRED:
 // rows in plain_center_wide_kernel's paired layout, one 16-byte load per operand pair).
-template <int LOGN, bool PAIRED>
-__global__ void __launch_bounds__(512, 2)
+// NKEY = 1 (round 6; N_enc = 8192): ONE key vector in the same shape -- half the accumulators and half the ciphertext registers,
+// so the kernel fits 128 VGPRs and TWO 512-thread workgroups share a CU: four waves per SIMD instead of mac_kernel_v3's two
+// (256 threads x 16 points, 240 VGPRs), the latency of the tile exchanges and of the one workgroup barrier per term hidden by
+// twice the waves.  Same arithmetic per coefficient as mac_kernel_v3 (stage 0 folded into the row load, 12 stages, the
+// multiply-accumulate one term behind): bit-identical results (mac_variant 6 / 5).
+template <int LOGN, bool PAIRED, int NKEY = 2>
+__global__ void __launch_bounds__(512, (NKEY == 1 ? 4 : 2))
 mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs) {
   constexpr int n = 1 << LOGN, H = 4096, LOGP = LOGN - 12, PARTS = 1 << LOGP, TILE = H + H / 8;
   static_assert(LOGN == 14 ? !PAIRED : LOGN == 13, "quarter spectrum at 16384 points, half spectrum at 8192");
@@ -692,17 +700,17 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
     }
 #pragma unroll
   for (int i = 0; i < 7; i++) {
-    pin(tw3[i]);
+    if (NKEY > 1) pin(tw3[i]);
     pin(tw4[i]);
   }
   const size_t enc_words = (size_t)L * 2 * K * n;
   const size_t slab = (((size_t)limb * 2) * K + j) * (size_t)n + (size_t)h * H;  // component 0; component 1 is + K*n
   const size_t comp = (size_t)K * n;
   const int r0 = wave * 512;  // the wave's range of the quarter: its 64 round-4 groups
-  uint64_t *part[2];
-  double acc[2][2][8];
+  uint64_t *part[NKEY];
+  double acc[NKEY][2][8];
 #pragma unroll
-  for (int kx = 0; kx < 2; kx++) {
+  for (int kx = 0; kx < NKEY; kx++) {
     part[kx] = a.partial[kx][g] + (size_t)chunk * a.part_stride + slab + r0;
 #pragma unroll
     for (int c = 0; c < 2; c++)
@@ -720,18 +728,18 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
   const unsigned long long tend = min(tbeg + (unsigned long long)a.terms_per_chunk, a.terms[g]);
   const double *crow = a.C[g] + ((size_t)tbeg * L + limb) * (size_t)n + (PAIRED ? 2 * t : t);
   const uint64_t *ctp0 = a.crs[0] + (size_t)tbeg * enc_words + slab + r0;
-  const uint64_t *ctp1 = a.crs[1] + (size_t)tbeg * enc_words + slab + r0;
-  u64x2 ct[2][2][4];
+  const uint64_t *ctp1 = NKEY > 1 ? a.crs[1] + (size_t)tbeg * enc_words + slab + r0 : nullptr;
+  u64x2 ct[NKEY][2][4];
   auto issue_ct = [&]() {
 #pragma unroll
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         ct[0][c][i] = stream_load(reinterpret_cast<const u64x2 *>(ctp0 + c * comp) + lane + 64 * i);
-        ct[1][c][i] = stream_load(reinterpret_cast<const u64x2 *>(ctp1 + c * comp) + lane + 64 * i);
+        if (NKEY > 1) ct[NKEY - 1][c][i] = stream_load(reinterpret_cast<const u64x2 *>(ctp1 + c * comp) + lane + 64 * i);
       }
     ctp0 += enc_words;
-    ctp1 += enc_words;
+    if (NKEY > 1) ctp1 += enc_words;
   };
   int since = 0;
   auto mac = [&](const double *tile) {
@@ -740,7 +748,7 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
     for (int i = 0; i < 4; i++) {
       const double u0 = tile[p0 + 144 * i], u1 = tile[p0 + 144 * i + 1];
 #pragma unroll
-      for (int kx = 0; kx < 2; kx++)
+      for (int kx = 0; kx < NKEY; kx++)
 #pragma unroll
         for (int c = 0; c < 2; c++) {
           acc[kx][c][2 * i] += mulmod(from_u64(ct[kx][c][i].x), u0, mod);
@@ -750,7 +758,7 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
     if (++since >= a.acc_period) {
       since = 0;
 #pragma unroll
-      for (int kx = 0; kx < 2; kx++)
+      for (int kx = 0; kx < NKEY; kx++)
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
@@ -761,6 +769,12 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
     double *tile = s + (int)((tt - tbeg) & 1) * TILE;
     double v[8], c2[8], c3[8];
     if (LOGN == 13) {
+      // NKEY = 1 (128 registers, four waves per SIMD): the multiply-accumulate of term tt - 1 FIRST, then the row loads -- the
+      // row registers would not fit beside the ciphertext words it consumes; the other three waves of the SIMD cover the latency
+      if (NKEY == 1 && tt > tbeg) {
+        mac(s + (int)((tt - tbeg + 1) & 1) * TILE);
+        mem_fence();
+      }
       // stage 0 (gap 4096) on x[n'], x[n' + 4096], n' = t + 512 e: this half's operand of the 4096-point sub-transform
 #pragma unroll
       for (int e = 0; e < 8; e++) {
@@ -775,7 +789,7 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
       }
       crow += (size_t)L * n;
       mem_fence();
-      if (tt > tbeg) mac(s + (int)((tt - tbeg + 1) & 1) * TILE);  // term tt - 1, under the row loads
+      if (NKEY > 1 && tt > tbeg) mac(s + (int)((tt - tbeg + 1) & 1) * TILE);  // term tt - 1, under the row loads
       mem_fence();
       if (red_mask & 1u) {  // a guarded pass: inside the element loop the reduction becomes compute-and-select
 #pragma unroll
@@ -873,6 +887,14 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
     wave_sync();
     {  // round 3: 64-element groups of 8 consecutive threads
       const int pb = (t >> 3) * 72 + (t & 7);
+      if (NKEY == 1) {  // 128 registers: this round's seven twiddles are re-read per term (eight lanes share each; L1 / L2 resident)
+        int g3 = t >> 3;
+        asm volatile("" : "+v"(g3));  // opaque: the loads must not be hoisted out of the term loop
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+          for (int bk = 0; bk < (1 << k); bk++) tw3[(1 << k) - 1 + bk] = tw[(root << (6 + k)) + (g3 << k) + bk];
+      }
 #pragma unroll
       for (int e = 0; e < 8; e++) v[e] = tile[pb + 9 * e];
       reg_fwd_stages<3, true>(v, mod, red_mask >> (LOGP + 6), [&](int k, int bk) { return tw3[(1 << k) - 1 + bk]; });
@@ -896,7 +918,7 @@ mac_kernel_v4(MacArgs4 a, int L, int K, const NttTable *__restrict__ coeff_tabs)
   }
   if (tend > tbeg) mac(s + (int)((tend - tbeg + 1) & 1) * TILE);  // the last term
 #pragma unroll
-  for (int kx = 0; kx < 2; kx++)
+  for (int kx = 0; kx < NKEY; kx++)
 #pragma unroll
     for (int c = 0; c < 2; c++)
 #pragma unroll

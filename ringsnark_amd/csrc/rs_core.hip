@@ -1028,6 +1028,8 @@ int rs_set_tuning(const char *key, int value) {
 #endif
   else if (std::string(key) == "mac_variant")
     g_mac_variant = value;
+  else if (std::string(key) == "mac_ct_temporal")
+    g_mac_ct_temporal = value ? 1 : 0;
   else if (std::string(key) == "plain_variant")
     g_plain_variant = value;
   else if (std::string(key) == "prover_lin_io")

@@ -299,6 +299,7 @@ extern int g_witness_cross_pair;           // witness.hip: paired groups / 16-by
 extern int g_witness_cross_maxr;           // witness.hip: stages per cross pass of the multi-pass transforms
 extern int g_witness_force_bc;             // witness.hip: cap on the transform length (block-convolution path)
 extern int g_witness_bc2;                  // witness.hip: two-dimensional block convolutions where they apply
+extern int g_mac_ct_temporal;             // msm.hip: mac_kernel_v3 reads ciphertext words with temporal loads
 extern int g_witness_inc;                  // witness.hip: incomplete transforms (witness_inc.hpp) where they apply, instead of block convolutions
 extern int g_prover_lin_io;               // prover.hip: io vectors as linear forms in groth16::prover
 extern int g_witness_tree_log;            // witness.hip: tile of the wide product-tree kernel (13 or 14)

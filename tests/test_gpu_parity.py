@@ -297,7 +297,7 @@ def test_wide_kernels_equal_their_predecessors_and_the_oracle(name):
     vecs = [(dev.put(v[0]), kinds, 0), (dev.put(v[1]), None, 0), (dev.put(v[2]), None, 1)]
     res = {}
     try:
-        for mv, pv in ((5, 1), (3, 0), (5, 0), (3, 1)):
+        for mv, pv in ((5, 1), (3, 0), (5, 0), (3, 1), (6, 1), (6, 0)):  # 6: one key vector in the 512-thread shape (mac_kernel_v4<13, ., 1>)
             _set_tuning(b"mac_variant", mv)
             _set_tuning(b"plain_variant", pv)
             out, used = dev.msm([dev.put(encs)], vecs, 2, want_used=True)

@@ -301,7 +301,9 @@ static WitnessPlan *build_plan(rs_ctx *ctx, size_t m) {
   // product tree's tiles; at most RS_INC_MAX stages missing, all of them inside the LAST round of a sub-transform block.
   {
     const int logT = std::min(g_witness_lds_logM, logM);
-    const bool multi = logM > g_witness_lds_logM && !(!ctx->use_int && single_tile_ok(logM));
+    // (M = 2^14 on the FP64 arithmetic normally runs in ONE 2^14 tile -- single_tile_ok -- whose Newton conversion needs a
+    // complete 2^15-point transform: a prime without it takes the multi-pass path on 2^13 tiles instead, one stage short)
+    const bool multi = logM > g_witness_lds_logM;
     P->incomplete = blocked && g_witness_inc && multi && vmin >= tree_tile_log(!ctx->use_int, logM) && logM + 1 - vmin <= RS_INC_MAX &&
                     std::min(logT, 12) > RS_INC_MAX;
   }
@@ -1660,7 +1662,7 @@ static void launch_interp(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> 
     return;
   }
   if constexpr (FP) {
-    if (single_tile_ok(P->logM)) {
+    if (single_tile_ok(P->logM) && !P->incomplete) {
       // one launch, tile = M, two workgroups per CU: Newton conversion by the two rooted M-point
       // sub-transforms, then the product tree in place
       launch_tree_tiles(ctx, cols, ncols, 0, P->logM, P->logM, S, slots_per_limb, cp, st, true);
@@ -1723,7 +1725,7 @@ static void launch_h(rs_ctx *ctx, const WitnessPlan *P, const ColPlansT<M> &cp, 
     return;
   }
   if constexpr (FP) {
-    if (single_tile_ok(P->logM)) {
+    if (single_tile_ok(P->logM) && !P->incomplete) {
       const size_t lds1 = padded_len(Mlen) * sizeof(double);
       const int thr = (int)(Mlen / 16);
       // ten M-point transforms, four pointwise products, the ZK patch

@@ -139,10 +139,10 @@ def _run_large(prm, m, zk, want=KEYS, **knobs):
     return dev, cs, asg, ds, w, names
 
 
-@pytest.mark.parametrize("m,zk", [(20000, True), (40000, False), (65536, True), (100000, False), (131072, True)])
+@pytest.mark.parametrize("m,zk", [(10000, True), (16384, False), (20000, True), (40000, False), (65536, True), (100000, False), (131072, True)])
 def test_headline_primes_through_the_tuned_kernels(m, zk):
-    """The ring primes of the headline (2-adicity 15, 15, 14, 14: per-limb launches of the tuned sub-transform kernels), M = 2^15
-    .. 2^17 (four stages short at most: 2^18 constraints on these primes take the block convolutions): every column through the identities, and every vector bit-equal to the two-dimensional block convolutions."""
+    """The ring primes of the headline (2-adicity 15, 15, 14, 14: per-limb launches of the tuned sub-transform kernels), M = 2^14
+    (the one-tile size: a prime without a 2^15-th root takes the multi-pass path there) .. 2^17 (four stages short at most: 2^18 constraints on these primes take the block convolutions): every column through the identities, and every vector bit-equal to the two-dimensional block convolutions."""
     prm = P.preset("toyC3")
     dev, cs, asg, ds, w, names = _run_large(prm, m, zk)
     logM = (m - 1).bit_length()
@@ -158,7 +158,7 @@ def test_headline_primes_through_the_tuned_kernels(m, zk):
         assert not got["H"][m - 1:].any()
     del dev, asg, w
     dev, cs, asg, ds, w, names = _run_large(prm, m, zk, witness_inc=0)
-    assert any(n.startswith("bc2_") for n in names), names
+    assert any(n.startswith("bc2_" if logM >= 15 else "bc_") for n in names), names  # M = 2^14: the pairwise block convolutions
     for k in KEYS:
         assert (_host(w[k]) == got[k]).all(), k
 

@@ -117,12 +117,17 @@ __device__ __forceinline__ void tree_wide_middle(double (&b)[32], double *s, con
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   {
     const double2 *src = reinterpret_cast<const double2 *>(dh_wave) + lane;
+    // tw_addr(2048 wave + 128 i + 2 lane) = pa0 + 132 i.  The base is made opaque HERE, per level: left to itself the compiler
+    // hoists the sixteen addresses out of the levels as kernel-lifetime registers, spills them (10 dwords at 256 VGPRs), and
+    // every reload -- a vector-memory operation -- puts an s_waitcnt vmcnt(0) behind the table load issued just before it:
+    // the sixteen loads of a level's table were serialised (round 6; found in the ISA).
+    int pa0 = tw_addr(2048 * wave + 2 * lane);
+    asm volatile("" : "+v"(pa0));
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const double2 v = src[64 * i];
-      const int pa = tw_addr(2048 * wave + 128 * i + 2 * lane);
-      s[pa] = v.x;
-      s[pa + 1] = v.y;
+      s[pa0 + 132 * i] = v.x;
+      s[pa0 + 132 * i + 1] = v.y;
     }
   }
   const uint32_t fmask = P.fmask[LV] >> c, imask = P.imask[LV];
@@ -334,12 +339,13 @@ tree_wide_kernel(double *__restrict__ cols, int logM, size_t col0, unsigned S, u
     // written bytes at the memory interface).
     {
       const double2 *src = reinterpret_cast<const double2 *>(c + 2048 * wave) + lane;
+      int pa0 = tw_addr(2048 * wave + 2 * lane);  // tw_addr(2048 wave + 128 i + 2 lane) = pa0 + 132 i
+      asm volatile("" : "+v"(pa0));
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const double2 v = src[64 * i];
-        const int pa = tw_addr(2048 * wave + 128 * i + 2 * lane);
-        s[pa] = v.x;
-        s[pa + 1] = v.y;
+        s[pa0 + 132 * i] = v.x;
+        s[pa0 + 132 * i + 1] = v.y;
       }
     }
     wave_sync();
@@ -381,11 +387,10 @@ tree_wide_kernel(double *__restrict__ cols, int logM, size_t col0, unsigned S, u
   if (LOGT >= 14) tree_wide_level_big<(LOGT >= 14 ? 14 : 13)>(s, P, mod, P.dhat + (size_t)14 * M + pos0, t);
   {  // the last level ended with a workgroup barrier: every coefficient of the tile is final
     double2 *dst = reinterpret_cast<double2 *>(c + 2048 * wave) + lane;
+    int pa0 = tw_addr(2048 * wave + 2 * lane);
+    asm volatile("" : "+v"(pa0));
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int pa = tw_addr(2048 * wave + 128 * i + 2 * lane);
-      dst[64 * i] = make_double2(canon(s[pa], mod), canon(s[pa + 1], mod));
-    }
+    for (int i = 0; i < 16; i++) dst[64 * i] = make_double2(canon(s[pa0 + 132 * i], mod), canon(s[pa0 + 132 * i + 1], mod));
   }
   if (RF > 0) {
     const unsigned ti = blockIdx.x % nb;

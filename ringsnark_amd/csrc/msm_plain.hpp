@@ -236,6 +236,8 @@ plain_center_wide_kernel(PlainArgs args, double *__restrict__ C, unsigned long l
     for (int e = 0; e < NE; e++) pre[e] = stream_load(s2 + 256 * e);
   };
   unsigned long long item = (unsigned long long)slot;
+  __shared__ unsigned nzflag[2][4];
+  int nzpar = 0;
   // MULTI == false: the single vector of every group; a term beyond its length or a constant-1 term has nothing to load
   auto loadable = [&](unsigned long long it) {
     const PlainGroup &G = args.g[it % (unsigned)n_groups];
@@ -293,7 +295,18 @@ plain_center_wide_kernel(PlainArgs args, double *__restrict__ C, unsigned long l
       if (MULTI) load_tw1(tw1);  // after the scatter: the coefficient registers are free
       prefetch_next();  // next item's coefficients: in flight during this transform
       mem_fence();
-      const bool any = __syncthreads_or(nz);
+      // "is any coefficient of this limb non-zero", over the workgroup -- the barrier that also publishes the scattered tile.
+      // Not __syncthreads_or: its lowering keeps the thread ids it needs in registers across the item loop, which in the LIN
+      // instantiation spills two of them, and the scratch reload right here is followed by s_waitcnt vmcnt(0) -- draining the
+      // next item's prefetch and the twiddle loads issued just above (round 6; found in the ISA).  One ballot per wave, one
+      // flag word per wave in LDS, two alternating flag sets (an item without a non-zero coefficient skips the later barriers).
+      {
+        const unsigned long long bal = __ballot(nz);
+        if ((t & 63) == 0) nzflag[nzpar][t >> 6] = bal != 0ull;
+      }
+      __syncthreads();
+      const bool any = (nzflag[nzpar][0] | nzflag[nzpar][1] | nzflag[nzpar][2] | nzflag[nzpar][3]) != 0u;
+      nzpar ^= 1;
       if (!any) continue;  // is_zero term (this limb): contributes nothing; nobody reads the tile
       if (t == 0 && G.nz[v]) atomicOr(&G.nz[v][term], 1u);
       // round 1: inverse stages 0..3 on 16 consecutive points

@@ -136,6 +136,16 @@ __device__ __forceinline__ void stream_store(u64x2 *p, u64x2 v) {
 #endif
 }
 
+// A table constant at a WAVE-UNIFORM address, through the scalar data cache (s_load_*: lgkmcnt, not vmcnt).  Inside a
+// persistent kernel that also stores, the compiler reads such a constant with a VECTOR load (the table is not provably
+// invariant across the loop's stores), and the s_waitcnt vmcnt(0) before its first use drains every vector load issued before
+// it -- the prefetch of the next block included (found in the ISA of sub_ntt_wide_kernel, round 6).  A load through the
+// CONSTANT address space is invariant by definition: uniform address -> SMEM.  The tables are written once, at plan / context
+// creation, long before any kernel reads them.
+__device__ __forceinline__ double ld_const(const double *p) {
+  typedef const double __attribute__((address_space(4))) *cptr4;
+  return *(cptr4)(unsigned long long)p;
+}
 // a wave-uniform value as scalar registers
 __device__ __forceinline__ double uniform_f64(double x) {
   union { double d; int i[2]; } u;

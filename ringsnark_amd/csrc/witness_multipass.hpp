@@ -836,13 +836,27 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
       pin(v[1][e]);
     }
     mem_fence();
+    // the lane's round-2 twiddles are requested BEFORE the next block's prefetch: vector loads complete in order, so waiting
+    // for them later (vmcnt(16)) leaves the sixteen prefetch loads in flight; round 1's wave-uniform twiddles come through
+    // the scalar cache (ld_const) and wait for no vector load at all -- the prefetch has rounds 1 and 2 to land (round 6:
+    // it used to be drained by the first twiddle of round 1, a vector load issued right after it)
+    double w2[31];
+    {
+      const int hi = t >> 4;
+      SubTw::run<1>(tw + (root << 4) + hi, w2);
+      SubTw::run<2>(tw + (root << 5) + (hi << 1), w2 + 1);
+      SubTw::run<4>(tw + (root << 6) + (hi << 2), w2 + 3);
+      SubTw::run<8>(tw + (root << 7) + (hi << 3), w2 + 7);
+      SubTw::run<16>(tw + (root << 8) + (hi << 4), w2 + 15);
+    }
+    mem_fence();
     const unsigned long long bn = blk + gridDim.x;
     if (bn < nblocks) issue_loads(bn);
     mem_fence();
     // ---- forward round 1: stages 0..3 on elements 2t+c + 512e, twiddles tw[2^k root + blk] (uniform)
 #pragma unroll
     for (int c = 0; c < 2; c++)
-      reg_fwd_stages<4, true>(v[c], mod, fmask, [&](int k, int b) { return tw[(root << k) + b]; });
+      reg_fwd_stages<4, true>(v[c], mod, fmask, [&](int k, int b) { return ld_const(tw + (root << k) + b); });
     __syncthreads();  // the previous block's last-round reads of the tile are done
     {
       const int pb = S::px(2 * t);
@@ -857,16 +871,10 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
     {
       const int lo = t & 15, hi = t >> 4;
       const int pb = hi * S::SP + lo;
-      double w[31];
-      SubTw::run<1>(tw + (root << 4) + hi, w);
-      SubTw::run<2>(tw + (root << 5) + (hi << 1), w + 1);
-      SubTw::run<4>(tw + (root << 6) + (hi << 2), w + 3);
-      SubTw::run<8>(tw + (root << 7) + (hi << 3), w + 7);
-      SubTw::run<16>(tw + (root << 8) + (hi << 4), w + 15);
       double x[32];
 #pragma unroll
       for (int e = 0; e < 32; e++) x[e] = s[pb + 17 * e];
-      reg_fwd_stages<5, true>(x, mod, fmask >> 4, [&](int k, int b) { return w[(1 << k) - 1 + b]; });
+      reg_fwd_stages<5, true>(x, mod, fmask >> 4, [&](int k, int b) { return w2[(1 << k) - 1 + b]; });
 #pragma unroll
       for (int e = 0; e < 32; e++) s[pb + 17 * e] = x[e];
     }
@@ -1008,7 +1016,7 @@ sub_ntt_wide_kernel(double *__restrict__ X, int log_n1, TabPtrs tabs, unsigned t
     }
 #pragma unroll
     for (int c = 0; c < 2; c++)
-      reg_inv_stages<4, true>(v[c], mod, imask >> 9, [&](int k, int i) { return itw[((8 >> k) * root) + i]; });
+      reg_inv_stages<4, true>(v[c], mod, imask >> 9, [&](int k, int i) { return ld_const(itw + ((8 >> k) * root) + i); });
     {
       double2 *dst = reinterpret_cast<double2 *>(X + blk * (size_t)S::N) + t;
 #pragma unroll

@@ -142,8 +142,9 @@ __device__ __forceinline__ void stream_store(u64x2 *p, u64x2 v) {
 // it -- the prefetch of the next block included (found in the ISA of sub_ntt_wide_kernel, round 6).  A load through the
 // CONSTANT address space is invariant by definition: uniform address -> SMEM.  The tables are written once, at plan / context
 // creation, long before any kernel reads them.
-__device__ __forceinline__ double ld_const(const double *p) {
-  typedef const double __attribute__((address_space(4))) *cptr4;
+template <class T>
+__device__ __forceinline__ T ld_const(const T *p) {
+  typedef const T __attribute__((address_space(4))) *cptr4;
   return *(cptr4)(unsigned long long)p;
 }
 // a wave-uniform value as scalar registers

@@ -229,7 +229,7 @@ __device__ __forceinline__ void fwd_round2(const In in, const Out out, int logto
       const int twbase = (1 << (s0 + k)) + (hi << k);
 #pragma unroll
       for (int blk = 0; blk < (1 << k); blk++) {
-        const T w = tw[twbase + blk];
+        const T w = ld_const(tw + twbase + blk);  // wave-uniform (hi_all): scalar cache, not a vector load behind the data loads
 #pragma unroll
         for (int e0 = 0; e0 < half; e0++) {
           const int ia = blk * 2 * half + e0, ib = ia + half;
@@ -281,7 +281,7 @@ __device__ __forceinline__ void inv_round2(const In in, const Out out, int logto
 #pragma unroll
       for (int e = 0; e < E; e++) {
         if (e & (1 << k)) continue;
-        const T w = itw[twbase + (e >> (k + 1))];
+        const T w = ld_const(itw + twbase + (e >> (k + 1)));
 #pragma unroll
         for (int c = 0; c < 2; c++) {
           const T a = v[c][e], b = v[c][e + (1 << k)];
@@ -1041,7 +1041,7 @@ __device__ __forceinline__ void w12_block(double (&v)[16], double *s, const doub
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int pt = t + (t >> 4);
   // ---- forward round 1: stages 0..3 on elements t + 256 e (uniform twiddles)
-  reg_fwd_stages<4, true>(v, mod, fmask, [&](int k, int b) { return tw[(root << k) + b]; });
+  reg_fwd_stages<4, true>(v, mod, fmask, [&](int k, int b) { return ld_const(tw + (root << k) + b); });  // wave-uniform: scalar cache (ntt_wide.hpp)
   __syncthreads();  // the previous block's last-round reads of the tile are done
 #pragma unroll
   for (int e = 0; e < 16; e++) s[pt + SP * e] = v[e];
@@ -1168,7 +1168,7 @@ __device__ __forceinline__ void w12_block(double (&v)[16], double *s, const doub
   // ---- inverse round 3: stages 8..11 on elements t + 256 e; block of stage 8+k: e >> (k+1) of 8 >> k
 #pragma unroll
   for (int e = 0; e < 16; e++) v[e] = s[pt + SP * e];
-  reg_inv_stages<4, true>(v, mod, imask >> 8, [&](int k, int i) { return itw[((8 >> k) * root) + i]; });
+  reg_inv_stages<4, true>(v, mod, imask >> 8, [&](int k, int i) { return ld_const(itw + ((8 >> k) * root) + i); });
 }
 
 // sub_ntt_wide_kernel on blocks of 2^12 (knob witness_sub_log = 12): 116-128 registers, a 34 KiB tile -- FOUR workgroups

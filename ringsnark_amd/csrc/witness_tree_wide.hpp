@@ -166,7 +166,7 @@ __device__ __forceinline__ void tree_wide_level(double *s, const ColPlan &P, con
     }
 #pragma unroll
   for (int k = 0; k < Q; k++)
-    reg_fwd_stages_zu<c>(X[k], mod, P.fmask[LV], [&](int st, int blk) { return tw[(1 << st) + blk]; });
+    reg_fwd_stages_zu<c>(X[k], mod, P.fmask[LV], [&](int st, int blk) { return ld_const(tw + (1 << st) + blk); });  // compile-time index: scalar cache (ntt_wide.hpp ld_const)
 #pragma unroll
   for (int k = 0; k < Q; k++)
 #pragma unroll
@@ -187,7 +187,7 @@ __device__ __forceinline__ void tree_wide_level(double *s, const ColPlan &P, con
     for (int tn = 0; tn < W; tn++) X[k][tn] = s[tw_addr(32 * (tb + tn) + u + W * k)];
 #pragma unroll
   for (int k = 0; k < Q; k++) {
-    reg_inv_stages<c, true>(X[k], mod, P.imask[LV] >> 5, [&](int st, int i) { return itw[(W >> (st + 1)) + i]; });
+    reg_inv_stages<c, true>(X[k], mod, P.imask[LV] >> 5, [&](int st, int i) { return ld_const(itw + (W >> (st + 1)) + i); });
 #pragma unroll
     for (int tn = 0; tn < W; tn++) {
       const double v = reduce(X[k][tn] + (tn < W / 2 ? Lf[k][tn] : 0.0), mod);
@@ -223,7 +223,7 @@ __device__ __forceinline__ void tree_wide_level_big(double *s, const ColPlan &P,
     }
 #pragma unroll
   for (int k = 0; k < Q1; k++) {
-    reg_fwd_stages_zu<c1>(X[k], mod, fmask, [&](int st, int blk) { return tw[(1 << st) + blk]; });
+    reg_fwd_stages_zu<c1>(X[k], mod, fmask, [&](int st, int blk) { return ld_const(tw + (1 << st) + blk); });  // compile-time index: scalar cache (ntt_wide.hpp ld_const)
 #pragma unroll
     for (int th = 0; th < R1; th++) s[x1_addr(k, th)] = X[k][th];
   }
@@ -271,7 +271,7 @@ __device__ __forceinline__ void tree_wide_level_big(double *s, const ColPlan &P,
   for (int k = 0; k < Q1; k++) {
 #pragma unroll
     for (int th = 0; th < R1; th++) X[k][th] = s[x1_addr(k, th)];
-    reg_inv_stages<c1, true>(X[k], mod, imask >> 10, [&](int st, int i) { return itw[(R1 >> (st + 1)) + i]; });
+    reg_inv_stages<c1, true>(X[k], mod, imask >> 10, [&](int st, int i) { return ld_const(itw + (R1 >> (st + 1)) + i); });
 #pragma unroll
     for (int th = 0; th < R1; th++) s[x1_addr(k, th)] = reduce(X[k][th] + (th < R1 / 2 ? Lf[k][th] : 0.0), mod);
   }

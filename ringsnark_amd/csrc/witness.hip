@@ -1885,8 +1885,9 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
   const size_t vec = C * M;
   T *colbuf = (T *)ws_get(ctx, 5, std::max<size_t>(1, (size_t)nvec * vec) * sizeof(T));
   auto colv = [&](int k) { return colbuf + (size_t)slot_of[k] * vec; };
-  const dim3 tgrid((unsigned)((C + 31) / 32), (unsigned)((M + 31) / 32));
-  const dim3 tgrid64((unsigned)((C + 63) / 64), (unsigned)((M + 31) / 32));
+  RS_REQUIRE((C % 2) == 0 && (M % 2) == 0, "column tiles move slot pairs and row pairs");
+  const dim3 tgrid((unsigned)((C + 63) / 64), (unsigned)((M + 63) / 64));    // transposing kernels: 64 x 64 tiles
+  const dim3 tgrid_ev((unsigned)((C + 63) / 64), (unsigned)((M + 31) / 32));  // the evaluation: 64 columns x 32 rows
   const T *ptab = reinterpret_cast<const T *>(cs->d_ptab);
   // the map of output vector k: its row range (rows == null: every row)
   auto cm_for = [&](int k) {
@@ -1903,7 +1904,7 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
       if (!needed(k)) continue;
       // per (row, slot): 8 bytes of assignment per non-zero + 8 bytes of column written
       ProfScope prof(ctx, st, "r1cs_eval_cols_kernel", (double)C * 8.0 * ((double)cs->nnz[w] + (double)M), 7.0 * (double)C * (double)cs->nnz[w]);
-      hipLaunchKernelGGL(r1cs_eval_cols_kernel<M_>, tgrid64, dim3(256), 0, st, cs->d_row_ptr[w], cs->d_col[w], coeff[w],
+      hipLaunchKernelGGL(r1cs_eval_cols_kernel<M_>, tgrid_ev, dim3(256), 0, st, cs->d_row_ptr[w], cs->d_col[w], coeff[w],
                          cs->nnz[w], d_asg, colv(k), m, C, M, kind == 2 ? (int)RS_EVAL_CONST : (kind ? (int)RS_EVAL_FULL : (int)RS_EVAL_IO),
                          (unsigned)cs->n_inputs, qmod, cm, cs->d_pidx[w], ptab);
     }
@@ -1942,7 +1943,7 @@ static void witness_chunk(rs_ctx *ctx, const rs_r1cs *cs, WitnessPlan *P, const 
         // 8 bytes of column read, 8 or 16 written, the primary inputs re-read per row (L2 resident)
         ProfScope prof(ctx, st, "io_mid_out_kernel", (double)C * (double)m * (outs[w] ? 24.0 : 16.0),
                        (double)C * (double)m * (7.0 * io.count + 4.0));
-        hipLaunchKernelGGL(io_mid_out_kernel<M_>, tgrid64, dim3(256), 0, st, colv(3 + w), io, io_cols, d_asg, cst, outs[w],
+        hipLaunchKernelGGL(io_mid_out_kernel<M_>, tgrid, dim3(256), 0, st, colv(3 + w), io, io_cols, d_asg, cst, outs[w],
                            outs[3 + w], m, C, M, qmod, cm_for(3 + w));  // io and mid of one matrix share their row range (checked by the caller)
       } else {  // io alone: no column work at all
         const unsigned by = (unsigned)((C / 2 + 255) / 256);
@@ -2057,7 +2058,8 @@ static void interpolate_arith(rs_ctx *ctx, const uint64_t *d_y, uint64_t *d_out,
   const ColMap cm{0, ctx->N, 0, ctx->N, ctx->L, ctx->N, 0};
   hipLaunchKernelGGL(transpose_in_kernel<T>, tgrid, dim3(256), 0, st, d_y, colbuf, n, S_, M);
   launch_interp<M_>(ctx, P, cp, colbuf, S_, S_, (size_t)ctx->N, 0, st);
-  hipLaunchKernelGGL(transpose_out_kernel<T>, tgrid, dim3(256), 0, st, colbuf, d_out, n, S_, M, cm);
+  const dim3 ogrid((unsigned)((S_ + 63) / 64), (unsigned)((M + 63) / 64));
+  hipLaunchKernelGGL(transpose_out_kernel<T>, ogrid, dim3(256), 0, st, colbuf, d_out, n, S_, M, cm);
   RS_HIP(hipGetLastError());
 }
 

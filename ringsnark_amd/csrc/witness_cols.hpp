@@ -64,6 +64,16 @@ struct ColMap {
   __host__ __device__ __forceinline__ size_t out_stride() const { return (size_t)L * out_N; }
 };
 
+// The kernels that move data between the term-major boundary layout and the column-major working layout do it in tiles of
+// 64 columns x 64 rows through LDS: 512-byte segments on both sides, 16 bytes per lane, eight loads per lane in flight before
+// the first is consumed (round 6; the 32 x 32 tiles before moved 8 bytes per lane in 256-byte segments).  grid (C/64, M/64),
+// columns fastest: numbering the tiles in super-blocks instead (so that the resident tiles cover longer contiguous runs of
+// every column) measured 1-3 % slower -- profiles/r06_tiles_ab.txt.
+template <class T>
+struct alignas(16) Pair2 {
+  T x, y;
+};
+
 // [rows][S] u64 (term-major, S = L*N) -> [S][M] f64 (column-major), rows >= m zero-filled.
 template <class T>
 __global__ void __launch_bounds__(256) transpose_in_kernel(const uint64_t *__restrict__ src, T *__restrict__ dst,
@@ -81,27 +91,42 @@ __global__ void __launch_bounds__(256) transpose_in_kernel(const uint64_t *__res
     if (sl < S && r < M) dst[sl * M + r] = tile[tx][k];
   }
 }
-// [C][M] f64 canonical columns -> [rows][L][out_N] u64 for rows < m_out
+// [C][M] f64 canonical columns -> [rows][L][out_N] u64 for rows < m_out (M, C even: the column tile holds a power of two
+// of rows, and chunks hold slot pairs)
 template <class T>
 __global__ void __launch_bounds__(256) transpose_out_kernel(const T *__restrict__ src, uint64_t *__restrict__ dst,
                                                             size_t m_out, size_t C, size_t M, ColMap cm) {
-  __shared__ T tile[32][33];
-  const size_t s0 = (size_t)blockIdx.x * 32, r0 = (size_t)blockIdx.y * 32;
-  if (r0 + 32 <= cm.row0 || r0 >= cm.row1) return;  // no row of this tile is wanted
+  __shared__ T tile[64][65];  // [column][row]
+  const size_t s0 = (size_t)blockIdx.x * 64, r0 = (size_t)blockIdx.y * 64;
+  if (r0 + 64 <= cm.row0 || r0 >= cm.row1 || r0 >= m_out) return;  // no row of this tile is wanted
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int k = ty; k < 32; k += 8) {
-    const size_t c = s0 + k, r = r0 + tx;
-    tile[k][tx] = (c < C && r < M) ? src[c * M + r] : T(0);
+  Pair2<T> v[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const size_t c = s0 + ty + 8 * j, r = r0 + 2 * tx;
+    v[j] = (c < C && r < M) ? *reinterpret_cast<const Pair2<T> *>(src + c * M + r) : Pair2<T>{T(0), T(0)};
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    tile[ty + 8 * j][2 * tx] = v[j].x;
+    tile[ty + 8 * j][2 * tx + 1] = v[j].y;
   }
   __syncthreads();
-  const size_t c = s0 + tx;
+  const size_t c = s0 + 2 * tx;  // this lane's column pair (ns is even: both slots in one limb)
   if (c >= C) return;
   int limb, slot;
   cm.locate(c, limb, slot);
-  const size_t o = cm.out_index(limb, slot), So = cm.out_stride();
-  for (int k = ty; k < 32; k += 8) {
+  const size_t o = cm.out_index(limb, slot) >> 1, So = cm.out_stride();
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int k = ty + 8 * j;
     const size_t r = r0 + k;
-    if (r < m_out && r >= cm.row0 && r < cm.row1) dst[(r - cm.row0) * So + o] = to_res(tile[tx][k]);
+    if (r < m_out && r >= cm.row0 && r < cm.row1) {
+      ulonglong2 w;
+      w.x = to_res(tile[2 * tx][k]);
+      w.y = to_res(tile[2 * tx + 1][k]);
+      reinterpret_cast<ulonglong2 *>(dst + (r - cm.row0) * So)[o] = w;
+    }
   }
 }
 
